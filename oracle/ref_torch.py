@@ -1,0 +1,316 @@
+"""ORACLE — test infrastructure only. Never imported by the product path (neuralsampleid_amd/).
+
+CPU fp32 restatement, in stock PyTorch ops, of the reference's GNN contrastive-fingerprint path
+(SURVEY.md §8a rows a1–a15).  It is deliberately NOT structured like the reference: features are
+node-major `(B, N, C)` rows, every 1x1 convolution is a row GEMM, the loss uses the closed form,
+and parameters come from a flat `{reference state_dict key: tensor}` mapping, so that the HIP
+kernels (which use the same layout) can be compared tensor-for-tensor, and gradients come from
+autograd.  Parity status: PINNED — `tests/test_oracle_golden.py` checks every function here against
+golden vectors produced by running the reference's own modules (`tests/golden/make_golden.py`).
+
+Only `tests/`, `__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline` leg may import this file.
+
+Reference sites restated (paths relative to the reference repo):
+  peak_patchify      peak_extractor.py:45-70
+  knn_graph          encoder/gcn_lib/torch_edge.py:7-18, 70-103, 245-255, 270-284
+  mr_aggregate       encoder/gcn_lib/torch_vertex.py:19-32 + torch_nn.py:79-98
+  grouped_linear     encoder/gcn_lib/torch_nn.py:52-60 (Conv2d 1x1, groups=4)
+  grapher / ffn      encoder/gcn_lib/torch_vertex.py:183-195, encoder/graph_encoder.py:82-89
+  downsample         encoder/graph_encoder.py:44-50 (3x3 s2 p1 on a width-1 map = 3-tap stride-2 conv along N)
+  graph_encoder      encoder/graph_encoder.py:190-214
+  simclr_forward     simclr/simclr.py:31-47
+  ntxent             simclr/ntxent.py:5-30
+  train_step         train.py:53-75
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Tuple
+
+import torch
+import torch.nn.functional as F
+
+Tensor = torch.Tensor
+BN_MOMENTUM = 0.1
+BN_EPS = 1e-5
+
+SIZES = {  # encoder/graph_encoder.py:118-129
+    "t": ([2, 2, 6, 2], [64, 128, 256, 512]),
+    "s": ([2, 2, 6, 2], [80, 160, 400, 640]),
+    "m": ([2, 2, 16, 2], [96, 192, 384, 768]),
+    "b": ([2, 2, 18, 2], [128, 256, 512, 1024]),
+}
+
+
+class BNState:
+    """Collects updated running statistics instead of mutating the parameter mapping."""
+
+    def __init__(self):
+        self.updates: Dict[str, Tensor] = {}
+
+
+def batchnorm_rows(x: Tensor, P: Dict[str, Tensor], pre: str, training: bool, st: Optional[BNState]) -> Tensor:
+    """nn.BatchNorm2d over the rows of x (M, C): biased variance to normalise, unbiased for running_var."""
+    w, b = P[pre + "weight"], P[pre + "bias"]
+    if training:
+        mean = x.mean(dim=0)
+        var = x.var(dim=0, unbiased=False)
+        if st is not None:
+            n = x.shape[0]
+            with torch.no_grad():
+                rm = P[pre + "running_mean"]
+                rv = P[pre + "running_var"]
+                key_m, key_v, key_n = pre + "running_mean", pre + "running_var", pre + "num_batches_tracked"
+                rm = st.updates.get(key_m, rm)
+                rv = st.updates.get(key_v, rv)
+                nb = st.updates.get(key_n, P.get(key_n, torch.zeros((), dtype=torch.int64)))
+                st.updates[key_m] = (1 - BN_MOMENTUM) * rm + BN_MOMENTUM * mean.detach()
+                st.updates[key_v] = (1 - BN_MOMENTUM) * rv + BN_MOMENTUM * var.detach() * (n / max(n - 1, 1))
+                st.updates[key_n] = nb + 1
+    else:
+        mean, var = P[pre + "running_mean"], P[pre + "running_var"]
+    return (x - mean) * torch.rsqrt(var + BN_EPS) * w + b
+
+
+def linear_rows(x: Tensor, P: Dict[str, Tensor], pre: str) -> Tensor:
+    """1x1 Conv2d / Linear as a row GEMM; weight (Cout, Cin[,1,1])."""
+    w = P[pre + "weight"]
+    w = w.reshape(w.shape[0], -1)
+    y = x @ w.t()
+    if pre + "bias" in P:
+        y = y + P[pre + "bias"]
+    return y
+
+
+def peak_patchify(spec: Tensor, P: Dict[str, Tensor], pre: str, cfg: dict) -> Tensor:
+    """(B, n_mels, n_frames) -> (B, N, n_filters) node-major; node n = (mel_patch, frame_patch) row-major."""
+    B, H, W = spec.shape
+    pb, pf = cfg["patch_bins"], cfg["patch_frames"]
+    lo = spec.amin(dim=(1, 2), keepdim=True)
+    hi = spec.amax(dim=(1, 2), keepdim=True)
+    s = (spec - lo) / (hi - lo)
+    t_ramp = torch.linspace(0, 1, steps=W).view(1, 1, W).expand(B, H, W)
+    f_ramp = torch.linspace(0, 1, steps=H).view(1, H, 1).expand(B, H, W)
+    img = torch.stack((t_ramp, f_ramp, s), dim=1)                                     # (B,3,H,W)
+    patches = img.unfold(2, pb, pb).unfold(3, pf, pf)                                  # (B,3,H/pb,W/pf,pb,pf)
+    patches = patches.permute(0, 2, 3, 1, 4, 5).reshape(B, (H // pb) * (W // pf), 3 * pb * pf)
+    w = P[pre + "convs.0.weight"].reshape(-1, 3 * pb * pf)
+    return torch.relu(patches @ w.t() + P[pre + "convs.0.bias"])
+
+
+class KnnTape:
+    """Test hook: record every kNN result of a forward pass, or replay recorded ones (teacher forcing).
+    kNN is discontinuous (a 1e-7 distance perturbation flips near-tied neighbours, and in train mode one flip
+    reaches every clip through the BN batch statistics), so end-to-end parity is checked in two halves:
+    indices agree outside near-ties, and outputs agree when the indices are forced to the reference's."""
+
+    def __init__(self, replay: Optional[List[Tensor]] = None):
+        self.replay = list(replay) if replay is not None else None
+        self.recorded: List[Tensor] = []
+        self.pos = 0
+
+
+TAPE: Optional[KnnTape] = None
+
+
+def knn_graph(y: Tensor, k: int, dilation: int = 1) -> Tensor:
+    """y (B,N,C) -> neighbour indices (B,N,k) int64, clip-local, ascending distance, self first.
+    L2-normalise channels, D = |a|^2 - 2ab + |b|^2 in fp32, k*dilation smallest, every dilation-th."""
+    idx = _knn_graph(y, k, dilation)
+    if TAPE is not None:
+        TAPE.recorded.append(idx)
+        if TAPE.replay is not None:
+            idx = TAPE.replay[TAPE.pos].long()
+            TAPE.pos += 1
+    return idx
+
+
+def _knn_graph(y: Tensor, k: int, dilation: int = 1) -> Tensor:
+    with torch.no_grad():
+        yn = y / y.norm(dim=-1, keepdim=True).clamp_min(1e-12)
+        sq = (yn * yn).sum(dim=-1, keepdim=True)
+        dist = sq + (-2.0 * torch.bmm(yn, yn.transpose(1, 2))) + sq.transpose(1, 2)
+        idx = torch.topk(-dist, k * dilation, dim=-1).indices
+        return idx[..., ::dilation].contiguous()
+
+
+def mr_aggregate(y: Tensor, idx: Tensor) -> Tensor:
+    """u[b,n,2c] = y[b,n,c]; u[b,n,2c+1] = max_j (y[b,idx[b,n,j],c] - y[b,n,c])."""
+    B, N, C = y.shape
+    k = idx.shape[-1]
+    nbr = torch.gather(y.unsqueeze(1).expand(B, N, N, C), 2, idx.unsqueeze(-1).expand(B, N, k, C))
+    m = (nbr - y.unsqueeze(2)).max(dim=2).values
+    return torch.stack((y, m), dim=-1).reshape(B, N, 2 * C)
+
+
+def grouped_linear(u: Tensor, P: Dict[str, Tensor], pre: str, groups: int = 4) -> Tensor:
+    """Conv2d(Cin->Cout, 1x1, groups=4) on rows: weight (Cout, Cin/groups, 1, 1)."""
+    w = P[pre + "weight"]
+    cout, cin_g = w.shape[0], w.shape[1]
+    wg = w.reshape(groups, cout // groups, cin_g)
+    ug = u.reshape(*u.shape[:-1], groups, cin_g)
+    out = torch.einsum("...gi,goi->...go", ug, wg).reshape(*u.shape[:-1], cout)
+    if pre + "bias" in P:
+        out = out + P[pre + "bias"]
+    return out
+
+
+def grapher(x: Tensor, P, pre: str, k: int, dilation: int, training: bool, st) -> Tensor:
+    B, N, C = x.shape
+    rows = x.reshape(B * N, C)
+    y = batchnorm_rows(linear_rows(rows, P, pre + "fc1.0."), P, pre + "fc1.1.", training, st).reshape(B, N, C)
+    idx = knn_graph(y.detach(), k, dilation)
+    u = mr_aggregate(y, idx).reshape(B * N, 2 * C)
+    v = torch.relu(batchnorm_rows(grouped_linear(u, P, pre + "graph_conv.gconv.nn.0."),
+                                  P, pre + "graph_conv.gconv.nn.1.", training, st))
+    w = batchnorm_rows(linear_rows(v, P, pre + "fc2.0."), P, pre + "fc2.1.", training, st)
+    return (w + rows).reshape(B, N, C)
+
+
+def ffn(x: Tensor, P, pre: str, training: bool, st) -> Tensor:
+    B, N, C = x.shape
+    rows = x.reshape(B * N, C)
+    hdn = torch.relu(batchnorm_rows(linear_rows(rows, P, pre + "fc1.0."), P, pre + "fc1.1.", training, st))
+    out = batchnorm_rows(linear_rows(hdn, P, pre + "fc2.0."), P, pre + "fc2.1.", training, st)
+    return (out + rows).reshape(B, N, C)
+
+
+def downsample(x: Tensor, P, pre: str, training: bool, st) -> Tensor:
+    """Only the centre column of the 3x3 kernel meets data on a width-1 map."""
+    B, N, C = x.shape
+    w = P[pre + "conv.0.weight"][:, :, :, 1]                       # (C', C, 3)
+    xp = F.pad(x, (0, 0, 1, 1))                                   # zero node either side
+    n_out = (N + 2 - 3) // 2 + 1
+    taps = [xp[:, t: t + 2 * n_out: 2, :] for t in range(3)]      # node 2n'-1+t
+    out = sum(taps[t] @ w[:, :, t].t() for t in range(3)) + P[pre + "conv.0.bias"]
+    cp = out.shape[-1]
+    return batchnorm_rows(out.reshape(B * n_out, cp), P, pre + "conv.1.", training, st).reshape(B, n_out, cp)
+
+
+def encoder_plan(size: str = "t", k: int = 3, blocks: Optional[List[int]] = None,
+                 channels: Optional[List[int]] = None, use_dilation: bool = False,
+                 n_nodes: int = 256) -> List[tuple]:
+    """Backbone entries in order: ('down', cin, cout) or ('block', C, k, dilation).
+    use_dilation=False reproduces the reference as shipped (graph_encoder.py:161: the block counter is never
+    advanced, so dilation is 1 everywhere); True gives the intended min(i//4+1, 128//k), capped so k*d <= N."""
+    b, c = SIZES[size]
+    blocks = blocks or b
+    channels = channels or c
+    plan, i, N = [], 0, n_nodes
+    max_d = max(128 // k, 1)
+    for s, nb in enumerate(blocks):
+        if s > 0:
+            plan.append(("down", channels[s - 1], channels[s]))
+            N = (N + 2 - 3) // 2 + 1
+        for _ in range(nb):
+            d = 1
+            if use_dilation:
+                d = max(1, min(i // 4 + 1, max_d, N // k))
+            plan.append(("block", channels[s], k, d))
+            i += 1
+    return plan
+
+
+def graph_encoder(x: Tensor, P, pre: str, plan: List[tuple], training: bool, st) -> Tensor:
+    """x (B, N, Cin) node-major -> (B, emb_dims)."""
+    B, N, Cin = x.shape
+    rows = linear_rows(x.reshape(B * N, Cin), P, pre + "stem.0.")
+    rows = F.leaky_relu(batchnorm_rows(rows, P, pre + "stem.1.", training, st), 0.2)
+    x = rows.reshape(B, N, -1)
+    for i, entry in enumerate(plan):
+        bp = f"{pre}backbone.{i}."
+        if entry[0] == "down":
+            x = downsample(x, P, bp, training, st)
+        else:
+            _, C, k, d = entry
+            x = grapher(x, P, bp + "0.", k, d, training, st)
+            x = ffn(x, P, bp + "1.", training, st)
+    B, N, C = x.shape
+    out = linear_rows(x.reshape(B * N, C), P, pre + "proj.").reshape(B, N, -1)
+    return out.mean(dim=1)
+
+
+def projector(h: Tensor, P, pre: str) -> Tensor:
+    z = linear_rows(F.elu(linear_rows(h, P, pre + "0.")), P, pre + "2.")
+    return z / z.norm(dim=1, keepdim=True).clamp_min(1e-10)
+
+
+def simclr_forward(x_i: Tensor, x_j: Tensor, P, cfg: dict, plan, training: bool, st=None):
+    """(h_i, h_j, z_i, z_j); the encoder runs once per view so BN statistics are per view."""
+    outs = []
+    for x in (x_i, x_j):
+        nodes = peak_patchify(x, P, "peak_extractor.", cfg)
+        h = graph_encoder(nodes, P, "encoder.", plan, training, st)
+        outs.append((h, projector(h, P, "projector.")))
+    return outs[0][0], outs[1][0], outs[0][1], outs[1][1]
+
+
+def ntxent(z_i: Tensor, z_j: Tensor, tau: float) -> Tensor:
+    """Closed form of simclr/ntxent.py: rows 2p,2p+1 are the two views of pair p; positive of i is i^1."""
+    B, d = z_i.shape
+    z = torch.stack((z_i, z_j), dim=1).reshape(2 * B, d)
+    a = (z @ z.t()) / tau
+    a = a.masked_fill(torch.eye(2 * B, dtype=torch.bool), float("-inf"))
+    pos = a[torch.arange(2 * B), torch.arange(2 * B) ^ 1]
+    return (torch.logsumexp(a, dim=1) - pos).mean()
+
+
+def ntxent_rows(z_all: Tensor, row0: int, nrows: int, tau: float) -> Tensor:
+    """Sum (not mean) of the per-row loss terms for rows [row0, row0+nrows) of the interleaved global z (M,d).
+    A rank that owns those rows contributes this / M to the global mean loss."""
+    M = z_all.shape[0]
+    a = (z_all[row0:row0 + nrows] @ z_all.t()) / tau
+    r = torch.arange(row0, row0 + nrows)
+    a = a.masked_fill(F.one_hot(r, M).bool(), float("-inf"))
+    pos = a[torch.arange(nrows), r ^ 1]
+    return (torch.logsumexp(a, dim=1) - pos).sum()
+
+
+# ------------------------------------------------------------------ training step (train.py:53-75)
+class AdamState:
+    def __init__(self, params: Dict[str, Tensor], lr: float, betas=(0.9, 0.999), eps: float = 1e-8):
+        self.lr, self.b1, self.b2, self.eps, self.t = lr, betas[0], betas[1], eps, 0
+        self.m = {k: torch.zeros_like(v) for k, v in params.items()}
+        self.v = {k: torch.zeros_like(v) for k, v in params.items()}
+
+
+def clip_and_adam(P: Dict[str, Tensor], grads: Dict[str, Tensor], opt: AdamState, max_norm: float = 1.0) -> float:
+    """clip_grad_norm_(max_norm) then torch.optim.Adam default step; returns the pre-clip global norm."""
+    total = math.sqrt(sum(float(g.double().pow(2).sum()) for g in grads.values()))
+    coef = min(1.0, max_norm / (total + 1e-6))
+    opt.t += 1
+    bc1 = 1 - opt.b1 ** opt.t
+    bc2 = 1 - opt.b2 ** opt.t
+    with torch.no_grad():
+        for k, g in grads.items():
+            g = g * coef
+            opt.m[k].mul_(opt.b1).add_(g, alpha=1 - opt.b1)
+            opt.v[k].mul_(opt.b2).addcmul_(g, g, value=1 - opt.b2)
+            denom = (opt.v[k].sqrt() / math.sqrt(bc2)).add_(opt.eps)
+            P[k].addcdiv_(opt.m[k], denom, value=-opt.lr / bc1)
+    return total
+
+
+def trainable_keys(P: Dict[str, Tensor]) -> List[str]:
+    return [k for k, v in P.items() if v.is_floating_point() and "running_" not in k and "relative_pos" not in k]
+
+
+def train_step(P: Dict[str, Tensor], x_i: Tensor, x_j: Tensor, cfg: dict, plan, opt: AdamState) -> Tuple[float, float]:
+    """One contrastive step in place on P (parameters and BN running stats); returns (loss, grad-norm)."""
+    keys = trainable_keys(P)
+    for k in keys:
+        P[k].requires_grad_(True)
+        P[k].grad = None
+    st = BNState()
+    _, _, z_i, z_j = simclr_forward(x_i, x_j, P, cfg, plan, True, st)
+    loss = ntxent(z_i, z_j, cfg["tau"])
+    loss.backward()
+    grads = {k: P[k].grad for k in keys if P[k].grad is not None}
+    for k in keys:
+        P[k].requires_grad_(False)
+    gn = clip_and_adam(P, grads, opt)
+    for k, v in st.updates.items():
+        P[k] = v
+    for k in keys:
+        P[k].grad = None
+    return float(loss), gn

@@ -1,0 +1,320 @@
+#!/usr/bin/env python3
+"""Generate golden vectors by running the REFERENCE's live modules (CPU, fp32) in this container.
+
+Run from the repo root, in the build container only (the reference never travels to the GPU box):
+
+    python tests/golden/make_golden.py
+
+It imports /root/reference with three stub modules in sys.modules for third-party imports that
+are unused on the hot path (timm.models.layers.DropPath / to_2tuple / trunc_normal_,
+torchmetrics.functional.pairwise_cosine_similarity, torchvision), feeds every module synthesized
+weights (synth.py) and seeded inputs, and writes small .npz fixtures next to this file.
+Only data (inputs, outputs, checksums) is written; no reference source is copied.
+"""
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+from synth import GRAFP_CFG, synth_clips, synth_randn, synth_state  # noqa: E402
+
+REF = os.environ.get("NSID_REFERENCE", "/root/reference")
+
+
+def _install_stubs():
+    def stub(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+        return m
+
+    class DropPath(nn.Module):  # timm 0.9.16 semantics; never instantiated with p>0 at default settings
+        def __init__(self, drop_prob=0.0, scale_by_keep=True):
+            super().__init__()
+            self.drop_prob, self.scale_by_keep = drop_prob, scale_by_keep
+
+        def forward(self, x):
+            if self.drop_prob == 0.0 or not self.training:
+                return x
+            keep = 1.0 - self.drop_prob
+            mask = x.new_empty((x.shape[0],) + (1,) * (x.ndim - 1)).bernoulli_(keep)
+            if keep > 0.0 and self.scale_by_keep:
+                mask.div_(keep)
+            return x * mask
+
+    stub("timm")
+    stub("timm.models")
+    stub("timm.models.layers", DropPath=DropPath, to_2tuple=lambda x: (x, x), trunc_normal_=None)
+    stub("torchmetrics")
+    stub("torchmetrics.functional", pairwise_cosine_similarity=None)
+    stub("torchvision")
+
+
+_install_stubs()
+sys.path.insert(0, REF)
+from encoder.gcn_lib.torch_edge import DenseDilatedKnnGraph  # noqa: E402
+from encoder.gcn_lib.torch_vertex import Grapher, MRConv2d  # noqa: E402
+from encoder.graph_encoder import FFN, Downsample, GraphEncoder  # noqa: E402
+from peak_extractor import GPUPeakExtractorv2  # noqa: E402
+from simclr.ntxent import ntxent_loss  # noqa: E402
+from simclr.simclr import SimCLR  # noqa: E402
+
+torch.set_num_threads(8)
+CFG = dict(GRAFP_CFG)
+
+
+def save(name, **arrays):
+    out = {}
+    for k, v in arrays.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        out[k] = v
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"  {name}.npz  {os.path.getsize(path) / 1024:.0f} KB")
+
+
+def load_synth(module, prefix=""):
+    module.load_state_dict(synth_state(module.state_dict(), prefix))
+    return module
+
+
+def bn_stats(module):
+    return {k: v.clone() for k, v in module.state_dict().items()
+            if k.endswith(("running_mean", "running_var", "num_batches_tracked"))}
+
+
+# ---------------------------------------------------------------- kNN graph
+def gold_knn():
+    print("knn")
+    cases = [("c64n256", 2, 64, 256, [(3, 1), (5, 1), (4, 2), (18, 3)]),
+             ("c128n128", 2, 128, 128, [(3, 1), (18, 2)]),
+             ("c512n32", 3, 512, 32, [(3, 1), (5, 2), (18, 1)])]
+    for tag, B, C, N, kds in cases:
+        x = synth_randn("knn_" + tag, B, C, N, 1)
+        out = {"x": x}
+        # the reference's own distance on its own normalised features, for the margin rule
+        xn = torch.nn.functional.normalize(x, p=2.0, dim=1).transpose(2, 1).squeeze(-1)
+        dist = (xn * xn).sum(-1, keepdim=True) + (-2 * xn @ xn.transpose(2, 1)) \
+            + (xn * xn).sum(-1, keepdim=True).transpose(2, 1)
+        dsort = dist.sort(dim=-1).values
+        for k, d in kds:
+            g = DenseDilatedKnnGraph(k, d, False, 0.0)
+            ei = g(x)
+            assert ei.shape == (2, B, N, k)
+            kd = k * d
+            top = dsort[..., : min(kd + 1, N)]
+            gaps = top[..., 1:] - top[..., :-1]
+            out[f"idx_k{k}_d{d}"] = ei[0].to(torch.int32)
+            out[f"center_k{k}_d{d}"] = ei[1].to(torch.int32)
+            out[f"mingap_k{k}_d{d}"] = gaps.min(dim=-1).values      # strict-order margin over ranks 0..kd
+            out[f"setgap_k{k}_d{d}"] = gaps[..., -1] if kd < N else torch.full((B, N), 1.0)
+        save("knn_" + tag, **out)
+
+
+# ---------------------------------------------------------------- MRConv2d (gather + max-relative + grouped conv)
+def gold_mrconv():
+    print("mrconv")
+    B, C, N, k = 2, 64, 256, 3
+    x = synth_randn("mr_x", B, C, N, 1).requires_grad_(True)
+    ei = DenseDilatedKnnGraph(k, 1, False, 0.0)(x.detach())
+    m = load_synth(MRConv2d(C, 2 * C, "relu", "batch", True), "mr.")
+    m.train()
+    captured = {}
+    m.nn.register_forward_pre_hook(lambda mod, inp: captured.__setitem__("u", inp[0].detach().clone()))
+    y = m(x, ei)
+    gout = synth_randn("mr_gout", *y.shape)
+    y.backward(gout)
+    save("mrconv_c64n256", x=x, idx=ei[0].to(torch.int32), u=captured["u"], y=y, gout=gout, dx=x.grad,
+         dweight=m.nn[0].weight.grad, dbias=m.nn[0].bias.grad,
+         dgamma=m.nn[1].weight.grad, dbeta=m.nn[1].bias.grad,
+         **{"post." + k_: v for k_, v in bn_stats(m).items()})
+    # aggregate-only backward: gradient of sum(u * gu) w.r.t. x, exercising the arg-max routing
+    x2 = x.detach().clone().requires_grad_(True)
+    m2 = MRConv2d(C, 2 * C, "relu", "batch", True)
+    cap2 = {}
+    m2.nn.register_forward_pre_hook(lambda mod, inp: cap2.__setitem__("u", inp[0]))
+    m2(x2, ei)
+    gu = synth_randn("mr_gu", B, 2 * C, N, 1)
+    (cap2["u"] * gu).sum().backward()
+    save("mragg_c64n256", x=x2, idx=ei[0].to(torch.int32), u=cap2["u"], gu=gu, dx=x2.grad)
+
+
+# ---------------------------------------------------------------- Grapher + FFN block
+def gold_block():
+    print("block")
+    cases = [("c64n256_k3d1", 2, 64, 256, 3, 1), ("c64n256_k4d2", 2, 64, 256, 4, 2),
+             ("c128n128_k5d1", 2, 128, 128, 5, 1), ("c512n32_k3d1", 4, 512, 32, 3, 1),
+             ("c64n256_k18d3", 2, 64, 256, 18, 3)]
+    for tag, B, C, N, k, d in cases:
+        blk = nn.Sequential(
+            Grapher(C, k, d, "mr", "relu", "batch", True, False, 0.2, 1, n=N, drop_path=0.0, relative_pos=True),
+            FFN(in_features=C, hidden_features=4 * C, out_features=C, act="relu", drop_path=0.0))
+        load_synth(blk, "blk.")
+        x = synth_randn("blk_x_" + tag, B, C, N, 1)
+        blk.eval()
+        with torch.no_grad():
+            y_eval = blk(x)
+        blk.train()
+        xg = x.clone().requires_grad_(True)
+        y = blk(xg)
+        gout = synth_randn("blk_g_" + tag, *y.shape)
+        y.backward(gout)
+        grads = {}
+        for n_, p in blk.named_parameters():
+            if p.grad is None:
+                continue
+            if p.grad.numel() <= 70000:
+                grads["grad." + n_] = p.grad
+            else:   # big weight grads: checksum + strided sample keeps the fixture small
+                g64 = p.grad.double()
+                grads["gradchk." + n_] = np.array([float(g64.sum()), float(g64.norm())])
+                grads["gradsample." + n_] = p.grad.flatten()[::997].clone()
+        save("block_" + tag, x=x, y_eval=y_eval, y_train=y, gout=gout, dx=xg.grad, **grads,
+             **{"post." + k_: v for k_, v in bn_stats(blk).items()})
+
+
+# ---------------------------------------------------------------- Downsample
+def gold_downsample():
+    print("downsample")
+    B, C, N = 2, 64, 256
+    ds = load_synth(Downsample(C, 2 * C), "ds.")
+    x = synth_randn("ds_x", B, C, N, 1)
+    ds.eval()
+    with torch.no_grad():
+        y_eval = ds(x)
+    ds.train()
+    xg = x.clone().requires_grad_(True)
+    y = ds(xg)
+    gout = synth_randn("ds_g", *y.shape)
+    y.backward(gout)
+    save("downsample_c64n256", x=x, y_eval=y_eval, y_train=y, gout=gout, dx=xg.grad,
+         dweight=ds.conv[0].weight.grad, dbias=ds.conv[0].bias.grad,
+         dgamma=ds.conv[1].weight.grad, dbeta=ds.conv[1].bias.grad,
+         **{"post." + k_: v for k_, v in bn_stats(ds).items()})
+
+
+# ---------------------------------------------------------------- peak extractor
+def gold_peak():
+    print("peak")
+    pe = load_synth(GPUPeakExtractorv2(CFG), "peak_extractor.")
+    x, _ = synth_clips(8)
+    y = pe(x)
+    gout = synth_randn("peak_g", *y.shape)
+    y.backward(gout)
+    save("peak_b8", x=x, y=y, gout=gout, dweight=pe.convs[0].weight.grad, dbias=pe.convs[0].bias.grad)
+
+
+# ---------------------------------------------------------------- NT-Xent
+def gold_ntxent():
+    print("ntxent")
+    for B in (2, 8, 256):
+        zi = torch.nn.functional.normalize(synth_randn(f"ntx_i{B}", B, 128), dim=1).requires_grad_(True)
+        zj = torch.nn.functional.normalize(
+            zi.detach() + 0.5 * synth_randn(f"ntx_j{B}", B, 128), dim=1).requires_grad_(True)
+        loss = ntxent_loss(zi, zj, CFG)
+        loss.backward()
+        save(f"ntxent_b{B}", z_i=zi, z_j=zj, loss=loss.detach().reshape(1), dz_i=zi.grad, dz_j=zj.grad,
+             tau=np.float32(CFG["tau"]))
+
+
+# ---------------------------------------------------------------- end to end
+def _checksums(named):
+    return {n: [float(t.double().sum()), float(t.double().norm())] for n, t in named}
+
+
+class KnnTape:
+    """Records, for every DenseDilatedKnnGraph call of the reference model, the neighbour indices it produced
+    and the oracle-side margin (k-th vs (k+1)-th distance) that decides whether a differing SET is a near-tie."""
+
+    def __init__(self, model):
+        self.idx, self.gap = [], []
+        for m in model.modules():
+            if isinstance(m, DenseDilatedKnnGraph):
+                m.register_forward_hook(self._hook)
+
+    def _hook(self, mod, inp, out):
+        x = inp[0].detach()
+        kd = mod.k * mod.dilation
+        xn = torch.nn.functional.normalize(x, p=2.0, dim=1).transpose(2, 1).squeeze(-1)
+        sq = (xn * xn).sum(-1, keepdim=True)
+        dist = sq + (-2 * xn @ xn.transpose(2, 1)) + sq.transpose(2, 1)
+        top = dist.sort(dim=-1).values[..., : min(kd + 1, dist.shape[-1])]
+        gaps = top[..., 1:] - top[..., :-1]
+        self.idx.append(out[0].to(torch.int16).clone())
+        self.gap.append((gaps.min(-1).values if mod.dilation > 1 else gaps[..., -1]).clone())
+
+    def take(self, tag):
+        out = {}
+        for c, (i, g) in enumerate(zip(self.idx, self.gap)):
+            out[f"knn.{tag}.{c}"] = i
+            out[f"gap.{tag}.{c}"] = g
+        self.idx, self.gap = [], []
+        return out
+
+
+def gold_e2e():
+    print("e2e")
+    B = 8
+    x_i, x_j = synth_clips(B)
+    for k in (3, 5):
+        torch.manual_seed(1234)
+        model = SimCLR(CFG, GraphEncoder(CFG, in_channels=CFG["n_filters"], k=k, size="t"))
+        load_synth(model)
+        tape = KnnTape(model)
+        model.eval()
+        with torch.no_grad():
+            h_i, h_j, z_i, z_j = model(x_i, x_j)
+            loss_eval = ntxent_loss(z_i, z_j, CFG)
+        ev = dict(h_i_eval=h_i, h_j_eval=h_j, z_i_eval=z_i, z_j_eval=z_j, loss_eval=loss_eval.reshape(1))
+        ev.update(tape.take("eval"))
+
+        model.train()
+        opt = torch.optim.Adam(model.parameters(), lr=CFG["lr"])
+        losses, gnorms = [], []
+        first = {}
+        for step in range(3):       # train.py:53-75 step semantics on a fixed batch
+            opt.zero_grad()
+            h_i, h_j, z_i, z_j = model(x_i, x_j)
+            loss = ntxent_loss(z_i, z_j, CFG)
+            loss.backward()
+            first.update(tape.take(f"s{step}"))
+            if step == 0:
+                first.update(h_i_train=h_i, h_j_train=h_j, z_i_train=z_i, z_j_train=z_j)
+                sums = _checksums((n, p.grad) for n, p in model.named_parameters() if p.grad is not None)
+                full = {"grad." + n: p.grad.clone() for n, p in model.named_parameters() if n in (
+                    "peak_extractor.convs.0.weight", "encoder.stem.0.weight", "encoder.backbone.0.0.fc1.0.weight",
+                    "encoder.backbone.0.0.graph_conv.gconv.nn.0.weight", "encoder.backbone.2.conv.0.bias",
+                    "encoder.backbone.14.1.fc2.1.weight", "encoder.proj.bias", "projector.2.bias")}
+                stats1 = _checksums((n, t.float()) for n, t in model.state_dict().items()
+                                    if n.endswith(("running_mean", "running_var")))
+            gn = torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=1.0)
+            opt.step()
+            losses.append(float(loss.detach()))
+            gnorms.append(float(gn))
+        save(f"e2e_b8_k{k}", x_i=x_i, x_j=x_j, **ev, **first, **full,
+             losses=np.array(losses, np.float64), gnorms=np.array(gnorms, np.float64))
+        with open(os.path.join(HERE, f"e2e_b8_k{k}_checksums.json"), "w") as f:
+            json.dump({"grad": sums, "bn_after_step1": stats1}, f, indent=0)
+        print("   losses", losses, "gnorm", gnorms)
+
+
+def gold_shapes():
+    """state_dict key names + shapes of SimCLR(GraphEncoder 't'): data for the state_dict-compat tests."""
+    print("shapes")
+    m = SimCLR(CFG, GraphEncoder(CFG, in_channels=CFG["n_filters"], k=3, size="t"))
+    with open(os.path.join(HERE, "state_shapes.json"), "w") as f:
+        json.dump({k: list(v.shape) for k, v in m.state_dict().items()}, f)
+
+
+if __name__ == "__main__":
+    torch.manual_seed(0)
+    only = sys.argv[1:] or ["shapes", "knn", "mrconv", "block", "downsample", "peak", "ntxent", "e2e"]
+    for name in only:
+        globals()["gold_" + name]()

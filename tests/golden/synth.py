@@ -1,0 +1,66 @@
+"""Deterministic per-key weight / input synthesis shared by the golden generator and the tests.
+
+The reference's full weights are 74 MB, so nothing but inputs, outputs and checksums is committed:
+both sides (the imported reference in `make_golden.py`, and the oracle / HIP modules in `tests/`)
+fill a `state_dict` from the same rule, keyed on the parameter NAME, so any module exposing the
+reference's key names and shapes gets bit-identical weights.
+"""
+import zlib
+
+import numpy as np
+import torch
+
+
+def _gen(key: str) -> torch.Generator:
+    g = torch.Generator(device="cpu")
+    g.manual_seed(zlib.crc32(key.encode("utf-8")))
+    return g
+
+
+def synth_tensor(key: str, like: torch.Tensor) -> torch.Tensor:
+    """Value for state_dict entry `key` with the shape/dtype of `like`."""
+    shape = tuple(like.shape)
+    g = _gen(key)
+    if key.endswith("num_batches_tracked"):
+        return torch.zeros(shape, dtype=torch.int64)
+    if "relative_pos" in key:
+        # dead buffer in the reference (torch_vertex.py:189 passes relative_pos=None); left as is
+        return like.detach().clone()
+    if key.endswith("running_var"):
+        return 0.5 + torch.rand(shape, generator=g)
+    if key.endswith("running_mean"):
+        return 0.1 * torch.randn(shape, generator=g)
+    if like.dim() <= 1:
+        if key.endswith("weight"):          # BatchNorm gamma
+            return 1.0 + 0.1 * torch.randn(shape, generator=g)
+        return 0.1 * torch.randn(shape, generator=g)   # conv / linear / BN bias
+    fan_in = int(np.prod(shape[1:]))
+    return torch.randn(shape, generator=g) * fan_in ** -0.5
+
+
+def synth_state(state: dict, prefix: str = "") -> dict:
+    """New state dict with every entry of `state` replaced by its synthesized value.
+    `prefix` is prepended to the key before hashing, so a sub-module tested stand-alone
+    (e.g. one Grapher) can be given the same numbers it would have inside the full model."""
+    return {k: synth_tensor(prefix + k, v) for k, v in state.items()}
+
+
+def synth_randn(tag: str, *shape) -> torch.Tensor:
+    return torch.randn(*shape, generator=_gen("input:" + tag))
+
+
+def synth_clips(batch: int, n_mels: int = 64, n_frames: int = 128):
+    """Log-mel-like synthetic clip pair: x_i = randn*20-40, x_j = x_i + 3*randn."""
+    gi = torch.Generator().manual_seed(0)
+    gj = torch.Generator().manual_seed(1)
+    x_i = torch.randn(batch, n_mels, n_frames, generator=gi) * 20.0 - 40.0
+    x_j = x_i + 3.0 * torch.randn(batch, n_mels, n_frames, generator=gj)
+    return x_i, x_j
+
+
+GRAFP_CFG = {
+    # hot-path keys of config/grafp.yaml (:14-68); the rest of the file is data/augmentation config
+    "arch": "grafp", "n_mels": 64, "n_frames": 128, "patch_bins": 4, "patch_frames": 8,
+    "n_filters": 8, "bsz_train": 256, "tau": 0.05, "lr": 8.0e-5, "min_lr": 7.0e-7, "T_max": 400,
+    "d": 128, "h": 1024, "u": 32, "dim": 2048,
+}
