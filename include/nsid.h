@@ -1,0 +1,158 @@
+/* nsid.h — C ABI of libnsid_hip.so: the MI355X (gfx950) kernels behind the GNN contrastive-fingerprint path.
+ *
+ * The reference (chymaera96/NeuralSampleID) has no FFI: its boundary is Python nn.Module.forward.  Each entry
+ * point below replaces the chain of stock ATen ops that one reference function issues (file:line cited per
+ * entry, paths relative to the reference repo); INTEGRATION.md shows the ctypes stub a maintainer would add.
+ *
+ * Conventions
+ *  - every pointer is DEVICE memory, fp32 unless typed otherwise, 16-byte aligned, row-major;
+ *  - features are node-major rows: a (B, C, N, 1) reference tensor is the matrix X[B*N][C] (row = b*N + n);
+ *  - `stream` is a hipStream_t; calls only enqueue work: no allocation, no synchronisation, no retained
+ *    pointers, safe under hipGraph stream capture;
+ *  - return value: NSID_OK, or a negative NSID_E* code (the Python host raises RuntimeError on it);
+ *  - buffers documented "+=" are accumulated into (zero them first for a fresh gradient).
+ */
+#ifndef NSID_H
+#define NSID_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NSID_OK 0
+#define NSID_EINVAL (-1)   /* unsupported shape / misaligned pointer / bad argument */
+#define NSID_ELAUNCH (-2)  /* the HIP runtime refused the launch */
+
+#define NSID_ACT_NONE 0
+#define NSID_ACT_RELU 1
+#define NSID_ACT_LEAKY 2 /* LeakyReLU(0.2), encoder/graph_encoder.py:153 */
+#define NSID_ACT_ELU 3   /* nn.ELU, simclr/simclr.py:26 */
+
+#define NSID_ROW_TILE 128 /* rows per BatchNorm partial-statistics tile (all kernels agree on it) */
+
+int nsid_version(void);
+/* number of NSID_ROW_TILE row tiles of an M-row matrix: size of the partial-statistics buffers */
+int nsid_row_tiles(int M);
+
+/* ---- 1x1 convolution / Linear as a row GEMM on MFMA (fp32 in, fp32 accumulate) -------------------------
+ * Replaces nn.Conv2d(…,1) / nn.Linear forward+backward at encoder/gcn_lib/torch_vertex.py:152-162,
+ * encoder/graph_encoder.py:74-77,151,179, encoder/gcn_lib/torch_nn.py:56 (groups=4), simclr/simclr.py:25-28.
+ *
+ * forward:  out[m, g*Nout+n] = act_out( bias[g*Nout+n] + sum_k f(x[m, g*K+k]) * w[g*Nout+n, k] )
+ *           f(v) = act_in(in_scale[g*K+k]*v + in_shift[g*K+k])  — the producer's BatchNorm(+activation) applied
+ *           on load, so normalised activations are never materialised (in_scale == NULL: f = identity).
+ *           stat (optional): [2][nsid_row_tiles(M)][groups*Nout] per-row-tile column sums / sums of squares of the
+ *           pre-activation output, the input of nsid_bn_finalize (training-mode BatchNorm statistics).
+ *           ksplit > 1 splits K over workgroups and accumulates atomically: `out` must be zeroed, stat == NULL,
+ *           act_out == NSID_ACT_NONE. */
+int nsid_linear_fwd(const float* x, int ldx, const float* w, const float* bias, float* out, int ldo, int M, int Nout,
+                    int K, int groups, const float* in_scale, const float* in_shift, int act_in, int act_out,
+                    float* stat, int ksplit, void* stream);
+/* backward-data: din[m, g*K+k] = addend[m, g*K+k] + sum_n dout[m, g*Nout+n] * w[g*Nout+n, k]   (addend optional) */
+int nsid_linear_bwd_data(const float* dout, int ldd, const float* w, const float* addend, int ldadd, float* din,
+                         int ldi, int M, int Nout, int K, int groups, void* stream);
+/* backward-weight: dw[g*Nout+n, k] += sum_m dout[m, g*Nout+n] * f(x[m, g*K+k])   (f as in forward; atomic) */
+int nsid_linear_bwd_weight(const float* dout, int ldd, const float* x, int ldx, float* dw, int M, int Nout, int K,
+                           int groups, const float* in_scale, const float* in_shift, int act_in, void* stream);
+/* out[c] += sum_m x[m, c]  (bias gradients) */
+int nsid_colsum_acc(const float* x, int ldx, int M, int C, float* out, void* stream);
+
+/* ---- BatchNorm2d, training mode, split around the GEMMs ------------------------------------------------
+ * Replaces nn.BatchNorm2d at encoder/graph_encoder.py:45,75,77,152, torch_vertex.py:154,161, torch_nn.py:32.
+ * finalize: reduces the GEMM's partial statistics (fp64), writes scale = gamma*invstd, shift = beta-mean*scale,
+ * mean, invstd, and updates running_mean / running_var (unbiased) / num_batches_tracked (momentum 0.1). */
+int nsid_bn_finalize(const float* stat, int tiles, int C, int M, const float* gamma, const float* beta,
+                     float* running_mean, float* running_var, int64_t* num_batches_tracked, float momentum,
+                     float eps, float* scale, float* shift, float* mean, float* invstd, void* stream);
+/* eval mode: scale/shift from the running statistics */
+int nsid_bn_eval_affine(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+                        float eps, int C, float* scale, float* shift, void* stream);
+/* out = act(scale*r + shift) + residual   (residual optional; materialises the residual stream) */
+int nsid_bn_apply(const float* r, const float* scale, const float* shift, int act, const float* residual,
+                  float* out, int M, int C, void* stream);
+/* backward, step 1: g = dout * act'(scale*r+shift); partial[2][tiles][C] = per-tile sums of g and g*xhat */
+int nsid_bn_bwd_reduce(const float* dout, const float* r, int M, int C, const float* scale, const float* shift,
+                       const float* mean, const float* invstd, int act, float* partial, void* stream);
+/* step 2: dgamma += sum g*xhat; dbeta += sum g; coef[2][C] = {sum g / M, sum g*xhat / M} */
+int nsid_bn_bwd_finalize(const float* partial, int tiles, int C, int M, float* dgamma, float* dbeta, float* coef,
+                         void* stream);
+/* step 3: dr = scale * (g - coef0 - xhat*coef1)   (dr may alias dout) */
+int nsid_bn_bwd_apply(const float* dout, const float* r, int M, int C, const float* scale, const float* shift,
+                      const float* mean, const float* invstd, int act, const float* coef, float* dr, void* stream);
+
+/* ---- dilated kNN graph ---------------------------------------------------------------------------------
+ * Replaces DenseDilatedKnnGraph.forward = F.normalize + pairwise_distance + topk + [::dilation]
+ * (encoder/gcn_lib/torch_edge.py:270-284, 70-103, 7-18, 245-255).  y = scale*r+shift (scale NULL: y = r) is
+ * L2-normalised over channels, D = |a|^2 - 2ab + |b|^2 is formed per clip in LDS (never written to HBM),
+ * the k*dilation nearest are selected in ascending distance (ties: lower index first) and every dilation-th is
+ * kept.  idx[(b*N+n)*k + j] is clip-local (0..N-1), int32; the reference's edge_index[1] (centre) is implicit.
+ * Limits: N % 16 == 0, N <= 256, C % 4 == 0, k*dilation <= N. */
+int nsid_knn_graph(const float* r, int ldr, const float* scale, const float* shift, int B, int N, int C, int k,
+                   int dilation, int32_t* idx, void* stream);
+
+/* ---- max-relative aggregation --------------------------------------------------------------------------
+ * Replaces MRConv2d.forward up to the grouped conv: 2x batched_index_select, max_k(x_j - x_i), interleave
+ * (encoder/gcn_lib/torch_vertex.py:21-32, torch_nn.py:79-98).
+ * u[row, 2c] = y[row, c]; u[row, 2c+1] = max_j y[b*N+idx[row,j], c] - y[row, c];  argmax[row, c] = winning j
+ * (first maximum, as torch.max). backward routes du to the winning neighbour and the centre. k <= 255. */
+int nsid_mr_aggregate_fwd(const float* r, int ldr, const float* scale, const float* shift, const int32_t* idx, int B,
+                          int N, int C, int k, float* u, uint8_t* argmax, void* stream);
+int nsid_mr_aggregate_bwd(const float* du, const int32_t* idx, const uint8_t* argmax, int B, int N, int C, int k,
+                          float* dy, void* stream);
+
+/* ---- Downsample: Conv2d 3x3 stride 2 pad 1 on a width-1 map (encoder/graph_encoder.py:44) ---------------
+ * Only kernel column 1 meets data, so it is a 3-tap stride-2 conv along N = one GEMM over gathered rows:
+ * col[b*No+n', t*C+c] = x[b*N + 2n'-1+t, c] (0 outside), wp[o, t*C+c] = w[o, c, t, 1]. */
+int nsid_im2col3_fwd(const float* x, int B, int N, int C, float* col, void* stream);
+int nsid_im2col3_bwd(const float* dcol, int B, int N, int C, float* dx, void* stream);
+int nsid_pack_ds_weight(const float* w, int Cout, int Cin, float* wp, void* stream);
+int nsid_unpack_ds_wgrad(const float* dwp, int Cout, int Cin, float* dw /* += */, void* stream);
+
+/* ---- GPUPeakExtractorv2 (peak_extractor.py:45-70) ------------------------------------------------------
+ * per-clip min-max normalise, [time ramp, freq ramp, spec] -> Conv2d(3->F, kernel=stride=(pb,pf)) + ReLU.
+ * out is node-major [B*(H/pb)*(W/pf)][ldo] (columns >= F untouched); minmax[B][2] is kept for backward.
+ * backward gives the conv weight/bias gradients only (the spectrogram is data). */
+int nsid_peak_patchify_fwd(const float* spec, const float* w, const float* bias, int B, int H, int W, int pb, int pf,
+                           int F, float* out, int ldo, float* minmax, void* stream);
+int nsid_peak_patchify_bwd(const float* spec, const float* minmax, const float* out, const float* dout, int ldo,
+                           int B, int H, int W, int pb, int pf, int F, float* dw /* += */, float* dbias /* += */,
+                           void* stream);
+
+/* ---- node mean (encoder/graph_encoder.py:211), ELU', L2 normalise (simclr/simclr.py:38,44) --------------*/
+int nsid_node_mean_fwd(const float* x, int B, int N, int C, float* out, void* stream);
+int nsid_node_mean_bwd(const float* dout, int B, int N, int C, float* dx, void* stream);
+int nsid_elu_bwd(const float* dout, const float* out, long n, float* din, void* stream);
+int nsid_l2norm_fwd(const float* p, int B, int d, float eps, float* z, float* norm, void* stream);
+int nsid_l2norm_bwd(const float* dz, const float* z, const float* norm, int B, int d, float eps, float* dp,
+                    void* stream);
+
+/* ---- NT-Xent (simclr/ntxent.py:5-30) -------------------------------------------------------------------
+ * Row i = 2p+v of the interleaved (2*Bg, d) matrix is view v of pair p: v ? z_j[p] : z_i[p]; positive = i^1.
+ * a = z z^T / tau with the diagonal masked; loss = (1/M) sum_i [logsumexp_j a_ij - a_i,i^1], M = 2*Bg.
+ * The similarity matrix lives in MFMA accumulators only.  A rank owning pairs [p0, p0+np) gets
+ * loss_out[0] = sum over its 2*np rows / M, and dz_i/dz_j (np x d) = d(global mean loss)/dz for its pairs.
+ * ws: float workspace of nsid_ntxent_ws_floats(Bg) elements. */
+size_t nsid_ntxent_ws_floats(int Bg);
+int nsid_ntxent_fwd_bwd(const float* z_i, const float* z_j, int Bg, int d, float tau, int p0, int np, float* ws,
+                        float* loss_out, float* dz_i, float* dz_j, void* stream);
+
+/* ---- optimiser (train.py:73-75: clip_grad_norm_(1.0) + Adam) -------------------------------------------
+ * sumsq: partial[blocks] sums of squares of g (blocks = nsid_sumsq_blocks(n)).
+ * adam:  norm = sqrt(sum partial); coef = min(1, max_norm/(norm+1e-6)); torch.optim.Adam update with g*coef.
+ * hyper (device): [0]=lr, [1]=beta1, [2]=beta2, [3]=eps, [4]=max_norm (<=0: no clipping);
+ * step (device int64) is incremented by the kernel; gnorm_out[0] = pre-clip norm. */
+int nsid_sumsq_blocks(long n);
+int nsid_sumsq_partial(const float* g, long n, float* partial, void* stream);
+int nsid_adam_step(float* p, const float* g, float* m, float* v, long n, const float* hyper, int64_t* step,
+                   const float* partial, int nblocks, float* gnorm_out, void* stream);
+
+/* ---- layout plumbing at the module boundary: (B, C, N) <-> node-major rows ------------------------------*/
+int nsid_bcn_to_rows(const float* x, int B, int C, int N, float* rows, int ld, void* stream);
+int nsid_rows_to_bcn(const float* rows, int ld, int B, int C, int N, float* x, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NSID_H */

@@ -1,0 +1,77 @@
+"""ctypes binding of libnsid_hip.so (C ABI: include/nsid.h).
+
+The product path has no CPU fallback: if the library is missing this module raises, and every op raises
+RuntimeError on a non-zero return code."""
+import ctypes
+import os
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "libnsid_hip.so")
+
+# signature letters: p = device pointer, i = int, l = long, f = float, s = stream (void*)
+SIGNATURES = {
+    "nsid_linear_fwd": "pipppiiiiippiipis",
+    "nsid_linear_bwd_data": "pippipiiiiis",
+    "nsid_linear_bwd_weight": "pipipiiiippis",
+    "nsid_colsum_acc": "piiips",
+    "nsid_bn_finalize": "piiipppppffpppps",
+    "nsid_bn_eval_affine": "ppppfipps",
+    "nsid_bn_apply": "pppippiis",
+    "nsid_bn_bwd_reduce": "ppiippppips",
+    "nsid_bn_bwd_finalize": "piiippps",
+    "nsid_bn_bwd_apply": "ppiippppipps",
+    "nsid_knn_graph": "pippiiiiips",
+    "nsid_mr_aggregate_fwd": "pipppiiiipps",
+    "nsid_mr_aggregate_bwd": "pppiiiips",
+    "nsid_im2col3_fwd": "piiips",
+    "nsid_im2col3_bwd": "piiips",
+    "nsid_pack_ds_weight": "piips",
+    "nsid_unpack_ds_wgrad": "piips",
+    "nsid_peak_patchify_fwd": "pppiiiiiipips",
+    "nsid_peak_patchify_bwd": "ppppiiiiiiipps",
+    "nsid_node_mean_fwd": "piiips",
+    "nsid_node_mean_bwd": "piiips",
+    "nsid_elu_bwd": "pplps",
+    "nsid_l2norm_fwd": "piifpps",
+    "nsid_l2norm_bwd": "pppiifps",
+    "nsid_ntxent_fwd_bwd": "ppiifiipppps",
+    "nsid_sumsq_partial": "plps",
+    "nsid_adam_step": "pppplpppips",
+    "nsid_bcn_to_rows": "piiipis",
+    "nsid_rows_to_bcn": "piiiips",
+}
+
+_CT = {"p": ctypes.c_void_p, "i": ctypes.c_int, "l": ctypes.c_long, "f": ctypes.c_float, "s": ctypes.c_void_p}
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -m neuralsampleid_amd.build` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback for the product path.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, sig in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.argtypes = [_CT[c] for c in sig]
+        fn.restype = ctypes.c_int
+    lib.nsid_version.restype = ctypes.c_int
+    lib.nsid_row_tiles.argtypes = [ctypes.c_int]
+    lib.nsid_row_tiles.restype = ctypes.c_int
+    lib.nsid_sumsq_blocks.argtypes = [ctypes.c_long]
+    lib.nsid_sumsq_blocks.restype = ctypes.c_int
+    lib.nsid_ntxent_ws_floats.argtypes = [ctypes.c_int]
+    lib.nsid_ntxent_ws_floats.restype = ctypes.c_size_t
+    return lib
+
+
+lib = _load()
+EXPORTS = list(SIGNATURES) + ["nsid_version", "nsid_row_tiles", "nsid_sumsq_blocks", "nsid_ntxent_ws_floats"]
+
+_ERR = {-1: "NSID_EINVAL (unsupported shape, misaligned pointer or bad argument)",
+        -2: "NSID_ELAUNCH (HIP runtime refused the launch)"}
+
+
+def call(name, *args):
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        raise RuntimeError(f"{name} failed: {_ERR.get(rc, rc)}")

@@ -1,0 +1,157 @@
+// Dilated kNN graph of one clip per workgroup: the whole clip (N nodes x C channels, 64 KB at every stage of
+// the 't' encoder) is staged once into LDS, BatchNorm-applied and L2-normalised there, the N x N distance matrix
+// is produced 16 rows at a time by fp32 MFMA straight from LDS and consumed by the top-k selection without ever
+// reaching HBM.  Algorithmic HBM traffic = read N*C*4 B, write N*k*4 B per clip.
+#include "nsid_common.h"
+
+namespace {
+
+constexpr int KNN_THREADS = 256;   // 4 waves, one 16-row strip each per pass
+constexpr int KNN_WAVES = 4;
+
+__device__ __forceinline__ unsigned orderable(float f) {
+  const unsigned u = __float_as_uint(f);
+  return u ^ ((u >> 31) ? 0xFFFFFFFFu : 0x80000000u);
+}
+
+__global__ __launch_bounds__(KNN_THREADS) void knn_kernel(const float* __restrict__ r, long ldr,
+                                                          const float* __restrict__ scale,
+                                                          const float* __restrict__ shift, int N, int C, int k,
+                                                          int dilation, int32_t* __restrict__ idx) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int LD = C + 4;                 // feature row stride (keeps 16-B alignment, staggers banks)
+  const int SLD = N + 4;                // distance strip row stride
+  float* yn = smem;                     // [N][LD]
+  float* sq = yn + (long)N * LD;        // [N]
+  float* strips = sq + N;               // [KNN_WAVES][16][SLD]
+
+  const int b = blockIdx.x;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const float* src = r + (long)b * N * ldr;
+  const int C4 = C >> 2;
+
+  // ---- phase 1a: stage y = scale*r + shift into LDS (coalesced float4)
+  for (int q = t; q < N * C4; q += KNN_THREADS) {
+    const int n = q / C4, c = (q % C4) * 4;
+    f32x4 v = *reinterpret_cast<const f32x4*>(src + (long)n * ldr + c);
+    if (scale != nullptr) {
+      const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + c);
+      const f32x4 sh = *reinterpret_cast<const f32x4*>(shift + c);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = sc[e] * v[e] + sh[e];
+    }
+    *reinterpret_cast<f32x4*>(yn + n * LD + c) = v;
+  }
+  __syncthreads();
+  // ---- phase 1b: F.normalize(p=2, dim=channels, eps=1e-12), then |y^|^2 as the reference recomputes it
+  for (int n = wave; n < N; n += KNN_WAVES) {
+    float ss = 0.f;
+    for (int c = lane; c < C; c += 64) { const float v = yn[n * LD + c]; ss += v * v; }
+    ss = wave_sum(ss);
+    const float denom = fmaxf(sqrtf(ss), 1e-12f);
+    float s2 = 0.f;
+    for (int c = lane; c < C; c += 64) {
+      const float v = yn[n * LD + c] / denom;
+      yn[n * LD + c] = v;
+      s2 += v * v;
+    }
+    s2 = wave_sum(s2);
+    if (lane == 0) sq[n] = s2;
+  }
+  __syncthreads();
+
+  const int lr = lane & 15, rq = lane >> 4;
+  const int NS = N >> 4;                 // 16-row strips
+  const int kd = k * dilation;
+  float* strip = strips + wave * 16 * SLD;
+  const int NE = (N + 63) >> 6;          // distance values per lane in the selection (<= 4)
+
+  for (int sb = 0; sb < NS; sb += KNN_WAVES) {
+    const int s = sb + wave;
+    const bool valid = s < NS;           // wave-uniform
+    if (valid) {
+      // ---- phase 2: D[16 rows of strip s][all N] = |a|^2 - 2 a.b + |b|^2, two column tiles at a time
+      const float* arow = yn + (16 * s + lr) * LD + 4 * rq;
+      for (int tn = 0; tn < NS; tn += 2) {
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+        const float* b0 = yn + (16 * tn + lr) * LD + 4 * rq;
+        const float* b1 = b0 + 16 * LD;
+        for (int ch = 0; ch < C; ch += 16) {
+          const f32x4 fa = *reinterpret_cast<const f32x4*>(arow + ch);
+          const f32x4 f0 = *reinterpret_cast<const f32x4*>(b0 + ch);
+          const f32x4 f1 = *reinterpret_cast<const f32x4*>(b1 + ch);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[e], f0[e], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[e], f1[e], acc1, 0, 0, 0);
+          }
+        }
+        // C/D layout: column (node j) = lane&15, row (node i) = 4*(lane>>4) + reg
+        const float sj0 = sq[16 * tn + lr], sj1 = sq[16 * tn + 16 + lr];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float si = sq[16 * s + 4 * rq + e];
+          strip[(4 * rq + e) * SLD + 16 * tn + lr] = (si + (-2.f * acc0[e])) + sj0;
+          strip[(4 * rq + e) * SLD + 16 * tn + 16 + lr] = (si + (-2.f * acc1[e])) + sj1;
+        }
+      }
+    }
+    __syncthreads();
+    if (valid) {
+      // ---- phase 3: k*dilation rounds of arg-min per row; key = (orderable distance, index) so ties take the
+      // lower index; a chosen element is retired by setting it to +inf in the owning lane's registers.
+      for (int i = 0; i < 16; ++i) {
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int j = lane + 64 * e;
+          v[e] = (e < NE && j < N) ? strip[i * SLD + j] : __builtin_inff();
+        }
+        int32_t* out = idx + ((long)b * N + 16 * s + i) * k;
+        for (int round = 0; round < kd; ++round) {
+          unsigned long long best = ~0ull;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const unsigned long long key = ((unsigned long long)orderable(v[e]) << 32) | (unsigned)(lane + 64 * e);
+            best = key < best ? key : best;
+          }
+#pragma unroll
+          for (int o = 32; o > 0; o >>= 1) {
+            const unsigned long long other = __shfl_xor(best, o, 64);
+            best = other < best ? other : best;
+          }
+          const int j = (int)(best & 0xFFFFFFFFull);
+          if (lane == (j & 63)) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (e == (j >> 6)) v[e] = __builtin_inff();
+          }
+          if (lane == 0 && (round % dilation) == 0) out[round / dilation] = j;
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+}  // namespace
+
+extern "C" int nsid_knn_graph(const float* r, int ldr, const float* scale, const float* shift, int B, int N, int C,
+                              int k, int dilation, int32_t* idx, void* stream) {
+  NSID_REQUIRE(r && idx && B > 0 && k > 0 && dilation > 0);
+  NSID_REQUIRE(N % 32 == 0 && N <= 256 && C % 16 == 0 && ldr % 4 == 0 && ldr >= C && nsid_aligned16(r));
+  NSID_REQUIRE(k * dilation <= N);
+  NSID_REQUIRE((scale == nullptr) == (shift == nullptr));
+  const size_t bytes = ((size_t)N * (C + 4) + N + (size_t)KNN_WAVES * 16 * (N + 4)) * sizeof(float);
+  NSID_REQUIRE(bytes <= 160 * 1024);
+  static size_t configured = 0;       // raise the dynamic-LDS cap once per size step (not a per-call sync)
+  if (bytes > configured) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(knn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            160 * 1024) != hipSuccess)
+      return NSID_ELAUNCH;
+    configured = 160 * 1024;
+  }
+  hipLaunchKernelGGL(knn_kernel, dim3(B), dim3(KNN_THREADS), bytes, static_cast<hipStream_t>(stream), r, (long)ldr,
+                     scale, shift, N, C, k, dilation, idx);
+  return nsid_launch_status();
+}

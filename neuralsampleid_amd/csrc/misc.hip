@@ -1,0 +1,414 @@
+// Small HBM-bound kernels of the path: downsample row gather, peak-extractor patchify, node mean, ELU', L2
+// normalise, clip+Adam, and the (B,C,N) <-> node-major layout change at the module boundary.
+#include "nsid_common.h"
+
+namespace {
+
+inline int grid_for(long n, int cap = 2048) {
+  long b = (n + 255) / 256;
+  return (int)(b > cap ? cap : (b < 1 ? 1 : b));
+}
+
+// ------------------------------------------------------------------ Downsample (3-tap stride-2 conv along N)
+__global__ __launch_bounds__(256) void im2col3_fwd_kernel(const float* __restrict__ x, int B, int N, int No, int C,
+                                                          float* __restrict__ col) {
+  const int C4 = C >> 2;
+  const long total = (long)B * No * 3 * C4;
+  for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += (long)gridDim.x * blockDim.x) {
+    const int c4 = (int)(q % C4);
+    const int t = (int)((q / C4) % 3);
+    const long orow = q / (3L * C4);
+    const int b = (int)(orow / No), no = (int)(orow % No);
+    const int n = 2 * no - 1 + t;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (n >= 0 && n < N) v = *reinterpret_cast<const f32x4*>(x + ((long)b * N + n) * C + 4 * c4);
+    *reinterpret_cast<f32x4*>(col + orow * (3L * C) + (long)t * C + 4 * c4) = v;
+  }
+}
+
+// dx[b,n,:] = sum over (n', t) with 2n'-1+t == n of dcol[b,n', t*C:(t+1)*C]   (gather form: no atomics)
+__global__ __launch_bounds__(256) void im2col3_bwd_kernel(const float* __restrict__ dcol, int B, int N, int No, int C,
+                                                          float* __restrict__ dx) {
+  const int C4 = C >> 2;
+  const long total = (long)B * N * C4;
+  for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += (long)gridDim.x * blockDim.x) {
+    const int c4 = (int)(q % C4);
+    const long row = q / C4;
+    const int b = (int)(row / N), n = (int)(row % N);
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      const int m = n + 1 - t;            // 2n' = n+1-t
+      if (m >= 0 && (m & 1) == 0 && (m >> 1) < No) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(dcol + ((long)b * No + (m >> 1)) * (3L * C) + (long)t * C + 4 * c4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s[e] += v[e];
+      }
+    }
+    *reinterpret_cast<f32x4*>(dx + row * C + 4 * c4) = s;
+  }
+}
+
+__global__ void pack_ds_weight_kernel(const float* __restrict__ w, int Cout, int Cin, float* __restrict__ wp) {
+  const long total = (long)Cout * 3 * Cin;
+  for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(q % Cin), t = (int)((q / Cin) % 3);
+    const long o = q / (3L * Cin);
+    wp[q] = w[((o * Cin + c) * 3 + t) * 3 + 1];     // w[o][c][t][1]
+  }
+}
+__global__ void unpack_ds_wgrad_kernel(const float* __restrict__ dwp, int Cout, int Cin, float* __restrict__ dw) {
+  const long total = (long)Cout * 3 * Cin;
+  for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(q % Cin), t = (int)((q / Cin) % 3);
+    const long o = q / (3L * Cin);
+    dw[((o * Cin + c) * 3 + t) * 3 + 1] += dwp[q];
+  }
+}
+
+// ------------------------------------------------------------------ GPUPeakExtractorv2
+// torch.linspace(0,1,steps)[i]: start + i*step in the lower half, end - (steps-1-i)*step in the upper half
+__device__ __forceinline__ float linspace01(int i, int steps) {
+  const float step = 1.0f / (float)(steps - 1);
+  return (i < steps / 2) ? (float)i * step : 1.0f - (float)(steps - 1 - i) * step;
+}
+
+__global__ __launch_bounds__(256) void patchify_fwd_kernel(const float* __restrict__ spec, const float* __restrict__ w,
+                                                           const float* __restrict__ bias, int H, int W, int pb,
+                                                           int pf, int F, float* __restrict__ out, int ldo,
+                                                           float* __restrict__ minmax) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];   // weights [F][3][pb][pf] then reduction scratch
+  const int b = blockIdx.x, t = threadIdx.x;
+  const float* x = spec + (long)b * H * W;
+  const int wn = F * 3 * pb * pf;
+  float* wl = sm;
+  float* red = sm + wn;      // [2][4 waves]
+  for (int i = t; i < wn; i += blockDim.x) wl[i] = w[i];
+  float lo = __builtin_inff(), hi = -__builtin_inff();
+  for (int i = t; i < H * W; i += blockDim.x) { const float v = x[i]; lo = fminf(lo, v); hi = fmaxf(hi, v); }
+  lo = wave_min(lo); hi = wave_max(hi);
+  if ((t & 63) == 0) { red[t >> 6] = lo; red[4 + (t >> 6)] = hi; }
+  __syncthreads();
+  lo = fminf(fminf(red[0], red[1]), fminf(red[2], red[3]));
+  hi = fmaxf(fmaxf(red[4], red[5]), fmaxf(red[6], red[7]));
+  if (t == 0 && minmax != nullptr) { minmax[2 * b] = lo; minmax[2 * b + 1] = hi; }
+  const float range = hi - lo;
+  const int Hp = H / pb, Wp = W / pf, NP = Hp * Wp;
+  for (int p = t; p < NP; p += blockDim.x) {
+    const int ph = p / Wp, pw = p % Wp;
+    float* dst = out + ((long)b * NP + p) * ldo;
+    for (int f = 0; f < F; ++f) {
+      float acc = bias[f];
+      const float* wf = wl + f * 3 * pb * pf;
+      for (int i = 0; i < pb; ++i) {
+        const int hh = ph * pb + i;
+        const float fr = linspace01(hh, H);
+        for (int j = 0; j < pf; ++j) {
+          const int ww = pw * pf + j;
+          const float s = (x[hh * W + ww] - lo) / range;
+          acc += wf[i * pf + j] * linspace01(ww, W);
+          acc += wf[pb * pf + i * pf + j] * fr;
+          acc += wf[2 * pb * pf + i * pf + j] * s;
+        }
+      }
+      dst[f] = acc > 0.f ? acc : 0.f;
+    }
+  }
+}
+
+// dw[f][c][i][j] += sum_{b,p} g[b,p,f] * img_c[b, ph*pb+i, pw*pf+j], g = dout * (out > 0); one block per clip
+__global__ __launch_bounds__(256) void patchify_bwd_kernel(const float* __restrict__ spec,
+                                                           const float* __restrict__ minmax,
+                                                           const float* __restrict__ out,
+                                                           const float* __restrict__ dout, int ldo, int H, int W,
+                                                           int pb, int pf, int F, float* __restrict__ dw,
+                                                           float* __restrict__ dbias) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];   // g [NP][F]
+  const int b = blockIdx.x, t = threadIdx.x;
+  const int Hp = H / pb, Wp = W / pf, NP = Hp * Wp;
+  const float* x = spec + (long)b * H * W;
+  const float lo = minmax[2 * b], range = minmax[2 * b + 1] - lo;
+  for (int q = t; q < NP * F; q += blockDim.x) {
+    const int p = q / F, f = q % F;
+    const long o = ((long)b * NP + p) * ldo + f;
+    sm[q] = out[o] > 0.f ? dout[o] : 0.f;
+  }
+  __syncthreads();
+  const int per_f = 3 * pb * pf;
+  for (int q = t; q < F * per_f; q += blockDim.x) {
+    const int f = q / per_f, rem = q % per_f;
+    const int c = rem / (pb * pf), i = (rem / pf) % pb, j = rem % pf;
+    float acc = 0.f;
+    for (int p = 0; p < NP; ++p) {
+      const int hh = (p / Wp) * pb + i, ww = (p % Wp) * pf + j;
+      const float v = c == 0 ? linspace01(ww, W) : (c == 1 ? linspace01(hh, H) : (x[hh * W + ww] - lo) / range);
+      acc += sm[p * F + f] * v;
+    }
+    atomicAdd(dw + q, acc);
+  }
+  for (int f = t; f < F; f += blockDim.x) {
+    float acc = 0.f;
+    for (int p = 0; p < NP; ++p) acc += sm[p * F + f];
+    atomicAdd(dbias + f, acc);
+  }
+}
+
+// ------------------------------------------------------------------ node mean
+__global__ __launch_bounds__(256) void node_mean_fwd_kernel(const float* __restrict__ x, int N, int C,
+                                                            float* __restrict__ out) {
+  const int b = blockIdx.x, C4 = C >> 2;
+  for (int c4 = blockIdx.y * blockDim.x + threadIdx.x; c4 < C4; c4 += gridDim.y * blockDim.x) {
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    for (int n = 0; n < N; ++n) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(x + ((long)b * N + n) * C + 4 * c4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) s[e] += v[e];
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) s[e] /= (float)N;
+    *reinterpret_cast<f32x4*>(out + (long)b * C + 4 * c4) = s;
+  }
+}
+__global__ __launch_bounds__(256) void node_mean_bwd_kernel(const float* __restrict__ dout, int N, int C, long total4,
+                                                            float* __restrict__ dx) {
+  const int C4 = C >> 2;
+  for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < total4; q += (long)gridDim.x * blockDim.x) {
+    const int c4 = (int)(q % C4);
+    const long b = q / ((long)C4 * N);
+    f32x4 v = *reinterpret_cast<const f32x4*>(dout + b * C + 4 * c4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] /= (float)N;
+    reinterpret_cast<f32x4*>(dx)[q] = v;
+  }
+}
+
+// ------------------------------------------------------------------ ELU', L2 normalise
+__global__ void elu_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ out, long n,
+                               float* __restrict__ din) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float o = out[i];
+    din[i] = dout[i] * (o > 0.f ? 1.f : o + 1.f);      // d/dx elu(x) = exp(x) = elu(x)+1 for x<=0
+  }
+}
+
+// z = p / max(|p|, eps): one wave per row
+__global__ __launch_bounds__(256) void l2norm_fwd_kernel(const float* __restrict__ p, int B, int d, float eps,
+                                                         float* __restrict__ z, float* __restrict__ norm) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= B) return;
+  float ss = 0.f;
+  for (int c = lane; c < d; c += 64) { const float v = p[(long)row * d + c]; ss += v * v; }
+  ss = wave_sum(ss);
+  const float nr = sqrtf(ss), den = fmaxf(nr, eps);
+  for (int c = lane; c < d; c += 64) z[(long)row * d + c] = p[(long)row * d + c] / den;
+  if (lane == 0) norm[row] = nr;
+}
+// dp = (dz - z (z.dz)) / |p|  when |p| > eps, else dz / eps
+__global__ __launch_bounds__(256) void l2norm_bwd_kernel(const float* __restrict__ dz, const float* __restrict__ z,
+                                                         const float* __restrict__ norm, int B, int d, float eps,
+                                                         float* __restrict__ dp) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= B) return;
+  float dot = 0.f;
+  for (int c = lane; c < d; c += 64) dot += z[(long)row * d + c] * dz[(long)row * d + c];
+  dot = wave_sum(dot);
+  const float nr = norm[row];
+  for (int c = lane; c < d; c += 64) {
+    const long o = (long)row * d + c;
+    dp[o] = nr > eps ? (dz[o] - z[o] * dot) / nr : dz[o] / eps;
+  }
+}
+
+// ------------------------------------------------------------------ clip_grad_norm_ + Adam
+constexpr int SUMSQ_PER_BLOCK = 256 * 4 * 16;
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, long n, float* __restrict__ partial) {
+  __shared__ double red[4];
+  const long base = (long)blockIdx.x * SUMSQ_PER_BLOCK;
+  double s = 0.0;
+  for (int it = 0; it < 16; ++it) {
+    const long i = base + ((long)it * 256 + threadIdx.x) * 4;
+    if (i + 3 < n) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(g + i);
+      s += (double)v[0] * v[0] + (double)v[1] * v[1] + (double)v[2] * v[2] + (double)v[3] * v[3];
+    } else {
+      for (long j = i; j < n && j < i + 4; ++j) s += (double)g[j] * g[j];
+    }
+  }
+  s = wave_sum_d(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = (float)(red[0] + red[1] + red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                   float* __restrict__ m, float* __restrict__ v, long n,
+                                                   const float* __restrict__ hyper, const int64_t* __restrict__ step,
+                                                   const float* __restrict__ partial, int nblocks,
+                                                   float* __restrict__ gnorm_out) {
+  __shared__ float coef_s;
+  __shared__ double red[4];
+  {  // every block recomputes the global norm from the partials (<= a few thousand floats, L2-resident)
+    double s = 0.0;
+    for (int i = threadIdx.x; i < nblocks; i += blockDim.x) s += (double)partial[i];
+    s = wave_sum_d(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const float norm = (float)sqrt(red[0] + red[1] + red[2] + red[3]);
+      const float max_norm = hyper[4];
+      float c = 1.f;
+      if (max_norm > 0.f) { c = max_norm / (norm + 1e-6f); c = c < 1.f ? c : 1.f; }   // torch: clamp(max=1)
+      coef_s = c;
+      if (blockIdx.x == 0 && gnorm_out != nullptr) gnorm_out[0] = norm;
+    }
+    __syncthreads();
+  }
+  const float coef = coef_s;
+  const float lr = hyper[0], b1 = hyper[1], b2 = hyper[2], eps = hyper[3];
+  const double t = (double)(*step + 1);                 // the host-visible counter is bumped by adam_tick_kernel
+  const float bc1 = (float)(1.0 - pow((double)b1, t));
+  const float bc2_sqrt = (float)sqrt(1.0 - pow((double)b2, t));
+  const float step_size = lr / bc1;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float gi = g[i] * coef;
+    const float mi = m[i] * b1 + (1.f - b1) * gi;       // exp_avg.lerp_(grad, 1-beta1)
+    const float vi = v[i] * b2 + (1.f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    p[i] -= step_size * (mi / denom);
+  }
+}
+__global__ void adam_tick_kernel(int64_t* step) { *step += 1; }
+
+// ------------------------------------------------------------------ (B,C,N) <-> rows (B*N, C): 32x32 LDS transpose
+__global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ src, long src_batch, long src_ld,
+                                                        float* __restrict__ dst, long dst_batch, long dst_ld,
+                                                        int R, int S) {   // src[b][r][s] -> dst[b][s][r]
+  __shared__ float tile[32][33];
+  const int b = blockIdx.z;
+  const int r0 = blockIdx.y * 32, s0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;    // 32 x 8
+  for (int i = ty; i < 32; i += 8) {
+    const int rr = r0 + i, ss = s0 + tx;
+    if (rr < R && ss < S) tile[i][tx] = src[b * src_batch + (long)rr * src_ld + ss];
+  }
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8) {
+    const int ss = s0 + i, rr = r0 + tx;
+    if (rr < R && ss < S) dst[b * dst_batch + (long)ss * dst_ld + rr] = tile[tx][i];
+  }
+}
+
+}  // namespace
+
+extern "C" int nsid_im2col3_fwd(const float* x, int B, int N, int C, float* col, void* stream) {
+  NSID_REQUIRE(x && col && B > 0 && N > 0 && C > 0 && C % 4 == 0 && nsid_aligned16(x) && nsid_aligned16(col));
+  const int No = (N - 1) / 2 + 1;
+  hipLaunchKernelGGL(im2col3_fwd_kernel, dim3(grid_for((long)B * No * 3 * (C / 4))), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), x, B, N, No, C, col);
+  return nsid_launch_status();
+}
+extern "C" int nsid_im2col3_bwd(const float* dcol, int B, int N, int C, float* dx, void* stream) {
+  NSID_REQUIRE(dcol && dx && B > 0 && N > 0 && C > 0 && C % 4 == 0 && nsid_aligned16(dcol) && nsid_aligned16(dx));
+  const int No = (N - 1) / 2 + 1;
+  hipLaunchKernelGGL(im2col3_bwd_kernel, dim3(grid_for((long)B * N * (C / 4))), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), dcol, B, N, No, C, dx);
+  return nsid_launch_status();
+}
+extern "C" int nsid_pack_ds_weight(const float* w, int Cout, int Cin, float* wp, void* stream) {
+  NSID_REQUIRE(w && wp && Cout > 0 && Cin > 0);
+  hipLaunchKernelGGL(pack_ds_weight_kernel, dim3(grid_for((long)Cout * 3 * Cin)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), w, Cout, Cin, wp);
+  return nsid_launch_status();
+}
+extern "C" int nsid_unpack_ds_wgrad(const float* dwp, int Cout, int Cin, float* dw, void* stream) {
+  NSID_REQUIRE(dwp && dw && Cout > 0 && Cin > 0);
+  hipLaunchKernelGGL(unpack_ds_wgrad_kernel, dim3(grid_for((long)Cout * 3 * Cin)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), dwp, Cout, Cin, dw);
+  return nsid_launch_status();
+}
+
+extern "C" int nsid_peak_patchify_fwd(const float* spec, const float* w, const float* bias, int B, int H, int W, int pb,
+                                      int pf, int F, float* out, int ldo, float* minmax, void* stream) {
+  NSID_REQUIRE(spec && w && bias && out && B > 0 && H > 1 && W > 1 && pb > 0 && pf > 0 && F > 0);
+  NSID_REQUIRE(H % pb == 0 && W % pf == 0 && ldo >= F);
+  const size_t bytes = ((size_t)F * 3 * pb * pf + 8) * sizeof(float);
+  NSID_REQUIRE(bytes <= 48 * 1024);
+  hipLaunchKernelGGL(patchify_fwd_kernel, dim3(B), dim3(256), bytes, static_cast<hipStream_t>(stream), spec, w, bias,
+                     H, W, pb, pf, F, out, ldo, minmax);
+  return nsid_launch_status();
+}
+extern "C" int nsid_peak_patchify_bwd(const float* spec, const float* minmax, const float* out, const float* dout,
+                                      int ldo, int B, int H, int W, int pb, int pf, int F, float* dw, float* dbias,
+                                      void* stream) {
+  NSID_REQUIRE(spec && minmax && out && dout && dw && dbias && B > 0 && H % pb == 0 && W % pf == 0 && ldo >= F);
+  const size_t bytes = (size_t)(H / pb) * (W / pf) * F * sizeof(float);
+  NSID_REQUIRE(bytes <= 48 * 1024);
+  hipLaunchKernelGGL(patchify_bwd_kernel, dim3(B), dim3(256), bytes, static_cast<hipStream_t>(stream), spec, minmax,
+                     out, dout, ldo, H, W, pb, pf, F, dw, dbias);
+  return nsid_launch_status();
+}
+
+extern "C" int nsid_node_mean_fwd(const float* x, int B, int N, int C, float* out, void* stream) {
+  NSID_REQUIRE(x && out && B > 0 && N > 0 && C > 0 && C % 4 == 0 && nsid_aligned16(x) && nsid_aligned16(out));
+  hipLaunchKernelGGL(node_mean_fwd_kernel, dim3(B, (C / 4 + 255) / 256), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), x, N, C, out);
+  return nsid_launch_status();
+}
+extern "C" int nsid_node_mean_bwd(const float* dout, int B, int N, int C, float* dx, void* stream) {
+  NSID_REQUIRE(dout && dx && B > 0 && N > 0 && C > 0 && C % 4 == 0 && nsid_aligned16(dout) && nsid_aligned16(dx));
+  const long total4 = (long)B * N * (C / 4);
+  hipLaunchKernelGGL(node_mean_bwd_kernel, dim3(grid_for(total4)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     dout, N, C, total4, dx);
+  return nsid_launch_status();
+}
+extern "C" int nsid_elu_bwd(const float* dout, const float* out, long n, float* din, void* stream) {
+  NSID_REQUIRE(dout && out && din && n > 0);
+  hipLaunchKernelGGL(elu_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, static_cast<hipStream_t>(stream), dout, out, n,
+                     din);
+  return nsid_launch_status();
+}
+extern "C" int nsid_l2norm_fwd(const float* p, int B, int d, float eps, float* z, float* norm, void* stream) {
+  NSID_REQUIRE(p && z && norm && B > 0 && d > 0);
+  hipLaunchKernelGGL(l2norm_fwd_kernel, dim3((B + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), p, B, d, eps,
+                     z, norm);
+  return nsid_launch_status();
+}
+extern "C" int nsid_l2norm_bwd(const float* dz, const float* z, const float* norm, int B, int d, float eps, float* dp,
+                               void* stream) {
+  NSID_REQUIRE(dz && z && norm && dp && B > 0 && d > 0);
+  hipLaunchKernelGGL(l2norm_bwd_kernel, dim3((B + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), dz, z, norm,
+                     B, d, eps, dp);
+  return nsid_launch_status();
+}
+
+extern "C" int nsid_sumsq_blocks(long n) { return (int)((n + SUMSQ_PER_BLOCK - 1) / SUMSQ_PER_BLOCK); }
+extern "C" int nsid_sumsq_partial(const float* g, long n, float* partial, void* stream) {
+  NSID_REQUIRE(g && partial && n > 0 && nsid_aligned16(g));
+  hipLaunchKernelGGL(sumsq_kernel, dim3(nsid_sumsq_blocks(n)), dim3(256), 0, static_cast<hipStream_t>(stream), g, n,
+                     partial);
+  return nsid_launch_status();
+}
+extern "C" int nsid_adam_step(float* p, const float* g, float* m, float* v, long n, const float* hyper, int64_t* step,
+                              const float* partial, int nblocks, float* gnorm_out, void* stream) {
+  NSID_REQUIRE(p && g && m && v && hyper && step && partial && n > 0 && nblocks > 0);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n, 4096)), dim3(256), 0, s, p, g, m, v, n, hyper, step, partial,
+                     nblocks, gnorm_out);
+  hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, s, step);
+  return nsid_launch_status();
+}
+
+extern "C" int nsid_bcn_to_rows(const float* x, int B, int C, int N, float* rows, int ld, void* stream) {
+  NSID_REQUIRE(x && rows && B > 0 && C > 0 && N > 0 && ld >= C);
+  hipLaunchKernelGGL(transpose_kernel, dim3((N + 31) / 32, (C + 31) / 32, B), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), x, (long)C * N, (long)N, rows, (long)N * ld, (long)ld, C, N);
+  return nsid_launch_status();
+}
+extern "C" int nsid_rows_to_bcn(const float* rows, int ld, int B, int C, int N, float* x, void* stream) {
+  NSID_REQUIRE(x && rows && B > 0 && C > 0 && N > 0 && ld >= C);
+  hipLaunchKernelGGL(transpose_kernel, dim3((C + 31) / 32, (N + 31) / 32, B), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), rows, (long)N * ld, (long)ld, x, (long)C * N, (long)N, N, C);
+  return nsid_launch_status();
+}

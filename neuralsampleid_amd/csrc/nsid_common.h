@@ -1,0 +1,60 @@
+// Shared device/host helpers for the gfx950 kernels. Internal header (the public C ABI is include/nsid.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/nsid.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define NSID_WAVE 64
+
+// activation codes shared by every kernel (include/nsid.h: NSID_ACT_*)
+__device__ __forceinline__ float nsid_act(float v, int act) {
+  switch (act) {
+    case NSID_ACT_RELU: return v > 0.f ? v : 0.f;
+    case NSID_ACT_LEAKY: return v > 0.f ? v : 0.2f * v;
+    case NSID_ACT_ELU: return v > 0.f ? v : expm1f(v);
+    default: return v;
+  }
+}
+// derivative of the activation, expressed on the pre-activation value
+__device__ __forceinline__ float nsid_act_grad(float pre, int act) {
+  switch (act) {
+    case NSID_ACT_RELU: return pre > 0.f ? 1.f : 0.f;
+    case NSID_ACT_LEAKY: return pre > 0.f ? 1.f : 0.2f;
+    default: return 1.f;
+  }
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ float wave_min(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+static inline int nsid_launch_status() {
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? NSID_OK : NSID_ELAUNCH;
+}
+static inline bool nsid_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+#define NSID_REQUIRE(cond) \
+  do {                     \
+    if (!(cond)) return NSID_EINVAL; \
+  } while (0)

@@ -1,0 +1,207 @@
+// Fused NT-Xent (simclr/ntxent.py:5-30): similarity GEMM on fp32 MFMA + masked online log-sum-exp + positive
+// pick (pass 1), and dZ = (G + G^T) Z / tau (pass 2). The (2B x 2B) logits never leave the accumulators.
+//
+// Orientation trick: each wave computes the TRANSPOSED tile T[j][i] = z_j . z_i (A operand = column block rows j,
+// B operand = its own 16 rows i). In the C/D layout a lane then holds, for its own row i = lane&15, the four
+// logits j = 4*(lane>>4)+reg — which is exactly the A-operand layout (row i, reduction index (lane>>4, reg)) of the
+// second product dZ[i][:] += Q[i][j] z_j[:], so Q is consumed from registers with no LDS round trip or shuffle.
+#include "nsid_common.h"
+
+namespace {
+
+constexpr int RB = 64;   // rows i per workgroup (16 per wave)
+constexpr int CBK = 32;  // rows j per staged column block
+
+__device__ __forceinline__ const float* zrow(const float* z_i, const float* z_j, int row, int d) {
+  return ((row & 1) ? z_j : z_i) + (long)(row >> 1) * d;
+}
+
+__device__ __forceinline__ void stage_rows(float* dst, int ld, const float* z_i, const float* z_j, int row0, int nrows,
+                                           int M, int d) {
+  const int d4 = d >> 2;
+  for (int q = threadIdx.x; q < nrows * d4; q += blockDim.x) {
+    const int rr = q / d4, c = (q % d4) * 4;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (row0 + rr < M) v = *reinterpret_cast<const f32x4*>(zrow(z_i, z_j, row0 + rr, d) + c);
+    *reinterpret_cast<f32x4*>(dst + rr * ld + c) = v;
+  }
+}
+
+// T tile for this wave's 16 rows i against 16 column rows j: acc[reg] = z_{j=4*rq+reg} . z_{i=lr}
+__device__ __forceinline__ f32x4 sim_tile(const float* zi_w, const float* zj_t, int ld, int d, int lr, int rq) {
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  const float* pa = zj_t + lr * ld + 4 * rq;     // A: row j = lr
+  const float* pb = zi_w + lr * ld + 4 * rq;     // B: column i = lr
+  for (int ch = 0; ch < d; ch += 16) {
+    const f32x4 fa = *reinterpret_cast<const f32x4*>(pa + ch);
+    const f32x4 fb = *reinterpret_cast<const f32x4*>(pb + ch);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[e], fb[e], acc, 0, 0, 0);
+  }
+  return acc;
+}
+
+// pass 1: lse[i] = logsumexp_{j != i} a_ij and rowloss[i] = lse[i] - a_{i, i^1}, for every row i < M
+__global__ __launch_bounds__(256) void ntxent_lse_kernel(const float* __restrict__ z_i, const float* __restrict__ z_j,
+                                                         int M, int d, float tau, float* __restrict__ lse,
+                                                         float* __restrict__ rowloss) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int ld = d + 4;
+  float* zi_s = sm;                 // [RB][ld]
+  float* zj_s = sm + RB * ld;       // [CBK][ld]
+  const int i0 = blockIdx.x * RB;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lr = lane & 15, rq = lane >> 4;
+  stage_rows(zi_s, ld, z_i, z_j, i0, RB, M, d);
+  const int i = i0 + 16 * wave + lr;
+  float mrun = -__builtin_inff(), srun = 0.f, pos = 0.f;
+  for (int j0 = 0; j0 < M; j0 += CBK) {
+    __syncthreads();
+    stage_rows(zj_s, ld, z_i, z_j, j0, CBK, M, d);
+    __syncthreads();
+#pragma unroll
+    for (int jt = 0; jt < CBK / 16; ++jt) {
+      const f32x4 acc = sim_tile(zi_s + 16 * wave * ld, zj_s + 16 * jt * ld, ld, d, lr, rq);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int j = j0 + 16 * jt + 4 * rq + e;
+        const float a = acc[e] / tau;
+        if (j < M && j != i) {
+          if (j == (i ^ 1)) pos = a;
+          const float mn = fmaxf(mrun, a);
+          srun = srun * expf(mrun - mn) + expf(a - mn);    // mrun = -inf first time: exp(-inf) = 0
+          mrun = mn;
+        }
+      }
+    }
+  }
+  // merge the four lanes (rq = 0..3) that share row i
+#pragma unroll
+  for (int o = 16; o <= 32; o <<= 1) {
+    const float m2 = __shfl_xor(mrun, o, 64), s2 = __shfl_xor(srun, o, 64), p2 = __shfl_xor(pos, o, 64);
+    const float mn = fmaxf(mrun, m2);
+    const float e1 = mrun == -__builtin_inff() ? 0.f : expf(mrun - mn);
+    const float e2 = m2 == -__builtin_inff() ? 0.f : expf(m2 - mn);
+    srun = srun * e1 + s2 * e2;
+    mrun = mn;
+    pos += p2;
+  }
+  if (rq == 0 && i < M) {
+    const float l = mrun + logf(srun);
+    lse[i] = l;
+    rowloss[i] = l - pos;
+  }
+}
+
+// pass 2: dz[i] = (1/(M tau)) * sum_j Q_ij z_j,  Q_ij = exp(a_ij - lse_i) + exp(a_ij - lse_j) - 2[j == i^1], Q_ii = 0
+template <int DT>   // d / 16 column tiles of the output
+__global__ __launch_bounds__(256) void ntxent_grad_kernel(const float* __restrict__ z_i, const float* __restrict__ z_j,
+                                                          int M, int d, float tau, const float* __restrict__ lse,
+                                                          int row0, int nrows, float* __restrict__ dz_i,
+                                                          float* __restrict__ dz_j) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int ld = d + 4;
+  float* zi_s = sm;
+  float* zj_s = sm + RB * ld;
+  const int i0 = row0 + blockIdx.x * RB;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lr = lane & 15, rq = lane >> 4;
+  stage_rows(zi_s, ld, z_i, z_j, i0, RB, M, d);
+  const int i = i0 + 16 * wave + lr;
+  const bool iok = i < row0 + nrows && i < M;
+  const float lse_i = iok ? lse[i] : 0.f;
+  f32x4 out[DT];
+#pragma unroll
+  for (int c = 0; c < DT; ++c) out[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int j0 = 0; j0 < M; j0 += CBK) {
+    __syncthreads();
+    stage_rows(zj_s, ld, z_i, z_j, j0, CBK, M, d);
+    __syncthreads();
+#pragma unroll
+    for (int jt = 0; jt < CBK / 16; ++jt) {
+      const f32x4 acc = sim_tile(zi_s + 16 * wave * ld, zj_s + 16 * jt * ld, ld, d, lr, rq);
+      f32x4 q;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int j = j0 + 16 * jt + 4 * rq + e;
+        float v = 0.f;
+        if (iok && j < M && j != i) {
+          const float a = acc[e] / tau;
+          v = expf(a - lse_i) + expf(a - lse[j]);
+          if (j == (i ^ 1)) v -= 2.f;
+        }
+        q[e] = v;
+      }
+      // dZ tile: A = Q (row i = lr, reduction (rq, e) <-> j = 4*rq+e), B = z_j[j][16*c + lr]
+      const float* zb = zj_s + (16 * jt + 4 * rq) * ld + lr;
+#pragma unroll
+      for (int c = 0; c < DT; ++c)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          out[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(q[e], zb[e * ld + 16 * c], out[c], 0, 0, 0);
+    }
+  }
+  // C/D layout of out[c]: column = feature 16*c + lr, row = local row 4*rq + reg
+  const float sc = 1.f / ((float)M * tau);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int row = i0 + 16 * wave + 4 * rq + e;
+    if (row < row0 + nrows && row < M) {
+      float* dst = ((row & 1) ? dz_j : dz_i) + (long)((row >> 1) - (row0 >> 1)) * d;
+#pragma unroll
+      for (int c = 0; c < DT; ++c) dst[16 * c + lr] = out[c][e] * sc;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void ntxent_loss_kernel(const float* __restrict__ rowloss, int row0, int nrows, int M,
+                                                          float* __restrict__ loss_out) {
+  __shared__ double red[4];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < nrows; i += blockDim.x) s += (double)rowloss[row0 + i];
+  s = wave_sum_d(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) loss_out[0] = (float)((red[0] + red[1] + red[2] + red[3]) / (double)M);
+}
+
+template <typename K>
+int raise_lds(K kernel, size_t bytes) {
+  if (bytes <= 64 * 1024) return NSID_OK;
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                             (int)bytes) == hipSuccess ? NSID_OK : NSID_ELAUNCH;
+}
+
+}  // namespace
+
+extern "C" size_t nsid_ntxent_ws_floats(int Bg) { return (size_t)4 * Bg + 8; }
+
+extern "C" int nsid_ntxent_fwd_bwd(const float* z_i, const float* z_j, int Bg, int d, float tau, int p0, int np,
+                                   float* ws, float* loss_out, float* dz_i, float* dz_j, void* stream) {
+  NSID_REQUIRE(z_i && z_j && ws && loss_out && Bg > 0 && np > 0 && p0 >= 0 && p0 + np <= Bg && tau > 0.f);
+  NSID_REQUIRE(d % 16 == 0 && d <= 256 && nsid_aligned16(z_i) && nsid_aligned16(z_j));
+  NSID_REQUIRE((dz_i == nullptr) == (dz_j == nullptr));
+  const int M = 2 * Bg;
+  float* lse = ws;
+  float* rowloss = ws + M;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const size_t bytes = (size_t)(RB + CBK) * (d + 4) * sizeof(float);
+  if (raise_lds(ntxent_lse_kernel, bytes) != NSID_OK) return NSID_ELAUNCH;
+  hipLaunchKernelGGL(ntxent_lse_kernel, dim3((M + RB - 1) / RB), dim3(256), bytes, s, z_i, z_j, M, d, tau, lse,
+                     rowloss);
+  hipLaunchKernelGGL(ntxent_loss_kernel, dim3(1), dim3(256), 0, s, rowloss, 2 * p0, 2 * np, M, loss_out);
+  if (dz_i != nullptr) {
+    const int row0 = 2 * p0, nrows = 2 * np;
+    dim3 grid((nrows + RB - 1) / RB);
+#define NSID_NTX_CASE(DTV)                                                                                   \
+  case DTV:                                                                                                  \
+    if (raise_lds(ntxent_grad_kernel<DTV>, bytes) != NSID_OK) return NSID_ELAUNCH;                           \
+    hipLaunchKernelGGL((ntxent_grad_kernel<DTV>), grid, dim3(256), bytes, s, z_i, z_j, M, d, tau, lse, row0, \
+                       nrows, dz_i, dz_j);                                                                   \
+    break;
+    switch (d / 16) {
+      NSID_NTX_CASE(1) NSID_NTX_CASE(2) NSID_NTX_CASE(4) NSID_NTX_CASE(8) NSID_NTX_CASE(16)
+      default: return NSID_EINVAL;
+    }
+#undef NSID_NTX_CASE
+  }
+  return nsid_launch_status();
+}

@@ -1,0 +1,291 @@
+"""Tensor-level wrappers over the C ABI (include/nsid.h): torch supplies device memory and the stream, nothing else.
+
+Every function enqueues HIP kernels from libnsid_hip.so on torch's current stream; none falls back to ATen."""
+from typing import Optional, Tuple
+
+import torch
+
+from ._lib import call, lib
+
+ACT_NONE, ACT_RELU, ACT_LEAKY, ACT_ELU = 0, 1, 2, 3
+ROW_TILE = 128
+BN_MOMENTUM = 0.1
+BN_EPS = 1e-5
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _chk(*ts):
+    for t in ts:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError("neuralsampleid_amd ops need tensors on the MI355X (cuda) device; there is no CPU path")
+        if t.dtype != torch.float32 or not t.is_contiguous():
+            raise RuntimeError(f"expected contiguous float32, got {t.dtype} contiguous={t.is_contiguous()}")
+
+
+def row_tiles(M: int) -> int:
+    return (M + ROW_TILE - 1) // ROW_TILE
+
+
+def w2d(w: torch.Tensor) -> torch.Tensor:
+    """conv weight (Cout, Cin/g, 1, 1) or linear weight (Cout, Cin) viewed as a matrix (no copy)"""
+    return w.reshape(w.shape[0], -1)
+
+
+# ------------------------------------------------------------------------------------------------ linear
+def linear_fwd(x, w, bias, M, Nout, K, groups=1, in_scale=None, in_shift=None, act_in=ACT_NONE, act_out=ACT_NONE,
+               want_stat=False, ksplit=1, out=None) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+    _chk(x, w, bias, in_scale, in_shift)
+    ldx = x.shape[-1]
+    if out is None:
+        out = (torch.zeros if ksplit > 1 else torch.empty)((M, groups * Nout), device=x.device, dtype=torch.float32)
+    stat = torch.empty((2, row_tiles(M), groups * Nout), device=x.device, dtype=torch.float32) if want_stat else None
+    call("nsid_linear_fwd", _p(x), ldx, _p(w), _p(bias), _p(out), out.shape[-1], M, Nout, K, groups, _p(in_scale),
+         _p(in_shift), act_in, act_out, _p(stat), ksplit, _stream())
+    return out, stat
+
+
+def linear_bwd_data(dout, w, M, Nout, K, groups=1, addend=None, out=None) -> torch.Tensor:
+    _chk(dout, w, addend)
+    if out is None:
+        out = torch.empty((M, groups * K), device=dout.device, dtype=torch.float32)
+    call("nsid_linear_bwd_data", _p(dout), dout.shape[-1], _p(w), _p(addend),
+         0 if addend is None else addend.shape[-1], _p(out), out.shape[-1], M, Nout, K, groups, _stream())
+    return out
+
+
+def linear_bwd_weight(dout, x, dw, M, Nout, K, groups=1, in_scale=None, in_shift=None, act_in=ACT_NONE) -> None:
+    """dw += dout^T f(x)"""
+    _chk(dout, x, dw, in_scale, in_shift)
+    call("nsid_linear_bwd_weight", _p(dout), dout.shape[-1], _p(x), x.shape[-1], _p(dw), M, Nout, K, groups,
+         _p(in_scale), _p(in_shift), act_in, _stream())
+
+
+def colsum_acc(x, out) -> None:
+    _chk(x, out)
+    call("nsid_colsum_acc", _p(x), x.shape[-1], x.shape[0], x.shape[1], _p(out), _stream())
+
+
+# ------------------------------------------------------------------------------------------------ batch norm
+class BNAffine:
+    """What a consumer needs to apply a producer's BatchNorm on load, plus what backward needs."""
+    __slots__ = ("scale", "shift", "mean", "invstd")
+
+    def __init__(self, scale, shift, mean=None, invstd=None):
+        self.scale, self.shift, self.mean, self.invstd = scale, shift, mean, invstd
+
+
+def bn_finalize(stat, M, gamma, beta, running_mean, running_var, num_batches_tracked,
+                momentum=BN_MOMENTUM, eps=BN_EPS) -> BNAffine:
+    C = gamma.numel()
+    buf = torch.empty((4, C), device=gamma.device, dtype=torch.float32)
+    call("nsid_bn_finalize", _p(stat), row_tiles(M), C, M, _p(gamma), _p(beta), _p(running_mean), _p(running_var),
+         _p(num_batches_tracked), momentum, eps, _p(buf[0]), _p(buf[1]), _p(buf[2]), _p(buf[3]), _stream())
+    return BNAffine(buf[0], buf[1], buf[2], buf[3])
+
+
+def bn_eval_affine(gamma, beta, running_mean, running_var, eps=BN_EPS) -> BNAffine:
+    C = gamma.numel()
+    buf = torch.empty((2, C), device=gamma.device, dtype=torch.float32)
+    call("nsid_bn_eval_affine", _p(gamma), _p(beta), _p(running_mean), _p(running_var), eps, C, _p(buf[0]),
+         _p(buf[1]), _stream())
+    return BNAffine(buf[0], buf[1])
+
+
+def bn_apply(r, aff: BNAffine, act=ACT_NONE, residual=None, out=None) -> torch.Tensor:
+    _chk(r, residual)
+    M, C = r.shape
+    if out is None:
+        out = torch.empty_like(r)
+    call("nsid_bn_apply", _p(r), _p(aff.scale), _p(aff.shift), act, _p(residual), _p(out), M, C, _stream())
+    return out
+
+
+def bn_backward(dout, r, aff: BNAffine, act, dgamma, dbeta, inplace=False) -> torch.Tensor:
+    """Gradient w.r.t. the raw conv output r of y = act(BN(r)), given dL/dy; dgamma/dbeta are accumulated."""
+    _chk(dout, r)
+    M, C = r.shape
+    tiles = row_tiles(M)
+    partial = torch.empty((2, tiles, C), device=r.device, dtype=torch.float32)
+    coef = torch.empty((2, C), device=r.device, dtype=torch.float32)
+    s = _stream()
+    call("nsid_bn_bwd_reduce", _p(dout), _p(r), M, C, _p(aff.scale), _p(aff.shift), _p(aff.mean), _p(aff.invstd),
+         act, _p(partial), s)
+    call("nsid_bn_bwd_finalize", _p(partial), tiles, C, M, _p(dgamma), _p(dbeta), _p(coef), s)
+    dr = dout if inplace else torch.empty_like(dout)
+    call("nsid_bn_bwd_apply", _p(dout), _p(r), M, C, _p(aff.scale), _p(aff.shift), _p(aff.mean), _p(aff.invstd),
+         act, _p(coef), _p(dr), s)
+    return dr
+
+
+# ------------------------------------------------------------------------------------------------ graph ops
+def knn_graph(r, B, N, C, k, dilation=1, aff: Optional[BNAffine] = None) -> torch.Tensor:
+    """(B*N, C) features (optionally with a pending BatchNorm affine) -> int32 (B, N, k) clip-local neighbour ids"""
+    _chk(r)
+    idx = torch.empty((B, N, k), device=r.device, dtype=torch.int32)
+    call("nsid_knn_graph", _p(r), r.shape[-1], _p(aff.scale) if aff else None, _p(aff.shift) if aff else None,
+         B, N, C, k, dilation, _p(idx), _stream())
+    return idx
+
+
+def mr_aggregate_fwd(r, idx, B, N, C, aff: Optional[BNAffine] = None, want_argmax=True):
+    _chk(r)
+    k = idx.shape[-1]
+    u = torch.empty((B * N, 2 * C), device=r.device, dtype=torch.float32)
+    amax = torch.empty((B * N, C), device=r.device, dtype=torch.uint8) if want_argmax else None
+    call("nsid_mr_aggregate_fwd", _p(r), r.shape[-1], _p(aff.scale) if aff else None,
+         _p(aff.shift) if aff else None, _p(idx), B, N, C, k, _p(u), _p(amax), _stream())
+    return u, amax
+
+
+def mr_aggregate_bwd(du, idx, amax, B, N, C) -> torch.Tensor:
+    _chk(du)
+    dy = torch.empty((B * N, C), device=du.device, dtype=torch.float32)
+    call("nsid_mr_aggregate_bwd", _p(du), _p(idx), _p(amax), B, N, C, idx.shape[-1], _p(dy), _stream())
+    return dy
+
+
+# ------------------------------------------------------------------------------------------------ downsample
+def ds_out_nodes(N: int) -> int:
+    return (N - 1) // 2 + 1
+
+
+def im2col3_fwd(x, B, N, C) -> torch.Tensor:
+    _chk(x)
+    col = torch.empty((B * ds_out_nodes(N), 3 * C), device=x.device, dtype=torch.float32)
+    call("nsid_im2col3_fwd", _p(x), B, N, C, _p(col), _stream())
+    return col
+
+
+def im2col3_bwd(dcol, B, N, C) -> torch.Tensor:
+    _chk(dcol)
+    dx = torch.empty((B * N, C), device=dcol.device, dtype=torch.float32)
+    call("nsid_im2col3_bwd", _p(dcol), B, N, C, _p(dx), _stream())
+    return dx
+
+
+def pack_ds_weight(w) -> torch.Tensor:
+    _chk(w)
+    Cout, Cin = w.shape[0], w.shape[1]
+    wp = torch.empty((Cout, 3 * Cin), device=w.device, dtype=torch.float32)
+    call("nsid_pack_ds_weight", _p(w), Cout, Cin, _p(wp), _stream())
+    return wp
+
+
+def unpack_ds_wgrad(dwp, dw) -> None:
+    _chk(dwp, dw)
+    call("nsid_unpack_ds_wgrad", _p(dwp), dw.shape[0], dw.shape[1], _p(dw), _stream())
+
+
+# ------------------------------------------------------------------------------------------------ peak extractor
+def peak_patchify_fwd(spec, w, bias, pb, pf):
+    _chk(spec, w, bias)
+    B, H, W = spec.shape
+    F = w.shape[0]
+    n = (H // pb) * (W // pf)
+    out = torch.empty((B * n, F), device=spec.device, dtype=torch.float32)
+    minmax = torch.empty((B, 2), device=spec.device, dtype=torch.float32)
+    call("nsid_peak_patchify_fwd", _p(spec), _p(w), _p(bias), B, H, W, pb, pf, F, _p(out), F, _p(minmax), _stream())
+    return out, minmax
+
+
+def peak_patchify_bwd(spec, minmax, out, dout, pb, pf, dw, dbias) -> None:
+    _chk(spec, minmax, out, dout, dw, dbias)
+    B, H, W = spec.shape
+    call("nsid_peak_patchify_bwd", _p(spec), _p(minmax), _p(out), _p(dout), out.shape[-1], B, H, W, pb, pf,
+         out.shape[-1], _p(dw), _p(dbias), _stream())
+
+
+# ------------------------------------------------------------------------------------------------ head
+def node_mean_fwd(x, B, N, C) -> torch.Tensor:
+    _chk(x)
+    out = torch.empty((B, C), device=x.device, dtype=torch.float32)
+    call("nsid_node_mean_fwd", _p(x), B, N, C, _p(out), _stream())
+    return out
+
+
+def node_mean_bwd(dout, B, N, C) -> torch.Tensor:
+    _chk(dout)
+    dx = torch.empty((B * N, C), device=dout.device, dtype=torch.float32)
+    call("nsid_node_mean_bwd", _p(dout), B, N, C, _p(dx), _stream())
+    return dx
+
+
+def elu_bwd(dout, out) -> torch.Tensor:
+    _chk(dout, out)
+    din = torch.empty_like(dout)
+    call("nsid_elu_bwd", _p(dout), _p(out), out.numel(), _p(din), _stream())
+    return din
+
+
+def l2norm_fwd(p, eps):
+    _chk(p)
+    B, d = p.shape
+    z = torch.empty_like(p)
+    norm = torch.empty((B,), device=p.device, dtype=torch.float32)
+    call("nsid_l2norm_fwd", _p(p), B, d, eps, _p(z), _p(norm), _stream())
+    return z, norm
+
+
+def l2norm_bwd(dz, z, norm, eps) -> torch.Tensor:
+    _chk(dz, z, norm)
+    B, d = z.shape
+    dp = torch.empty_like(z)
+    call("nsid_l2norm_bwd", _p(dz), _p(z), _p(norm), B, d, eps, _p(dp), _stream())
+    return dp
+
+
+def ntxent_fwd_bwd(z_i, z_j, tau, p0=0, npairs=None, want_grad=True):
+    """z_i, z_j: (Bg, d) global embeddings; this rank owns pairs [p0, p0+npairs).
+    Returns (loss contribution of the owned rows / (2*Bg), dz_i, dz_j) — dz_* have npairs rows."""
+    _chk(z_i, z_j)
+    Bg, d = z_i.shape
+    npairs = Bg if npairs is None else npairs
+    ws = torch.empty((lib.nsid_ntxent_ws_floats(Bg),), device=z_i.device, dtype=torch.float32)
+    loss = torch.empty((1,), device=z_i.device, dtype=torch.float32)
+    dzi = torch.empty((npairs, d), device=z_i.device, dtype=torch.float32) if want_grad else None
+    dzj = torch.empty((npairs, d), device=z_i.device, dtype=torch.float32) if want_grad else None
+    call("nsid_ntxent_fwd_bwd", _p(z_i), _p(z_j), Bg, d, float(tau), p0, npairs, _p(ws), _p(loss), _p(dzi), _p(dzj),
+         _stream())
+    return loss, dzi, dzj
+
+
+# ------------------------------------------------------------------------------------------------ optimiser
+def sumsq_partial(g_flat) -> torch.Tensor:
+    _chk(g_flat)
+    n = g_flat.numel()
+    partial = torch.empty((lib.nsid_sumsq_blocks(n),), device=g_flat.device, dtype=torch.float32)
+    call("nsid_sumsq_partial", _p(g_flat), n, _p(partial), _stream())
+    return partial
+
+
+def adam_step(p, g, m, v, hyper, step, partial, gnorm_out) -> None:
+    _chk(p, g, m, v, hyper, partial, gnorm_out)
+    call("nsid_adam_step", _p(p), _p(g), _p(m), _p(v), p.numel(), _p(hyper), _p(step), _p(partial), partial.numel(),
+         _p(gnorm_out), _stream())
+
+
+# ------------------------------------------------------------------------------------------------ layout
+def bcn_to_rows(x) -> torch.Tensor:
+    """(B, C, N[, 1]) reference layout -> node-major (B*N, C)"""
+    _chk(x)
+    B, C, N = x.shape[0], x.shape[1], x.shape[2]
+    rows = torch.empty((B * N, C), device=x.device, dtype=torch.float32)
+    call("nsid_bcn_to_rows", _p(x), B, C, N, _p(rows), C, _stream())
+    return rows
+
+
+def rows_to_bcn(rows, B, N) -> torch.Tensor:
+    _chk(rows)
+    C = rows.shape[-1]
+    x = torch.empty((B, C, N), device=rows.device, dtype=torch.float32)
+    call("nsid_rows_to_bcn", _p(rows), C, B, C, N, _p(x), _stream())
+    return x
