@@ -101,31 +101,29 @@ __global__ __launch_bounds__(KNN_THREADS) void knn_kernel(const float* __restric
       // ---- phase 3: k*dilation rounds of arg-min per row; key = (orderable distance, index) so ties take the
       // lower index; a chosen element is retired by setting it to +inf in the owning lane's registers.
       for (int i = 0; i < 16; ++i) {
-        float v[4];
+        // keys are (orderable distance << 32 | node id); a slot that is out of range or already taken holds ~0,
+        // which loses against every live key (NaN distances included), so an emitted id is always < N.
+        unsigned long long key[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int j = lane + 64 * e;
-          v[e] = (e < NE && j < N) ? strip[i * SLD + j] : __builtin_inff();
+          key[e] = (e < NE && j < N) ? (((unsigned long long)orderable(strip[i * SLD + j]) << 32) | (unsigned)j)
+                                     : ~0ull;
         }
         int32_t* out = idx + ((long)b * N + 16 * s + i) * k;
         for (int round = 0; round < kd; ++round) {
-          unsigned long long best = ~0ull;
+          unsigned long long best = key[0];
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const unsigned long long key = ((unsigned long long)orderable(v[e]) << 32) | (unsigned)(lane + 64 * e);
-            best = key < best ? key : best;
-          }
+          for (int e = 1; e < 4; ++e) best = key[e] < best ? key[e] : best;
 #pragma unroll
           for (int o = 32; o > 0; o >>= 1) {
             const unsigned long long other = __shfl_xor(best, o, 64);
             best = other < best ? other : best;
           }
-          const int j = (int)(best & 0xFFFFFFFFull);
-          if (lane == (j & 63)) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
-              if (e == (j >> 6)) v[e] = __builtin_inff();
-          }
+          for (int e = 0; e < 4; ++e)
+            if (key[e] == best) key[e] = ~0ull;            // node ids are unique, so exactly one slot matches
+          const int j = min((int)(best & 0xFFFFFFFFull), N - 1);
           if (lane == 0 && (round % dilation) == 0) out[round / dilation] = j;
         }
       }

@@ -246,6 +246,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
                                                    const float* __restrict__ partial, int nblocks,
                                                    float* __restrict__ gnorm_out) {
   __shared__ float coef_s;
+  __shared__ int skip_s;
   __shared__ double red[4];
   {  // every block recomputes the global norm from the partials (<= a few thousand floats, L2-resident)
     double s = 0.0;
@@ -259,10 +260,12 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
       float c = 1.f;
       if (max_norm > 0.f) { c = max_norm / (norm + 1e-6f); c = c < 1.f ? c : 1.f; }   // torch: clamp(max=1)
       coef_s = c;
+      skip_s = !isfinite(norm);     // NaN/Inf loss => NaN/Inf gradients: skip the batch like train.py:65-68
       if (blockIdx.x == 0 && gnorm_out != nullptr) gnorm_out[0] = norm;
     }
     __syncthreads();
   }
+  if (skip_s) return;
   const float coef = coef_s;
   const float lr = hyper[0], b1 = hyper[1], b2 = hyper[2], eps = hyper[3];
   const double t = (double)(*step + 1);                 // the host-visible counter is bumped by adam_tick_kernel
@@ -279,7 +282,9 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     p[i] -= step_size * (mi / denom);
   }
 }
-__global__ void adam_tick_kernel(int64_t* step) { *step += 1; }
+__global__ void adam_tick_kernel(int64_t* step, const float* gnorm) {
+  if (gnorm == nullptr || isfinite(gnorm[0])) *step += 1;
+}
 
 // ------------------------------------------------------------------ (B,C,N) <-> rows (B*N, C): 32x32 LDS transpose
 __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ src, long src_batch, long src_ld,
@@ -396,7 +401,7 @@ extern "C" int nsid_adam_step(float* p, const float* g, float* m, float* v, long
   hipStream_t s = static_cast<hipStream_t>(stream);
   hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n, 4096)), dim3(256), 0, s, p, g, m, v, n, hyper, step, partial,
                      nblocks, gnorm_out);
-  hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, s, step);
+  hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, s, step, (const float*)gnorm_out);
   return nsid_launch_status();
 }
 

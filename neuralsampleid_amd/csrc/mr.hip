@@ -28,7 +28,7 @@ __global__ __launch_bounds__(256) void mr_fwd_kernel(const float* __restrict__ r
     int arg[4] = {0, 0, 0, 0};
     const int32_t* nb = idx + row * k;
     for (int j = 0; j < k; ++j) {
-      const long nrow = clip0 + nb[j];
+      const long nrow = clip0 + min(max(nb[j], 0), N - 1);     // ids come from the caller: never fault on them
       f32x4 v = *reinterpret_cast<const f32x4*>(r + nrow * ldr + c);
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -67,8 +67,10 @@ __global__ __launch_bounds__(256) void mr_bwd_kernel(const float* __restrict__ d
     const f32x4 g = *reinterpret_cast<const f32x4*>(du + (row0 + n) * (2L * C) + 2 * c);
     const uint8_t* am = argmax + (row0 + n) * C + c;
     const int32_t* nb = idx + (row0 + n) * k;
-    atomicAdd(&acc[nb[am[0]] * C + c], g[1]);
-    atomicAdd(&acc[nb[am[1]] * C + c + 1], g[3]);
+    const int t0 = min(max(nb[min((int)am[0], k - 1)], 0), N - 1);
+    const int t1 = min(max(nb[min((int)am[1], k - 1)], 0), N - 1);
+    atomicAdd(&acc[t0 * C + c], g[1]);
+    atomicAdd(&acc[t1 * C + c + 1], g[3]);
   }
   __syncthreads();
   const int C4 = C >> 2;

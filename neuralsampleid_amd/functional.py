@@ -1,0 +1,311 @@
+"""Block-level forward/backward of the Grapher/FFN stack, composed from the HIP ops (ops.py).
+
+Layout: node-major rows (B*N, C).  A conv+BN(+act) layer keeps only its RAW conv output `r`; the BatchNorm
+affine (scale, shift) rides along as a `BNAffine` and is applied by whichever kernel consumes `r` next (the next
+GEMM's operand load, the kNN/aggregation kernels, or `bn_apply` where the residual stream is materialised).
+
+Every `*_forward(x, P, S, ...)` takes the parameters as a dict `P` of tensors named after the reference's
+state_dict suffixes, and stashes what backward needs in the plain dict `S` (None: inference, nothing kept).
+Every `*_backward(dout, P, S, G)` accumulates parameter gradients INTO the tensors of `G` (same keys as P) and
+returns the input gradient.  The autograd wrappers below and the fused training step share these functions.
+
+Reference sites: Grapher.forward encoder/gcn_lib/torch_vertex.py:183-195, DyGraphConv2d :126-139, MRConv2d :19-34,
+FFN.forward encoder/graph_encoder.py:82-89, Downsample :48-50, GraphEncoder.forward :190-214,
+SimCLR.forward simclr/simclr.py:31-47, GPUPeakExtractorv2.forward peak_extractor.py:45-70.
+"""
+from typing import Dict, List, Optional
+
+import torch
+
+from . import ops
+from .ops import ACT_ELU, ACT_LEAKY, ACT_NONE, ACT_RELU, BNAffine
+
+Tensor = torch.Tensor
+
+
+class KnnTape:
+    """Debug/test hook: record the neighbour indices of every kNN call, optionally replacing them (teacher forcing).
+    kNN is discontinuous, so end-to-end parity is stated as: indices equal outside near-ties, outputs equal when the
+    indices are forced (tests/test_e2e_gpu.py)."""
+
+    def __init__(self, replay: Optional[List[Tensor]] = None):
+        self.replay = list(replay) if replay is not None else None
+        self.recorded: List[Tensor] = []
+        self.pos = 0
+
+
+TAPE: Optional[KnnTape] = None
+
+
+def _bn(P, S_unused, pre):
+    return P[pre + "weight"], P[pre + "bias"], P[pre + "running_mean"], P[pre + "running_var"], \
+        P.get(pre + "num_batches_tracked")
+
+
+def conv_bn(x: Tensor, M: int, K: int, Nout: int, w: Tensor, bias: Optional[Tensor], bn, training: bool,
+            groups: int = 1, in_aff: Optional[BNAffine] = None, act_in: int = ACT_NONE):
+    """r = f(x) W^T (+b) on MFMA, plus the affine of the BatchNorm that follows (batch stats when training)."""
+    gamma, beta, rm, rv, nbt = bn
+    r, stat = ops.linear_fwd(x, ops.w2d(w), bias, M, Nout, K, groups,
+                             in_aff.scale if in_aff else None, in_aff.shift if in_aff else None, act_in,
+                             ACT_NONE, want_stat=training)
+    if training:
+        aff = ops.bn_finalize(stat, M, gamma, beta, rm, rv, nbt)
+    else:
+        aff = ops.bn_eval_affine(gamma, beta, rm, rv)
+    return r, aff
+
+
+# ------------------------------------------------------------------------------------------------ stem
+def stem_forward(nodes: Tensor, P: Dict[str, Tensor], S: Optional[dict], training: bool) -> Tensor:
+    M, K = nodes.shape
+    C = P["0.weight"].shape[0]
+    r, aff = conv_bn(nodes, M, K, C, P["0.weight"], None, _bn(P, S, "1."), training)
+    x0 = ops.bn_apply(r, aff, ACT_LEAKY)
+    if S is not None:
+        S.update(nodes=nodes, r=r, aff=aff)
+    return x0
+
+
+def stem_backward(dx0: Tensor, P, S, G, need_input_grad: bool = True) -> Optional[Tensor]:
+    nodes, r, aff = S["nodes"], S["r"], S["aff"]
+    M, K = nodes.shape
+    C = r.shape[1]
+    dr = ops.bn_backward(dx0, r, aff, ACT_LEAKY, G["1.weight"], G["1.bias"])
+    ops.linear_bwd_weight(dr, nodes, ops.w2d(G["0.weight"]), M, C, K)
+    return ops.linear_bwd_data(dr, ops.w2d(P["0.weight"]), M, C, K) if need_input_grad else None
+
+
+# ------------------------------------------------------------------------------------------------ Grapher
+def grapher_forward(x0: Tensor, P, S: Optional[dict], B: int, N: int, k: int, dilation: int, training: bool) -> Tensor:
+    M, C = x0.shape
+    r1, a1 = conv_bn(x0, M, C, C, P["fc1.0.weight"], P["fc1.0.bias"], _bn(P, S, "fc1.1."), training)
+    idx = ops.knn_graph(r1, B, N, C, k, dilation, a1)
+    if TAPE is not None:
+        TAPE.recorded.append(idx)
+        if TAPE.replay is not None:
+            idx = TAPE.replay[TAPE.pos].to(device=idx.device, dtype=torch.int32).contiguous()
+            TAPE.pos += 1
+    u, amax = ops.mr_aggregate_fwd(r1, idx, B, N, C, a1, want_argmax=S is not None)
+    pre = "graph_conv.gconv.nn."
+    r2, a2 = conv_bn(u, M, C // 2, C // 2, P[pre + "0.weight"], P[pre + "0.bias"], _bn(P, S, pre + "1."), training,
+                     groups=4)
+    r3, a3 = conv_bn(r2, M, 2 * C, C, P["fc2.0.weight"], P["fc2.0.bias"], _bn(P, S, "fc2.1."), training,
+                     in_aff=a2, act_in=ACT_RELU)
+    x1 = ops.bn_apply(r3, a3, ACT_NONE, residual=x0)
+    if S is not None:
+        S.update(x0=x0, r1=r1, a1=a1, idx=idx, amax=amax, u=u, r2=r2, a2=a2, r3=r3, a3=a3, B=B, N=N)
+    return x1
+
+
+def grapher_backward(dx1: Tensor, P, S, G) -> Tensor:
+    x0, r1, a1, idx, amax, u, r2, a2, r3, a3 = (S[k_] for k_ in ("x0", "r1", "a1", "idx", "amax", "u", "r2", "a2",
+                                                                  "r3", "a3"))
+    B, N = S["B"], S["N"]
+    M, C = x0.shape
+    pre = "graph_conv.gconv.nn."
+    # fc2 (+BN), input = relu(BN(r2))
+    dr3 = ops.bn_backward(dx1, r3, a3, ACT_NONE, G["fc2.1.weight"], G["fc2.1.bias"])
+    ops.colsum_acc(dr3, G["fc2.0.bias"])
+    ops.linear_bwd_weight(dr3, r2, ops.w2d(G["fc2.0.weight"]), M, C, 2 * C, 1, a2.scale, a2.shift, ACT_RELU)
+    dv = ops.linear_bwd_data(dr3, ops.w2d(P["fc2.0.weight"]), M, C, 2 * C)
+    # grouped conv (+BN+ReLU), input = u
+    dr2 = ops.bn_backward(dv, r2, a2, ACT_RELU, G[pre + "1.weight"], G[pre + "1.bias"], inplace=True)
+    ops.colsum_acc(dr2, G[pre + "0.bias"])
+    ops.linear_bwd_weight(dr2, u, ops.w2d(G[pre + "0.weight"]), M, C // 2, C // 2, 4)
+    du = ops.linear_bwd_data(dr2, ops.w2d(P[pre + "0.weight"]), M, C // 2, C // 2, 4)
+    # max-relative aggregation: route to arg-max neighbour and centre; kNN itself carries no gradient
+    dy = ops.mr_aggregate_bwd(du, idx, amax, B, N, C)
+    # fc1 (+BN), input = x0
+    dr1 = ops.bn_backward(dy, r1, a1, ACT_NONE, G["fc1.1.weight"], G["fc1.1.bias"], inplace=True)
+    ops.colsum_acc(dr1, G["fc1.0.bias"])
+    ops.linear_bwd_weight(dr1, x0, ops.w2d(G["fc1.0.weight"]), M, C, C)
+    return ops.linear_bwd_data(dr1, ops.w2d(P["fc1.0.weight"]), M, C, C, 1, addend=dx1)
+
+
+# ------------------------------------------------------------------------------------------------ FFN
+def ffn_forward(x1: Tensor, P, S: Optional[dict], training: bool) -> Tensor:
+    M, C = x1.shape
+    H = P["fc1.0.weight"].shape[0]
+    r4, a4 = conv_bn(x1, M, C, H, P["fc1.0.weight"], None, _bn(P, S, "fc1.1."), training)
+    r5, a5 = conv_bn(r4, M, H, C, P["fc2.0.weight"], None, _bn(P, S, "fc2.1."), training, in_aff=a4, act_in=ACT_RELU)
+    x2 = ops.bn_apply(r5, a5, ACT_NONE, residual=x1)
+    if S is not None:
+        S.update(x1=x1, r4=r4, a4=a4, r5=r5, a5=a5)
+    return x2
+
+
+def ffn_backward(dx2: Tensor, P, S, G) -> Tensor:
+    x1, r4, a4, r5, a5 = S["x1"], S["r4"], S["a4"], S["r5"], S["a5"]
+    M, C = x1.shape
+    H = r4.shape[1]
+    dr5 = ops.bn_backward(dx2, r5, a5, ACT_NONE, G["fc2.1.weight"], G["fc2.1.bias"])
+    ops.linear_bwd_weight(dr5, r4, ops.w2d(G["fc2.0.weight"]), M, C, H, 1, a4.scale, a4.shift, ACT_RELU)
+    dh = ops.linear_bwd_data(dr5, ops.w2d(P["fc2.0.weight"]), M, C, H)
+    dr4 = ops.bn_backward(dh, r4, a4, ACT_RELU, G["fc1.1.weight"], G["fc1.1.bias"], inplace=True)
+    ops.linear_bwd_weight(dr4, x1, ops.w2d(G["fc1.0.weight"]), M, H, C)
+    return ops.linear_bwd_data(dr4, ops.w2d(P["fc1.0.weight"]), M, H, C, 1, addend=dx2)
+
+
+# ------------------------------------------------------------------------------------------------ Downsample
+def downsample_forward(x: Tensor, P, S: Optional[dict], B: int, N: int, training: bool) -> Tensor:
+    M, C = x.shape
+    Co = P["conv.0.weight"].shape[0]
+    No = ops.ds_out_nodes(N)
+    col = ops.im2col3_fwd(x, B, N, C)
+    wp = ops.pack_ds_weight(P["conv.0.weight"])
+    r, aff = conv_bn(col, B * No, 3 * C, Co, wp, P["conv.0.bias"], _bn(P, S, "conv.1."), training)
+    out = ops.bn_apply(r, aff, ACT_NONE)
+    if S is not None:
+        S.update(col=col, wp=wp, r=r, aff=aff, B=B, N=N, C=C)
+    return out
+
+
+def downsample_backward(dout: Tensor, P, S, G) -> Tensor:
+    col, wp, r, aff, B, N, C = (S[k_] for k_ in ("col", "wp", "r", "aff", "B", "N", "C"))
+    Mo, Co = r.shape
+    dr = ops.bn_backward(dout, r, aff, ACT_NONE, G["conv.1.weight"], G["conv.1.bias"])
+    ops.colsum_acc(dr, G["conv.0.bias"])
+    dwp = torch.zeros_like(wp)
+    ops.linear_bwd_weight(dr, col, dwp, Mo, Co, 3 * C)
+    ops.unpack_ds_wgrad(dwp, G["conv.0.weight"])
+    dcol = ops.linear_bwd_data(dr, wp, Mo, Co, 3 * C)
+    return ops.im2col3_bwd(dcol, B, N, C)
+
+
+# ------------------------------------------------------------------------------------------------ proj + node mean
+def proj_mean_forward(x: Tensor, P, S: Optional[dict], B: int, N: int) -> Tensor:
+    """mean over nodes commutes with the 1x1 projection: h = W mean_n(x) + b (32x fewer FLOPs than proj-then-mean)"""
+    M, C = x.shape
+    E = P["weight"].shape[0]
+    xm = ops.node_mean_fwd(x, B, N, C)
+    h, _ = ops.linear_fwd(xm, ops.w2d(P["weight"]), P["bias"], B, E, C)
+    if S is not None:
+        S.update(xm=xm, B=B, N=N, C=C)
+    return h
+
+
+def proj_mean_backward(dh: Tensor, P, S, G) -> Tensor:
+    xm, B, N, C = S["xm"], S["B"], S["N"], S["C"]
+    E = dh.shape[1]
+    ops.linear_bwd_weight(dh, xm, ops.w2d(G["weight"]), B, E, C)
+    ops.colsum_acc(dh, G["bias"])
+    dxm = ops.linear_bwd_data(dh, ops.w2d(P["weight"]), B, E, C)
+    return ops.node_mean_bwd(dxm, B, N, C)
+
+
+# ------------------------------------------------------------------------------------------------ projector
+def projector_forward(h: Tensor, P, S: Optional[dict], eps: float = 1e-10) -> Tensor:
+    B, Hin = h.shape
+    Hid, D = P["0.weight"].shape[0], P["2.weight"].shape[0]
+    a1, _ = ops.linear_fwd(h, P["0.weight"], P["0.bias"], B, Hid, Hin, act_out=ACT_ELU)
+    ks = 8 if Hid >= 2048 else 1
+    p, _ = ops.linear_fwd(a1, P["2.weight"], P["2.bias"], B, D, Hid, ksplit=ks)
+    z, norm = ops.l2norm_fwd(p, eps)
+    if S is not None:
+        S.update(h=h, a1=a1, z=z, norm=norm, eps=eps)
+    return z
+
+
+def projector_backward(dz: Tensor, P, S, G) -> Tensor:
+    h, a1, z, norm, eps = S["h"], S["a1"], S["z"], S["norm"], S["eps"]
+    B, Hin = h.shape
+    Hid, D = a1.shape[1], z.shape[1]
+    dp = ops.l2norm_bwd(dz, z, norm, eps)
+    ops.linear_bwd_weight(dp, a1, G["2.weight"], B, D, Hid)
+    ops.colsum_acc(dp, G["2.bias"])
+    da1 = ops.linear_bwd_data(dp, P["2.weight"], B, D, Hid)
+    dpre = ops.elu_bwd(da1, a1)
+    ops.linear_bwd_weight(dpre, h, G["0.weight"], B, Hid, Hin)
+    ops.colsum_acc(dpre, G["0.bias"])
+    return ops.linear_bwd_data(dpre, P["0.weight"], B, Hid, Hin)
+
+
+# ------------------------------------------------------------------------------------------------ peak extractor
+def patchify_forward(spec: Tensor, P, S: Optional[dict], pb: int, pf: int) -> Tensor:
+    out, minmax = ops.peak_patchify_fwd(spec, P["convs.0.weight"], P["convs.0.bias"], pb, pf)
+    if S is not None:
+        S.update(spec=spec, minmax=minmax, out=out, pb=pb, pf=pf)
+    return out
+
+
+def patchify_backward(dout: Tensor, P, S, G) -> None:
+    ops.peak_patchify_bwd(S["spec"], S["minmax"], S["out"], dout, S["pb"], S["pf"], G["convs.0.weight"],
+                          G["convs.0.bias"])
+
+
+# ================================================================================================ autograd
+class _BlockFn(torch.autograd.Function):
+    """Generic wrapper: forward(fwd, bwd, names, buffers, meta, x, *params) with P assembled from names."""
+
+    @staticmethod
+    def forward(ctx, fwd, bwd, names, buffers, meta, x, *params):
+        P = dict(zip(names, params))
+        P.update(buffers)
+        need = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in params))
+        S = {} if need else None
+        out = fwd(x.contiguous(), P, S, *meta)
+        ctx.S, ctx.P, ctx.bwd, ctx.names = S, P, bwd, names
+        ctx.x_needs = x.requires_grad
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        P, S, names = ctx.P, ctx.S, ctx.names
+        G = {n: torch.zeros_like(P[n]) for n in names}
+        dx = ctx.bwd(dout.contiguous(), P, S, G)
+        ctx.S = None
+        return (None, None, None, None, None, dx if ctx.x_needs else None) + tuple(G[n] for n in names)
+
+
+def run_block(fwd, bwd, module_params: Dict[str, Tensor], module_buffers: Dict[str, Tensor], x: Tensor, *meta):
+    names = tuple(module_params.keys())
+    return _BlockFn.apply(fwd, bwd, names, module_buffers, meta, x, *module_params.values())
+
+
+class _ToRows(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):           # (B, C, N[,1]) -> (B*N, C)
+        ctx.shape = x.shape
+        return ops.bcn_to_rows(x.contiguous())
+
+    @staticmethod
+    def backward(ctx, d):
+        B, N = ctx.shape[0], ctx.shape[2]
+        return ops.rows_to_bcn(d.contiguous(), B, N).reshape(ctx.shape)
+
+
+class _FromRows(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, rows, B, N):  # (B*N, C) -> (B, C, N)
+        return ops.rows_to_bcn(rows.contiguous(), B, N)
+
+    @staticmethod
+    def backward(ctx, d):
+        return ops.bcn_to_rows(d.contiguous()), None, None
+
+
+def to_rows(x: Tensor) -> Tensor:
+    return _ToRows.apply(x)
+
+
+def from_rows(rows: Tensor, B: int, N: int) -> Tensor:
+    return _FromRows.apply(rows, B, N)
+
+
+class _NtxentFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, z_i, z_j, tau):
+        need = z_i.requires_grad or z_j.requires_grad
+        loss, dzi, dzj = ops.ntxent_fwd_bwd(z_i.contiguous(), z_j.contiguous(), tau, want_grad=need)
+        ctx.save_for_backward(dzi, dzj) if need else None
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        dzi, dzj = ctx.saved_tensors
+        return dzi * g, dzj * g, None
+
+
+def ntxent(z_i: Tensor, z_j: Tensor, tau: float) -> Tensor:
+    return _NtxentFn.apply(z_i, z_j, tau)

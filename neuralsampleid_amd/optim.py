@@ -1,0 +1,53 @@
+"""clip_grad_norm_(max_norm) + Adam as two HIP kernels over ONE flat parameter buffer (train.py:73-75, :126).
+
+Parameters, gradients and both Adam moments live in four flat fp32 buffers; every nn.Parameter (and its .grad)
+becomes a 16-byte-aligned view, so the whole optimiser is 2 launches, the gradient all-reduce is one contiguous
+buffer (parallel.py), and nothing here synchronises with the host (hipGraph-capturable; lr lives on the device)."""
+from typing import Iterable, List
+
+import torch
+
+from . import ops
+
+
+class FusedClipAdam:
+    def __init__(self, params: Iterable[torch.nn.Parameter], lr: float = 8e-5, betas=(0.9, 0.999), eps: float = 1e-8,
+                 max_norm: float = 1.0):
+        self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
+        if not self.params:
+            raise ValueError("no trainable parameters")
+        dev = self.params[0].device
+        if dev.type != "cuda":
+            raise RuntimeError("FusedClipAdam needs parameters on the MI355X (cuda) device")
+        self.offsets, total = [], 0
+        for p in self.params:
+            self.offsets.append(total)
+            total += (p.numel() + 3) // 4 * 4              # keep every view 16-byte aligned
+        self.numel = total
+        self.flat_p = torch.zeros(total, device=dev)
+        self.flat_g = torch.zeros(total, device=dev)
+        self.exp_avg = torch.zeros(total, device=dev)
+        self.exp_avg_sq = torch.zeros(total, device=dev)
+        for p, off in zip(self.params, self.offsets):
+            view = self.flat_p[off:off + p.numel()].view_as(p)
+            view.copy_(p.data)
+            p.data = view
+            p.grad = self.flat_g[off:off + p.numel()].view_as(p)
+        self.hyper = torch.tensor([lr, betas[0], betas[1], eps, max_norm if max_norm else 0.0], device=dev)
+        self.step_count = torch.zeros((), dtype=torch.int64, device=dev)
+        self.grad_norm = torch.zeros(1, device=dev)       # pre-clip global norm of the last step
+
+    def zero_grad(self, set_to_none: bool = False):
+        self.flat_g.zero_()
+
+    def set_lr(self, lr: float):
+        self.hyper[0:1].fill_(lr)
+
+    @property
+    def lr(self) -> float:
+        return float(self.hyper[0])
+
+    def step(self):
+        partial = ops.sumsq_partial(self.flat_g)
+        ops.adam_step(self.flat_p, self.flat_g, self.exp_avg, self.exp_avg_sq, self.hyper, self.step_count, partial,
+                      self.grad_norm)

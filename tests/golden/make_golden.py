@@ -313,8 +313,19 @@ def gold_shapes():
         json.dump({k: list(v.shape) for k, v in m.state_dict().items()}, f)
 
 
+def gold_init():
+    """per-key checksums of the reference's default initialisation under torch.manual_seed(42)"""
+    print("init")
+    torch.manual_seed(42)
+    m = SimCLR(CFG, GraphEncoder(CFG, in_channels=CFG["n_filters"], k=3, size="t"))
+    chk = {k: [float(v.double().sum()), float(v.double().norm())] for k, v in m.state_dict().items()
+           if v.is_floating_point() and "relative_pos" not in k}
+    with open(os.path.join(HERE, "init_seed42_checksums.json"), "w") as f:
+        json.dump(chk, f, indent=0)
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
-    only = sys.argv[1:] or ["shapes", "knn", "mrconv", "block", "downsample", "peak", "ntxent", "e2e"]
+    only = sys.argv[1:] or ["shapes", "init", "knn", "mrconv", "block", "downsample", "peak", "ntxent", "e2e"]
     for name in only:
         globals()["gold_" + name]()
