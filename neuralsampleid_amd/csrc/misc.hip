@@ -111,7 +111,7 @@ __global__ __launch_bounds__(256) void patchify_fwd_kernel(const float* __restri
           acc += wf[2 * pb * pf + i * pf + j] * s;
         }
       }
-      dst[f] = acc > 0.f ? acc : 0.f;
+      dst[f] = acc < 0.f ? 0.f : acc;     // NaN (constant clip: 0/0) propagates, as in the reference
     }
   }
 }

@@ -12,7 +12,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // activation codes shared by every kernel (include/nsid.h: NSID_ACT_*)
 __device__ __forceinline__ float nsid_act(float v, int act) {
   switch (act) {
-    case NSID_ACT_RELU: return v > 0.f ? v : 0.f;
+    case NSID_ACT_RELU: return v < 0.f ? 0.f : v;      // NaN-propagating, as torch.relu
     case NSID_ACT_LEAKY: return v > 0.f ? v : 0.2f * v;
     case NSID_ACT_ELU: return v > 0.f ? v : expm1f(v);
     default: return v;

@@ -242,7 +242,7 @@ class _BlockFn(torch.autograd.Function):
     def forward(ctx, fwd, bwd, names, buffers, meta, x, *params):
         P = dict(zip(names, params))
         P.update(buffers)
-        need = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in params))
+        need = any(ctx.needs_input_grad)       # grad mode is always off inside Function.forward
         S = {} if need else None
         out = fwd(x.contiguous(), P, S, *meta)
         ctx.S, ctx.P, ctx.bwd, ctx.names = S, P, bwd, names
@@ -296,7 +296,7 @@ def from_rows(rows: Tensor, B: int, N: int) -> Tensor:
 class _NtxentFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, z_i, z_j, tau):
-        need = z_i.requires_grad or z_j.requires_grad
+        need = any(ctx.needs_input_grad)
         loss, dzi, dzj = ops.ntxent_fwd_bwd(z_i.contiguous(), z_j.contiguous(), tau, want_grad=need)
         ctx.save_for_backward(dzi, dzj) if need else None
         return loss.reshape(())

@@ -13,7 +13,7 @@ class _PatchifyFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, spec, weight, bias, pb, pf):
         P = {"convs.0.weight": weight, "convs.0.bias": bias}
-        need = torch.is_grad_enabled() and (weight.requires_grad or bias.requires_grad)
+        need = any(ctx.needs_input_grad)
         S = {} if need else None
         out = F_.patchify_forward(spec.contiguous(), P, S, pb, pf)
         ctx.S, ctx.P = S, P

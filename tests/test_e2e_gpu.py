@@ -21,6 +21,14 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
 
+@pytest.fixture(autouse=True)
+def _reset_tape():
+    yield
+    from neuralsampleid_amd import functional as F_
+    F_.TAPE = None
+    R.TAPE = None
+
+
 def relerr(a, b):
     a, b = a.detach().cpu().double(), b.detach().cpu().double()
     return float((a - b).norm() / b.norm().clamp_min(1e-30))
@@ -138,8 +146,9 @@ def test_block_modules(golden, tag, C, N, k, d):
     for name, p in blk.named_parameters():
         if "grad." + name in g:
             ref = g.t("grad." + name)
-            if float(ref.norm()) < 1e-4:      # conv bias in front of a BatchNorm: analytically zero
-                assert float(p.grad.norm()) < 1e-3, name
+            if float(ref.abs().max()) < 1e-3:
+                # analytically zero (a bias or BN beta whose shift the next BatchNorm removes): roundoff on both sides
+                assert float(p.grad.abs().max()) < 1e-3, name
             else:
                 assert relerr(p.grad, ref) < 2e-3, (name, relerr(p.grad, ref))
         elif "gradchk." + name in g:
