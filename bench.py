@@ -1,0 +1,194 @@
+#!/usr/bin/env python3
+"""Contrastive-step throughput of the GraFP (GNN) encoder path on MI355X — BASELINE.json's metric.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One step = train.py:53-75 on one synthetic batch, inputs resident in HBM: zero_grad -> peak-extract -> GraphEncoder
+x2 views -> projector -> NT-Xent (global batch) -> backward -> clip_grad_norm_(1.0) -> Adam.  A "clip" is one
+(x_i, x_j) pair.  Every kernel in the step is hand-written HIP from libnsid_hip.so; torch supplies memory, streams,
+the autograd tape and torch.distributed.  Per-GPU batch is fixed (weak scaling); world > 1 adds the z all-gather and
+a SUM all-reduce of the flat gradient buffer over RCCL.
+
+Prints ONE JSON line on rank 0 (fields: the driver's contract + `roofline` + `cpu_baseline`)."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+CFG = {  # hot-path keys of config/grafp.yaml
+    "arch": "grafp", "n_mels": 64, "n_frames": 128, "patch_bins": 4, "patch_frames": 8, "n_filters": 8,
+    "bsz_train": 256, "tau": 0.05, "lr": 8.0e-5, "d": 128, "h": 1024, "u": 32, "dim": 2048,
+}
+FP32_MFMA_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, 64 FLOP/clk/SIMD (= fp32 vector peak)
+HBM_PEAK_GBPS = 8000.0
+
+
+def synth_clips(batch, seed, device):
+    """x_i = randn*20-40 (log-mel-like dB), x_j = x_i + 3*randn"""
+    gi = torch.Generator().manual_seed(seed)
+    gj = torch.Generator().manual_seed(seed + 1)
+    x_i = torch.randn(batch, CFG["n_mels"], CFG["n_frames"], generator=gi) * 20.0 - 40.0
+    x_j = x_i + 3.0 * torch.randn(batch, CFG["n_mels"], CFG["n_frames"], generator=gj)
+    return x_i.to(device), x_j.to(device)
+
+
+def cpu_baseline(k, batch=32, steps=3):
+    """The oracle (CPU restatement of the reference path, pinned to the reference's goldens) timed on this host."""
+    from oracle import ref_torch as R
+    torch.set_num_threads(os.cpu_count() or 1)
+    from neuralsampleid_amd.encoder.graph_encoder import GraphEncoder
+    from neuralsampleid_amd.simclr.simclr import SimCLR
+    torch.manual_seed(42)
+    sd = SimCLR(CFG, GraphEncoder(CFG, in_channels=CFG["n_filters"], k=k, size="t")).state_dict()   # weights only
+    P = {n: v.clone() for n, v in sd.items()}
+    plan = R.encoder_plan("t", k)
+    opt = R.AdamState({n: P[n] for n in R.trainable_keys(P)}, lr=CFG["lr"])
+    x_i, x_j = synth_clips(batch, 0, "cpu")
+    R.train_step(P, x_i, x_j, CFG, plan, opt)          # warm-up
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        R.train_step(P, x_i, x_j, CFG, plan, opt)
+    dt = (time.perf_counter() - t0) / steps
+    return {"value": round(batch / dt, 2), "unit": "clips/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{steps} full contrastive steps at batch {batch} (fp32, oracle/ref_torch.py), {dt:.2f} s/step"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=CFG["bsz_train"], help="clips (pairs) per GPU")
+    ap.add_argument("--k", type=int, default=3, help="kNN neighbours (GraphEncoder default 3; train.py --k default 5)")
+    ap.add_argument("--no-graph", action="store_true", help="do not capture the step in a hipGraph")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    import torch.distributed as dist
+    from neuralsampleid_amd import ops, parallel
+    from neuralsampleid_amd.encoder.graph_encoder import GraphEncoder
+    from neuralsampleid_amd.optim import FusedClipAdam
+    from neuralsampleid_amd.simclr.simclr import SimCLR
+
+    rank, local, world = parallel.init_from_env("nccl")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    torch.manual_seed(42)                                   # identical initial weights on every rank
+    model = SimCLR(CFG, GraphEncoder(CFG, in_channels=CFG["n_filters"], k=args.k, size="t")).to(dev).train()
+    opt = FusedClipAdam(model.parameters(), lr=CFG["lr"], max_norm=1.0)
+    x_i, x_j = synth_clips(args.batch, 1000 + 2 * rank, dev)   # each rank owns different clips
+    loss_buf = torch.zeros((), device=dev)
+
+    def step():
+        opt.zero_grad()
+        _, _, z_i, z_j = model(x_i, x_j)
+        loss = parallel.dist_ntxent_loss(z_i, z_j, CFG)
+        loss.backward()
+        parallel.allreduce_gradients(opt.flat_g)
+        opt.step()
+        loss_buf.copy_(loss.detach())
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # ---- warm-up (eager), then capture the whole step in a hipGraph (launch-bound inner loop: ~1.2k kernels/step)
+    n_eager = max(1, min(args.warmup, 3))
+    for _ in range(n_eager):
+        step()
+    graph = None
+    if not args.no_graph and world == 1:
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                step()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                step()
+        except Exception as e:        # capture is an optimisation, never a requirement
+            print(f"[bench] hipGraph capture unavailable ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
+            graph = None
+            torch.cuda.synchronize()
+    run = graph.replay if graph is not None else step
+    for _ in range(max(0, args.warmup - n_eager)):
+        run()
+
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        run()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t)
+    final_loss = float(loss_buf)
+
+    roofline, kernels = None, None
+    if rank == 0 and not args.no_roofline:
+        # per-launch HIP-event timing of the GEMM family in one instrumented eager step (events on the launch stream)
+        ops.PROFILE = ops.KernelProfile()
+        step()
+        prof = ops.PROFILE.summary()
+        ops.PROFILE = None
+        kernels = {n: {"launches": d["launches"], "avg_us": round(1e3 * d["ms"] / d["launches"], 2),
+                       "tflops": round(d["flops"] / (d["ms"] * 1e-3) / 1e12, 2),
+                       "share_of_step": round(d["ms"] / (1e3 * elapsed / args.steps), 3)} for n, d in prof.items()}
+        dom = max(prof, key=lambda n: prof[n]["ms"])
+        d = prof[dom]
+        ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
+        roofline = {"kernel": dom, "bound": "mfma", "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
+                    "unit": "TFLOP/s", "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                    "launches_per_step": d["launches"], "avg_launch_us": round(1e3 * d["ms"] / d["launches"], 2),
+                    "flops_per_launch": round(d["flops"] / d["launches"]),
+                    "method": "HIP events around every launch in one instrumented eager step after the timed region"}
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(args.k)
+
+    if rank == 0:
+        clips = args.batch * world * args.steps
+        ms = 1e3 * elapsed / args.steps
+        step_bytes = 57e6 * 2.0 * args.batch       # 57 MB / clip-pair at 2 B/elem -> x2 for fp32 storage
+        out = {
+            "metric": "audio clips/sec (contrastive step, grafp encoder)", "value": round(clips / elapsed, 1),
+            "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"grafp.yaml GraphEncoder('t', k={args.k}) full contrastive step "
+                                   f"(fwd x2 views + NT-Xent + bwd + clip + Adam), batch={args.batch} synthetic "
+                                   f"(64,128) log-mel clip pairs per GPU, random-init weights",
+                       "global_batch": args.batch * world, "k": args.k, "parallelism": f"dp{world}",
+                       "hipgraph": graph is not None, "final_loss": round(final_loss, 5)},
+            "roofline": roofline,
+            "step_hbm_frac_algorithmic": round(step_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+            "kernels": kernels,
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

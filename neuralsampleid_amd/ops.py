@@ -13,6 +13,38 @@ BN_MOMENTUM = 0.1
 BN_EPS = 1e-5
 
 
+class KernelProfile:
+    """Opt-in per-launch timing of the GEMM family with HIP events recorded on the launch stream (bench.py roofline).
+    Keys follow the kernel template instantiation that the C side dispatches to (csrc/gemm.hip)."""
+
+    def __init__(self):
+        self.records = []          # (kernel, flops, algorithmic bytes, start event, end event)
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for name, flops, nbytes, e0, e1 in self.records:
+            d = out.setdefault(name, {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
+            d["launches"] += 1
+            d["ms"] += e0.elapsed_time(e1)
+            d["flops"] += flops
+            d["bytes"] += nbytes
+        return out
+
+
+PROFILE: Optional[KernelProfile] = None
+
+
+def _timed(name, flops, nbytes, fn):
+    if PROFILE is None:
+        return fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    fn()
+    e1.record()
+    PROFILE.records.append((name, flops, nbytes, e0, e1))
+
+
 def _p(t: Optional[torch.Tensor]):
     return None if t is None else t.data_ptr()
 
@@ -48,8 +80,10 @@ def linear_fwd(x, w, bias, M, Nout, K, groups=1, in_scale=None, in_shift=None, a
     if out is None:
         out = (torch.zeros if ksplit > 1 else torch.empty)((M, groups * Nout), device=x.device, dtype=torch.float32)
     stat = torch.empty((2, row_tiles(M), groups * Nout), device=x.device, dtype=torch.float32) if want_stat else None
-    call("nsid_linear_fwd", _p(x), ldx, _p(w), _p(bias), _p(out), out.shape[-1], M, Nout, K, groups, _p(in_scale),
-         _p(in_shift), act_in, act_out, _p(stat), ksplit, _stream())
+    name = "gemm_kernel<128,%d,true,true>" % (64 if Nout <= 64 else 128)
+    _timed(name, 2.0 * M * Nout * K * groups, 4.0 * groups * (M * K + Nout * K + M * Nout), lambda: call(
+        "nsid_linear_fwd", _p(x), ldx, _p(w), _p(bias), _p(out), out.shape[-1], M, Nout, K, groups, _p(in_scale),
+        _p(in_shift), act_in, act_out, _p(stat), ksplit, _stream()))
     return out, stat
 
 
@@ -57,16 +91,21 @@ def linear_bwd_data(dout, w, M, Nout, K, groups=1, addend=None, out=None) -> tor
     _chk(dout, w, addend)
     if out is None:
         out = torch.empty((M, groups * K), device=dout.device, dtype=torch.float32)
-    call("nsid_linear_bwd_data", _p(dout), dout.shape[-1], _p(w), _p(addend),
-         0 if addend is None else addend.shape[-1], _p(out), out.shape[-1], M, Nout, K, groups, _stream())
+    name = "gemm_kernel<128,%d,true,false>" % (64 if K <= 64 else 128)
+    _timed(name, 2.0 * M * Nout * K * groups,
+           4.0 * groups * (M * Nout + Nout * K + M * K * (2 if addend is not None else 1)), lambda: call(
+               "nsid_linear_bwd_data", _p(dout), dout.shape[-1], _p(w), _p(addend),
+               0 if addend is None else addend.shape[-1], _p(out), out.shape[-1], M, Nout, K, groups, _stream()))
     return out
 
 
 def linear_bwd_weight(dout, x, dw, M, Nout, K, groups=1, in_scale=None, in_shift=None, act_in=ACT_NONE) -> None:
     """dw += dout^T f(x)"""
     _chk(dout, x, dw, in_scale, in_shift)
-    call("nsid_linear_bwd_weight", _p(dout), dout.shape[-1], _p(x), x.shape[-1], _p(dw), M, Nout, K, groups,
-         _p(in_scale), _p(in_shift), act_in, _stream())
+    name = "gemm_kernel<%s,false,false>" % ("64,64" if (Nout <= 64 or K <= 64) else "128,128")
+    _timed(name, 2.0 * M * Nout * K * groups, 4.0 * groups * (M * Nout + M * K + Nout * K), lambda: call(
+        "nsid_linear_bwd_weight", _p(dout), dout.shape[-1], _p(x), x.shape[-1], _p(dw), M, Nout, K, groups,
+        _p(in_scale), _p(in_shift), act_in, _stream()))
 
 
 def colsum_acc(x, out) -> None:
