@@ -43,7 +43,11 @@ def synth_clips(batch, seed, device):
 def cpu_baseline(k, batch=32, steps=3):
     """The oracle (CPU restatement of the reference path, pinned to the reference's goldens) timed on this host."""
     from oracle import ref_torch as R
-    torch.set_num_threads(os.cpu_count() or 1)
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    torch.set_num_threads(max(1, min(cores, 16)))      # the GPU box gives one GPU a 16-core share
     from neuralsampleid_amd.encoder.graph_encoder import GraphEncoder
     from neuralsampleid_amd.simclr.simclr import SimCLR
     torch.manual_seed(42)
@@ -59,6 +63,10 @@ def cpu_baseline(k, batch=32, steps=3):
     dt = (time.perf_counter() - t0) / steps
     return {"value": round(batch / dt, 2), "unit": "clips/s", "cores": torch.get_num_threads(), "kind": "port",
             "sample": f"{steps} full contrastive steps at batch {batch} (fp32, oracle/ref_torch.py), {dt:.2f} s/step"}
+
+
+def log(msg):
+    print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
 
 def main():
@@ -108,8 +116,11 @@ def main():
 
     # ---- warm-up (eager), then capture the whole step in a hipGraph (launch-bound inner loop: ~1.2k kernels/step)
     n_eager = max(1, min(args.warmup, 3))
-    for _ in range(n_eager):
+    for i in range(n_eager):
         step()
+        torch.cuda.synchronize()
+        if rank == 0:
+            log(f"eager warm-up step {i} done, loss {float(loss_buf):.4f}")
     graph = None
     if not args.no_graph and world == 1:
         try:
@@ -122,6 +133,8 @@ def main():
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
                 step()
+            if rank == 0:
+                log("step captured in a hipGraph")
         except Exception as e:        # capture is an optimisation, never a requirement
             print(f"[bench] hipGraph capture unavailable ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
             graph = None
@@ -136,6 +149,8 @@ def main():
         run()
     barrier()
     elapsed = time.perf_counter() - t0
+    if rank == 0:
+        log(f"timed {args.steps} steps: {1e3 * elapsed / args.steps:.2f} ms/step")
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -163,7 +178,9 @@ def main():
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        log("timing the CPU baseline (oracle) ...")
         cpu = cpu_baseline(args.k)
+        log(f"cpu baseline {cpu['value']} clips/s on {cpu['cores']} threads")
 
     if rank == 0:
         clips = args.batch * world * args.steps

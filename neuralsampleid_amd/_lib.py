@@ -5,6 +5,9 @@ RuntimeError on a non-zero return code."""
 import ctypes
 import os
 
+import torch  # noqa: F401  -- must come first: torch bundles its own libamdhip64; loading the kernel library before it
+#                              would bind the system HIP runtime and leave two runtimes in one process
+
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libnsid_hip.so")
 

@@ -28,7 +28,22 @@ def _deps():
     return max(os.path.getmtime(h) for h in hdrs)
 
 
+def _source_hash() -> str:
+    import hashlib
+    h = hashlib.sha256(" ".join(FLAGS[:6]).encode())
+    for f in [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(CSRC, "nsid_common.h"),
+                                                         os.path.join(ROOT, "include", "nsid.h")]:
+        h.update(open(f, "rb").read())
+    return h.hexdigest()
+
+
 def build_lib(force: bool = False, verbose: bool = True) -> str:
+    # the .so travels to the GPU box without its objects and with fresh mtimes: decide by content, not by time
+    stamp = LIB + ".srchash"
+    digest = _source_hash()
+    if not force and os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read().strip() == digest:
+        return LIB
+    force = True
     os.makedirs(OBJ_DIR, exist_ok=True)
     hdr_time = _deps()
     jobs = []
@@ -59,6 +74,8 @@ def build_lib(force: bool = False, verbose: bool = True) -> str:
             raise RuntimeError("link failed:\n" + r.stderr)
         if verbose:
             print(f"built {LIB} ({os.path.getsize(LIB) / 1024:.0f} KB)")
+    with open(stamp, "w") as f:
+        f.write(digest)
     return LIB
 
 

@@ -199,7 +199,7 @@ extern "C" int nsid_bn_finalize(const float* stat, int tiles, int C, int M, cons
   NSID_REQUIRE(stat && gamma && beta && scale && shift && mean && invstd && C > 0 && M > 0);
   NSID_REQUIRE(tiles == nsid_row_tiles(M));
   NSID_REQUIRE((running_mean == nullptr) == (running_var == nullptr));
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 127) / 128), dim3(128), 0, static_cast<hipStream_t>(stream), stat,
+  NSID_LAUNCH(bn_finalize_kernel, dim3((C + 127) / 128), dim3(128), 0, static_cast<hipStream_t>(stream), stat,
                      tiles, C, M, gamma, beta, running_mean, running_var, nbt, momentum, eps, scale, shift, mean,
                      invstd);
   return nsid_launch_status();
@@ -209,7 +209,7 @@ extern "C" int nsid_bn_eval_affine(const float* gamma, const float* beta, const 
                                    const float* running_var, float eps, int C, float* scale, float* shift,
                                    void* stream) {
   NSID_REQUIRE(gamma && beta && running_mean && running_var && scale && shift && C > 0);
-  hipLaunchKernelGGL(bn_eval_affine_kernel, dim3((C + 127) / 128), dim3(128), 0, static_cast<hipStream_t>(stream),
+  NSID_LAUNCH(bn_eval_affine_kernel, dim3((C + 127) / 128), dim3(128), 0, static_cast<hipStream_t>(stream),
                      gamma, beta, running_mean, running_var, eps, C, scale, shift);
   return nsid_launch_status();
 }
@@ -219,7 +219,7 @@ extern "C" int nsid_bn_apply(const float* r, const float* scale, const float* sh
   NSID_REQUIRE(r && scale && shift && out && M > 0 && C > 0 && C % 4 == 0);
   NSID_REQUIRE(nsid_aligned16(r) && nsid_aligned16(out) && nsid_aligned16(scale) && nsid_aligned16(shift));
   const long n4 = (long)M * C / 4;
-  hipLaunchKernelGGL(bn_apply_kernel, dim3(stream_grid(n4)), dim3(256), 0, static_cast<hipStream_t>(stream), r, scale,
+  NSID_LAUNCH(bn_apply_kernel, dim3(stream_grid(n4)), dim3(256), 0, static_cast<hipStream_t>(stream), r, scale,
                      shift, act, residual, out, n4, C / 4);
   return nsid_launch_status();
 }
@@ -229,7 +229,7 @@ extern "C" int nsid_bn_bwd_reduce(const float* dout, const float* r, int M, int 
                                   void* stream) {
   NSID_REQUIRE(dout && r && scale && shift && mean && invstd && partial && M > 0 && C > 0 && C % 4 == 0);
   const int tiles = nsid_row_tiles(M);
-  hipLaunchKernelGGL((col_reduce_kernel<1>), dim3(tiles), dim3(256), 0, static_cast<hipStream_t>(stream), dout, r,
+  NSID_LAUNCH((col_reduce_kernel<1>), dim3(tiles), dim3(256), 0, static_cast<hipStream_t>(stream), dout, r,
                      (long)C, M, C, scale, shift, mean, invstd, act, partial, tiles);
   return nsid_launch_status();
 }
@@ -237,7 +237,7 @@ extern "C" int nsid_bn_bwd_reduce(const float* dout, const float* r, int M, int 
 extern "C" int nsid_bn_bwd_finalize(const float* partial, int tiles, int C, int M, float* dgamma, float* dbeta,
                                     float* coef, void* stream) {
   NSID_REQUIRE(partial && coef && C > 0 && M > 0 && tiles == nsid_row_tiles(M));
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 127) / 128), dim3(128), 0, static_cast<hipStream_t>(stream),
+  NSID_LAUNCH(bn_bwd_finalize_kernel, dim3((C + 127) / 128), dim3(128), 0, static_cast<hipStream_t>(stream),
                      partial, tiles, C, M, dgamma, dbeta, coef);
   return nsid_launch_status();
 }
@@ -247,7 +247,7 @@ extern "C" int nsid_bn_bwd_apply(const float* dout, const float* r, int M, int C
                                  const float* coef, float* dr, void* stream) {
   NSID_REQUIRE(dout && r && scale && shift && mean && invstd && coef && dr && M > 0 && C > 0 && C % 4 == 0);
   const long n4 = (long)M * C / 4;
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(stream_grid(n4)), dim3(256), 0, static_cast<hipStream_t>(stream), dout,
+  NSID_LAUNCH(bn_bwd_apply_kernel, dim3(stream_grid(n4)), dim3(256), 0, static_cast<hipStream_t>(stream), dout,
                      r, n4, C / 4, scale, shift, mean, invstd, act, coef, dr);
   return nsid_launch_status();
 }
@@ -294,7 +294,7 @@ __global__ __launch_bounds__(256) void colsum_atomic_kernel(const float* __restr
 
 extern "C" int nsid_colsum_acc(const float* x, int ldx, int M, int C, float* out, void* stream) {
   NSID_REQUIRE(x && out && M > 0 && C > 0 && C % 4 == 0 && ldx % 4 == 0 && nsid_aligned16(x));
-  hipLaunchKernelGGL(colsum_atomic_kernel, dim3(nsid_row_tiles(M)), dim3(256), 0, static_cast<hipStream_t>(stream), x,
+  NSID_LAUNCH(colsum_atomic_kernel, dim3(nsid_row_tiles(M)), dim3(256), 0, static_cast<hipStream_t>(stream), x,
                      (long)ldx, M, C, out);
   return nsid_launch_status();
 }

@@ -254,7 +254,7 @@ template <int BM, int BN, bool AR, bool BR>
 int launch(const GemmArgs& p, int groups, hipStream_t s) {
   const int tiles = ((p.I + BM - 1) / BM) * ((p.J + BN - 1) / BN);
   dim3 grid(tiles, p.rsplit, groups);
-  hipLaunchKernelGGL((gemm_kernel<BM, BN, AR, BR>), grid, dim3(256), 0, s, p);
+  NSID_LAUNCH((gemm_kernel<BM, BN, AR, BR>), grid, dim3(256), 0, s, p);
   return nsid_launch_status();
 }
 

@@ -149,7 +149,7 @@ extern "C" int nsid_knn_graph(const float* r, int ldr, const float* scale, const
       return NSID_ELAUNCH;
     configured = 160 * 1024;
   }
-  hipLaunchKernelGGL(knn_kernel, dim3(B), dim3(KNN_THREADS), bytes, static_cast<hipStream_t>(stream), r, (long)ldr,
+  NSID_LAUNCH(knn_kernel, dim3(B), dim3(KNN_THREADS), bytes, static_cast<hipStream_t>(stream), r, (long)ldr,
                      scale, shift, N, C, k, dilation, idx);
   return nsid_launch_status();
 }

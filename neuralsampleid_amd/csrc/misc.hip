@@ -310,26 +310,26 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict_
 extern "C" int nsid_im2col3_fwd(const float* x, int B, int N, int C, float* col, void* stream) {
   NSID_REQUIRE(x && col && B > 0 && N > 0 && C > 0 && C % 4 == 0 && nsid_aligned16(x) && nsid_aligned16(col));
   const int No = (N - 1) / 2 + 1;
-  hipLaunchKernelGGL(im2col3_fwd_kernel, dim3(grid_for((long)B * No * 3 * (C / 4))), dim3(256), 0,
+  NSID_LAUNCH(im2col3_fwd_kernel, dim3(grid_for((long)B * No * 3 * (C / 4))), dim3(256), 0,
                      static_cast<hipStream_t>(stream), x, B, N, No, C, col);
   return nsid_launch_status();
 }
 extern "C" int nsid_im2col3_bwd(const float* dcol, int B, int N, int C, float* dx, void* stream) {
   NSID_REQUIRE(dcol && dx && B > 0 && N > 0 && C > 0 && C % 4 == 0 && nsid_aligned16(dcol) && nsid_aligned16(dx));
   const int No = (N - 1) / 2 + 1;
-  hipLaunchKernelGGL(im2col3_bwd_kernel, dim3(grid_for((long)B * N * (C / 4))), dim3(256), 0,
+  NSID_LAUNCH(im2col3_bwd_kernel, dim3(grid_for((long)B * N * (C / 4))), dim3(256), 0,
                      static_cast<hipStream_t>(stream), dcol, B, N, No, C, dx);
   return nsid_launch_status();
 }
 extern "C" int nsid_pack_ds_weight(const float* w, int Cout, int Cin, float* wp, void* stream) {
   NSID_REQUIRE(w && wp && Cout > 0 && Cin > 0);
-  hipLaunchKernelGGL(pack_ds_weight_kernel, dim3(grid_for((long)Cout * 3 * Cin)), dim3(256), 0,
+  NSID_LAUNCH(pack_ds_weight_kernel, dim3(grid_for((long)Cout * 3 * Cin)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), w, Cout, Cin, wp);
   return nsid_launch_status();
 }
 extern "C" int nsid_unpack_ds_wgrad(const float* dwp, int Cout, int Cin, float* dw, void* stream) {
   NSID_REQUIRE(dwp && dw && Cout > 0 && Cin > 0);
-  hipLaunchKernelGGL(unpack_ds_wgrad_kernel, dim3(grid_for((long)Cout * 3 * Cin)), dim3(256), 0,
+  NSID_LAUNCH(unpack_ds_wgrad_kernel, dim3(grid_for((long)Cout * 3 * Cin)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), dwp, Cout, Cin, dw);
   return nsid_launch_status();
 }
@@ -340,7 +340,7 @@ extern "C" int nsid_peak_patchify_fwd(const float* spec, const float* w, const f
   NSID_REQUIRE(H % pb == 0 && W % pf == 0 && ldo >= F);
   const size_t bytes = ((size_t)F * 3 * pb * pf + 8) * sizeof(float);
   NSID_REQUIRE(bytes <= 48 * 1024);
-  hipLaunchKernelGGL(patchify_fwd_kernel, dim3(B), dim3(256), bytes, static_cast<hipStream_t>(stream), spec, w, bias,
+  NSID_LAUNCH(patchify_fwd_kernel, dim3(B), dim3(256), bytes, static_cast<hipStream_t>(stream), spec, w, bias,
                      H, W, pb, pf, F, out, ldo, minmax);
   return nsid_launch_status();
 }
@@ -350,40 +350,40 @@ extern "C" int nsid_peak_patchify_bwd(const float* spec, const float* minmax, co
   NSID_REQUIRE(spec && minmax && out && dout && dw && dbias && B > 0 && H % pb == 0 && W % pf == 0 && ldo >= F);
   const size_t bytes = (size_t)(H / pb) * (W / pf) * F * sizeof(float);
   NSID_REQUIRE(bytes <= 48 * 1024);
-  hipLaunchKernelGGL(patchify_bwd_kernel, dim3(B), dim3(256), bytes, static_cast<hipStream_t>(stream), spec, minmax,
+  NSID_LAUNCH(patchify_bwd_kernel, dim3(B), dim3(256), bytes, static_cast<hipStream_t>(stream), spec, minmax,
                      out, dout, ldo, H, W, pb, pf, F, dw, dbias);
   return nsid_launch_status();
 }
 
 extern "C" int nsid_node_mean_fwd(const float* x, int B, int N, int C, float* out, void* stream) {
   NSID_REQUIRE(x && out && B > 0 && N > 0 && C > 0 && C % 4 == 0 && nsid_aligned16(x) && nsid_aligned16(out));
-  hipLaunchKernelGGL(node_mean_fwd_kernel, dim3(B, (C / 4 + 255) / 256), dim3(256), 0,
+  NSID_LAUNCH(node_mean_fwd_kernel, dim3(B, (C / 4 + 255) / 256), dim3(256), 0,
                      static_cast<hipStream_t>(stream), x, N, C, out);
   return nsid_launch_status();
 }
 extern "C" int nsid_node_mean_bwd(const float* dout, int B, int N, int C, float* dx, void* stream) {
   NSID_REQUIRE(dout && dx && B > 0 && N > 0 && C > 0 && C % 4 == 0 && nsid_aligned16(dout) && nsid_aligned16(dx));
   const long total4 = (long)B * N * (C / 4);
-  hipLaunchKernelGGL(node_mean_bwd_kernel, dim3(grid_for(total4)), dim3(256), 0, static_cast<hipStream_t>(stream),
+  NSID_LAUNCH(node_mean_bwd_kernel, dim3(grid_for(total4)), dim3(256), 0, static_cast<hipStream_t>(stream),
                      dout, N, C, total4, dx);
   return nsid_launch_status();
 }
 extern "C" int nsid_elu_bwd(const float* dout, const float* out, long n, float* din, void* stream) {
   NSID_REQUIRE(dout && out && din && n > 0);
-  hipLaunchKernelGGL(elu_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, static_cast<hipStream_t>(stream), dout, out, n,
+  NSID_LAUNCH(elu_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, static_cast<hipStream_t>(stream), dout, out, n,
                      din);
   return nsid_launch_status();
 }
 extern "C" int nsid_l2norm_fwd(const float* p, int B, int d, float eps, float* z, float* norm, void* stream) {
   NSID_REQUIRE(p && z && norm && B > 0 && d > 0);
-  hipLaunchKernelGGL(l2norm_fwd_kernel, dim3((B + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), p, B, d, eps,
+  NSID_LAUNCH(l2norm_fwd_kernel, dim3((B + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), p, B, d, eps,
                      z, norm);
   return nsid_launch_status();
 }
 extern "C" int nsid_l2norm_bwd(const float* dz, const float* z, const float* norm, int B, int d, float eps, float* dp,
                                void* stream) {
   NSID_REQUIRE(dz && z && norm && dp && B > 0 && d > 0);
-  hipLaunchKernelGGL(l2norm_bwd_kernel, dim3((B + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), dz, z, norm,
+  NSID_LAUNCH(l2norm_bwd_kernel, dim3((B + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), dz, z, norm,
                      B, d, eps, dp);
   return nsid_launch_status();
 }
@@ -391,7 +391,7 @@ extern "C" int nsid_l2norm_bwd(const float* dz, const float* z, const float* nor
 extern "C" int nsid_sumsq_blocks(long n) { return (int)((n + SUMSQ_PER_BLOCK - 1) / SUMSQ_PER_BLOCK); }
 extern "C" int nsid_sumsq_partial(const float* g, long n, float* partial, void* stream) {
   NSID_REQUIRE(g && partial && n > 0 && nsid_aligned16(g));
-  hipLaunchKernelGGL(sumsq_kernel, dim3(nsid_sumsq_blocks(n)), dim3(256), 0, static_cast<hipStream_t>(stream), g, n,
+  NSID_LAUNCH(sumsq_kernel, dim3(nsid_sumsq_blocks(n)), dim3(256), 0, static_cast<hipStream_t>(stream), g, n,
                      partial);
   return nsid_launch_status();
 }
@@ -399,21 +399,21 @@ extern "C" int nsid_adam_step(float* p, const float* g, float* m, float* v, long
                               const float* partial, int nblocks, float* gnorm_out, void* stream) {
   NSID_REQUIRE(p && g && m && v && hyper && step && partial && n > 0 && nblocks > 0);
   hipStream_t s = static_cast<hipStream_t>(stream);
-  hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n, 4096)), dim3(256), 0, s, p, g, m, v, n, hyper, step, partial,
+  NSID_LAUNCH(adam_kernel, dim3(grid_for(n, 4096)), dim3(256), 0, s, p, g, m, v, n, hyper, step, partial,
                      nblocks, gnorm_out);
-  hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, s, step, (const float*)gnorm_out);
+  NSID_LAUNCH(adam_tick_kernel, dim3(1), dim3(1), 0, s, step, (const float*)gnorm_out);
   return nsid_launch_status();
 }
 
 extern "C" int nsid_bcn_to_rows(const float* x, int B, int C, int N, float* rows, int ld, void* stream) {
   NSID_REQUIRE(x && rows && B > 0 && C > 0 && N > 0 && ld >= C);
-  hipLaunchKernelGGL(transpose_kernel, dim3((N + 31) / 32, (C + 31) / 32, B), dim3(256), 0,
+  NSID_LAUNCH(transpose_kernel, dim3((N + 31) / 32, (C + 31) / 32, B), dim3(256), 0,
                      static_cast<hipStream_t>(stream), x, (long)C * N, (long)N, rows, (long)N * ld, (long)ld, C, N);
   return nsid_launch_status();
 }
 extern "C" int nsid_rows_to_bcn(const float* rows, int ld, int B, int C, int N, float* x, void* stream) {
   NSID_REQUIRE(x && rows && B > 0 && C > 0 && N > 0 && ld >= C);
-  hipLaunchKernelGGL(transpose_kernel, dim3((C + 31) / 32, (N + 31) / 32, B), dim3(256), 0,
+  NSID_LAUNCH(transpose_kernel, dim3((C + 31) / 32, (N + 31) / 32, B), dim3(256), 0,
                      static_cast<hipStream_t>(stream), rows, (long)N * ld, (long)ld, x, (long)C * N, (long)N, N, C);
   return nsid_launch_status();
 }

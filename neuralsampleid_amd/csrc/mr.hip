@@ -89,7 +89,7 @@ extern "C" int nsid_mr_aggregate_fwd(const float* r, int ldr, const float* scale
   const long total = (long)B * N * (C / 4);
   long blocks = (total + 255) / 256;
   if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(mr_fwd_kernel, dim3((int)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), r, (long)ldr,
+  NSID_LAUNCH(mr_fwd_kernel, dim3((int)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), r, (long)ldr,
                      scale, shift, idx, (long)B * N, N, C, k, u, argmax);
   return nsid_launch_status();
 }
@@ -107,7 +107,7 @@ extern "C" int nsid_mr_aggregate_bwd(const float* du, const int32_t* idx, const 
       return NSID_ELAUNCH;
     configured = true;
   }
-  hipLaunchKernelGGL(mr_bwd_kernel, dim3(B), dim3(256), bytes, static_cast<hipStream_t>(stream), du, idx, argmax, N, C,
+  NSID_LAUNCH(mr_bwd_kernel, dim3(B), dim3(256), bytes, static_cast<hipStream_t>(stream), du, idx, argmax, N, C,
                      k, dy);
   return nsid_launch_status();
 }

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
 
 #include "../../include/nsid.h"
 
@@ -48,8 +49,17 @@ __device__ __forceinline__ float wave_min(float v) {
   return v;
 }
 
+// hipGetLastError() reports the last error of ANY earlier runtime call on this thread (torch's own included), so the
+// error state is cleared right before a launch and read right after it.
+#define NSID_LAUNCH(kernel, grid, block, shmem, stream, ...)                \
+  do {                                                                      \
+    (void)hipGetLastError();                                                \
+    hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__);    \
+  } while (0)
+
 static inline int nsid_launch_status() {
   hipError_t e = hipGetLastError();
+  if (e != hipSuccess) fprintf(stderr, "[nsid] kernel launch failed: %s\n", hipGetErrorString(e));
   return e == hipSuccess ? NSID_OK : NSID_ELAUNCH;
 }
 static inline bool nsid_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }

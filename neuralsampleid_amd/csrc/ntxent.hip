@@ -185,16 +185,16 @@ extern "C" int nsid_ntxent_fwd_bwd(const float* z_i, const float* z_j, int Bg, i
   hipStream_t s = static_cast<hipStream_t>(stream);
   const size_t bytes = (size_t)(RB + CBK) * (d + 4) * sizeof(float);
   if (raise_lds(ntxent_lse_kernel, bytes) != NSID_OK) return NSID_ELAUNCH;
-  hipLaunchKernelGGL(ntxent_lse_kernel, dim3((M + RB - 1) / RB), dim3(256), bytes, s, z_i, z_j, M, d, tau, lse,
+  NSID_LAUNCH(ntxent_lse_kernel, dim3((M + RB - 1) / RB), dim3(256), bytes, s, z_i, z_j, M, d, tau, lse,
                      rowloss);
-  hipLaunchKernelGGL(ntxent_loss_kernel, dim3(1), dim3(256), 0, s, rowloss, 2 * p0, 2 * np, M, loss_out);
+  NSID_LAUNCH(ntxent_loss_kernel, dim3(1), dim3(256), 0, s, rowloss, 2 * p0, 2 * np, M, loss_out);
   if (dz_i != nullptr) {
     const int row0 = 2 * p0, nrows = 2 * np;
     dim3 grid((nrows + RB - 1) / RB);
 #define NSID_NTX_CASE(DTV)                                                                                   \
   case DTV:                                                                                                  \
     if (raise_lds(ntxent_grad_kernel<DTV>, bytes) != NSID_OK) return NSID_ELAUNCH;                           \
-    hipLaunchKernelGGL((ntxent_grad_kernel<DTV>), grid, dim3(256), bytes, s, z_i, z_j, M, d, tau, lse, row0, \
+    NSID_LAUNCH((ntxent_grad_kernel<DTV>), grid, dim3(256), bytes, s, z_i, z_j, M, d, tau, lse, row0, \
                        nrows, dz_i, dz_j);                                                                   \
     break;
     switch (d / 16) {
