@@ -163,6 +163,9 @@ def main():
         ops.PROFILE = ops.KernelProfile()
         step()
         prof = ops.PROFILE.summary()
+        if os.environ.get("NSID_BENCH_SHAPES"):
+            with open(os.environ["NSID_BENCH_SHAPES"], "w") as f:
+                json.dump(ops.PROFILE.by_shape(), f, indent=0)
         ops.PROFILE = None
         kernels = {n: {"launches": d["launches"], "avg_us": round(1e3 * d["ms"] / d["launches"], 2),
                        "tflops": round(d["flops"] / (d["ms"] * 1e-3) / 1e12, 2),

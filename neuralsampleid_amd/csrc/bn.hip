@@ -6,21 +6,37 @@
 
 namespace {
 
-// One thread per channel; combines the per-tile partial sums in fp64 (Chan-style: tile M2 = sumsq - sum^2/n).
-__global__ void bn_finalize_kernel(const float* __restrict__ stat, int tiles, int C, int M, const float* gamma,
-                                   const float* beta, float* running_mean, float* running_var, int64_t* nbt,
-                                   float momentum, float eps, float* scale, float* shift, float* mean_out,
-                                   float* invstd_out) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c == 0 && nbt != nullptr) *nbt += 1;
-  if (c >= C) return;
-  const float* s0 = stat;
-  const float* s1 = stat + (long)tiles * C;
-  double sum = 0.0, sq = 0.0;
-  for (int t = 0; t < tiles; ++t) {
-    sum += (double)s0[(long)t * C + c];
-    sq += (double)s1[(long)t * C + c];
-  }
+// 1024 threads = 16 tile groups x 64 channels: lanes run along channels (coalesced 256-B rows of the partial
+// matrix), tile groups stride over the row tiles; partial sums are combined in fp64 in a fixed order (deterministic).
+constexpr int FIN_CH = 64, FIN_TG = 16;
+
+__device__ __forceinline__ void tile_sums(const float* __restrict__ p0, const float* __restrict__ p1, int tiles,
+                                          int C, int c, int tg, bool ok, double* red0, double* red1, double& sum,
+                                          double& sq) {
+  double a = 0.0, b = 0.0;
+  if (ok)
+    for (int t = tg; t < tiles; t += FIN_TG) {
+      a += (double)p0[(long)t * C + c];
+      b += (double)p1[(long)t * C + c];
+    }
+  red0[threadIdx.x] = a;
+  red1[threadIdx.x] = b;
+  __syncthreads();
+  sum = 0.0; sq = 0.0;
+  if (tg == 0)
+    for (int g = 0; g < FIN_TG; ++g) { sum += red0[g * FIN_CH + (threadIdx.x & (FIN_CH - 1))]; sq += red1[g * FIN_CH + (threadIdx.x & (FIN_CH - 1))]; }
+}
+
+__global__ __launch_bounds__(FIN_CH * FIN_TG) void bn_finalize_kernel(
+    const float* __restrict__ stat, int tiles, int C, int M, const float* gamma, const float* beta,
+    float* running_mean, float* running_var, int64_t* nbt, float momentum, float eps, float* scale, float* shift,
+    float* mean_out, float* invstd_out) {
+  __shared__ double red0[FIN_CH * FIN_TG], red1[FIN_CH * FIN_TG];
+  const int c = blockIdx.x * FIN_CH + (threadIdx.x & (FIN_CH - 1)), tg = threadIdx.x / FIN_CH;
+  if (blockIdx.x == 0 && threadIdx.x == 0 && nbt != nullptr) *nbt += 1;
+  double sum, sq;
+  tile_sums(stat, stat + (long)tiles * C, tiles, C, c, tg, c < C, red0, red1, sum, sq);
+  if (tg != 0 || c >= C) return;
   const double mean = sum / M;
   double var = sq / M - mean * mean;
   if (var < 0.0) var = 0.0;
@@ -135,15 +151,14 @@ __global__ __launch_bounds__(256) void col_reduce_kernel(const float* __restrict
   }
 }
 
-__global__ void bn_bwd_finalize_kernel(const float* __restrict__ partial, int tiles, int C, int M, float* dgamma,
-                                       float* dbeta, float* coef) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  double sg = 0.0, sgx = 0.0;
-  for (int t = 0; t < tiles; ++t) {
-    sg += (double)partial[(long)t * C + c];
-    sgx += (double)partial[(long)(tiles + t) * C + c];
-  }
+__global__ __launch_bounds__(FIN_CH * FIN_TG) void bn_bwd_finalize_kernel(const float* __restrict__ partial,
+                                                                           int tiles, int C, int M, float* dgamma,
+                                                                           float* dbeta, float* coef) {
+  __shared__ double red0[FIN_CH * FIN_TG], red1[FIN_CH * FIN_TG];
+  const int c = blockIdx.x * FIN_CH + (threadIdx.x & (FIN_CH - 1)), tg = threadIdx.x / FIN_CH;
+  double sg, sgx;
+  tile_sums(partial, partial + (long)tiles * C, tiles, C, c, tg, c < C, red0, red1, sg, sgx);
+  if (tg != 0 || c >= C) return;
   if (dbeta) dbeta[c] += (float)sg;
   if (dgamma) dgamma[c] += (float)sgx;
   coef[c] = (float)(sg / M);
@@ -199,7 +214,7 @@ extern "C" int nsid_bn_finalize(const float* stat, int tiles, int C, int M, cons
   NSID_REQUIRE(stat && gamma && beta && scale && shift && mean && invstd && C > 0 && M > 0);
   NSID_REQUIRE(tiles == nsid_row_tiles(M));
   NSID_REQUIRE((running_mean == nullptr) == (running_var == nullptr));
-  NSID_LAUNCH(bn_finalize_kernel, dim3((C + 127) / 128), dim3(128), 0, static_cast<hipStream_t>(stream), stat,
+  NSID_LAUNCH(bn_finalize_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_TG), 0, static_cast<hipStream_t>(stream), stat,
                      tiles, C, M, gamma, beta, running_mean, running_var, nbt, momentum, eps, scale, shift, mean,
                      invstd);
   return nsid_launch_status();
@@ -237,7 +252,7 @@ extern "C" int nsid_bn_bwd_reduce(const float* dout, const float* r, int M, int 
 extern "C" int nsid_bn_bwd_finalize(const float* partial, int tiles, int C, int M, float* dgamma, float* dbeta,
                                     float* coef, void* stream) {
   NSID_REQUIRE(partial && coef && C > 0 && M > 0 && tiles == nsid_row_tiles(M));
-  NSID_LAUNCH(bn_bwd_finalize_kernel, dim3((C + 127) / 128), dim3(128), 0, static_cast<hipStream_t>(stream),
+  NSID_LAUNCH(bn_bwd_finalize_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_TG), 0, static_cast<hipStream_t>(stream),
                      partial, tiles, C, M, dgamma, dbeta, coef);
   return nsid_launch_status();
 }

@@ -17,16 +17,18 @@
 
 namespace {
 
+inline float act_slope(int act) { return act == NSID_ACT_RELU ? 0.f : (act == NSID_ACT_LEAKY ? 0.2f : 1.f); }
+
 struct GemmArgs {
   const float* A; long lda; long a_goff;   // group offset in elements
   const float* B; long ldb; long b_goff;
   float* C; long ldc; long c_goff;
   int I, J, R;
-  const float* a_scale; const float* a_shift; int a_act; long a_aff_goff;   // per-R affine on A (forward)
-  const float* b_scale; const float* b_shift; int b_act; long b_aff_goff;   // per-j affine on B (backward-wgt)
+  // operand-load activation as a negative-side slope (1 = none, 0 = ReLU, 0.2 = LeakyReLU): one branch-free select
+  const float* a_scale; const float* a_shift; float a_slope; long a_aff_goff;   // per-R affine on A (forward)
+  const float* b_scale; const float* b_shift; float b_slope; long b_aff_goff;   // per-j affine on B (backward-wgt)
   const float* bias; long bias_goff;                                        // per-j
   const float* addend; long ldadd;                                          // same indexing as C
-  int out_act;
   float* stat; long stat_plane;    // stat[0*plane + tile*stat_ld + col], stat[1*plane + ...]
   long stat_ld;
   int rsplit;     // number of R-splits (grid.y); >1 => atomic epilogue
@@ -44,62 +46,92 @@ struct TileGeom {
   static constexpr int VEC = ROWS * BK / 4 / 256;   // float4 per thread per stage
 };
 
-// global -> registers for one stage of one operand, with optional affine+activation, zero fill out of range
+// Staging is split in two so that the global-load latency hides under the MFMA block of the current stage
+// (issue early / write late): stage_load only ISSUES the loads (raw operand quads plus the producer-BatchNorm
+// scale/shift quads they will need); stage_store, which runs after the MFMAs, applies affine + activation, zero-fills
+// out-of-range quads and writes LDS.  Nothing consumes a load result before the MFMA block.
 template <int ROWS, bool RMAJOR>
-__device__ __forceinline__ void stage_load(f32x4* v, const float* __restrict__ base,
-                                           long ld, int row0, int nrows, int r0, int rend, const float* scale,
-                                           const float* shift, int act, bool affine_on_r) {
+struct StageRegs {
+  static constexpr int VEC = TileGeom<ROWS, RMAJOR>::VEC;
+  f32x4 v[VEC];
+  f32x4 sc[RMAJOR ? VEC : 1], sh[RMAJOR ? VEC : 1];   // RMAJOR: affine follows the reduction index -> per stage
+  bool ok[VEC];
+};
+
+template <int ROWS, bool RMAJOR>
+__device__ __forceinline__ void stage_load(StageRegs<ROWS, RMAJOR>& s, const float* __restrict__ base, long ld,
+                                           int row0, int nrows, int r0, int rend, const float* scale,
+                                           const float* shift) {
   constexpr int VEC = TileGeom<ROWS, RMAJOR>::VEC;
   const int t = threadIdx.x;
 #pragma unroll
   for (int q = 0; q < VEC; ++q) {
     const int idx = t + 256 * q;
-    f32x4 x = {0.f, 0.f, 0.f, 0.f};
     if (RMAJOR) {
       const int row = idx >> 2, rv = (idx & 3) * 4;   // 4 float4 per row of BK=16
       const int gi = row0 + row, gr = r0 + rv;
-      if (gi < nrows && gr < rend) {                  // R extents are multiples of 4, so a float4 is all-in or all-out
-        x = *reinterpret_cast<const f32x4*>(base + (long)gi * ld + gr);
-        if (scale != nullptr && affine_on_r) {
-          const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + gr);
-          const f32x4 sh = *reinterpret_cast<const f32x4*>(shift + gr);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) x[e] = nsid_act(sc[e] * x[e] + sh[e], act);
-        }
+      s.ok[q] = gi < nrows && gr < rend;              // extents are multiples of 4: a quad is all-in or all-out
+      // out-of-range quads read a valid dummy address (row/col 0 of the tile origin clamped) and are zeroed later
+      const long off = s.ok[q] ? (long)gi * ld + gr : 0;
+      s.v[q] = *reinterpret_cast<const f32x4*>(base + off);
+      if (scale != nullptr) {
+        const int ga = s.ok[q] ? gr : 0;
+        s.sc[q] = *reinterpret_cast<const f32x4*>(scale + ga);
+        s.sh[q] = *reinterpret_cast<const f32x4*>(shift + ga);
       }
     } else {
       constexpr int V_PER_ROW = ROWS / 4;
       const int rr = idx / V_PER_ROW, cv = (idx % V_PER_ROW) * 4;
       const int gr = r0 + rr, gc = row0 + cv;
-      if (gr < rend && gc < nrows) {                  // column extents are multiples of 4 as well
-        x = *reinterpret_cast<const f32x4*>(base + (long)gr * ld + gc);
-        if (scale != nullptr && !affine_on_r) {
-          const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + gc);
-          const f32x4 sh = *reinterpret_cast<const f32x4*>(shift + gc);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) x[e] = nsid_act(sc[e] * x[e] + sh[e], act);
-        }
-      }
+      s.ok[q] = gr < rend && gc < nrows;
+      const long off = s.ok[q] ? (long)gr * ld + gc : 0;
+      s.v[q] = *reinterpret_cast<const f32x4*>(base + off);
     }
-    v[q] = x;
+  }
+}
+
+// column-indexed affine of an i/j-major operand is the same for every stage: fetched once per kernel
+template <int ROWS>
+__device__ __forceinline__ void colaffine_load(f32x4* sc, f32x4* sh, int row0, int nrows, const float* scale,
+                                               const float* shift) {
+  constexpr int VEC = TileGeom<ROWS, false>::VEC;
+  constexpr int V_PER_ROW = ROWS / 4;
+#pragma unroll
+  for (int q = 0; q < VEC; ++q) {
+    const int cv = ((threadIdx.x + 256 * q) % V_PER_ROW) * 4;
+    const int gc = row0 + cv < nrows ? row0 + cv : 0;
+    sc[q] = *reinterpret_cast<const f32x4*>(scale + gc);
+    sh[q] = *reinterpret_cast<const f32x4*>(shift + gc);
   }
 }
 
 template <int ROWS, bool RMAJOR>
-__device__ __forceinline__ void stage_store(float* lds, const f32x4* v) {
+__device__ __forceinline__ void stage_store(float* lds, const StageRegs<ROWS, RMAJOR>& s, bool affine, float slope,
+                                            const f32x4* csc, const f32x4* csh) {
   constexpr int VEC = TileGeom<ROWS, RMAJOR>::VEC;
   constexpr int LD = TileGeom<ROWS, RMAJOR>::LD;
   const int t = threadIdx.x;
 #pragma unroll
   for (int q = 0; q < VEC; ++q) {
     const int idx = t + 256 * q;
+    f32x4 x = s.v[q];
+    if (affine) {
+      const f32x4 sc = RMAJOR ? s.sc[q] : csc[q];
+      const f32x4 sh = RMAJOR ? s.sh[q] : csh[q];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float v = sc[e] * x[e] + sh[e];
+        x[e] = v < 0.f ? v * slope : v;          // NaN compares false and passes through, as torch's activations do
+      }
+    }
+    if (!s.ok[q]) x = f32x4{0.f, 0.f, 0.f, 0.f};
     if (RMAJOR) {
       const int row = idx >> 2, rv = (idx & 3) * 4;
-      *reinterpret_cast<f32x4*>(lds + row * LD + rv) = v[q];
+      *reinterpret_cast<f32x4*>(lds + row * LD + rv) = x;
     } else {
       constexpr int V_PER_ROW = ROWS / 4;
       const int rr = idx / V_PER_ROW, cv = (idx % V_PER_ROW) * 4;
-      *reinterpret_cast<f32x4*>(lds + rr * LD + cv) = v[q];
+      *reinterpret_cast<f32x4*>(lds + rr * LD + cv) = x;
     }
   }
 }
@@ -124,7 +156,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
   using GB = TileGeom<BN, B_RMAJOR>;
   constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 16, TN = WN / 16;
   constexpr int STAGE = GA::FLOATS + GB::FLOATS;
-  __shared__ __attribute__((aligned(16))) float lds[2 * STAGE];
+  constexpr int OUT_STAGE = 4 * 32 * (WN + 4);          // epilogue transpose buffers (4 waves x 32 rows)
+  constexpr int LDS_FLOATS = 2 * STAGE > OUT_STAGE ? 2 * STAGE : OUT_STAGE;
+  __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
 
   const int tiles_j = (p.J + BN - 1) / BN;
   const int tiles_i = (p.I + BM - 1) / BM;
@@ -158,23 +192,30 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
 #pragma unroll
     for (int b = 0; b < TN; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  f32x4 ra[GA::VEC], rb[GB::VEC];
+  StageRegs<BM, A_RMAJOR> ra;
+  StageRegs<BN, B_RMAJOR> rb;
+  // only these operand/affine pairings exist: forward (A reduction-major, affine on the reduction index) and
+  // backward-weight (B column-major, affine on the column index)
+  const bool a_aff = A_RMAJOR && a_sc != nullptr;
+  const bool b_aff = !B_RMAJOR && b_sc != nullptr;
+  f32x4 bcs[GB::VEC], bch[GB::VEC];
+  if (b_aff) colaffine_load<BN>(bcs, bch, j0, p.J, b_sc, b_sh);
   const int nstage = (rend - rbeg + BK - 1) / BK;
   if (nstage > 0) {
-    stage_load<BM, A_RMAJOR>(ra, A, p.lda, i0, p.I, rbeg, rend, a_sc, a_sh, p.a_act, true);
-    stage_load<BN, B_RMAJOR>(rb, B, p.ldb, j0, p.J, rbeg, rend, b_sc, b_sh, p.b_act, false);
-    stage_store<BM, A_RMAJOR>(lds, ra);
-    stage_store<BN, B_RMAJOR>(lds + GA::FLOATS, rb);
+    stage_load<BM, A_RMAJOR>(ra, A, p.lda, i0, p.I, rbeg, rend, a_aff ? a_sc : nullptr, a_sh);
+    stage_load<BN, B_RMAJOR>(rb, B, p.ldb, j0, p.J, rbeg, rend, nullptr, nullptr);
+    stage_store<BM, A_RMAJOR>(lds, ra, a_aff, p.a_slope, nullptr, nullptr);
+    stage_store<BN, B_RMAJOR>(lds + GA::FLOATS, rb, b_aff, p.b_slope, bcs, bch);
   }
   __syncthreads();
   for (int st = 0; st < nstage; ++st) {
     const float* la = lds + (st & 1) * STAGE;
     const float* lb = la + GA::FLOATS;
     const bool more = st + 1 < nstage;
-    if (more) {
+    if (more) {      // issue the next stage's global loads; they complete under the MFMA block below
       const int r0 = rbeg + (st + 1) * BK;
-      stage_load<BM, A_RMAJOR>(ra, A, p.lda, i0, p.I, r0, rend, a_sc, a_sh, p.a_act, true);
-      stage_load<BN, B_RMAJOR>(rb, B, p.ldb, j0, p.J, r0, rend, b_sc, b_sh, p.b_act, false);
+      stage_load<BM, A_RMAJOR>(ra, A, p.lda, i0, p.I, r0, rend, a_aff ? a_sc : nullptr, a_sh);
+      stage_load<BN, B_RMAJOR>(rb, B, p.ldb, j0, p.J, r0, rend, nullptr, nullptr);
     }
     f32x4 fa[TM], fb[TN];
 #pragma unroll
@@ -190,38 +231,89 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
           acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[a][s], fb[b][s], acc[a][b], 0, 0, 0);
     if (more) {
       float* na = lds + ((st + 1) & 1) * STAGE;
-      stage_store<BM, A_RMAJOR>(na, ra);
-      stage_store<BN, B_RMAJOR>(na + GA::FLOATS, rb);
+      stage_store<BM, A_RMAJOR>(na, ra, a_aff, p.a_slope, nullptr, nullptr);
+      stage_store<BN, B_RMAJOR>(na + GA::FLOATS, rb, b_aff, p.b_slope, bcs, bch);
     }
     __syncthreads();
   }
 
-  // ---------------- epilogue: C/D layout col = lane&15, row = 4*(lane>>4) + reg
+  // ---------------- epilogue. C/D layout: col = lane&15, row = 4*(lane>>4) + reg.
   float* C = p.C + g * p.c_goff;
   const float* bias = (p.bias && blockIdx.y == 0) ? p.bias + g * p.bias_goff : nullptr;
   float csum[TN], csq[TN];
 #pragma unroll
   for (int b = 0; b < TN; ++b) csum[b] = csq[b] = 0.f;
+  if (p.atomic_out) {
+    // split-reduction outputs (weight gradients, split-K): one atomic per element
 #pragma unroll
-  for (int b = 0; b < TN; ++b) {
-    const int j = j0 + wn0 + 16 * b + lr;
-    const bool jok = j < p.J;
-    const float bj = (bias && jok) ? bias[j] : 0.f;
+    for (int b = 0; b < TN; ++b) {
+      const int j = j0 + wn0 + 16 * b + lr;
+      const bool jok = j < p.J;
+      const float bj = (bias && jok) ? bias[j] : 0.f;
 #pragma unroll
-    for (int a = 0; a < TM; ++a) {
+      for (int a = 0; a < TM; ++a)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int i = i0 + wm0 + 16 * a + 4 * rq + r;
-        if (i < p.I && jok) {
-          float v = acc[a][b][r] + bj;
-          csum[b] += v;
-          csq[b] += v * v;
-          if (p.addend) v += p.addend[g * p.c_goff + (long)i * p.ldadd + j];
-          v = nsid_act(v, p.out_act);
-          float* dst = C + (long)i * p.ldc + j;
-          if (p.atomic_out) atomicAdd(dst, v);
-          else *dst = v;
+        for (int r = 0; r < 4; ++r) {
+          const int i = i0 + wm0 + 16 * a + 4 * rq + r;
+          if (i < p.I && jok) atomicAdd(C + (long)i * p.ldc + j, acc[a][b][r] + bj);
         }
+    }
+  } else {
+    // Stores go through LDS so that every lane writes 16 contiguous bytes of an output row (4-byte stores from the
+    // accumulator layout are store-issue bound). Each wave transposes its own 64 x WN sub-tile, 32 rows at a time.
+    constexpr int OLD = WN + 4;                  // staggers rq groups over the banks, keeps rows 16-B aligned
+    float* ost = lds + wave * (32 * OLD);        // 4 waves x 32 x (WN+4) floats <= one stage buffer
+    constexpr int Q_PER_ROW = WN / 4, ROWS_PER_PASS = 64 / Q_PER_ROW;
+    const int orow = lane / Q_PER_ROW, oq = (lane % Q_PER_ROW) * 4;
+    const int jq = j0 + wn0 + oq;
+    const bool jqok = jq < p.J;                  // J % 4 == 0: a quad is all-in or all-out
+    f32x4 bq = {0.f, 0.f, 0.f, 0.f};
+    if (bias && jqok) bq = *reinterpret_cast<const f32x4*>(bias + jq);
+#pragma unroll
+    for (int h = 0; h < TM / 2; ++h) {
+#pragma unroll
+      for (int a2 = 0; a2 < 2; ++a2)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) ost[(16 * a2 + 4 * rq + r) * OLD + 16 * b + lr] = acc[2 * h + a2][b][r];
+      __syncthreads();
+#pragma unroll
+      for (int pass = 0; pass < 32 / ROWS_PER_PASS; ++pass) {
+        const int rr = pass * ROWS_PER_PASS + orow;
+        const int i = i0 + wm0 + 32 * h + rr;
+        if (i < p.I && jqok) {
+          f32x4 v = *reinterpret_cast<const f32x4*>(ost + rr * OLD + oq);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] += bq[e];
+          if (p.addend) {
+            const f32x4 ad = *reinterpret_cast<const f32x4*>(p.addend + g * p.c_goff + (long)i * p.ldadd + jq);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += ad[e];
+          }
+          *reinterpret_cast<f32x4*>(C + (long)i * p.ldc + jq) = v;
+        }
+      }
+      __syncthreads();
+    }
+    if (p.stat != nullptr) {
+      // BatchNorm partial statistics of (acc + bias), from the accumulator registers
+#pragma unroll
+      for (int b = 0; b < TN; ++b) {
+        const int j = j0 + wn0 + 16 * b + lr;
+        const bool jok = j < p.J;
+        const float bj = (bias && jok) ? bias[j] : 0.f;
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int i = i0 + wm0 + 16 * a + 4 * rq + r;
+            if (i < p.I && jok) {
+              const float v = acc[a][b][r] + bj;
+              csum[b] += v;
+              csq[b] += v * v;
+            }
+          }
       }
     }
   }
@@ -250,6 +342,17 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
   }
 }
 
+// ELU of the projector (simclr/simclr.py:26) runs as its own in-place pass: expm1f inlined into the fully unrolled
+// GEMM epilogue would bloat every instantiation for a 256 x 4096 tensor.
+__global__ void elu_inplace_kernel(float* __restrict__ x, long rows, int cols, long ld) {
+  const long n = rows * cols;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    float* q = x + (i / cols) * ld + (i % cols);
+    const float v = *q;
+    *q = v > 0.f ? v : expm1f(v);
+  }
+}
+
 template <int BM, int BN, bool AR, bool BR>
 int launch(const GemmArgs& p, int groups, hipStream_t s) {
   const int tiles = ((p.I + BM - 1) / BM) * ((p.J + BN - 1) / BN);
@@ -269,31 +372,37 @@ extern "C" int nsid_linear_fwd(const float* x, int ldx, const float* w, const fl
   NSID_REQUIRE(x && w && out && M > 0 && Nout > 0 && K > 0 && groups > 0 && ksplit >= 1);
   NSID_REQUIRE(K % 4 == 0 && ldx % 4 == 0 && nsid_aligned16(x) && nsid_aligned16(w));
   NSID_REQUIRE(ldx >= groups * K && ldo >= groups * Nout);
+  NSID_REQUIRE(Nout % 4 == 0 && ldo % 4 == 0 && nsid_aligned16(out) && (bias == nullptr || nsid_aligned16(bias)));
   NSID_REQUIRE((in_scale == nullptr) == (in_shift == nullptr));
   NSID_REQUIRE(ksplit == 1 || (stat == nullptr && act_out == NSID_ACT_NONE));
+  NSID_REQUIRE(act_in != NSID_ACT_ELU && (act_out == NSID_ACT_NONE || act_out == NSID_ACT_ELU));
   GemmArgs p{};
   p.A = x; p.lda = ldx; p.a_goff = K;
   p.B = w; p.ldb = K; p.b_goff = (long)Nout * K;
   p.C = out; p.ldc = ldo; p.c_goff = Nout;
   p.I = M; p.J = Nout; p.R = K;
-  p.a_scale = in_scale; p.a_shift = in_shift; p.a_act = act_in; p.a_aff_goff = K;
+  p.a_scale = in_scale; p.a_shift = in_shift; p.a_slope = act_slope(act_in); p.a_aff_goff = K;
   p.bias = bias; p.bias_goff = Nout;
-  p.out_act = act_out;
   p.stat = stat; p.stat_ld = (long)groups * Nout; p.stat_plane = (long)nsid_row_tiles(M) * groups * Nout;
   p.rsplit = ksplit;
   p.rchunk = ((K + ksplit - 1) / ksplit + BK - 1) / BK * BK;
   p.atomic_out = ksplit > 1;
   hipStream_t s = static_cast<hipStream_t>(stream);
   // the statistics tile must be NSID_ROW_TILE rows, so BM = 128 always; narrow outputs take the 64-column tile
-  if (Nout <= 64) return launch<128, 64, true, true>(p, groups, s);
-  return launch<128, 128, true, true>(p, groups, s);
+  const int rc = Nout <= 64 ? launch<128, 64, true, true>(p, groups, s) : launch<128, 128, true, true>(p, groups, s);
+  if (rc != NSID_OK || act_out != NSID_ACT_ELU) return rc;
+  const long n = (long)M * groups * Nout;
+  NSID_LAUNCH(elu_inplace_kernel, dim3((int)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256)), dim3(256), 0, s, out,
+              (long)M, groups * Nout, (long)ldo);
+  return nsid_launch_status();
 }
 
 extern "C" int nsid_linear_bwd_data(const float* dout, int ldd, const float* w, const float* addend, int ldadd,
                                     float* din, int ldi, int M, int Nout, int K, int groups, void* stream) {
   NSID_REQUIRE(dout && w && din && M > 0 && Nout > 0 && K > 0 && groups > 0);
   NSID_REQUIRE(Nout % 4 == 0 && K % 4 == 0 && ldd % 4 == 0 && nsid_aligned16(dout) && nsid_aligned16(w));
-  NSID_REQUIRE(ldd >= groups * Nout && ldi >= groups * K);
+  NSID_REQUIRE(ldd >= groups * Nout && ldi >= groups * K && ldi % 4 == 0 && nsid_aligned16(din));
+  NSID_REQUIRE(addend == nullptr || (ldadd % 4 == 0 && ldadd >= groups * K && nsid_aligned16(addend)));
   GemmArgs p{};
   p.A = dout; p.lda = ldd; p.a_goff = Nout;
   p.B = w; p.ldb = K; p.b_goff = (long)Nout * K;     // B[R = n][j = k]
@@ -317,14 +426,15 @@ extern "C" int nsid_linear_bwd_weight(const float* dout, int ldd, const float* x
   p.B = x; p.ldb = ldx; p.b_goff = K;                // B[R = m][j = k]
   p.C = dw; p.ldc = K; p.c_goff = (long)Nout * K;
   p.I = Nout; p.J = K; p.R = M;
-  p.b_scale = in_scale; p.b_shift = in_shift; p.b_act = act_in; p.b_aff_goff = K;
+  p.b_scale = in_scale; p.b_shift = in_shift; p.b_slope = act_slope(act_in); p.b_aff_goff = K;
   p.atomic_out = 1;
   const bool small = (Nout <= 64 || K <= 64);
   const int bm = small ? 64 : 128;
   const long tiles = (long)((Nout + bm - 1) / bm) * ((K + bm - 1) / bm) * groups;
-  // split the row reduction so that about 1024 workgroups are in flight, each reducing >= 256 rows
-  long want = (1024 + tiles - 1) / tiles;
-  long maxsplit = (M + 255) / 256;
+  // split the row reduction so that about 2 workgroups per CU are in flight, each reducing >= 512 rows: every split
+  // ends in a tile-sized burst of atomics (~1.3 TB/s chip-wide), so fewer, longer splits beat many short ones
+  long want = (512 + tiles - 1) / tiles;
+  long maxsplit = (M + 511) / 512;
   int rsplit = (int)(want < 1 ? 1 : (want > maxsplit ? maxsplit : want));
   p.rsplit = rsplit;
   p.rchunk = ((M + rsplit - 1) / rsplit + BK - 1) / BK * BK;

@@ -33,7 +33,7 @@ def mrconv_backward(dout, P, S, G):
     M, Co = r.shape
     dr = ops.bn_backward(dout, r, aff, ops.ACT_RELU, G["nn.1.weight"], G["nn.1.bias"])
     if "nn.0.bias" in G:
-        ops.colsum_acc(dr, G["nn.0.bias"])
+        F_._bias_grad_before_bn(dr, G["nn.0.bias"])
     ops.linear_bwd_weight(dr, u, ops.w2d(G["nn.0.weight"]), M, Co // 4, C // 2, 4)
     du = ops.linear_bwd_data(dr, ops.w2d(P["nn.0.weight"]), M, Co // 4, C // 2, 4)
     return ops.mr_aggregate_bwd(du, idx, amax, B, N, C)

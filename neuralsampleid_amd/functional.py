@@ -36,6 +36,23 @@ class KnnTape:
 
 TAPE: Optional[KnnTape] = None
 
+# A conv bias that feeds a training-mode BatchNorm directly has an analytically ZERO gradient (BN subtracts the batch
+# mean, so sum_m dL/dr[m, c] == 0).  The reference's autograd still evaluates that sum and gets +-1e-7 roundoff, which
+# Adam then normalises into a +-lr random walk of a parameter with no effect on the output.  By default the column sum
+# is skipped and the gradient left at exactly 0; NSID_EXACT_BIAS_GRAD=1 evaluates it like the reference does.
+import os as _os
+EXACT_BIAS_GRAD = _os.environ.get("NSID_EXACT_BIAS_GRAD", "0") == "1"
+
+# When every parameter of a block already owns a gradient buffer and this flag is set (optim.FusedClipAdam sets it),
+# backward accumulates straight into p.grad (views of the flat gradient buffer) instead of returning fresh tensors
+# for autograd to add: saves one zero-fill and one add per parameter per view.
+DIRECT_GRADS = False
+
+
+def _bias_grad_before_bn(dr, g):
+    if EXACT_BIAS_GRAD:
+        ops.colsum_acc(dr, g)
+
 
 def _bn(P, S_unused, pre):
     return P[pre + "weight"], P[pre + "bias"], P[pre + "running_mean"], P[pre + "running_var"], \
@@ -106,19 +123,19 @@ def grapher_backward(dx1: Tensor, P, S, G) -> Tensor:
     pre = "graph_conv.gconv.nn."
     # fc2 (+BN), input = relu(BN(r2))
     dr3 = ops.bn_backward(dx1, r3, a3, ACT_NONE, G["fc2.1.weight"], G["fc2.1.bias"])
-    ops.colsum_acc(dr3, G["fc2.0.bias"])
+    _bias_grad_before_bn(dr3, G["fc2.0.bias"])
     ops.linear_bwd_weight(dr3, r2, ops.w2d(G["fc2.0.weight"]), M, C, 2 * C, 1, a2.scale, a2.shift, ACT_RELU)
     dv = ops.linear_bwd_data(dr3, ops.w2d(P["fc2.0.weight"]), M, C, 2 * C)
     # grouped conv (+BN+ReLU), input = u
     dr2 = ops.bn_backward(dv, r2, a2, ACT_RELU, G[pre + "1.weight"], G[pre + "1.bias"], inplace=True)
-    ops.colsum_acc(dr2, G[pre + "0.bias"])
+    _bias_grad_before_bn(dr2, G[pre + "0.bias"])
     ops.linear_bwd_weight(dr2, u, ops.w2d(G[pre + "0.weight"]), M, C // 2, C // 2, 4)
     du = ops.linear_bwd_data(dr2, ops.w2d(P[pre + "0.weight"]), M, C // 2, C // 2, 4)
     # max-relative aggregation: route to arg-max neighbour and centre; kNN itself carries no gradient
     dy = ops.mr_aggregate_bwd(du, idx, amax, B, N, C)
     # fc1 (+BN), input = x0
     dr1 = ops.bn_backward(dy, r1, a1, ACT_NONE, G["fc1.1.weight"], G["fc1.1.bias"], inplace=True)
-    ops.colsum_acc(dr1, G["fc1.0.bias"])
+    _bias_grad_before_bn(dr1, G["fc1.0.bias"])
     ops.linear_bwd_weight(dr1, x0, ops.w2d(G["fc1.0.weight"]), M, C, C)
     return ops.linear_bwd_data(dr1, ops.w2d(P["fc1.0.weight"]), M, C, C, 1, addend=dx1)
 
@@ -165,7 +182,7 @@ def downsample_backward(dout: Tensor, P, S, G) -> Tensor:
     col, wp, r, aff, B, N, C = (S[k_] for k_ in ("col", "wp", "r", "aff", "B", "N", "C"))
     Mo, Co = r.shape
     dr = ops.bn_backward(dout, r, aff, ACT_NONE, G["conv.1.weight"], G["conv.1.bias"])
-    ops.colsum_acc(dr, G["conv.0.bias"])
+    _bias_grad_before_bn(dr, G["conv.0.bias"])
     dwp = torch.zeros_like(wp)
     ops.linear_bwd_weight(dr, col, dwp, Mo, Co, 3 * C)
     ops.unpack_ds_wgrad(dwp, G["conv.0.weight"])
@@ -252,10 +269,12 @@ class _BlockFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         P, S, names = ctx.P, ctx.S, ctx.names
-        G = {n: torch.zeros_like(P[n]) for n in names}
+        direct = DIRECT_GRADS and all(P[n].grad is not None and P[n].grad.is_contiguous() for n in names)
+        G = {n: (P[n].grad if direct else torch.zeros_like(P[n])) for n in names}
         dx = ctx.bwd(dout.contiguous(), P, S, G)
         ctx.S = None
-        return (None, None, None, None, None, dx if ctx.x_needs else None) + tuple(G[n] for n in names)
+        head = (None, None, None, None, None, dx if ctx.x_needs else None)
+        return head + tuple(None if direct else G[n] for n in names)
 
 
 def run_block(fwd, bwd, module_params: Dict[str, Tensor], module_buffers: Dict[str, Tensor], x: Tensor, *meta):

@@ -18,12 +18,12 @@ class KernelProfile:
     Keys follow the kernel template instantiation that the C side dispatches to (csrc/gemm.hip)."""
 
     def __init__(self):
-        self.records = []          # (kernel, flops, algorithmic bytes, start event, end event)
+        self.records = []          # (kernel, flops, algorithmic bytes, start event, end event, shape)
 
     def summary(self):
         torch.cuda.synchronize()
         out = {}
-        for name, flops, nbytes, e0, e1 in self.records:
+        for name, flops, nbytes, e0, e1, shape in self.records:
             d = out.setdefault(name, {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
             d["launches"] += 1
             d["ms"] += e0.elapsed_time(e1)
@@ -31,18 +31,34 @@ class KernelProfile:
             d["bytes"] += nbytes
         return out
 
+    def by_shape(self):
+        """per (kernel, M, Nout, K, groups): launches, average us, TFLOP/s, algorithmic GB/s"""
+        torch.cuda.synchronize()
+        out = {}
+        for name, flops, nbytes, e0, e1, shape in self.records:
+            d = out.setdefault((name,) + shape, [0, 0.0, flops, nbytes])
+            d[0] += 1
+            d[1] += e0.elapsed_time(e1)
+        rows = []
+        for key, (n, ms, flops, nbytes) in out.items():
+            us = 1e3 * ms / n
+            rows.append({"kernel": key[0], "M": key[1], "Nout": key[2], "K": key[3], "groups": key[4], "launches": n,
+                         "avg_us": round(us, 1), "tflops": round(flops / us / 1e6, 1),
+                         "alg_GBps": round(nbytes / us / 1e3, 0), "total_ms": round(ms, 3)})
+        return sorted(rows, key=lambda r: -r["total_ms"])
+
 
 PROFILE: Optional[KernelProfile] = None
 
 
-def _timed(name, flops, nbytes, fn):
+def _timed(name, flops, nbytes, fn, shape=()):
     if PROFILE is None:
         return fn()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     fn()
     e1.record()
-    PROFILE.records.append((name, flops, nbytes, e0, e1))
+    PROFILE.records.append((name, flops, nbytes, e0, e1, shape))
 
 
 def _p(t: Optional[torch.Tensor]):
@@ -83,7 +99,7 @@ def linear_fwd(x, w, bias, M, Nout, K, groups=1, in_scale=None, in_shift=None, a
     name = "gemm_kernel<128,%d,true,true>" % (64 if Nout <= 64 else 128)
     _timed(name, 2.0 * M * Nout * K * groups, 4.0 * groups * (M * K + Nout * K + M * Nout), lambda: call(
         "nsid_linear_fwd", _p(x), ldx, _p(w), _p(bias), _p(out), out.shape[-1], M, Nout, K, groups, _p(in_scale),
-        _p(in_shift), act_in, act_out, _p(stat), ksplit, _stream()))
+        _p(in_shift), act_in, act_out, _p(stat), ksplit, _stream()), (M, Nout, K, groups))
     return out, stat
 
 
@@ -95,7 +111,8 @@ def linear_bwd_data(dout, w, M, Nout, K, groups=1, addend=None, out=None) -> tor
     _timed(name, 2.0 * M * Nout * K * groups,
            4.0 * groups * (M * Nout + Nout * K + M * K * (2 if addend is not None else 1)), lambda: call(
                "nsid_linear_bwd_data", _p(dout), dout.shape[-1], _p(w), _p(addend),
-               0 if addend is None else addend.shape[-1], _p(out), out.shape[-1], M, Nout, K, groups, _stream()))
+               0 if addend is None else addend.shape[-1], _p(out), out.shape[-1], M, Nout, K, groups, _stream()),
+           (M, Nout, K, groups))
     return out
 
 
@@ -105,7 +122,7 @@ def linear_bwd_weight(dout, x, dw, M, Nout, K, groups=1, in_scale=None, in_shift
     name = "gemm_kernel<%s,false,false>" % ("64,64" if (Nout <= 64 or K <= 64) else "128,128")
     _timed(name, 2.0 * M * Nout * K * groups, 4.0 * groups * (M * Nout + M * K + Nout * K), lambda: call(
         "nsid_linear_bwd_weight", _p(dout), dout.shape[-1], _p(x), x.shape[-1], _p(dw), M, Nout, K, groups,
-        _p(in_scale), _p(in_shift), act_in, _stream()))
+        _p(in_scale), _p(in_shift), act_in, _stream()), (M, Nout, K, groups))
 
 
 def colsum_acc(x, out) -> None:

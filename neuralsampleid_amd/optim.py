@@ -12,7 +12,7 @@ from . import ops
 
 class FusedClipAdam:
     def __init__(self, params: Iterable[torch.nn.Parameter], lr: float = 8e-5, betas=(0.9, 0.999), eps: float = 1e-8,
-                 max_norm: float = 1.0):
+                 max_norm: float = 1.0, direct_grads: bool = True):
         self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
         if not self.params:
             raise ValueError("no trainable parameters")
@@ -36,6 +36,9 @@ class FusedClipAdam:
         self.hyper = torch.tensor([lr, betas[0], betas[1], eps, max_norm if max_norm else 0.0], device=dev)
         self.step_count = torch.zeros((), dtype=torch.int64, device=dev)
         self.grad_norm = torch.zeros(1, device=dev)       # pre-clip global norm of the last step
+        if direct_grads:      # block backward kernels accumulate straight into the flat gradient buffer
+            from . import functional
+            functional.DIRECT_GRADS = True
 
     def zero_grad(self, set_to_none: bool = False):
         self.flat_g.zero_()

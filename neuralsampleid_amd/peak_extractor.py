@@ -21,9 +21,12 @@ class _PatchifyFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dout):
-        G = {k: torch.zeros_like(v) for k, v in ctx.P.items()}
+        direct = F_.DIRECT_GRADS and all(v.grad is not None for v in ctx.P.values())
+        G = {k: (v.grad if direct else torch.zeros_like(v)) for k, v in ctx.P.items()}
         F_.patchify_backward(dout.contiguous(), ctx.P, ctx.S, G)
         ctx.S = None
+        if direct:
+            return None, None, None, None, None
         return None, G["convs.0.weight"], G["convs.0.bias"], None, None
 
 
