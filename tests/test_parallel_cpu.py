@@ -1,0 +1,125 @@
+"""CPU, world_size = 2 over gloo: the data-parallel host path (neuralsampleid_amd/parallel.py) reproduces the
+single-process global-batch step — loss, embedding gradients and parameter gradients — when each rank owns half of
+the clips.  The collective plumbing under test is the product's; the per-rank loss rows come from the oracle here
+(the HIP kernel is injected on the GPU, tests/test_ops_gpu.py::test_ntxent_sharded checks the same split there)."""
+import os
+import socket
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for _p in (ROOT, os.path.join(ROOT, "tests", "golden"), os.path.join(ROOT, "tests")):
+    if _p not in sys.path:           # spawned ranks re-import this module without conftest.py
+        sys.path.insert(0, _p)
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import ref_torch as R
+from synth import GRAFP_CFG, synth_randn
+
+WORLD = 2
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def oracle_rows(zi_all, zj_all, tau, p0, n):
+    """same contract as ops.ntxent_fwd_bwd: (sum of owned rows / M, dz_i, dz_j for the owned pairs)"""
+    with torch.enable_grad():          # called from inside autograd.Function.forward, where grad mode is off
+        zi = zi_all.detach().clone().requires_grad_(True)
+        zj = zj_all.detach().clone().requires_grad_(True)
+        M = 2 * zi.shape[0]
+        z = torch.stack((zi, zj), dim=1).reshape(M, -1)
+        # d(global mean loss)/dz for the owned pairs needs the FULL loss (other ranks' rows see these columns too)
+        full = R.ntxent(zi, zj, tau)
+        full.backward()
+    part = R.ntxent_rows(z.detach(), 2 * p0, 2 * n, tau) / M
+    return part.reshape(1), zi.grad[p0:p0 + n].clone(), zj.grad[p0:p0 + n].clone()
+
+
+def tiny_params():
+    g = torch.Generator().manual_seed(5)
+    return {"w1": torch.randn(24, 16, generator=g) * 0.3, "w2": torch.randn(8, 24, generator=g) * 0.3}
+
+
+def embed(x, P):
+    z = torch.tanh(x @ P["w1"].t()) @ P["w2"].t()
+    return z / z.norm(dim=1, keepdim=True).clamp_min(1e-10)
+
+
+def _worker(rank, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(WORLD),
+                      LOCAL_RANK=str(rank))
+    torch.set_num_threads(1)
+    from neuralsampleid_amd import parallel
+    r, local, world = parallel.init_from_env("gloo")
+    assert (r, world) == (rank, WORLD)
+    B = 6
+    p0, n = parallel.shard_range(B, rank, world)
+    x_i, x_j = synth_randn("par_xi", B, 16), synth_randn("par_xj", B, 16)
+    P = {k: v.clone().requires_grad_(True) for k, v in tiny_params().items()}
+    z_i, z_j = embed(x_i[p0:p0 + n], P), embed(x_j[p0:p0 + n], P)
+    loss = parallel.dist_ntxent_loss(z_i, z_j, GRAFP_CFG, rows_fn=oracle_rows)
+    loss.backward()
+    flat = torch.cat([P[k].grad.reshape(-1) for k in sorted(P)])
+    bucketed = flat.clone()
+    parallel.allreduce_gradients(flat)                                  # one collective
+    works = parallel.allreduce_gradients(bucketed, bucket_bytes=256, async_op=True)   # bucketed + async
+    for w in works:
+        w.wait()
+    gz = parallel.gather_embeddings(z_i.detach())
+    if rank == 0:
+        out.put((float(loss.detach()), flat.tolist(), bucketed.tolist(), gz.tolist()))   # plain data: no shared-memory handles
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_step_matches_single_process():
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, port, q)) for r in range(WORLD)]
+    for p in procs:
+        p.start()
+    deadline = time.time() + 120
+    while q.empty():
+        assert time.time() < deadline and all(p.exitcode in (None, 0) for p in procs), \
+            f"ranks died or hung: {[p.exitcode for p in procs]}"
+        time.sleep(0.2)
+    loss2, flat2, bucketed2, gz = q.get()
+    flat2, bucketed2, gz = torch.tensor(flat2), torch.tensor(bucketed2), torch.tensor(gz)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+
+    B = 6
+    x_i, x_j = synth_randn("par_xi", B, 16), synth_randn("par_xj", B, 16)
+    P = {k: v.clone().requires_grad_(True) for k, v in tiny_params().items()}
+    z_i, z_j = embed(x_i, P), embed(x_j, P)
+    loss1 = R.ntxent(z_i, z_j, GRAFP_CFG["tau"])
+    loss1.backward()
+    flat1 = torch.cat([P[k].grad.reshape(-1) for k in sorted(P)])
+    assert abs(loss2 - float(loss1)) < 1e-5
+    assert torch.allclose(flat2, flat1, atol=1e-5, rtol=1e-4)          # SUM of per-rank grads == global-batch grad
+    assert torch.allclose(bucketed2, flat1, atol=1e-5, rtol=1e-4)
+    assert torch.allclose(gz, z_i.detach(), atol=1e-6)                  # rank-major gather == global pair order
+
+
+def test_shard_range():
+    from neuralsampleid_amd import parallel
+    assert [parallel.shard_range(2048, r, 8) for r in (0, 7)] == [(0, 256), (1792, 256)]
+    with pytest.raises(ValueError):
+        parallel.shard_range(10, 0, 4)
+
+
+def test_single_process_paths_need_no_process_group():
+    from neuralsampleid_amd import parallel
+    g = torch.zeros(10)
+    assert parallel.allreduce_gradients(g) == []
+    assert parallel.shard_range(256, 0, 1) == (0, 256)
