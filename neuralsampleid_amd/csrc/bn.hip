@@ -84,70 +84,70 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
   }
 }
 
-// Column reductions over a 128-row tile. Block = 256 threads laid out as (row groups) x (column quads);
-// wide matrices are walked in column passes. MODE 0: sums of x (colsum). MODE 1: BN backward pair.
+// Column reductions over a 128-row tile x 64-channel chunk per block (grid = tiles x C/64, so the deep stages with
+// few row tiles still fill the chip). 256 threads = 16 row groups x 16 channel quads; each thread walks 8 rows with
+// all 16 loads issued before the first use; fixed-order LDS combine (deterministic).
+// MODE 0: column sums of `dout` (bias gradients).  MODE 1: BatchNorm backward pair (sum g, sum g*xhat).
+constexpr int CR_CH = 64, CR_Q = CR_CH / 4, CR_RG = 256 / CR_Q, CR_ROWS = NSID_ROW_TILE / CR_RG;
+
 template <int MODE>
 __global__ __launch_bounds__(256) void col_reduce_kernel(const float* __restrict__ dout, const float* __restrict__ r,
                                                          long ld, int M, int C, const float* __restrict__ scale,
                                                          const float* __restrict__ shift,
                                                          const float* __restrict__ mean,
-                                                         const float* __restrict__ invstd, int act,
+                                                         const float* __restrict__ invstd, float slope,
                                                          float* __restrict__ partial, int tiles) {
   __shared__ f32x4 red[2][256];
   const int tile = blockIdx.x;
   const int row0 = tile * NSID_ROW_TILE;
-  const int rows = min(NSID_ROW_TILE, M - row0);
-  const int C4 = C >> 2;
-  const int cpp = C4 < 256 ? C4 : 256;         // column quads per pass (power of two or C4 itself)
-  // row groups: largest power of two with cpp*rg <= 256
-  int rg = 1;
-  while (cpp * rg * 2 <= 256) rg *= 2;
-  const int t = threadIdx.x;
-  const int my_c = t % cpp, my_g = t / cpp;
-  const bool active = my_g < rg;
-  for (int cbase = 0; cbase < C4; cbase += cpp) {
-    const int c4 = cbase + my_c;
-    f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
-    if (active && c4 < C4) {
-      f32x4 sc, sh, mu, is;
-      if (MODE == 1) {
-        sc = *reinterpret_cast<const f32x4*>(scale + 4 * c4);
-        sh = *reinterpret_cast<const f32x4*>(shift + 4 * c4);
-        mu = *reinterpret_cast<const f32x4*>(mean + 4 * c4);
-        is = *reinterpret_cast<const f32x4*>(invstd + 4 * c4);
-      }
-      for (int rr = my_g; rr < rows; rr += rg) {
-        const long off = (long)(row0 + rr) * ld + 4 * c4;
-        const f32x4 d = *reinterpret_cast<const f32x4*>(dout + off);
+  const int t = threadIdx.x, q = t % CR_Q, rgp = t / CR_Q;
+  const int c = blockIdx.y * CR_CH + 4 * q;
+  const bool cok = c < C;
+  f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+  if (cok) {
+    f32x4 d[CR_ROWS], x[CR_ROWS];
+#pragma unroll
+    for (int i = 0; i < CR_ROWS; ++i) {
+      const int row = row0 + rgp + CR_RG * i;
+      const long off = (long)(row < M ? row : row0) * ld + c;
+      d[i] = *reinterpret_cast<const f32x4*>(dout + off);
+      if (MODE == 1) x[i] = *reinterpret_cast<const f32x4*>(r + off);
+    }
+    f32x4 sc, sh, mu, is;
+    if (MODE == 1) {
+      sc = *reinterpret_cast<const f32x4*>(scale + c);
+      sh = *reinterpret_cast<const f32x4*>(shift + c);
+      mu = *reinterpret_cast<const f32x4*>(mean + c);
+      is = *reinterpret_cast<const f32x4*>(invstd + c);
+    }
+#pragma unroll
+    for (int i = 0; i < CR_ROWS; ++i) {
+      if (row0 + rgp + CR_RG * i >= M) continue;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
         if (MODE == 0) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) s0[e] += d[e];
+          s0[e] += d[i][e];
         } else {
-          const f32x4 x = *reinterpret_cast<const f32x4*>(r + off);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const float g = d[e] * nsid_act_grad(sc[e] * x[e] + sh[e], act);
-            s0[e] += g;
-            s1[e] += g * ((x[e] - mu[e]) * is[e]);
-          }
+          const float g = (sc[e] * x[i][e] + sh[e]) > 0.f ? d[i][e] : d[i][e] * slope;   // act'(pre) = 1 or slope
+          s0[e] += g;
+          s1[e] += g * ((x[i][e] - mu[e]) * is[e]);
         }
       }
     }
-    red[0][t] = s0;
-    red[1][t] = s1;
-    __syncthreads();
-    if (t < cpp && cbase + t < C4) {     // fixed-order sum over the row groups: deterministic
-      f32x4 a0 = red[0][t], a1 = red[1][t];
-      for (int gI = 1; gI < rg; ++gI) {
-        const f32x4 b0 = red[0][gI * cpp + t], b1 = red[1][gI * cpp + t];
+  }
+  red[0][t] = s0;
+  red[1][t] = s1;
+  __syncthreads();
+  if (t < CR_Q && cok) {
+    f32x4 a0 = red[0][t], a1 = red[1][t];
+    for (int g = 1; g < CR_RG; ++g) {
+      const f32x4 b0 = red[0][g * CR_Q + t], b1 = red[1][g * CR_Q + t];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { a0[e] += b0[e]; a1[e] += b1[e]; }
-      }
-      const long o = (long)tile * C + 4 * (cbase + t);
-      *reinterpret_cast<f32x4*>(partial + o) = a0;
-      if (MODE == 1) *reinterpret_cast<f32x4*>(partial + (long)tiles * C + o) = a1;
+      for (int e = 0; e < 4; ++e) { a0[e] += b0[e]; a1[e] += b1[e]; }
     }
-    __syncthreads();
+    const long o = (long)tile * C + c;
+    *reinterpret_cast<f32x4*>(partial + o) = a0;
+    if (MODE == 1) *reinterpret_cast<f32x4*>(partial + (long)tiles * C + o) = a1;
   }
 }
 
@@ -165,19 +165,11 @@ __global__ __launch_bounds__(FIN_CH * FIN_TG) void bn_bwd_finalize_kernel(const 
   coef[C + c] = (float)(sgx / M);
 }
 
-__global__ void colsum_finalize_kernel(const float* __restrict__ partial, int tiles, int C, float* out) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  double s = 0.0;
-  for (int t = 0; t < tiles; ++t) s += (double)partial[(long)t * C + c];
-  out[c] += (float)s;
-}
-
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dout, const float* __restrict__ r,
                                                            long n4, int C4, const float* __restrict__ scale,
                                                            const float* __restrict__ shift,
                                                            const float* __restrict__ mean,
-                                                           const float* __restrict__ invstd, int act,
+                                                           const float* __restrict__ invstd, float slope,
                                                            const float* __restrict__ coef, float* __restrict__ dr) {
   const int C = C4 * 4;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
@@ -193,13 +185,16 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
     f32x4 o;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const float g = d[e] * nsid_act_grad(sc[e] * x[e] + sh[e], act);
+      const float g = (sc[e] * x[e] + sh[e]) > 0.f ? d[e] : d[e] * slope;
       const float xh = (x[e] - mu[e]) * is[e];
       o[e] = sc[e] * (g - c0[e] - xh * c1[e]);
     }
     reinterpret_cast<f32x4*>(dr)[i] = o;
   }
 }
+
+// derivative of the activation on the non-positive side (1 on the positive side): none 1, ReLU 0, LeakyReLU 0.2
+inline float bn_slope(int act) { return act == NSID_ACT_RELU ? 0.f : (act == NSID_ACT_LEAKY ? 0.2f : 1.f); }
 
 inline int stream_grid(long n4) {
   long b = (n4 + 255) / 256;
@@ -244,8 +239,10 @@ extern "C" int nsid_bn_bwd_reduce(const float* dout, const float* r, int M, int 
                                   void* stream) {
   NSID_REQUIRE(dout && r && scale && shift && mean && invstd && partial && M > 0 && C > 0 && C % 4 == 0);
   const int tiles = nsid_row_tiles(M);
-  NSID_LAUNCH((col_reduce_kernel<1>), dim3(tiles), dim3(256), 0, static_cast<hipStream_t>(stream), dout, r,
-                     (long)C, M, C, scale, shift, mean, invstd, act, partial, tiles);
+  NSID_REQUIRE(act == NSID_ACT_NONE || act == NSID_ACT_RELU || act == NSID_ACT_LEAKY);
+  NSID_LAUNCH((col_reduce_kernel<1>), dim3(tiles, (C + CR_CH - 1) / CR_CH), dim3(256), 0,
+              static_cast<hipStream_t>(stream), dout, r, (long)C, M, C, scale, shift, mean, invstd, bn_slope(act),
+              partial, tiles);
   return nsid_launch_status();
 }
 
@@ -262,54 +259,51 @@ extern "C" int nsid_bn_bwd_apply(const float* dout, const float* r, int M, int C
                                  const float* coef, float* dr, void* stream) {
   NSID_REQUIRE(dout && r && scale && shift && mean && invstd && coef && dr && M > 0 && C > 0 && C % 4 == 0);
   const long n4 = (long)M * C / 4;
+  NSID_REQUIRE(act == NSID_ACT_NONE || act == NSID_ACT_RELU || act == NSID_ACT_LEAKY);
   NSID_LAUNCH(bn_bwd_apply_kernel, dim3(stream_grid(n4)), dim3(256), 0, static_cast<hipStream_t>(stream), dout,
-                     r, n4, C / 4, scale, shift, mean, invstd, act, coef, dr);
+                     r, n4, C / 4, scale, shift, mean, invstd, bn_slope(act), coef, dr);
   return nsid_launch_status();
 }
 
-// out[c] += sum_m x[m,c]. Two launches (tile partials in a caller-invisible static scratch would need allocation,
-// so the partial buffer is carved from `out`'s caller: see the Python host) — here: direct atomics per tile.
 namespace {
 __global__ __launch_bounds__(256) void colsum_atomic_kernel(const float* __restrict__ x, long ld, int M, int C,
                                                             float* __restrict__ out) {
-  // each block reduces a 128-row tile per column quad, then one atomic per column
   __shared__ f32x4 red[256];
   const int row0 = blockIdx.x * NSID_ROW_TILE;
-  const int rows = min(NSID_ROW_TILE, M - row0);
-  const int C4 = C >> 2;
-  const int cpp = C4 < 256 ? C4 : 256;
-  int rg = 1;
-  while (cpp * rg * 2 <= 256) rg *= 2;
-  const int t = threadIdx.x, my_c = t % cpp, my_g = t / cpp;
-  for (int cbase = 0; cbase < C4; cbase += cpp) {
-    const int c4 = cbase + my_c;
-    f32x4 s = {0.f, 0.f, 0.f, 0.f};
-    if (my_g < rg && c4 < C4)
-      for (int rr = my_g; rr < rows; rr += rg) {
-        const f32x4 d = *reinterpret_cast<const f32x4*>(x + (long)(row0 + rr) * ld + 4 * c4);
+  const int t = threadIdx.x, q = t % CR_Q, rgp = t / CR_Q;
+  const int c = blockIdx.y * CR_CH + 4 * q;
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  if (c < C)
+    for (int i = 0; i < CR_ROWS; ++i) {
+      const int row = row0 + rgp + CR_RG * i;
+      if (row < M) {
+        const f32x4 d = *reinterpret_cast<const f32x4*>(x + (long)row * ld + c);
 #pragma unroll
         for (int e = 0; e < 4; ++e) s[e] += d[e];
       }
-    red[t] = s;
-    __syncthreads();
-    if (t < cpp && cbase + t < C4) {
-      f32x4 a = red[t];
-      for (int gI = 1; gI < rg; ++gI) {
-        const f32x4 b = red[gI * cpp + t];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) a[e] += b[e];
-      }
-#pragma unroll
-      for (int e = 0; e < 4; ++e) atomicAdd(out + 4 * (cbase + t) + e, a[e]);
     }
-    __syncthreads();
+  red[t] = s;
+  __syncthreads();
+  if (t < CR_Q && c < C) {
+    f32x4 a = red[t];
+    for (int g = 1; g < CR_RG; ++g) {
+      const f32x4 b = red[g * CR_Q + t];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) a[e] += b[e];
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) atomicAdd(out + c + e, a[e]);
   }
 }
 }  // namespace
 
+// out[c] += sum_m x[m,c]: per-tile partial sums (col_reduce<0>) then a fixed-order fp64 combine; `partial` scratch
+// is the caller's (tiles x C floats) so that nothing is allocated here.
 extern "C" int nsid_colsum_acc(const float* x, int ldx, int M, int C, float* out, void* stream) {
   NSID_REQUIRE(x && out && M > 0 && C > 0 && C % 4 == 0 && ldx % 4 == 0 && nsid_aligned16(x));
-  NSID_LAUNCH(colsum_atomic_kernel, dim3(nsid_row_tiles(M)), dim3(256), 0, static_cast<hipStream_t>(stream), x,
-                     (long)ldx, M, C, out);
+  // direct atomics per tile keep this entry allocation-free; it only serves the few biases that are not in front of
+  // a BatchNorm (proj, projector: M <= batch), so contention is irrelevant
+  NSID_LAUNCH(colsum_atomic_kernel, dim3(nsid_row_tiles(M), (C + CR_CH - 1) / CR_CH), dim3(256), 0,
+              static_cast<hipStream_t>(stream), x, (long)ldx, M, C, out);
   return nsid_launch_status();
 }

@@ -428,7 +428,10 @@ extern "C" int nsid_linear_bwd_weight(const float* dout, int ldd, const float* x
   p.I = Nout; p.J = K; p.R = M;
   p.b_scale = in_scale; p.b_shift = in_shift; p.b_slope = act_slope(act_in); p.b_aff_goff = K;
   p.atomic_out = 1;
-  const bool small = (Nout <= 64 || K <= 64);
+  // 64x64 tiles when the output is narrow, or when 128x128 tiles times the deepest useful split (>= 512 rows each)
+  // would leave most of the 256 CUs idle
+  const long t128 = (long)((Nout + 127) / 128) * ((K + 127) / 128) * groups;
+  const bool small = (Nout <= 64 || K <= 64) || t128 * ((M + 511) / 512) < 256;
   const int bm = small ? 64 : 128;
   const long tiles = (long)((Nout + bm - 1) / bm) * ((K + bm - 1) / bm) * groups;
   // split the row reduction so that about 2 workgroups per CU are in flight, each reducing >= 512 rows: every split

@@ -119,7 +119,9 @@ def linear_bwd_data(dout, w, M, Nout, K, groups=1, addend=None, out=None) -> tor
 def linear_bwd_weight(dout, x, dw, M, Nout, K, groups=1, in_scale=None, in_shift=None, act_in=ACT_NONE) -> None:
     """dw += dout^T f(x)"""
     _chk(dout, x, dw, in_scale, in_shift)
-    name = "gemm_kernel<%s,false,false>" % ("64,64" if (Nout <= 64 or K <= 64) else "128,128")
+    t128 = ((Nout + 127) // 128) * ((K + 127) // 128) * groups
+    small = Nout <= 64 or K <= 64 or t128 * ((M + 511) // 512) < 256
+    name = "gemm_kernel<%s,false,false>" % ("64,64" if small else "128,128")
     _timed(name, 2.0 * M * Nout * K * groups, 4.0 * groups * (M * Nout + M * K + Nout * K), lambda: call(
         "nsid_linear_bwd_weight", _p(dout), dout.shape[-1], _p(x), x.shape[-1], _p(dw), M, Nout, K, groups,
         _p(in_scale), _p(in_shift), act_in, _stream()), (M, Nout, K, groups))
