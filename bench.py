@@ -28,6 +28,7 @@ CFG = {  # hot-path keys of config/grafp.yaml
     "bsz_train": 256, "tau": 0.05, "lr": 8.0e-5, "d": 128, "h": 1024, "u": 32, "dim": 2048,
 }
 FP32_MFMA_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, 64 FLOP/clk/SIMD (= fp32 vector peak)
+BF16_MFMA_PEAK_TFLOPS = 2500.0    # dense bf16 MFMA (MI355X_MICROARCH.md)
 HBM_PEAK_GBPS = 8000.0
 
 
@@ -76,6 +77,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=CFG["bsz_train"], help="clips (pairs) per GPU")
     ap.add_argument("--k", type=int, default=3, help="kNN neighbours (GraphEncoder default 3; train.py --k default 5)")
+    ap.add_argument("--precision", choices=["fp32", "bf16"], default=os.environ.get("NSID_BENCH_PRECISION", "bf16"),
+                    help="GEMM operand arithmetic: bf16 operands / fp32 storage+accumulate (BASELINE config 2, default) "
+                         "or fp32 (exact fp32 MFMA, the strict-parity path); the other mode is timed as a side number")
     ap.add_argument("--no-graph", action="store_true", help="do not capture the step in a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -93,6 +97,7 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
+    ops.set_gemm_precision(args.precision)
     torch.manual_seed(42)                                   # identical initial weights on every rank
     model = SimCLR(CFG, GraphEncoder(CFG, in_channels=CFG["n_filters"], k=args.k, size="t")).to(dev).train()
     opt = FusedClipAdam(model.parameters(), lr=CFG["lr"], max_norm=1.0)
@@ -172,12 +177,38 @@ def main():
                        "share_of_step": round(d["ms"] / (1e3 * elapsed / args.steps), 3)} for n, d in prof.items()}
         dom = max(prof, key=lambda n: prof[n]["ms"])
         d = prof[dom]
-        ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
-        roofline = {"kernel": dom, "bound": "mfma", "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
-                    "launches_per_step": d["launches"], "avg_launch_us": round(1e3 * d["ms"] / d["launches"], 2),
-                    "flops_per_launch": round(d["flops"] / d["launches"]),
-                    "method": "HIP events around every launch in one instrumented eager step after the timed region"}
+        common = {"kernel": dom, "traffic": None, "launches_per_step": d["launches"],
+                  "avg_launch_us": round(1e3 * d["ms"] / d["launches"], 2),
+                  "flops_per_launch": round(d["flops"] / d["launches"]),
+                  "alg_bytes_per_launch": round(d["bytes"] / d["launches"]),
+                  "method": "HIP events around every launch in one instrumented eager step after the timed region"}
+        if args.precision == "fp32":      # fp32 MFMA runs at 1/16 of the bf16 rate: the GEMMs are matrix-pipe bound
+            ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
+            roofline = {"bound": "mfma", "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), **common}
+        else:   # bf16 MFMA with fp32 storage: every layer's intensity (<= 195 flop/B) is under the 312 flop/B ridge
+            ach = d["bytes"] / (d["ms"] * 1e-3) / 1e9
+            roofline = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                        "frac": round(ach / HBM_PEAK_GBPS, 4), **common}
+
+    other = None
+    if world == 1 and not args.no_roofline:
+        # side number: the same step in the other arithmetic (eager; the GPU time dominates the host time)
+        alt = "fp32" if args.precision == "bf16" else "bf16"
+        ops.set_gemm_precision(alt)
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        n_alt = max(3, min(args.steps, 10))
+        for _ in range(n_alt):
+            step()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t1) / n_alt
+        other = {"precision": alt, "ms_per_step": round(1e3 * dt, 3), "value": round(args.batch / dt, 1),
+                 "unit": "clips/s", "note": "eager launches, same model continued; fp32 = strict-parity arithmetic"}
+        ops.set_gemm_precision(args.precision)
+        log(f"{alt}: {1e3 * dt:.2f} ms/step")
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -188,20 +219,23 @@ def main():
     if rank == 0:
         clips = args.batch * world * args.steps
         ms = 1e3 * elapsed / args.steps
-        step_bytes = 57e6 * 2.0 * args.batch       # 57 MB / clip-pair at 2 B/elem -> x2 for fp32 storage
+        step_bytes = 57e6 * 2.0 * args.batch       # 57 MB / clip-pair at 2 B/elem -> x2: storage is fp32
         out = {
             "metric": "audio clips/sec (contrastive step, grafp encoder)", "value": round(clips / elapsed, 1),
             "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f32" if args.precision == "fp32" else "bf16", "data": "synthetic",
             "config": {"workload": f"grafp.yaml GraphEncoder('t', k={args.k}) full contrastive step "
                                    f"(fwd x2 views + NT-Xent + bwd + clip + Adam), batch={args.batch} synthetic "
                                    f"(64,128) log-mel clip pairs per GPU, random-init weights",
                        "global_batch": args.batch * world, "k": args.k, "parallelism": f"dp{world}",
+                       "gemm_arithmetic": ("bf16 operands (RNE at LDS staging), fp32 storage + fp32 accumulate"
+                                           if args.precision == "bf16" else "fp32 operands, fp32 accumulate"),
                        "hipgraph": graph is not None, "final_loss": round(final_loss, 5)},
             "roofline": roofline,
             "step_hbm_frac_algorithmic": round(step_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
             "kernels": kernels,
+            "other_precision": other,
             "cpu_baseline": cpu,
         }
         print(json.dumps(out))

@@ -32,7 +32,13 @@ extern "C" {
 
 #define NSID_ROW_TILE 128 /* rows per BatchNorm partial-statistics tile (all kernels agree on it) */
 
+#define NSID_GEMM_FP32 0 /* fp32 operands on v_mfma_f32_16x16x4_f32: exact fp32, the parity path (default) */
+#define NSID_GEMM_BF16 1 /* operands rounded to bf16 while staged into LDS, fp32 storage + fp32 accumulate */
+
 int nsid_version(void);
+/* process-wide arithmetic of the nsid_linear_* GEMMs (BASELINE config 2 names bf16 compute); returns NSID_OK/EINVAL */
+int nsid_set_gemm_precision(int mode);
+int nsid_get_gemm_precision(void);
 /* number of NSID_ROW_TILE row tiles of an M-row matrix: size of the partial-statistics buffers */
 int nsid_row_tiles(int M);
 

@@ -13,6 +13,7 @@ LIB_PATH = os.path.join(_PKG, "libnsid_hip.so")
 
 # signature letters: p = device pointer, i = int, l = long, f = float, s = stream (void*)
 SIGNATURES = {
+    "nsid_set_gemm_precision": "i",
     "nsid_linear_fwd": "pipppiiiiippiipis",
     "nsid_linear_bwd_data": "pippipiiiiis",
     "nsid_linear_bwd_weight": "pipipiiiippis",
@@ -58,6 +59,7 @@ def _load():
         fn.argtypes = [_CT[c] for c in sig]
         fn.restype = ctypes.c_int
     lib.nsid_version.restype = ctypes.c_int
+    lib.nsid_get_gemm_precision.restype = ctypes.c_int
     lib.nsid_row_tiles.argtypes = [ctypes.c_int]
     lib.nsid_row_tiles.restype = ctypes.c_int
     lib.nsid_sumsq_blocks.argtypes = [ctypes.c_long]
@@ -68,7 +70,7 @@ def _load():
 
 
 lib = _load()
-EXPORTS = list(SIGNATURES) + ["nsid_version", "nsid_row_tiles", "nsid_sumsq_blocks", "nsid_ntxent_ws_floats"]
+EXPORTS = list(SIGNATURES) + ["nsid_version", "nsid_get_gemm_precision", "nsid_row_tiles", "nsid_sumsq_blocks", "nsid_ntxent_ws_floats"]
 
 _ERR = {-1: "NSID_EINVAL (unsupported shape, misaligned pointer or bad argument)",
         -2: "NSID_ELAUNCH (HIP runtime refused the launch)"}

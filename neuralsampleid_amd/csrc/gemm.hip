@@ -36,43 +36,51 @@ struct GemmArgs {
   int atomic_out;
 };
 
-constexpr int BK = 16;
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-template <int ROWS, bool RMAJOR>
+// Precision H = false: fp32 operands, v_mfma_f32_16x16x4_f32, BK = 16 (exact fp32 — the parity path).
+// Precision H = true : operands rounded to bf16 (RNE, v_cvt_pk_bf16_f32) as they are written to LDS, fp32 storage in
+//                      HBM and fp32 accumulation, v_mfma_f32_16x16x32_bf16 (16x the fp32 matrix rate), BK = 32.
+template <bool H> struct Prec { static constexpr int BK = H ? 32 : 16; static constexpr int ESZ = H ? 2 : 4; };
+
+template <int ROWS, bool RMAJOR, bool H>
 struct TileGeom {
-  // RMAJOR: lds[row][BK+4] (row = i or j, R contiguous); else lds[BK][ROWS+4] (R = row, i/j contiguous)
-  static constexpr int LD = RMAJOR ? (BK + 4) : (ROWS + 4);
-  static constexpr int FLOATS = RMAJOR ? ROWS * LD : BK * LD;
-  static constexpr int VEC = ROWS * BK / 4 / 256;   // float4 per thread per stage
+  static constexpr int BK = Prec<H>::BK, ESZ = Prec<H>::ESZ;
+  // RMAJOR: lds[row][BK elements + 16 B pad] (row = i or j, R contiguous): 80-byte rows in both precisions.
+  // else  : lds[BK][ROWS elements + 16 B pad] (R = row, i/j contiguous)
+  static constexpr int STRIDE = RMAJOR ? BK * ESZ + 16 : ROWS * ESZ + 16;   // bytes
+  static constexpr int BYTES = (RMAJOR ? ROWS : BK) * STRIDE;
+  static constexpr int VEC = ROWS * BK / 4 / 256;   // float4 (of fp32 source) per thread per stage
+  static constexpr int QPR = BK / 4;                // source quads per row of an R-major tile
 };
 
 // Staging is split in two so that the global-load latency hides under the MFMA block of the current stage
 // (issue early / write late): stage_load only ISSUES the loads (raw operand quads plus the producer-BatchNorm
 // scale/shift quads they will need); stage_store, which runs after the MFMAs, applies affine + activation, zero-fills
-// out-of-range quads and writes LDS.  Nothing consumes a load result before the MFMA block.
-template <int ROWS, bool RMAJOR>
+// out-of-range quads, rounds to bf16 in the H path, and writes LDS.  Nothing consumes a load result before the MFMAs.
+template <int ROWS, bool RMAJOR, bool H>
 struct StageRegs {
-  static constexpr int VEC = TileGeom<ROWS, RMAJOR>::VEC;
+  static constexpr int VEC = TileGeom<ROWS, RMAJOR, H>::VEC;
   f32x4 v[VEC];
   f32x4 sc[RMAJOR ? VEC : 1], sh[RMAJOR ? VEC : 1];   // RMAJOR: affine follows the reduction index -> per stage
   bool ok[VEC];
 };
 
-template <int ROWS, bool RMAJOR>
-__device__ __forceinline__ void stage_load(StageRegs<ROWS, RMAJOR>& s, const float* __restrict__ base, long ld,
+template <int ROWS, bool RMAJOR, bool H>
+__device__ __forceinline__ void stage_load(StageRegs<ROWS, RMAJOR, H>& s, const float* __restrict__ base, long ld,
                                            int row0, int nrows, int r0, int rend, const float* scale,
                                            const float* shift) {
-  constexpr int VEC = TileGeom<ROWS, RMAJOR>::VEC;
+  using G = TileGeom<ROWS, RMAJOR, H>;
   const int t = threadIdx.x;
 #pragma unroll
-  for (int q = 0; q < VEC; ++q) {
+  for (int q = 0; q < G::VEC; ++q) {
     const int idx = t + 256 * q;
     if (RMAJOR) {
-      const int row = idx >> 2, rv = (idx & 3) * 4;   // 4 float4 per row of BK=16
+      const int row = idx / G::QPR, rv = (idx % G::QPR) * 4;
       const int gi = row0 + row, gr = r0 + rv;
       s.ok[q] = gi < nrows && gr < rend;              // extents are multiples of 4: a quad is all-in or all-out
-      // out-of-range quads read a valid dummy address (row/col 0 of the tile origin clamped) and are zeroed later
-      const long off = s.ok[q] ? (long)gi * ld + gr : 0;
+      const long off = s.ok[q] ? (long)gi * ld + gr : 0;   // out-of-range quads read element 0 and are zeroed later
       s.v[q] = *reinterpret_cast<const f32x4*>(base + off);
       if (scale != nullptr) {
         const int ga = s.ok[q] ? gr : 0;
@@ -91,10 +99,10 @@ __device__ __forceinline__ void stage_load(StageRegs<ROWS, RMAJOR>& s, const flo
 }
 
 // column-indexed affine of an i/j-major operand is the same for every stage: fetched once per kernel
-template <int ROWS>
+template <int ROWS, bool H>
 __device__ __forceinline__ void colaffine_load(f32x4* sc, f32x4* sh, int row0, int nrows, const float* scale,
                                                const float* shift) {
-  constexpr int VEC = TileGeom<ROWS, false>::VEC;
+  constexpr int VEC = TileGeom<ROWS, false, H>::VEC;
   constexpr int V_PER_ROW = ROWS / 4;
 #pragma unroll
   for (int q = 0; q < VEC; ++q) {
@@ -105,14 +113,13 @@ __device__ __forceinline__ void colaffine_load(f32x4* sc, f32x4* sh, int row0, i
   }
 }
 
-template <int ROWS, bool RMAJOR>
-__device__ __forceinline__ void stage_store(float* lds, const StageRegs<ROWS, RMAJOR>& s, bool affine, float slope,
+template <int ROWS, bool RMAJOR, bool H>
+__device__ __forceinline__ void stage_store(char* lds, const StageRegs<ROWS, RMAJOR, H>& s, bool affine, float slope,
                                             const f32x4* csc, const f32x4* csh) {
-  constexpr int VEC = TileGeom<ROWS, RMAJOR>::VEC;
-  constexpr int LD = TileGeom<ROWS, RMAJOR>::LD;
+  using G = TileGeom<ROWS, RMAJOR, H>;
   const int t = threadIdx.x;
 #pragma unroll
-  for (int q = 0; q < VEC; ++q) {
+  for (int q = 0; q < G::VEC; ++q) {
     const int idx = t + 256 * q;
     f32x4 x = s.v[q];
     if (affine) {
@@ -125,40 +132,61 @@ __device__ __forceinline__ void stage_store(float* lds, const StageRegs<ROWS, RM
       }
     }
     if (!s.ok[q]) x = f32x4{0.f, 0.f, 0.f, 0.f};
+    int off;
     if (RMAJOR) {
-      const int row = idx >> 2, rv = (idx & 3) * 4;
-      *reinterpret_cast<f32x4*>(lds + row * LD + rv) = x;
+      off = (idx / G::QPR) * G::STRIDE + (idx % G::QPR) * 4 * G::ESZ;
     } else {
       constexpr int V_PER_ROW = ROWS / 4;
-      const int rr = idx / V_PER_ROW, cv = (idx % V_PER_ROW) * 4;
-      *reinterpret_cast<f32x4*>(lds + rr * LD + cv) = x;
+      off = (idx / V_PER_ROW) * G::STRIDE + (idx % V_PER_ROW) * 4 * G::ESZ;
     }
+    if (H) *reinterpret_cast<bf16x4*>(lds + off) = __builtin_convertvector(x, bf16x4);
+    else *reinterpret_cast<f32x4*>(lds + off) = x;
   }
 }
 
-// fragment of one 16-row tile: element s feeds MFMA sub-step s (reduction index 4*(lane>>4)+s of the chunk)
+// fp32 fragment of one 16-row tile: element s feeds MFMA sub-step s (reduction index 4*(lane>>4)+s of the chunk)
 template <int ROWS, bool RMAJOR>
-__device__ __forceinline__ f32x4 frag_read(const float* lds, int row, int rq) {
-  constexpr int LD = TileGeom<ROWS, RMAJOR>::LD;
+__device__ __forceinline__ f32x4 frag_read_f32(const char* lds, int row, int rq) {
+  using G = TileGeom<ROWS, RMAJOR, false>;
   if (RMAJOR) {
-    return *reinterpret_cast<const f32x4*>(lds + row * LD + 4 * rq);
+    return *reinterpret_cast<const f32x4*>(lds + row * G::STRIDE + 16 * rq);
   } else {
     f32x4 f;
 #pragma unroll
-    for (int s = 0; s < 4; ++s) f[s] = lds[(4 * rq + s) * LD + row];
+    for (int s = 0; s < 4; ++s) f[s] = *reinterpret_cast<const float*>(lds + (4 * rq + s) * G::STRIDE + 4 * row);
     return f;
   }
 }
 
-template <int BM, int BN, bool A_RMAJOR, bool B_RMAJOR>
+// bf16 fragment for v_mfma_f32_16x16x32_bf16: lane (lr, rq) holds 8 consecutive reduction elements 8*rq .. 8*rq+7 of
+// tile row lr.  R-major tiles: one ds_read_b128.  i/j-major tiles: two ds_read_b64_tr_b16 — per 16-lane group the
+// hardware gathers a 4 (reduction) x 16 (i/j) block and hands every lane its column, i.e. a free transpose; lane
+// 4q+p of the group supplies the address of block row q, columns 4p..4p+3 (EXEC is all ones here: no divergence).
+template <int ROWS, bool RMAJOR>
+__device__ __forceinline__ bf16x8 frag_read_bf16(const char* lds, int tile_row0, int lr, int rq) {
+  using G = TileGeom<ROWS, RMAJOR, true>;
+  if (RMAJOR) {
+    return *reinterpret_cast<const bf16x8*>(lds + (tile_row0 + lr) * G::STRIDE + 16 * rq);
+  } else {
+    typedef bf16x4 __attribute__((address_space(3))) * lds_bf16x4_ptr;
+    const char* base = lds + (8 * rq + (lr >> 2)) * G::STRIDE + (tile_row0 + 4 * (lr & 3)) * 2;
+    const bf16x4 t0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(base));
+    const bf16x4 t1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(base + 4 * G::STRIDE));
+    return __builtin_shufflevector(t0, t1, 0, 1, 2, 3, 4, 5, 6, 7);
+  }
+}
+
+template <int BM, int BN, bool A_RMAJOR, bool B_RMAJOR, bool H>
 __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
-  using GA = TileGeom<BM, A_RMAJOR>;
-  using GB = TileGeom<BN, B_RMAJOR>;
+  using GA = TileGeom<BM, A_RMAJOR, H>;
+  using GB = TileGeom<BN, B_RMAJOR, H>;
+  constexpr int BK = Prec<H>::BK;
   constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 16, TN = WN / 16;
-  constexpr int STAGE = GA::FLOATS + GB::FLOATS;
-  constexpr int OUT_STAGE = 4 * 32 * (WN + 4);          // epilogue transpose buffers (4 waves x 32 rows)
-  constexpr int LDS_FLOATS = 2 * STAGE > OUT_STAGE ? 2 * STAGE : OUT_STAGE;
-  __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
+  constexpr int STAGE = GA::BYTES + GB::BYTES;
+  constexpr int OUT_STAGE = 4 * 32 * (WN + 4) * 4;      // epilogue transpose buffers (4 waves x 32 rows), bytes
+  constexpr int LDS_BYTES = 2 * STAGE > OUT_STAGE ? 2 * STAGE : OUT_STAGE;
+  __shared__ __attribute__((aligned(16))) char lds_raw[LDS_BYTES];
+  float* lds = reinterpret_cast<float*>(lds_raw);
 
   const int tiles_j = (p.J + BN - 1) / BN;
   const int tiles_i = (p.I + BM - 1) / BM;
@@ -192,47 +220,60 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
 #pragma unroll
     for (int b = 0; b < TN; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  StageRegs<BM, A_RMAJOR> ra;
-  StageRegs<BN, B_RMAJOR> rb;
+  StageRegs<BM, A_RMAJOR, H> ra;
+  StageRegs<BN, B_RMAJOR, H> rb;
   // only these operand/affine pairings exist: forward (A reduction-major, affine on the reduction index) and
   // backward-weight (B column-major, affine on the column index)
   const bool a_aff = A_RMAJOR && a_sc != nullptr;
   const bool b_aff = !B_RMAJOR && b_sc != nullptr;
   f32x4 bcs[GB::VEC], bch[GB::VEC];
-  if (b_aff) colaffine_load<BN>(bcs, bch, j0, p.J, b_sc, b_sh);
+  if (b_aff) colaffine_load<BN, H>(bcs, bch, j0, p.J, b_sc, b_sh);
   const int nstage = (rend - rbeg + BK - 1) / BK;
   if (nstage > 0) {
-    stage_load<BM, A_RMAJOR>(ra, A, p.lda, i0, p.I, rbeg, rend, a_aff ? a_sc : nullptr, a_sh);
-    stage_load<BN, B_RMAJOR>(rb, B, p.ldb, j0, p.J, rbeg, rend, nullptr, nullptr);
-    stage_store<BM, A_RMAJOR>(lds, ra, a_aff, p.a_slope, nullptr, nullptr);
-    stage_store<BN, B_RMAJOR>(lds + GA::FLOATS, rb, b_aff, p.b_slope, bcs, bch);
+    stage_load<BM, A_RMAJOR, H>(ra, A, p.lda, i0, p.I, rbeg, rend, a_aff ? a_sc : nullptr, a_sh);
+    stage_load<BN, B_RMAJOR, H>(rb, B, p.ldb, j0, p.J, rbeg, rend, nullptr, nullptr);
+    stage_store<BM, A_RMAJOR, H>(lds_raw, ra, a_aff, p.a_slope, nullptr, nullptr);
+    stage_store<BN, B_RMAJOR, H>(lds_raw + GA::BYTES, rb, b_aff, p.b_slope, bcs, bch);
   }
   __syncthreads();
   for (int st = 0; st < nstage; ++st) {
-    const float* la = lds + (st & 1) * STAGE;
-    const float* lb = la + GA::FLOATS;
+    const char* la = lds_raw + (st & 1) * STAGE;
+    const char* lb = la + GA::BYTES;
     const bool more = st + 1 < nstage;
     if (more) {      // issue the next stage's global loads; they complete under the MFMA block below
       const int r0 = rbeg + (st + 1) * BK;
-      stage_load<BM, A_RMAJOR>(ra, A, p.lda, i0, p.I, r0, rend, a_aff ? a_sc : nullptr, a_sh);
-      stage_load<BN, B_RMAJOR>(rb, B, p.ldb, j0, p.J, r0, rend, nullptr, nullptr);
+      stage_load<BM, A_RMAJOR, H>(ra, A, p.lda, i0, p.I, r0, rend, a_aff ? a_sc : nullptr, a_sh);
+      stage_load<BN, B_RMAJOR, H>(rb, B, p.ldb, j0, p.J, r0, rend, nullptr, nullptr);
     }
-    f32x4 fa[TM], fb[TN];
+    if (H) {
+      bf16x8 fa[TM], fb[TN];
 #pragma unroll
-    for (int a = 0; a < TM; ++a) fa[a] = frag_read<BM, A_RMAJOR>(la, wm0 + 16 * a + lr, rq);
+      for (int a = 0; a < TM; ++a) fa[a] = frag_read_bf16<BM, A_RMAJOR>(la, wm0 + 16 * a, lr, rq);
 #pragma unroll
-    for (int b = 0; b < TN; ++b) fb[b] = frag_read<BN, B_RMAJOR>(lb, wn0 + 16 * b + lr, rq);
-#pragma unroll
-    for (int s = 0; s < 4; ++s)
+      for (int b = 0; b < TN; ++b) fb[b] = frag_read_bf16<BN, B_RMAJOR>(lb, wn0 + 16 * b, lr, rq);
 #pragma unroll
       for (int a = 0; a < TM; ++a)
 #pragma unroll
         for (int b = 0; b < TN; ++b)
-          acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[a][s], fb[b][s], acc[a][b], 0, 0, 0);
+          acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[a], fb[b], acc[a][b], 0, 0, 0);
+    } else {
+      f32x4 fa[TM], fb[TN];
+#pragma unroll
+      for (int a = 0; a < TM; ++a) fa[a] = frag_read_f32<BM, A_RMAJOR>(la, wm0 + 16 * a + lr, rq);
+#pragma unroll
+      for (int b = 0; b < TN; ++b) fb[b] = frag_read_f32<BN, B_RMAJOR>(lb, wn0 + 16 * b + lr, rq);
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+          for (int b = 0; b < TN; ++b)
+            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[a][s], fb[b][s], acc[a][b], 0, 0, 0);
+    }
     if (more) {
-      float* na = lds + ((st + 1) & 1) * STAGE;
-      stage_store<BM, A_RMAJOR>(na, ra, a_aff, p.a_slope, nullptr, nullptr);
-      stage_store<BN, B_RMAJOR>(na + GA::FLOATS, rb, b_aff, p.b_slope, bcs, bch);
+      char* na = lds_raw + ((st + 1) & 1) * STAGE;
+      stage_store<BM, A_RMAJOR, H>(na, ra, a_aff, p.a_slope, nullptr, nullptr);
+      stage_store<BN, B_RMAJOR, H>(na + GA::BYTES, rb, b_aff, p.b_slope, bcs, bch);
     }
     __syncthreads();
   }
@@ -353,17 +394,30 @@ __global__ void elu_inplace_kernel(float* __restrict__ x, long rows, int cols, l
   }
 }
 
+int g_gemm_precision = NSID_GEMM_FP32;     // process-wide (nsid_set_gemm_precision)
+
 template <int BM, int BN, bool AR, bool BR>
-int launch(const GemmArgs& p, int groups, hipStream_t s) {
+int launch(GemmArgs p, int groups, hipStream_t s) {
   const int tiles = ((p.I + BM - 1) / BM) * ((p.J + BN - 1) / BN);
+  const bool half = g_gemm_precision == NSID_GEMM_BF16;
+  const int bk = half ? 32 : 16;
+  p.rchunk = (p.rchunk + bk - 1) / bk * bk;            // whole stages per split
+  p.rsplit = (p.R + p.rchunk - 1) / p.rchunk;
   dim3 grid(tiles, p.rsplit, groups);
-  NSID_LAUNCH((gemm_kernel<BM, BN, AR, BR>), grid, dim3(256), 0, s, p);
+  if (half) NSID_LAUNCH((gemm_kernel<BM, BN, AR, BR, true>), grid, dim3(256), 0, s, p);
+  else NSID_LAUNCH((gemm_kernel<BM, BN, AR, BR, false>), grid, dim3(256), 0, s, p);
   return nsid_launch_status();
 }
 
 }  // namespace
 
-extern "C" int nsid_version(void) { return 1; }
+extern "C" int nsid_version(void) { return 2; }
+extern "C" int nsid_set_gemm_precision(int mode) {
+  if (mode != NSID_GEMM_FP32 && mode != NSID_GEMM_BF16) return NSID_EINVAL;
+  g_gemm_precision = mode;
+  return NSID_OK;
+}
+extern "C" int nsid_get_gemm_precision(void) { return g_gemm_precision; }
 extern "C" int nsid_row_tiles(int M) { return (M + NSID_ROW_TILE - 1) / NSID_ROW_TILE; }
 
 extern "C" int nsid_linear_fwd(const float* x, int ldx, const float* w, const float* bias, float* out, int ldo, int M,
@@ -385,11 +439,15 @@ extern "C" int nsid_linear_fwd(const float* x, int ldx, const float* w, const fl
   p.bias = bias; p.bias_goff = Nout;
   p.stat = stat; p.stat_ld = (long)groups * Nout; p.stat_plane = (long)nsid_row_tiles(M) * groups * Nout;
   p.rsplit = ksplit;
-  p.rchunk = ((K + ksplit - 1) / ksplit + BK - 1) / BK * BK;
+  p.rchunk = (K + ksplit - 1) / ksplit;
   p.atomic_out = ksplit > 1;
   hipStream_t s = static_cast<hipStream_t>(stream);
   // the statistics tile must be NSID_ROW_TILE rows, so BM = 128 always; narrow outputs take the 64-column tile
-  const int rc = Nout <= 64 ? launch<128, 64, true, true>(p, groups, s) : launch<128, 128, true, true>(p, groups, s);
+  // bf16 operands make the kernel latency/HBM-bound: when 128-wide tiles would give fewer than two workgroups per CU,
+  // halve the tile width to double the loads in flight (the statistics tile stays 128 rows)
+  const long t128 = (long)nsid_row_tiles(M) * ((Nout + 127) / 128) * groups;
+  const bool narrow = Nout <= 64 || (g_gemm_precision == NSID_GEMM_BF16 && t128 < 512);
+  const int rc = narrow ? launch<128, 64, true, true>(p, groups, s) : launch<128, 128, true, true>(p, groups, s);
   if (rc != NSID_OK || act_out != NSID_ACT_ELU) return rc;
   const long n = (long)M * groups * Nout;
   NSID_LAUNCH(elu_inplace_kernel, dim3((int)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256)), dim3(256), 0, s, out,
@@ -409,9 +467,10 @@ extern "C" int nsid_linear_bwd_data(const float* dout, int ldd, const float* w, 
   p.C = din; p.ldc = ldi; p.c_goff = K;
   p.I = M; p.J = K; p.R = Nout;
   p.addend = addend; p.ldadd = ldadd;
-  p.rsplit = 1; p.rchunk = (Nout + BK - 1) / BK * BK;
+  p.rsplit = 1; p.rchunk = Nout;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (K <= 64) return launch<128, 64, true, false>(p, groups, s);
+  const long t128 = (long)nsid_row_tiles(M) * ((K + 127) / 128) * groups;
+  if (K <= 64 || (g_gemm_precision == NSID_GEMM_BF16 && t128 < 512)) return launch<128, 64, true, false>(p, groups, s);
   return launch<128, 128, true, false>(p, groups, s);
 }
 
@@ -440,8 +499,7 @@ extern "C" int nsid_linear_bwd_weight(const float* dout, int ldd, const float* x
   long maxsplit = (M + 511) / 512;
   int rsplit = (int)(want < 1 ? 1 : (want > maxsplit ? maxsplit : want));
   p.rsplit = rsplit;
-  p.rchunk = ((M + rsplit - 1) / rsplit + BK - 1) / BK * BK;
-  p.rsplit = (M + p.rchunk - 1) / p.rchunk;
+  p.rchunk = (M + rsplit - 1) / rsplit;
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (small) return launch<64, 64, false, false>(p, groups, s);
   return launch<128, 128, false, false>(p, groups, s);

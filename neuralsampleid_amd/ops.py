@@ -79,6 +79,19 @@ def _chk(*ts):
             raise RuntimeError(f"expected contiguous float32, got {t.dtype} contiguous={t.is_contiguous()}")
 
 
+GEMM_FP32, GEMM_BF16 = 0, 1
+
+
+def set_gemm_precision(mode: str) -> None:
+    """'fp32' (default; exact fp32 MFMA, the strict-parity path) or 'bf16' (operands rounded to bf16 as they are
+    staged into LDS; fp32 storage in HBM, fp32 accumulation; 16x the matrix rate — BASELINE config 2's arithmetic)."""
+    call("nsid_set_gemm_precision", {"fp32": GEMM_FP32, "bf16": GEMM_BF16}[mode])
+
+
+def get_gemm_precision() -> str:
+    return "bf16" if lib.nsid_get_gemm_precision() == GEMM_BF16 else "fp32"
+
+
 def row_tiles(M: int) -> int:
     return (M + ROW_TILE - 1) // ROW_TILE
 
@@ -96,7 +109,9 @@ def linear_fwd(x, w, bias, M, Nout, K, groups=1, in_scale=None, in_shift=None, a
     if out is None:
         out = (torch.zeros if ksplit > 1 else torch.empty)((M, groups * Nout), device=x.device, dtype=torch.float32)
     stat = torch.empty((2, row_tiles(M), groups * Nout), device=x.device, dtype=torch.float32) if want_stat else None
-    name = "gemm_kernel<128,%d,true,true>" % (64 if Nout <= 64 else 128)
+    narrow = Nout <= 64 or (lib.nsid_get_gemm_precision() == GEMM_BF16
+                            and row_tiles(M) * ((Nout + 127) // 128) * groups < 512)
+    name = "gemm_kernel<128,%d,true,true>" % (64 if narrow else 128)
     _timed(name, 2.0 * M * Nout * K * groups, 4.0 * groups * (M * K + Nout * K + M * Nout), lambda: call(
         "nsid_linear_fwd", _p(x), ldx, _p(w), _p(bias), _p(out), out.shape[-1], M, Nout, K, groups, _p(in_scale),
         _p(in_shift), act_in, act_out, _p(stat), ksplit, _stream()), (M, Nout, K, groups))
@@ -107,7 +122,9 @@ def linear_bwd_data(dout, w, M, Nout, K, groups=1, addend=None, out=None) -> tor
     _chk(dout, w, addend)
     if out is None:
         out = torch.empty((M, groups * K), device=dout.device, dtype=torch.float32)
-    name = "gemm_kernel<128,%d,true,false>" % (64 if K <= 64 else 128)
+    narrow = K <= 64 or (lib.nsid_get_gemm_precision() == GEMM_BF16
+                         and row_tiles(M) * ((K + 127) // 128) * groups < 512)
+    name = "gemm_kernel<128,%d,true,false>" % (64 if narrow else 128)
     _timed(name, 2.0 * M * Nout * K * groups,
            4.0 * groups * (M * Nout + Nout * K + M * K * (2 if addend is not None else 1)), lambda: call(
                "nsid_linear_bwd_data", _p(dout), dout.shape[-1], _p(w), _p(addend),

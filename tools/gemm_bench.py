@@ -1,0 +1,66 @@
+#!/usr/bin/env python3
+"""GEMM-family microbench on the shapes of the 't' encoder at B=256 (one view): per shape and direction, average
+launch time from HIP events, TFLOP/s and algorithmic GB/s.  Usage: python tools/gemm_bench.py [--reps 20] [--only fwd]"""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from neuralsampleid_amd import ops  # noqa: E402
+
+SHAPES = [  # (M, Nout, K, groups, affine)
+    (65536, 64, 64, 1, False), (65536, 32, 32, 4, False), (65536, 64, 128, 1, True), (65536, 256, 64, 1, False),
+    (65536, 64, 256, 1, True), (32768, 128, 128, 1, False), (32768, 512, 128, 1, False), (32768, 128, 512, 1, True),
+    (16384, 256, 256, 1, False), (16384, 128, 128, 4, False), (16384, 256, 512, 1, True), (16384, 1024, 256, 1, False),
+    (16384, 256, 1024, 1, True), (8192, 512, 512, 1, False), (8192, 2048, 512, 1, False), (8192, 512, 2048, 1, True),
+]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--reps", type=int, default=20)
+    ap.add_argument("--only", default="fwd,bwd_data,bwd_weight")
+    ap.add_argument("--shapes", default="")
+    ap.add_argument("--precision", default="fp32")
+    args = ap.parse_args()
+    dev = "cuda"
+    ops.set_gemm_precision(args.precision)
+    shapes = SHAPES
+    if args.shapes:
+        shapes = [tuple(int(v) for v in s.split("x")) + (False,) for s in args.shapes.split(",")]
+    for M, N, K, G, aff in shapes:
+        x = torch.randn(M, G * K, device=dev)
+        w = torch.randn(G * N, K, device=dev) * K ** -0.5
+        dout = torch.randn(M, G * N, device=dev)
+        sc = (1 + 0.1 * torch.randn(G * K, device=dev)) if aff else None
+        sh = (0.1 * torch.randn(G * K, device=dev)) if aff else None
+        dw = torch.zeros(G * N, K, device=dev)
+        out = torch.empty(M, G * N, device=dev)
+        din = torch.empty(M, G * K, device=dev)
+        runs = {
+            "fwd": lambda: ops.linear_fwd(x, w, None, M, N, K, G, sc, sh, ops.ACT_RELU if aff else 0, 0, want_stat=True,
+                                          out=out),
+            "bwd_data": lambda: ops.linear_bwd_data(dout, w, M, N, K, G, out=din),
+            "bwd_weight": lambda: ops.linear_bwd_weight(dout, x, dw, M, N, K, G, sc, sh, ops.ACT_RELU if aff else 0),
+        }
+        flops = 2.0 * M * N * K * G
+        line = f"M={M:6d} N={N:5d} K={K:5d} G={G}"
+        for name in args.only.split(","):
+            fn = runs[name]
+            for _ in range(3):
+                fn()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(args.reps):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            us = 1e3 * e0.elapsed_time(e1) / args.reps
+            line += f" | {name} {us:7.1f} us {flops / us / 1e6:6.1f} TF"
+        print(line, flush=True)
+
+
+if __name__ == "__main__":
+    main()
