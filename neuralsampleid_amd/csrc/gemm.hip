@@ -34,6 +34,7 @@ struct GemmArgs {
   int rsplit;     // number of R-splits (grid.y); >1 => atomic epilogue
   int rchunk;     // R elements per split (multiple of 16)
   int atomic_out;
+  int split_major;  // grid = (splits, tiles): the tiles of one split share an XCD (blocks b, b+8 share an L2)
 };
 
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
@@ -190,9 +191,11 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
 
   const int tiles_j = (p.J + BN - 1) / BN;
   const int tiles_i = (p.I + BM - 1) / BM;
-  int bid = blockIdx.x;
-  {  // XCD-aware remap (blocks b and b+8 share an L2): give each XCD a contiguous run of tiles so the
-     // column tiles that re-read one A row-panel hit the same L2. Bijective only when the grid divides by 8.
+  int bid = p.split_major ? blockIdx.y : blockIdx.x;
+  const int split = p.split_major ? blockIdx.x : blockIdx.y;
+  if (!p.split_major) {
+    // XCD-aware remap (blocks b and b+8 share an L2): give each XCD a contiguous run of tiles so the
+    // column tiles that re-read one A row-panel hit the same L2. Bijective only when the grid divides by 8.
     const int nwg = gridDim.x;
     if ((nwg & 7) == 0) bid = (bid & 7) * (nwg >> 3) + (bid >> 3);
   }
@@ -200,7 +203,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
   if (ti >= tiles_i) return;
   const int g = blockIdx.z;
   const int i0 = ti * BM, j0 = tj * BN;
-  const int rbeg = blockIdx.y * p.rchunk;
+  const int rbeg = split * p.rchunk;
   const int rend = min(p.R, rbeg + p.rchunk);
 
   const float* A = p.A + g * p.a_goff;
@@ -280,7 +283,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
 
   // ---------------- epilogue. C/D layout: col = lane&15, row = 4*(lane>>4) + reg.
   float* C = p.C + g * p.c_goff;
-  const float* bias = (p.bias && blockIdx.y == 0) ? p.bias + g * p.bias_goff : nullptr;
+  const float* bias = (p.bias && split == 0) ? p.bias + g * p.bias_goff : nullptr;
   float csum[TN], csq[TN];
 #pragma unroll
   for (int b = 0; b < TN; ++b) csum[b] = csq[b] = 0.f;
@@ -403,7 +406,10 @@ int launch(GemmArgs p, int groups, hipStream_t s) {
   const int bk = half ? 32 : 16;
   p.rchunk = (p.rchunk + bk - 1) / bk * bk;            // whole stages per split
   p.rsplit = (p.R + p.rchunk - 1) / p.rchunk;
-  dim3 grid(tiles, p.rsplit, groups);
+  // a split re-reads nothing another split reads; tiles of ONE split share both operand row-panels. With the split
+  // index fastest (and a multiple of 8 of them) consecutive blocks go to different XCDs and one split stays on one L2.
+  p.split_major = p.rsplit > 1 && (p.rsplit % 8) == 0;
+  dim3 grid(p.split_major ? p.rsplit : tiles, p.split_major ? tiles : p.rsplit, groups);
   if (half) NSID_LAUNCH((gemm_kernel<BM, BN, AR, BR, true>), grid, dim3(256), 0, s, p);
   else NSID_LAUNCH((gemm_kernel<BM, BN, AR, BR, false>), grid, dim3(256), 0, s, p);
   return nsid_launch_status();

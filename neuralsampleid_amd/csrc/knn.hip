@@ -14,6 +14,19 @@ __device__ __forceinline__ unsigned orderable(float f) {
   return u ^ ((u >> 31) ? 0xFFFFFFFFu : 0x80000000u);
 }
 
+// wave-wide unsigned minimum with DPP only (no LDS permutes): xor-1, xor-2 inside quads, mirror inside 8 and 16 lanes,
+// then row broadcasts 15 / 31; lane 63 ends with the minimum of all 64 lanes and is read back as a scalar.
+__device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
+  unsigned t;
+  t = (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0xB1, 0xF, 0xF, false); v = v < t ? v : t;    // quad_perm [1,0,3,2]
+  t = (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x4E, 0xF, 0xF, false); v = v < t ? v : t;    // quad_perm [2,3,0,1]
+  t = (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x141, 0xF, 0xF, false); v = v < t ? v : t;   // row_half_mirror
+  t = (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x140, 0xF, 0xF, false); v = v < t ? v : t;   // row_mirror
+  t = (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x142, 0xA, 0xF, false); v = v < t ? v : t;   // row_bcast:15
+  t = (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x143, 0xC, 0xF, false); v = v < t ? v : t;   // row_bcast:31
+  return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+
 __global__ __launch_bounds__(KNN_THREADS) void knn_kernel(const float* __restrict__ r, long ldr,
                                                           const float* __restrict__ scale,
                                                           const float* __restrict__ shift, int N, int C, int k,
@@ -98,33 +111,39 @@ __global__ __launch_bounds__(KNN_THREADS) void knn_kernel(const float* __restric
     }
     __syncthreads();
     if (valid) {
-      // ---- phase 3: k*dilation rounds of arg-min per row; key = (orderable distance, index) so ties take the
-      // lower index; a chosen element is retired by setting it to +inf in the owning lane's registers.
+      // ---- phase 3: k*dilation rounds of arg-min per row. Each lane owns up to 4 distances (node lane + 64e) as
+      // order-preserving 32-bit keys plus a live bit; a round is: lane-local min, DPP wave min, then ballots pick the
+      // lowest node id among the lanes that hold that minimum (ties -> lower index), and that slot is retired.
+      // Emitted ids are always < N (padding slots are never live), also when the distances are NaN.
       for (int i = 0; i < 16; ++i) {
-        // keys are (orderable distance << 32 | node id); a slot that is out of range or already taken holds ~0,
-        // which loses against every live key (NaN distances included), so an emitted id is always < N.
-        unsigned long long key[4];
+        unsigned key[4];
+        bool live[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int j = lane + 64 * e;
-          key[e] = (e < NE && j < N) ? (((unsigned long long)orderable(strip[i * SLD + j]) << 32) | (unsigned)j)
-                                     : ~0ull;
+          live[e] = e < NE && j < N;
+          key[e] = live[e] ? orderable(strip[i * SLD + j]) : 0xFFFFFFFFu;
         }
         int32_t* out = idx + ((long)b * N + 16 * s + i) * k;
         for (int round = 0; round < kd; ++round) {
-          unsigned long long best = key[0];
+          unsigned loc = 0xFFFFFFFFu;
 #pragma unroll
-          for (int e = 1; e < 4; ++e) best = key[e] < best ? key[e] : best;
+          for (int e = 0; e < 4; ++e) loc = (live[e] && key[e] < loc) ? key[e] : loc;
+          const unsigned m = wave_min_u32(loc);
+          int j = 0;
+          bool found = false;
 #pragma unroll
-          for (int o = 32; o > 0; o >>= 1) {
-            const unsigned long long other = __shfl_xor(best, o, 64);
-            best = other < best ? other : best;
+          for (int e = 0; e < 4; ++e) {
+            const unsigned long long hit = __ballot(live[e] && key[e] == m);
+            if (!found && hit != 0ull) {          // wave-uniform
+              found = true;
+              j = 64 * e + (__ffsll((long long)hit) - 1);
+            }
           }
 #pragma unroll
           for (int e = 0; e < 4; ++e)
-            if (key[e] == best) key[e] = ~0ull;            // node ids are unique, so exactly one slot matches
-          const int j = min((int)(best & 0xFFFFFFFFull), N - 1);
-          if (lane == 0 && (round % dilation) == 0) out[round / dilation] = j;
+            if (lane + 64 * e == j) live[e] = false;
+          if (lane == 0 && (round % dilation) == 0) out[round / dilation] = j < N ? j : N - 1;
         }
       }
     }

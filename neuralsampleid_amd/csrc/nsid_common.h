@@ -28,10 +28,18 @@ __device__ __forceinline__ float nsid_act_grad(float pre, int act) {
   }
 }
 
+// 64-lane sum with DPP only (xor-1 / xor-2 in quads, mirrors within 8 and 16 lanes, row broadcasts 15 and 31) and a
+// scalar read-back of lane 63: no LDS permutes on the critical path. Every lane receives the total.
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));
+  // row_bcast adds lane 15 of each 16-lane row into the next row (rows 1,3), then lane 31 into rows 2,3; lanes outside
+  // the row mask add the bound_ctrl zero
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x142, 0xA, 0xF, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x143, 0xC, 0xF, true));
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 __device__ __forceinline__ double wave_sum_d(double v) {
 #pragma unroll
