@@ -64,14 +64,12 @@ template <int ROWS, bool RMAJOR, bool H>
 struct StageRegs {
   static constexpr int VEC = TileGeom<ROWS, RMAJOR, H>::VEC;
   f32x4 v[VEC];
-  f32x4 sc[RMAJOR ? VEC : 1], sh[RMAJOR ? VEC : 1];   // RMAJOR: affine follows the reduction index -> per stage
   bool ok[VEC];
 };
 
 template <int ROWS, bool RMAJOR, bool H>
 __device__ __forceinline__ void stage_load(StageRegs<ROWS, RMAJOR, H>& s, const float* __restrict__ base, long ld,
-                                           int row0, int nrows, int r0, int rend, const float* scale,
-                                           const float* shift) {
+                                           int row0, int nrows, int r0, int rend) {
   using G = TileGeom<ROWS, RMAJOR, H>;
   const int t = threadIdx.x;
 #pragma unroll
@@ -83,11 +81,6 @@ __device__ __forceinline__ void stage_load(StageRegs<ROWS, RMAJOR, H>& s, const 
       s.ok[q] = gi < nrows && gr < rend;              // extents are multiples of 4: a quad is all-in or all-out
       const long off = s.ok[q] ? (long)gi * ld + gr : 0;   // out-of-range quads read element 0 and are zeroed later
       s.v[q] = *reinterpret_cast<const f32x4*>(base + off);
-      if (scale != nullptr) {
-        const int ga = s.ok[q] ? gr : 0;
-        s.sc[q] = *reinterpret_cast<const f32x4*>(scale + ga);
-        s.sh[q] = *reinterpret_cast<const f32x4*>(shift + ga);
-      }
     } else {
       constexpr int V_PER_ROW = ROWS / 4;
       const int rr = idx / V_PER_ROW, cv = (idx % V_PER_ROW) * 4;
@@ -116,7 +109,8 @@ __device__ __forceinline__ void colaffine_load(f32x4* sc, f32x4* sh, int row0, i
 
 template <int ROWS, bool RMAJOR, bool H>
 __device__ __forceinline__ void stage_store(char* lds, const StageRegs<ROWS, RMAJOR, H>& s, bool affine, float slope,
-                                            const f32x4* csc, const f32x4* csh) {
+                                            const f32x4* csc, const f32x4* csh, const float* rscale,
+                                            const float* rshift, int r0, int rend) {
   using G = TileGeom<ROWS, RMAJOR, H>;
   const int t = threadIdx.x;
 #pragma unroll
@@ -124,8 +118,16 @@ __device__ __forceinline__ void stage_store(char* lds, const StageRegs<ROWS, RMA
     const int idx = t + 256 * q;
     f32x4 x = s.v[q];
     if (affine) {
-      const f32x4 sc = RMAJOR ? s.sc[q] : csc[q];
-      const f32x4 sh = RMAJOR ? s.sh[q] : csh[q];
+      f32x4 sc, sh;
+      if (RMAJOR) {   // reduction-indexed affine (producer BatchNorm): tiny cache-hot vectors, fetched at commit time
+        const int gr = r0 + (idx % G::QPR) * 4;
+        const int ga = gr < rend ? gr : 0;
+        sc = *reinterpret_cast<const f32x4*>(rscale + ga);
+        sh = *reinterpret_cast<const f32x4*>(rshift + ga);
+      } else {
+        sc = csc[q];
+        sh = csh[q];
+      }
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const float v = sc[e] * x[e] + sh[e];
@@ -178,7 +180,7 @@ __device__ __forceinline__ bf16x8 frag_read_bf16(const char* lds, int tile_row0,
 }
 
 template <int BM, int BN, bool A_RMAJOR, bool B_RMAJOR, bool H>
-__global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
+__global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {   // >= 2 waves/SIMD: <= 256 VGPR+AGPR
   using GA = TileGeom<BM, A_RMAJOR, H>;
   using GB = TileGeom<BN, B_RMAJOR, H>;
   constexpr int BK = Prec<H>::BK;
@@ -223,8 +225,6 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
 #pragma unroll
     for (int b = 0; b < TN; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  StageRegs<BM, A_RMAJOR, H> ra;
-  StageRegs<BN, B_RMAJOR, H> rb;
   // only these operand/affine pairings exist: forward (A reduction-major, affine on the reduction index) and
   // backward-weight (B column-major, affine on the column index)
   const bool a_aff = A_RMAJOR && a_sc != nullptr;
@@ -232,22 +232,28 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
   f32x4 bcs[GB::VEC], bch[GB::VEC];
   if (b_aff) colaffine_load<BN, H>(bcs, bch, j0, p.J, b_sc, b_sh);
   const int nstage = (rend - rbeg + BK - 1) / BK;
-  if (nstage > 0) {
-    stage_load<BM, A_RMAJOR, H>(ra, A, p.lda, i0, p.I, rbeg, rend, a_aff ? a_sc : nullptr, a_sh);
-    stage_load<BN, B_RMAJOR, H>(rb, B, p.ldb, j0, p.J, rbeg, rend, nullptr, nullptr);
-    stage_store<BM, A_RMAJOR, H>(lds_raw, ra, a_aff, p.a_slope, nullptr, nullptr);
-    stage_store<BN, B_RMAJOR, H>(lds_raw + GA::BYTES, rb, b_aff, p.b_slope, bcs, bch);
-  }
-  __syncthreads();
-  for (int st = 0; st < nstage; ++st) {
+
+  // Register prefetch depth: fp32 MFMA blocks (64 x 32 cycles) cover one memory round trip, so one stage in flight
+  // is enough; the bf16 MFMA block (16 x 16 cycles) is far shorter than the round trip, so TWO stages are kept in
+  // flight (two register sets, static indices through the 2x unrolled loop body below).
+  constexpr int DEPTH = H ? 2 : 1;
+  StageRegs<BM, A_RMAJOR, H> ra[DEPTH];
+  StageRegs<BN, B_RMAJOR, H> rb[DEPTH];
+
+  auto issue = [&](auto& sa, auto& sb, int st) {
+    const int r0 = rbeg + st * BK;
+    stage_load<BM, A_RMAJOR, H>(sa, A, p.lda, i0, p.I, r0, rend);
+    stage_load<BN, B_RMAJOR, H>(sb, B, p.ldb, j0, p.J, r0, rend);
+  };
+  auto commit = [&](const auto& sa, const auto& sb, int st) {
+    char* dst = lds_raw + (st & 1) * STAGE;
+    const int r0 = rbeg + st * BK;
+    stage_store<BM, A_RMAJOR, H>(dst, sa, a_aff, p.a_slope, nullptr, nullptr, a_sc, a_sh, r0, rend);
+    stage_store<BN, B_RMAJOR, H>(dst + GA::BYTES, sb, b_aff, p.b_slope, bcs, bch, nullptr, nullptr, r0, rend);
+  };
+  auto compute = [&](int st) {
     const char* la = lds_raw + (st & 1) * STAGE;
     const char* lb = la + GA::BYTES;
-    const bool more = st + 1 < nstage;
-    if (more) {      // issue the next stage's global loads; they complete under the MFMA block below
-      const int r0 = rbeg + (st + 1) * BK;
-      stage_load<BM, A_RMAJOR, H>(ra, A, p.lda, i0, p.I, r0, rend, a_aff ? a_sc : nullptr, a_sh);
-      stage_load<BN, B_RMAJOR, H>(rb, B, p.ldb, j0, p.J, r0, rend, nullptr, nullptr);
-    }
     if (H) {
       bf16x8 fa[TM], fb[TN];
 #pragma unroll
@@ -273,12 +279,37 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
           for (int b = 0; b < TN; ++b)
             acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[a][s], fb[b][s], acc[a][b], 0, 0, 0);
     }
-    if (more) {
-      char* na = lds_raw + ((st + 1) & 1) * STAGE;
-      stage_store<BM, A_RMAJOR, H>(na, ra, a_aff, p.a_slope, nullptr, nullptr);
-      stage_store<BN, B_RMAJOR, H>(na + GA::BYTES, rb, b_aff, p.b_slope, bcs, bch);
+  };
+
+  if (nstage > 0) {
+    issue(ra[0], rb[0], 0);
+    commit(ra[0], rb[0], 0);
+    if (DEPTH == 2 && nstage > 1) issue(ra[DEPTH - 1], rb[DEPTH - 1], 1);     // stage 1 -> register set 1
+  }
+  __syncthreads();
+  if (DEPTH == 1) {
+    for (int st = 0; st < nstage; ++st) {
+      const bool more = st + 1 < nstage;
+      if (more) issue(ra[0], rb[0], st + 1);        // lands under the MFMA block below
+      compute(st);
+      if (more) commit(ra[0], rb[0], st + 1);
+      __syncthreads();
     }
-    __syncthreads();
+  } else {
+    // invariant at the top of iteration st: LDS[st&1] holds stage st; register set (st+1)&1 holds stage st+1 (loads
+    // possibly still in flight); register set st&1 is free. Plain loads stay in flight across __syncthreads().
+    for (int st = 0; st < nstage; st += 2) {
+      if (st + 2 < nstage) issue(ra[0], rb[0], st + 2);
+      compute(st);
+      if (st + 1 < nstage) commit(ra[DEPTH - 1], rb[DEPTH - 1], st + 1);
+      __syncthreads();
+      if (st + 1 < nstage) {
+        if (st + 3 < nstage) issue(ra[DEPTH - 1], rb[DEPTH - 1], st + 3);
+        compute(st + 1);
+        if (st + 2 < nstage) commit(ra[0], rb[0], st + 2);
+        __syncthreads();
+      }
+    }
   }
 
   // ---------------- epilogue. C/D layout: col = lane&15, row = 4*(lane>>4) + reg.
