@@ -103,13 +103,15 @@ def main():
     opt = FusedClipAdam(model.parameters(), lr=CFG["lr"], max_norm=1.0)
     x_i, x_j = synth_clips(args.batch, 1000 + 2 * rank, dev)   # each rank owns different clips
     loss_buf = torch.zeros((), device=dev)
+    reducer = parallel.GradReducer(opt.params, opt.flat_g, opt.offsets, bucket_bytes=16 << 20).install()
 
     def step():
         opt.zero_grad()
+        reducer.start_step()
         _, _, z_i, z_j = model(x_i, x_j)
-        loss = parallel.dist_ntxent_loss(z_i, z_j, CFG)
-        loss.backward()
-        parallel.allreduce_gradients(opt.flat_g)
+        loss = parallel.dist_ntxent_loss(z_i, z_j, CFG)      # z all-gather; NT-Xent over the global batch
+        loss.backward()                                      # bucketed all-reduce fires as buckets complete
+        reducer.finish()
         opt.step()
         loss_buf.copy_(loss.detach())
 
@@ -127,7 +129,7 @@ def main():
         if rank == 0:
             log(f"eager warm-up step {i} done, loss {float(loss_buf):.4f}")
     graph = None
-    if not args.no_graph and world == 1:
+    if not args.no_graph:
         try:
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
@@ -229,6 +231,8 @@ def main():
                                    f"(fwd x2 views + NT-Xent + bwd + clip + Adam), batch={args.batch} synthetic "
                                    f"(64,128) log-mel clip pairs per GPU, random-init weights",
                        "global_batch": args.batch * world, "k": args.k, "parallelism": f"dp{world}",
+                       "collectives": ("z all-gather + bucketed SUM all-reduce of gradients overlapped with backward"
+                                       if parallel._distributed() else "none (single process)"),
                        "gemm_arithmetic": ("bf16 operands (RNE at LDS staging), fp32 storage + fp32 accumulate"
                                            if args.precision == "bf16" else "fp32 operands, fp32 accumulate"),
                        "hipgraph": graph is not None, "final_loss": round(final_loss, 5)},

@@ -48,6 +48,10 @@ EXACT_BIAS_GRAD = _os.environ.get("NSID_EXACT_BIAS_GRAD", "0") == "1"
 # for autograd to add: saves one zero-fill and one add per parameter per view.
 DIRECT_GRADS = False
 
+# Called at the end of every block backward with the parameter tensors whose gradient contribution has just been
+# enqueued (parallel.GradReducer uses it to overlap the bucketed all-reduce with the rest of backward).
+GRAD_READY_HOOK = None
+
 
 def _bias_grad_before_bn(dr, g):
     if EXACT_BIAS_GRAD:
@@ -273,6 +277,8 @@ class _BlockFn(torch.autograd.Function):
         G = {n: (P[n].grad if direct else torch.zeros_like(P[n])) for n in names}
         dx = ctx.bwd(dout.contiguous(), P, S, G)
         ctx.S = None
+        if direct and GRAD_READY_HOOK is not None:
+            GRAD_READY_HOOK([P[n] for n in names])
         head = (None, None, None, None, None, dx if ctx.x_needs else None)
         return head + tuple(None if direct else G[n] for n in names)
 

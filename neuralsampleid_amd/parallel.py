@@ -29,7 +29,7 @@ def shard_range(global_batch: int, rank: int, world: int) -> Tuple[int, int]:
 def gather_embeddings(z: torch.Tensor, group=None) -> torch.Tensor:
     """(B_local, d) -> (B_global, d), rank-major so that global pair p = rank*B_local + local index"""
     world = dist.get_world_size(group)
-    if world == 1:
+    if world == 1 and not _distributed(group):
         return z
     out = torch.empty((world * z.shape[0], z.shape[1]), device=z.device, dtype=z.dtype)
     dist.all_gather_into_tensor(out, z.contiguous(), group=group)
@@ -47,7 +47,7 @@ class _DistNtxent(torch.autograd.Function):
         p0, n = shard_range(zi_all.shape[0], rank, world)
         part, dzi, dzj = rows_fn(zi_all, zj_all, tau, p0, n)        # part = sum of owned rows / (2*B_global)
         loss = part.reshape(()).clone()
-        if world > 1:
+        if _distributed(group):
             dist.all_reduce(loss, op=dist.ReduceOp.SUM, group=group)   # every rank reports the global loss
         ctx.save_for_backward(dzi, dzj)
         return loss
@@ -66,7 +66,7 @@ def _hip_rows(zi_all, zj_all, tau, p0, n):
 def dist_ntxent_loss(z_i: torch.Tensor, z_j: torch.Tensor, cfg: dict, group=None,
                      rows_fn: Optional[Callable] = None) -> torch.Tensor:
     """Drop-in for simclr.ntxent.ntxent_loss under data parallelism: negatives come from the GLOBAL batch."""
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if not _distributed(group):
         from .simclr.ntxent import ntxent_loss
         if rows_fn is None:
             return ntxent_loss(z_i, z_j, cfg)
@@ -76,7 +76,7 @@ def dist_ntxent_loss(z_i: torch.Tensor, z_j: torch.Tensor, cfg: dict, group=None
 def allreduce_gradients(flat_grad: torch.Tensor, group=None, bucket_bytes: int = 0, async_op: bool = False):
     """SUM the flat gradient buffer over ranks. bucket_bytes > 0 splits it into contiguous buckets (each its own
     collective, so early buckets can overlap the rest of backward when launched from a side stream)."""
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if not _distributed(group):
         return []
     if bucket_bytes <= 0:
         w = dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
@@ -90,13 +90,87 @@ def allreduce_gradients(flat_grad: torch.Tensor, group=None, bucket_bytes: int =
     return works
 
 
+def _distributed(group=None) -> bool:
+    """collectives are issued when a process group exists and has >1 rank (NSID_FORCE_COLLECTIVES=1: also with one
+    rank, so that the collective code path — including hipGraph capture of it — can be exercised on a single GPU)"""
+    import os
+    if not dist.is_initialized():
+        return False
+    return dist.get_world_size(group) > 1 or os.environ.get("NSID_FORCE_COLLECTIVES", "0") == "1"
+
+
+class GradReducer:
+    """Bucketed SUM all-reduce of the flat gradient buffer, overlapped with backward.
+
+    Parameters sit in the flat buffer in registration (= forward) order and backward completes them last-to-first, so
+    buckets are cut from the END of the buffer. Every parameter receives `uses_per_step` contributions per step (two:
+    the encoder runs once per view); when the last contribution of a bucket has been ENQUEUED, its all-reduce is
+    launched with async_op=True — the collective's stream waits for the compute stream at that point and then runs
+    concurrently with the remaining backward kernels (xGMI links are otherwise idle during backward). `finish()`
+    reduces whatever did not fire and makes the compute stream wait for all of it before the optimiser step."""
+
+    def __init__(self, params, flat_grad: torch.Tensor, offsets, group=None, bucket_bytes: int = 16 << 20,
+                 uses_per_step: int = 2):
+        self.flat, self.group, self.uses = flat_grad, group, uses_per_step
+        self.bucket_of, self.bounds, self.need = {}, [], []
+        esz = flat_grad.element_size()
+        end = flat_grad.numel()
+        cur_start, count = end, 0
+        for p, off in zip(reversed(list(params)), reversed(list(offsets))):
+            cur_start = off
+            count += 1
+            self.bucket_of[id(p)] = len(self.bounds)
+            if (end - cur_start) * esz >= bucket_bytes:
+                self.bounds.append((cur_start, end))
+                self.need.append(count * uses_per_step)
+                end, count = cur_start, 0
+        if count:
+            self.bounds.append((0, end))
+            self.need.append(count * uses_per_step)
+        self.remaining, self.works, self.fired = [], [], []
+
+    def start_step(self):
+        self.remaining = list(self.need)
+        self.works, self.fired = [], []
+
+    def block_done(self, params):
+        for p in params:
+            b = self.bucket_of.get(id(p))
+            if b is None:
+                continue
+            self.remaining[b] -= 1
+            if self.remaining[b] == 0:
+                self._fire(b)
+
+    def _fire(self, b: int):
+        self.fired.append(b)
+        if _distributed(self.group):
+            s, e = self.bounds[b]
+            self.works.append(dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def finish(self):
+        for b, r in enumerate(self.remaining):
+            if r > 0:                      # a parameter that got fewer contributions than expected this step
+                self.remaining[b] = 0
+                self._fire(b)
+        for w in self.works:
+            w.wait()
+        self.works = []
+
+    def install(self):
+        from . import functional
+        functional.GRAD_READY_HOOK = self.block_done
+        return self
+
+
 def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
     """torchrun contract: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT. Returns (rank, local, world)."""
     import os
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    import os as _os
+    if (world > 1 or _os.environ.get("NSID_FORCE_COLLECTIVES", "0") == "1") and not dist.is_initialized():
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         if backend == "nccl":

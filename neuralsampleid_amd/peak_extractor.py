@@ -26,6 +26,8 @@ class _PatchifyFn(torch.autograd.Function):
         F_.patchify_backward(dout.contiguous(), ctx.P, ctx.S, G)
         ctx.S = None
         if direct:
+            if F_.GRAD_READY_HOOK is not None:
+                F_.GRAD_READY_HOOK(list(ctx.P.values()))
             return None, None, None, None, None
         return None, G["convs.0.weight"], G["convs.0.bias"], None, None
 

@@ -111,6 +111,58 @@ def test_two_rank_step_matches_single_process():
     assert torch.allclose(gz, z_i.detach(), atol=1e-6)                  # rank-major gather == global pair order
 
 
+def _reducer_worker(rank, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(WORLD),
+                      LOCAL_RANK=str(rank))
+    from neuralsampleid_amd import parallel
+    parallel.init_from_env("gloo")
+    sizes = [40, 8, 300, 12, 64, 700]            # "parameters" in forward order
+    offs, tot = [], 0
+    for n in sizes:
+        offs.append(tot)
+        tot += (n + 3) // 4 * 4
+    flat = torch.zeros(tot)
+    params = [flat[o:o + n] for o, n in zip(offs, sizes)]
+    red = parallel.GradReducer(params, flat, offs, bucket_bytes=1024, uses_per_step=2)
+    red.start_step()
+    order = []
+    for view in range(2):                        # two views; backward visits parameters last-to-first
+        for i in reversed(range(len(params))):
+            params[i] += (rank + 1) * (i + 1)    # this rank's gradient contribution
+            before = len(red.fired)
+            red.block_done([params[i]])
+            if len(red.fired) > before:
+                order.append((view, i, list(red.fired)))
+    red.finish()
+    if rank == 0:
+        out.put((flat.tolist(), red.bounds, order, offs, sizes))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_grad_reducer_buckets_fire_early_and_sum():
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    port = _free_port()
+    procs = [ctx.Process(target=_reducer_worker, args=(r, port, q)) for r in range(WORLD)]
+    for p in procs:
+        p.start()
+    deadline = time.time() + 120
+    while q.empty():
+        assert time.time() < deadline and all(p.exitcode in (None, 0) for p in procs)
+        time.sleep(0.2)
+    flat, bounds, order, offs, sizes = q.get()
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    flat = torch.tensor(flat)
+    for i, (o, n) in enumerate(zip(offs, sizes)):            # sum over ranks (1+2) x two views
+        assert torch.equal(flat[o:o + n], torch.full((n,), 2.0 * 3 * (i + 1)))
+    assert bounds[0][1] == flat.numel() and bounds[-1][0] == 0 and len(bounds) >= 3
+    assert all(view == 1 for view, _, _ in order)             # nothing fires before the second view contributed
+    assert order[0][2] == [0] and order[0][1] > 0             # the LAST parameters' bucket fires first, mid-backward
+
+
 def test_shard_range():
     from neuralsampleid_amd import parallel
     assert [parallel.shard_range(2048, r, 8) for r in (0, 7)] == [(0, 256), (1792, 256)]
