@@ -66,6 +66,49 @@ def cpu_baseline(k, batch=32, steps=3):
             "sample": f"{steps} full contrastive steps at batch {batch} (fp32, oracle/ref_torch.py), {dt:.2f} s/step"}
 
 
+def infer_bench(args, model, rank, world, dev, dist):
+    """config 5: forward-only, eval-mode BN, contiguous shard per rank, no collective on the data path"""
+    from neuralsampleid_amd import fingerprint
+    lo, hi = fingerprint.shard_bounds(args.clips, rank, world)
+    mb = 1024
+    pool, _ = synth_clips(4 * mb, 77 + rank, dev)                 # synthetic clips, reused round-robin
+    n_mb = (hi - lo + mb - 1) // mb
+    out = torch.empty((mb, CFG["d"]), device=dev)
+    for i in range(max(1, args.warmup)):
+        fingerprint.extract_fingerprints(model, pool[:mb], mb, out)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    done = 0
+    for i in range(n_mb):
+        n = min(mb, hi - lo - done)
+        s = (i % 4) * mb
+        fingerprint.extract_fingerprints(model, pool[s:s + n], mb, out[:n])
+        done += n
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t)
+    if rank == 0:
+        print(json.dumps({
+            "metric": "audio clips/sec (forward-only fingerprint extraction, grafp encoder)",
+            "value": round(args.clips / elapsed, 1), "unit": "clips/s", "n_gpus": world, "steps": n_mb,
+            "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / n_mb, 3), "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32" if args.precision == "fp32" else "bf16",
+            "data": "synthetic",
+            "config": {"workload": f"fingerprint inference, {args.clips} synthetic clips, eval-mode BN, micro-batch {mb}, "
+                                   f"GraphEncoder('t', k={args.k}{', deep' if args.deep else ''})",
+                       "parallelism": f"shard{world}"}}))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def log(msg):
     print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
@@ -80,6 +123,12 @@ def main():
     ap.add_argument("--precision", choices=["fp32", "bf16"], default=os.environ.get("NSID_BENCH_PRECISION", "bf16"),
                     help="GEMM operand arithmetic: bf16 operands / fp32 storage+accumulate (BASELINE config 2, default) "
                          "or fp32 (exact fp32 MFMA, the strict-parity path); the other mode is timed as a side number")
+    ap.add_argument("--mode", choices=["train", "infer"], default="train",
+                    help="train: contrastive step (BASELINE config 2/3, default); infer: forward-only fingerprint "
+                         "extraction in eval mode (config 5), --clips per job sharded over the ranks")
+    ap.add_argument("--clips", type=int, default=100000, help="infer mode: total clips of the job")
+    ap.add_argument("--deep", action="store_true",
+                    help="BASELINE config 4: blocks [4,4,12,4], k=18, intended dilation schedule (capped by N)")
     ap.add_argument("--no-graph", action="store_true", help="do not capture the step in a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -99,7 +148,12 @@ def main():
 
     ops.set_gemm_precision(args.precision)
     torch.manual_seed(42)                                   # identical initial weights on every rank
-    model = SimCLR(CFG, GraphEncoder(CFG, in_channels=CFG["n_filters"], k=args.k, size="t")).to(dev).train()
+    enc_kw = dict(blocks=[4, 4, 12, 4], use_dilation=True) if args.deep else {}
+    if args.deep:
+        args.k = 18
+    model = SimCLR(CFG, GraphEncoder(CFG, in_channels=CFG["n_filters"], k=args.k, size="t", **enc_kw)).to(dev).train()
+    if args.mode == "infer":
+        return infer_bench(args, model, rank, world, dev, dist)
     opt = FusedClipAdam(model.parameters(), lr=CFG["lr"], max_norm=1.0)
     x_i, x_j = synth_clips(args.batch, 1000 + 2 * rank, dev)   # each rank owns different clips
     loss_buf = torch.zeros((), device=dev)

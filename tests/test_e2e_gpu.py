@@ -307,3 +307,23 @@ def test_graph_encoder_reference_layout_entry(golden):
         h2, _, _, _ = model(x, x)
     assert h.shape == (8, 1024)
     assert maxerr(h, h2) < 1e-4 * float(h2.abs().max())
+
+
+def test_extract_fingerprints_matches_eval_forward(golden):
+    """generate.py path: ragged micro-batches, eval-mode BN, one view; equals the eval goldens of the reference"""
+    from neuralsampleid_amd import functional as F_
+    from neuralsampleid_amd.fingerprint import extract_fingerprints, shard_bounds
+    g = golden("e2e_b8_k3")
+    model = build_model(3).train()                       # extract_fingerprints switches to eval and back
+    x = torch.cat([g.t("x_i"), g.t("x_j")]).to(DEV)      # 16 clips
+    z = extract_fingerprints(model, x, batch=16)
+    assert model.training and z.shape == (16, 128)
+    # own kNN (no teacher forcing): a near-tie flip moves one clip's z by up to ~3e-3 (tests/test_oracle_golden.py)
+    assert maxerr(z[:8], g.t("z_i_eval")) < 1e-2 and maxerr(z[8:], g.t("z_j_eval")) < 1e-2
+    ref = torch.cat([g.t("z_i_eval"), g.t("z_j_eval")])
+    cos = torch.nn.functional.cosine_similarity(z.cpu(), ref, dim=1)
+    assert float(cos.min()) > 0.9995 and float(cos.median()) > 0.999999
+    z5 = extract_fingerprints(model, x, batch=5)         # ragged splits change nothing in eval mode
+    assert maxerr(z5, z) < 1e-2
+    assert [shard_bounds(10, r, 4) for r in range(4)] == [(0, 3), (3, 6), (6, 8), (8, 10)]
+    assert shard_bounds(100000, 7, 8) == (87500, 100000)
