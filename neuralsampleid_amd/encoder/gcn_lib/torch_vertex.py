@@ -7,6 +7,7 @@ from torch import nn
 
 from ... import functional as F_
 from ... import ops
+from .pos_embed import relative_pos_table
 from .torch_edge import DenseDilatedKnnGraph
 from .torch_nn import BasicConv
 
@@ -106,8 +107,8 @@ class Grapher(nn.Module):
         self.relative_pos = None
         if relative_pos:
             # state_dict compatibility only: the reference builds a sin-cos table here (torch_vertex.py:165-172) and
-            # never reads it (forward passes relative_pos=None, :189). Same key, shape and requires_grad=False.
-            self.relative_pos = nn.Parameter(torch.zeros(1, n, n // (r * r)), requires_grad=False)
+            # never reads it (forward passes relative_pos=None, :189). Same key, shape, values, requires_grad=False.
+            self.relative_pos = nn.Parameter(relative_pos_table(in_channels, n, r), requires_grad=False)
 
     def forward_rows(self, rows, B, N):
         params, buffers = _split(self)

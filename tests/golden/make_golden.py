@@ -324,8 +324,17 @@ def gold_init():
         json.dump(chk, f, indent=0)
 
 
+def gold_relpos():
+    """the (dead) relative_pos buffers the reference's Grapher constructor builds, one per distinct (C, n)"""
+    print("relpos")
+    m = GraphEncoder(CFG, in_channels=CFG["n_filters"], k=3, size="t")
+    sd = m.state_dict()
+    save("relative_pos_t", **{k: sd[k] for k in ("backbone.0.0.relative_pos", "backbone.3.0.relative_pos",
+                                                 "backbone.6.0.relative_pos", "backbone.13.0.relative_pos")})
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
-    only = sys.argv[1:] or ["shapes", "init", "knn", "mrconv", "block", "downsample", "peak", "ntxent", "e2e"]
+    only = sys.argv[1:] or ["shapes", "init", "relpos", "knn", "mrconv", "block", "downsample", "peak", "ntxent", "e2e"]
     for name in only:
         globals()["gold_" + name]()

@@ -50,3 +50,14 @@ def test_deep_config_plan():
     from oracle import ref_torch as R
     plan = R.encoder_plan("t", 18, blocks=[4, 4, 12, 4], use_dilation=True)
     assert [e[3] for e in plan if e[0] == "block"] == ds
+
+
+def test_relative_pos_matches_reference(golden):
+    """the dead relative_pos buffers carry the reference's values (<= 1 fp32 ulp)"""
+    g = golden("relative_pos_t")
+    sd = build().state_dict()
+    for key in g:
+        ref = g.t(key)
+        got = sd["encoder." + key]
+        assert got.shape == ref.shape and not got.requires_grad
+        assert float((got - ref).abs().max()) <= 2.4e-7 * max(1.0, float(ref.abs().max())), key
