@@ -107,8 +107,9 @@ class GraphEncoder(nn.Module):
         self.backbone = Seq(*self.backbone)
         self.proj = nn.Conv2d(self.channels[-1], self.emb_dims, 1, bias=True)
 
-    def forward_rows(self, nodes, B, N):
-        """nodes (B*N, in_channels) node-major -> (B, emb_dims)"""
+    def forward_rows(self, nodes, B, N, return_nodes=False):
+        """nodes (B*N, in_channels) node-major -> (B, emb_dims); with return_nodes also the pre-projection node
+        matrix as (rows (B*N_last, C_last), N_last, emb)"""
         params, buffers = _split(self.stem)
         x = F_.run_block(F_.stem_forward, F_.stem_backward, params, buffers, nodes, self.training)
         for entry in self.backbone:
@@ -119,7 +120,8 @@ class GraphEncoder(nn.Module):
                 x = entry[0].forward_rows(x, B, N)
                 x = entry[1].forward_rows(x)
         params, buffers = _split(self.proj)
-        return F_.run_block(F_.proj_mean_forward, F_.proj_mean_backward, params, buffers, x, B, N)
+        emb = F_.run_block(F_.proj_mean_forward, F_.proj_mean_backward, params, buffers, x, B, N)
+        return (x, N, emb) if return_nodes else emb
 
     def forward(self, x):
         B, C, N = x.shape

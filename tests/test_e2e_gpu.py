@@ -327,3 +327,26 @@ def test_extract_fingerprints_matches_eval_forward(golden):
     assert maxerr(z5, z) < 1e-2
     assert [shard_bounds(10, r, 4) for r in range(4)] == [(0, 3), (3, 6), (6, 8), (8, 10)]
     assert shard_bounds(100000, 7, 8) == (87500, 100000)
+
+
+def test_graph_encoder_dgl_signature_shim(golden):
+    """train.py:111 / test_fp.py:235 / downstream.py:112 call sites: GraphEncoderDGL(cfg=..., in_channels=..., k=...)"""
+    from neuralsampleid_amd.encoder.dgl.graph_encoder import GraphEncoderDGL
+    from neuralsampleid_amd.simclr.simclr import SimCLR
+    g = golden("e2e_b8_k3")
+    model = SimCLR(GRAFP_CFG, encoder=GraphEncoderDGL(cfg=GRAFP_CFG, in_channels=GRAFP_CFG["n_filters"], k=3, size="t"))
+    load_synth(model)
+    model.eval()
+    x = g.t("x_i").to(DEV)
+    with torch.no_grad():
+        p = model.peak_extractor(x)
+        x_nodes, x_emb = model.encoder(p, return_pre_proj=True)
+        emb_only = model.encoder(p)
+        h_i, _, _, _ = model(x, x)
+    assert x_nodes.shape == (8, 512, 32) and x_emb.shape == (8, 1024)
+    assert maxerr(emb_only, x_emb) < 2e-3 and maxerr(h_i, x_emb) < 2e-3
+    assert relerr(x_emb, g.t("h_i_eval")) < 1e-2       # the gcn_lib encoder's numbers (own kNN: one near-tie flip)
+    # proj + node mean of the returned node matrix reproduces the embedding (reference :136-140)
+    w = model.encoder.proj.weight.reshape(1024, 512)
+    ref = (x_nodes.mean(dim=2) @ w.t()) + model.encoder.proj.bias
+    assert maxerr(ref, x_emb) < 1e-3
