@@ -109,6 +109,24 @@ def infer_bench(args, model, rank, world, dev, dist):
         dist.destroy_process_group()
 
 
+def measured_traffic(kernel, precision):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/*/hbm_traffic.json: separate
+    --pmc FETCH_SIZE / WRITE_SIZE runs of this same bench, gfx950 FETCH_SIZE x2 correction applied), or None."""
+    import glob
+    key = kernel.replace(" ", "")[:-1] + "," + ("true" if precision == "bf16" else "false") + ">"
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "hbm_traffic.json"))):
+        try:
+            with open(path) as f:
+                ks = json.load(f)["kernels"]
+        except (OSError, ValueError, KeyError):
+            continue
+        for name, v in ks.items():
+            if name.replace(" ", "") == key:
+                best = (int(v["hbm_bytes_per_launch"]), os.path.relpath(path, ROOT))
+    return best
+
+
 def log(msg):
     print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
@@ -233,7 +251,10 @@ def main():
                        "share_of_step": round(d["ms"] / (1e3 * elapsed / args.steps), 3)} for n, d in prof.items()}
         dom = max(prof, key=lambda n: prof[n]["ms"])
         d = prof[dom]
-        common = {"kernel": dom, "traffic": None, "launches_per_step": d["launches"],
+        tr = measured_traffic(dom, args.precision)
+        common = {"kernel": dom, "traffic": tr[0] if tr else None,
+                  "traffic_source": (tr[1] + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, bytes per launch)") if tr else None,
+                  "launches_per_step": d["launches"],
                   "avg_launch_us": round(1e3 * d["ms"] / d["launches"], 2),
                   "flops_per_launch": round(d["flops"] / d["launches"]),
                   "alg_bytes_per_launch": round(d["bytes"] / d["launches"]),
