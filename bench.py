@@ -141,6 +141,9 @@ def main():
     ap.add_argument("--precision", choices=["fp32", "bf16"], default=os.environ.get("NSID_BENCH_PRECISION", "bf16"),
                     help="GEMM operand arithmetic: bf16 operands / fp32 storage+accumulate (BASELINE config 2, default) "
                          "or fp32 (exact fp32 MFMA, the strict-parity path); the other mode is timed as a side number")
+    ap.add_argument("--storage", choices=["fp32", "bf16"], default=None,
+                    help="activation storage in HBM (default: bf16 with --precision bf16 = BASELINE config 2's "
+                         "'bf16 storage / fp32 accumulate'; fp32 with --precision fp32)")
     ap.add_argument("--mode", choices=["train", "infer"], default="train",
                     help="train: contrastive step (BASELINE config 2/3, default); infer: forward-only fingerprint "
                          "extraction in eval mode (config 5), --clips per job sharded over the ranks")
@@ -164,7 +167,13 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
+    from neuralsampleid_amd import functional as F_
+    if args.storage is None:
+        args.storage = "bf16" if args.precision == "bf16" else "fp32"
+    if args.storage == "bf16" and args.precision != "bf16":
+        raise SystemExit("--storage bf16 needs --precision bf16 (bf16 tensors feed the bf16 MFMA path)")
     ops.set_gemm_precision(args.precision)
+    F_.set_activation_dtype(args.storage)
     torch.manual_seed(42)                                   # identical initial weights on every rank
     enc_kw = dict(blocks=[4, 4, 12, 4], use_dilation=True) if args.deep else {}
     if args.deep:
@@ -273,6 +282,7 @@ def main():
         # side number: the same step in the other arithmetic (eager; the GPU time dominates the host time)
         alt = "fp32" if args.precision == "bf16" else "bf16"
         ops.set_gemm_precision(alt)
+        F_.set_activation_dtype(alt)
         for _ in range(2):
             step()
         torch.cuda.synchronize()
@@ -285,6 +295,7 @@ def main():
         other = {"precision": alt, "ms_per_step": round(1e3 * dt, 3), "value": round(args.batch / dt, 1),
                  "unit": "clips/s", "note": "eager launches, same model continued; fp32 = strict-parity arithmetic"}
         ops.set_gemm_precision(args.precision)
+        F_.set_activation_dtype(args.storage)
         log(f"{alt}: {1e3 * dt:.2f} ms/step")
 
     cpu = None
@@ -296,7 +307,7 @@ def main():
     if rank == 0:
         clips = args.batch * world * args.steps
         ms = 1e3 * elapsed / args.steps
-        step_bytes = 57e6 * 2.0 * args.batch       # 57 MB / clip-pair at 2 B/elem -> x2: storage is fp32
+        step_bytes = 57e6 * (1.0 if args.storage == "bf16" else 2.0) * args.batch   # 57 MB/pair at 2 B/elem
         out = {
             "metric": "audio clips/sec (contrastive step, grafp encoder)", "value": round(clips / elapsed, 1),
             "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -308,8 +319,9 @@ def main():
                        "global_batch": args.batch * world, "k": args.k, "parallelism": f"dp{world}",
                        "collectives": ("z all-gather + bucketed SUM all-reduce of gradients overlapped with backward"
                                        if parallel._distributed() else "none (single process)"),
-                       "gemm_arithmetic": ("bf16 operands (RNE at LDS staging), fp32 storage + fp32 accumulate"
-                                           if args.precision == "bf16" else "fp32 operands, fp32 accumulate"),
+                       "gemm_arithmetic": ("bf16 MFMA operands, fp32 accumulate" if args.precision == "bf16"
+                                           else "fp32 operands, fp32 accumulate"),
+                       "activation_storage": args.storage,
                        "hipgraph": graph is not None, "final_loss": round(final_loss, 5)},
             "roofline": roofline,
             "step_hbm_frac_algorithmic": round(step_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),

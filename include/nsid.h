@@ -32,6 +32,13 @@ extern "C" {
 
 #define NSID_ROW_TILE 128 /* rows per BatchNorm partial-statistics tile (all kernels agree on it) */
 
+/* storage type of ACTIVATION tensors (features, raw conv outputs, their gradients): every `void*` activation argument
+ * below comes with a dtype code. Parameters, parameter gradients, BatchNorm vectors/statistics, indices and the small
+ * head tensors (pooled features, projector, embeddings) are always fp32. Arithmetic is always fp32-accumulated.
+ * bf16 rows need C % 8 == 0 (16-byte chunks). */
+#define NSID_F32 0
+#define NSID_BF16 1
+
 #define NSID_GEMM_FP32 0 /* fp32 operands on v_mfma_f32_16x16x4_f32: exact fp32, the parity path (default) */
 #define NSID_GEMM_BF16 1 /* operands rounded to bf16 while staged into LDS, fp32 storage + fp32 accumulate */
 
@@ -42,7 +49,9 @@ int nsid_get_gemm_precision(void);
 /* number of NSID_ROW_TILE row tiles of an M-row matrix: size of the partial-statistics buffers */
 int nsid_row_tiles(int M);
 
-/* ---- 1x1 convolution / Linear as a row GEMM on MFMA (fp32 in, fp32 accumulate) -------------------------
+/* ---- 1x1 convolution / Linear as a row GEMM on MFMA (fp32 accumulate) ------------------------------------
+ * act_dtype = NSID_BF16: the activation operands/outputs are bf16 in HBM (weights, bias, statistics, weight gradients
+ * stay fp32) and the bf16 MFMA path is used whatever nsid_set_gemm_precision says.
  * Replaces nn.Conv2d(…,1) / nn.Linear forward+backward at encoder/gcn_lib/torch_vertex.py:152-162,
  * encoder/graph_encoder.py:74-77,151,179, encoder/gcn_lib/torch_nn.py:56 (groups=4), simclr/simclr.py:25-28.
  *
@@ -53,17 +62,19 @@ int nsid_row_tiles(int M);
  *           pre-activation output, the input of nsid_bn_finalize (training-mode BatchNorm statistics).
  *           ksplit > 1 splits K over workgroups and accumulates atomically: `out` must be zeroed, stat == NULL,
  *           act_out == NSID_ACT_NONE. */
-int nsid_linear_fwd(const float* x, int ldx, const float* w, const float* bias, float* out, int ldo, int M, int Nout,
+int nsid_linear_fwd(const void* x, int ldx, const float* w, const float* bias, void* out, int ldo, int M, int Nout,
                     int K, int groups, const float* in_scale, const float* in_shift, int act_in, int act_out,
-                    float* stat, int ksplit, void* stream);
+                    float* stat, int ksplit, int act_dtype /* of x and out */, void* stream);
 /* backward-data: din[m, g*K+k] = addend[m, g*K+k] + sum_n dout[m, g*Nout+n] * w[g*Nout+n, k]   (addend optional) */
-int nsid_linear_bwd_data(const float* dout, int ldd, const float* w, const float* addend, int ldadd, float* din,
-                         int ldi, int M, int Nout, int K, int groups, void* stream);
+int nsid_linear_bwd_data(const void* dout, int ldd, const float* w, const void* addend, int ldadd, void* din,
+                         int ldi, int M, int Nout, int K, int groups, int act_dtype /* dout, addend, din */,
+                         void* stream);
 /* backward-weight: dw[g*Nout+n, k] += sum_m dout[m, g*Nout+n] * f(x[m, g*K+k])   (f as in forward; atomic) */
-int nsid_linear_bwd_weight(const float* dout, int ldd, const float* x, int ldx, float* dw, int M, int Nout, int K,
-                           int groups, const float* in_scale, const float* in_shift, int act_in, void* stream);
+int nsid_linear_bwd_weight(const void* dout, int ldd, const void* x, int ldx, float* dw, int M, int Nout, int K,
+                           int groups, const float* in_scale, const float* in_shift, int act_in,
+                           int act_dtype /* dout and x */, void* stream);
 /* out[c] += sum_m x[m, c]  (bias gradients) */
-int nsid_colsum_acc(const float* x, int ldx, int M, int C, float* out, void* stream);
+int nsid_colsum_acc(const void* x, int ldx, int M, int C, float* out, int dtype, void* stream);
 
 /* ---- BatchNorm2d, training mode, split around the GEMMs ------------------------------------------------
  * Replaces nn.BatchNorm2d at encoder/graph_encoder.py:45,75,77,152, torch_vertex.py:154,161, torch_nn.py:32.
@@ -76,17 +87,18 @@ int nsid_bn_finalize(const float* stat, int tiles, int C, int M, const float* ga
 int nsid_bn_eval_affine(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
                         float eps, int C, float* scale, float* shift, void* stream);
 /* out = act(scale*r + shift) + residual   (residual optional; materialises the residual stream) */
-int nsid_bn_apply(const float* r, const float* scale, const float* shift, int act, const float* residual,
-                  float* out, int M, int C, void* stream);
+int nsid_bn_apply(const void* r, const float* scale, const float* shift, int act, const void* residual,
+                  void* out, int M, int C, int dtype, void* stream);
 /* backward, step 1: g = dout * act'(scale*r+shift); partial[2][tiles][C] = per-tile sums of g and g*xhat */
-int nsid_bn_bwd_reduce(const float* dout, const float* r, int M, int C, const float* scale, const float* shift,
-                       const float* mean, const float* invstd, int act, float* partial, void* stream);
+int nsid_bn_bwd_reduce(const void* dout, const void* r, int M, int C, const float* scale, const float* shift,
+                       const float* mean, const float* invstd, int act, float* partial, int dtype, void* stream);
 /* step 2: dgamma += sum g*xhat; dbeta += sum g; coef[2][C] = {sum g / M, sum g*xhat / M} */
 int nsid_bn_bwd_finalize(const float* partial, int tiles, int C, int M, float* dgamma, float* dbeta, float* coef,
                          void* stream);
 /* step 3: dr = scale * (g - coef0 - xhat*coef1)   (dr may alias dout) */
-int nsid_bn_bwd_apply(const float* dout, const float* r, int M, int C, const float* scale, const float* shift,
-                      const float* mean, const float* invstd, int act, const float* coef, float* dr, void* stream);
+int nsid_bn_bwd_apply(const void* dout, const void* r, int M, int C, const float* scale, const float* shift,
+                      const float* mean, const float* invstd, int act, const float* coef, void* dr, int dtype,
+                      void* stream);
 
 /* ---- dilated kNN graph ---------------------------------------------------------------------------------
  * Replaces DenseDilatedKnnGraph.forward = F.normalize + pairwise_distance + topk + [::dilation]
@@ -95,24 +107,24 @@ int nsid_bn_bwd_apply(const float* dout, const float* r, int M, int C, const flo
  * the k*dilation nearest are selected in ascending distance (ties: lower index first) and every dilation-th is
  * kept.  idx[(b*N+n)*k + j] is clip-local (0..N-1), int32; the reference's edge_index[1] (centre) is implicit.
  * Limits: N % 16 == 0, N <= 256, C % 4 == 0, k*dilation <= N. */
-int nsid_knn_graph(const float* r, int ldr, const float* scale, const float* shift, int B, int N, int C, int k,
-                   int dilation, int32_t* idx, void* stream);
+int nsid_knn_graph(const void* r, int ldr, const float* scale, const float* shift, int B, int N, int C, int k,
+                   int dilation, int32_t* idx, int dtype, void* stream);
 
 /* ---- max-relative aggregation --------------------------------------------------------------------------
  * Replaces MRConv2d.forward up to the grouped conv: 2x batched_index_select, max_k(x_j - x_i), interleave
  * (encoder/gcn_lib/torch_vertex.py:21-32, torch_nn.py:79-98).
  * u[row, 2c] = y[row, c]; u[row, 2c+1] = max_j y[b*N+idx[row,j], c] - y[row, c];  argmax[row, c] = winning j
  * (first maximum, as torch.max). backward routes du to the winning neighbour and the centre. k <= 255. */
-int nsid_mr_aggregate_fwd(const float* r, int ldr, const float* scale, const float* shift, const int32_t* idx, int B,
-                          int N, int C, int k, float* u, uint8_t* argmax, void* stream);
-int nsid_mr_aggregate_bwd(const float* du, const int32_t* idx, const uint8_t* argmax, int B, int N, int C, int k,
-                          float* dy, void* stream);
+int nsid_mr_aggregate_fwd(const void* r, int ldr, const float* scale, const float* shift, const int32_t* idx, int B,
+                          int N, int C, int k, void* u, uint8_t* argmax, int dtype, void* stream);
+int nsid_mr_aggregate_bwd(const void* du, const int32_t* idx, const uint8_t* argmax, int B, int N, int C, int k,
+                          void* dy, int dtype, void* stream);
 
 /* ---- Downsample: Conv2d 3x3 stride 2 pad 1 on a width-1 map (encoder/graph_encoder.py:44) ---------------
  * Only kernel column 1 meets data, so it is a 3-tap stride-2 conv along N = one GEMM over gathered rows:
  * col[b*No+n', t*C+c] = x[b*N + 2n'-1+t, c] (0 outside), wp[o, t*C+c] = w[o, c, t, 1]. */
-int nsid_im2col3_fwd(const float* x, int B, int N, int C, float* col, void* stream);
-int nsid_im2col3_bwd(const float* dcol, int B, int N, int C, float* dx, void* stream);
+int nsid_im2col3_fwd(const void* x, int B, int N, int C, void* col, int dtype, void* stream);
+int nsid_im2col3_bwd(const void* dcol, int B, int N, int C, void* dx, int dtype, void* stream);
 int nsid_pack_ds_weight(const float* w, int Cout, int Cin, float* wp, void* stream);
 int nsid_unpack_ds_wgrad(const float* dwp, int Cout, int Cin, float* dw /* += */, void* stream);
 
@@ -121,14 +133,14 @@ int nsid_unpack_ds_wgrad(const float* dwp, int Cout, int Cin, float* dw /* += */
  * out is node-major [B*(H/pb)*(W/pf)][ldo] (columns >= F untouched); minmax[B][2] is kept for backward.
  * backward gives the conv weight/bias gradients only (the spectrogram is data). */
 int nsid_peak_patchify_fwd(const float* spec, const float* w, const float* bias, int B, int H, int W, int pb, int pf,
-                           int F, float* out, int ldo, float* minmax, void* stream);
-int nsid_peak_patchify_bwd(const float* spec, const float* minmax, const float* out, const float* dout, int ldo,
+                           int F, void* out, int ldo, float* minmax, int out_dtype, void* stream);
+int nsid_peak_patchify_bwd(const float* spec, const float* minmax, const void* out, const void* dout, int ldo,
                            int B, int H, int W, int pb, int pf, int F, float* dw /* += */, float* dbias /* += */,
-                           void* stream);
+                           int out_dtype, void* stream);
 
 /* ---- node mean (encoder/graph_encoder.py:211), ELU', L2 normalise (simclr/simclr.py:38,44) --------------*/
-int nsid_node_mean_fwd(const float* x, int B, int N, int C, float* out, void* stream);
-int nsid_node_mean_bwd(const float* dout, int B, int N, int C, float* dx, void* stream);
+int nsid_node_mean_fwd(const void* x, int B, int N, int C, float* out, int x_dtype, void* stream);
+int nsid_node_mean_bwd(const float* dout, int B, int N, int C, void* dx, int dx_dtype, void* stream);
 int nsid_elu_bwd(const float* dout, const float* out, long n, float* din, void* stream);
 int nsid_l2norm_fwd(const float* p, int B, int d, float eps, float* z, float* norm, void* stream);
 int nsid_l2norm_bwd(const float* dz, const float* z, const float* norm, int B, int d, float eps, float* dp,
@@ -155,8 +167,8 @@ int nsid_adam_step(float* p, const float* g, float* m, float* v, long n, const f
                    const float* partial, int nblocks, float* gnorm_out, void* stream);
 
 /* ---- layout plumbing at the module boundary: (B, C, N) <-> node-major rows ------------------------------*/
-int nsid_bcn_to_rows(const float* x, int B, int C, int N, float* rows, int ld, void* stream);
-int nsid_rows_to_bcn(const float* rows, int ld, int B, int C, int N, float* x, void* stream);
+int nsid_bcn_to_rows(const float* x, int B, int C, int N, void* rows, int ld, int rows_dtype, void* stream);
+int nsid_rows_to_bcn(const void* rows, int ld, int B, int C, int N, float* x, int rows_dtype, void* stream);
 
 #ifdef __cplusplus
 }

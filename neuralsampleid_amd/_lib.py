@@ -14,35 +14,35 @@ LIB_PATH = os.path.join(_PKG, "libnsid_hip.so")
 # signature letters: p = device pointer, i = int, l = long, f = float, s = stream (void*)
 SIGNATURES = {
     "nsid_set_gemm_precision": "i",
-    "nsid_linear_fwd": "pipppiiiiippiipis",
-    "nsid_linear_bwd_data": "pippipiiiiis",
-    "nsid_linear_bwd_weight": "pipipiiiippis",
-    "nsid_colsum_acc": "piiips",
+    "nsid_linear_fwd": "pipppiiiiippiipiis",
+    "nsid_linear_bwd_data": "pippipiiiiiis",
+    "nsid_linear_bwd_weight": "pipipiiiippiis",
+    "nsid_colsum_acc": "piiipis",
     "nsid_bn_finalize": "piiipppppffpppps",
     "nsid_bn_eval_affine": "ppppfipps",
-    "nsid_bn_apply": "pppippiis",
-    "nsid_bn_bwd_reduce": "ppiippppips",
+    "nsid_bn_apply": "pppippiiis",
+    "nsid_bn_bwd_reduce": "ppiippppipis",
     "nsid_bn_bwd_finalize": "piiippps",
-    "nsid_bn_bwd_apply": "ppiippppipps",
-    "nsid_knn_graph": "pippiiiiips",
-    "nsid_mr_aggregate_fwd": "pipppiiiipps",
-    "nsid_mr_aggregate_bwd": "pppiiiips",
-    "nsid_im2col3_fwd": "piiips",
-    "nsid_im2col3_bwd": "piiips",
+    "nsid_bn_bwd_apply": "ppiippppippis",
+    "nsid_knn_graph": "pippiiiiipis",
+    "nsid_mr_aggregate_fwd": "pipppiiiippis",
+    "nsid_mr_aggregate_bwd": "pppiiiipis",
+    "nsid_im2col3_fwd": "piiipis",
+    "nsid_im2col3_bwd": "piiipis",
     "nsid_pack_ds_weight": "piips",
     "nsid_unpack_ds_wgrad": "piips",
-    "nsid_peak_patchify_fwd": "pppiiiiiipips",
-    "nsid_peak_patchify_bwd": "ppppiiiiiiipps",
-    "nsid_node_mean_fwd": "piiips",
-    "nsid_node_mean_bwd": "piiips",
+    "nsid_peak_patchify_fwd": "pppiiiiiipipis",
+    "nsid_peak_patchify_bwd": "ppppiiiiiiippis",
+    "nsid_node_mean_fwd": "piiipis",
+    "nsid_node_mean_bwd": "piiipis",
     "nsid_elu_bwd": "pplps",
     "nsid_l2norm_fwd": "piifpps",
     "nsid_l2norm_bwd": "pppiifps",
     "nsid_ntxent_fwd_bwd": "ppiifiipppps",
     "nsid_sumsq_partial": "plps",
     "nsid_adam_step": "pppplpppips",
-    "nsid_bcn_to_rows": "piiipis",
-    "nsid_rows_to_bcn": "piiiips",
+    "nsid_bcn_to_rows": "piiipiis",
+    "nsid_rows_to_bcn": "piiiipis",
 }
 
 _CT = {"p": ctypes.c_void_p, "i": ctypes.c_int, "l": ctypes.c_long, "f": ctypes.c_float, "s": ctypes.c_void_p}

@@ -1,7 +1,8 @@
-// Training-mode BatchNorm2d split around the GEMMs (all HBM-bound streaming kernels, 16 B per lane):
+// Training-mode BatchNorm2d split around the GEMMs (all HBM-bound streaming kernels, one 16-byte chunk per lane):
 //   GEMM epilogue -> per-row-tile column sums  -> bn_finalize (fp64 combine, running stats)  -> scale/shift
 //   consumer GEMM applies scale/shift(+act) on load; the residual stream is materialised by bn_apply.
 // Backward: bn_bwd_reduce (two column reductions) -> bn_bwd_finalize -> bn_bwd_apply (dr, in place).
+// Activation tensors are fp32 or bf16 (template parameter T); statistics, coefficients and arithmetic are fp32/fp64.
 #include "nsid_common.h"
 
 namespace {
@@ -24,7 +25,10 @@ __device__ __forceinline__ void tile_sums(const float* __restrict__ p0, const fl
   __syncthreads();
   sum = 0.0; sq = 0.0;
   if (tg == 0)
-    for (int g = 0; g < FIN_TG; ++g) { sum += red0[g * FIN_CH + (threadIdx.x & (FIN_CH - 1))]; sq += red1[g * FIN_CH + (threadIdx.x & (FIN_CH - 1))]; }
+    for (int g = 0; g < FIN_TG; ++g) {
+      sum += red0[g * FIN_CH + (threadIdx.x & (FIN_CH - 1))];
+      sq += red1[g * FIN_CH + (threadIdx.x & (FIN_CH - 1))];
+    }
 }
 
 __global__ __launch_bounds__(FIN_CH * FIN_TG) void bn_finalize_kernel(
@@ -62,92 +66,93 @@ __global__ void bn_eval_affine_kernel(const float* gamma, const float* beta, con
   shift[c] = beta[c] - rm[c] * sc;
 }
 
-// out = act(scale*r+shift) + residual, float4 per thread, grid-stride
-__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ r, const float* __restrict__ scale,
+// out = act(scale*r+shift) + residual, one chunk per thread, grid-stride
+template <typename T>
+__global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ r, const float* __restrict__ scale,
                                                        const float* __restrict__ shift, int act,
-                                                       const float* __restrict__ residual, float* __restrict__ out,
-                                                       long n4, int C4) {
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
-    const int c = (int)(i % C4) * 4;
-    f32x4 v = reinterpret_cast<const f32x4*>(r)[i];
-    const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + c);
-    const f32x4 sh = *reinterpret_cast<const f32x4*>(shift + c);
-    f32x4 o;
+                                                       const T* __restrict__ residual, T* __restrict__ out,
+                                                       long nchunks, int CV) {
+  constexpr int N = Chunk<T>::N;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nchunks; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % CV) * N;
+    float v[N], o[N];
+    Chunk<T>::load(r + i * N, v);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) o[e] = nsid_act(sc[e] * v[e] + sh[e], act);
+    for (int e = 0; e < N; ++e) o[e] = nsid_act(scale[c + e] * v[e] + shift[c + e], act);
     if (residual != nullptr) {
-      const f32x4 rs = reinterpret_cast<const f32x4*>(residual)[i];
+      float rs[N];
+      Chunk<T>::load(residual + i * N, rs);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) o[e] += rs[e];
+      for (int e = 0; e < N; ++e) o[e] += rs[e];
     }
-    reinterpret_cast<f32x4*>(out)[i] = o;
+    Chunk<T>::store(out + i * N, o);
   }
 }
 
 // Column reductions over a 128-row tile x 64-channel chunk per block (grid = tiles x C/64, so the deep stages with
-// few row tiles still fill the chip). 256 threads = 16 row groups x 16 channel quads; each thread walks 8 rows with
-// all 16 loads issued before the first use; fixed-order LDS combine (deterministic).
+// few row tiles still fill the chip). 256 threads = (row groups) x (chunks of the 64 channels); every thread walks its
+// rows with all loads issued before the first use; fixed-order LDS combine (deterministic).
 // MODE 0: column sums of `dout` (bias gradients).  MODE 1: BatchNorm backward pair (sum g, sum g*xhat).
-constexpr int CR_CH = 64, CR_Q = CR_CH / 4, CR_RG = 256 / CR_Q, CR_ROWS = NSID_ROW_TILE / CR_RG;
+constexpr int CR_CH = 64;
 
-template <int MODE>
-__global__ __launch_bounds__(256) void col_reduce_kernel(const float* __restrict__ dout, const float* __restrict__ r,
+template <int MODE, typename T>
+__global__ __launch_bounds__(256) void col_reduce_kernel(const T* __restrict__ dout, const T* __restrict__ r,
                                                          long ld, int M, int C, const float* __restrict__ scale,
                                                          const float* __restrict__ shift,
                                                          const float* __restrict__ mean,
                                                          const float* __restrict__ invstd, float slope,
                                                          float* __restrict__ partial, int tiles) {
-  __shared__ f32x4 red[2][256];
+  constexpr int N = Chunk<T>::N;
+  constexpr int CQ = CR_CH / N;            // chunks across the 64 channels: 16 (fp32) or 8 (bf16)
+  constexpr int RG = 256 / CQ;             // row groups: 16 or 32
+  constexpr int ROWS = NSID_ROW_TILE / RG; // rows per thread: 8 or 4
+  __shared__ float red[2][RG][CR_CH];
   const int tile = blockIdx.x;
   const int row0 = tile * NSID_ROW_TILE;
-  const int t = threadIdx.x, q = t % CR_Q, rgp = t / CR_Q;
-  const int c = blockIdx.y * CR_CH + 4 * q;
+  const int t = threadIdx.x, q = t % CQ, rgp = t / CQ;
+  const int c = blockIdx.y * CR_CH + N * q;
   const bool cok = c < C;
-  f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+  float s0[N], s1[N];
+#pragma unroll
+  for (int e = 0; e < N; ++e) s0[e] = s1[e] = 0.f;
   if (cok) {
-    f32x4 d[CR_ROWS], x[CR_ROWS];
+    float d[ROWS][N], x[ROWS][N];
 #pragma unroll
-    for (int i = 0; i < CR_ROWS; ++i) {
-      const int row = row0 + rgp + CR_RG * i;
+    for (int i = 0; i < ROWS; ++i) {
+      const int row = row0 + rgp + RG * i;
       const long off = (long)(row < M ? row : row0) * ld + c;
-      d[i] = *reinterpret_cast<const f32x4*>(dout + off);
-      if (MODE == 1) x[i] = *reinterpret_cast<const f32x4*>(r + off);
-    }
-    f32x4 sc, sh, mu, is;
-    if (MODE == 1) {
-      sc = *reinterpret_cast<const f32x4*>(scale + c);
-      sh = *reinterpret_cast<const f32x4*>(shift + c);
-      mu = *reinterpret_cast<const f32x4*>(mean + c);
-      is = *reinterpret_cast<const f32x4*>(invstd + c);
+      Chunk<T>::load(dout + off, d[i]);
+      if (MODE == 1) Chunk<T>::load(r + off, x[i]);
     }
 #pragma unroll
-    for (int i = 0; i < CR_ROWS; ++i) {
-      if (row0 + rgp + CR_RG * i >= M) continue;
+    for (int i = 0; i < ROWS; ++i) {
+      if (row0 + rgp + RG * i >= M) continue;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
+      for (int e = 0; e < N; ++e) {
         if (MODE == 0) {
           s0[e] += d[i][e];
         } else {
-          const float g = (sc[e] * x[i][e] + sh[e]) > 0.f ? d[i][e] : d[i][e] * slope;   // act'(pre) = 1 or slope
+          const float g = (scale[c + e] * x[i][e] + shift[c + e]) > 0.f ? d[i][e] : d[i][e] * slope;
           s0[e] += g;
-          s1[e] += g * ((x[i][e] - mu[e]) * is[e]);
+          s1[e] += g * ((x[i][e] - mean[c + e]) * invstd[c + e]);
         }
       }
     }
   }
-  red[0][t] = s0;
-  red[1][t] = s1;
-  __syncthreads();
-  if (t < CR_Q && cok) {
-    f32x4 a0 = red[0][t], a1 = red[1][t];
-    for (int g = 1; g < CR_RG; ++g) {
-      const f32x4 b0 = red[0][g * CR_Q + t], b1 = red[1][g * CR_Q + t];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { a0[e] += b0[e]; a1[e] += b1[e]; }
+  for (int e = 0; e < N; ++e) {
+    red[0][rgp][N * q + e] = s0[e];
+    red[1][rgp][N * q + e] = s1[e];
+  }
+  __syncthreads();
+  if (t < CR_CH) {
+    const int cc = blockIdx.y * CR_CH + t;
+    if (cc < C) {
+      float a0 = 0.f, a1 = 0.f;
+      for (int g = 0; g < RG; ++g) { a0 += red[0][g][t]; a1 += red[1][g][t]; }
+      partial[(long)tile * C + cc] = a0;
+      if (MODE == 1) partial[(long)tiles * C + (long)tile * C + cc] = a1;
     }
-    const long o = (long)tile * C + c;
-    *reinterpret_cast<f32x4*>(partial + o) = a0;
-    if (MODE == 1) *reinterpret_cast<f32x4*>(partial + (long)tiles * C + o) = a1;
   }
 }
 
@@ -165,40 +170,69 @@ __global__ __launch_bounds__(FIN_CH * FIN_TG) void bn_bwd_finalize_kernel(const 
   coef[C + c] = (float)(sgx / M);
 }
 
-__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dout, const float* __restrict__ r,
-                                                           long n4, int C4, const float* __restrict__ scale,
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ dout, const T* __restrict__ r,
+                                                           long nchunks, int CV, const float* __restrict__ scale,
                                                            const float* __restrict__ shift,
                                                            const float* __restrict__ mean,
                                                            const float* __restrict__ invstd, float slope,
-                                                           const float* __restrict__ coef, float* __restrict__ dr) {
-  const int C = C4 * 4;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
-    const int c = (int)(i % C4) * 4;
-    const f32x4 d = reinterpret_cast<const f32x4*>(dout)[i];
-    const f32x4 x = reinterpret_cast<const f32x4*>(r)[i];
-    const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + c);
-    const f32x4 sh = *reinterpret_cast<const f32x4*>(shift + c);
-    const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + c);
-    const f32x4 is = *reinterpret_cast<const f32x4*>(invstd + c);
-    const f32x4 c0 = *reinterpret_cast<const f32x4*>(coef + c);
-    const f32x4 c1 = *reinterpret_cast<const f32x4*>(coef + C + c);
-    f32x4 o;
+                                                           const float* __restrict__ coef, T* __restrict__ dr) {
+  constexpr int N = Chunk<T>::N;
+  const int C = CV * N;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nchunks; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % CV) * N;
+    float d[N], x[N], o[N];
+    Chunk<T>::load(dout + i * N, d);
+    Chunk<T>::load(r + i * N, x);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const float g = (sc[e] * x[e] + sh[e]) > 0.f ? d[e] : d[e] * slope;
-      const float xh = (x[e] - mu[e]) * is[e];
-      o[e] = sc[e] * (g - c0[e] - xh * c1[e]);
+    for (int e = 0; e < N; ++e) {
+      const float sc = scale[c + e];
+      const float g = (sc * x[e] + shift[c + e]) > 0.f ? d[e] : d[e] * slope;
+      const float xh = (x[e] - mean[c + e]) * invstd[c + e];
+      o[e] = sc * (g - coef[c + e] - xh * coef[C + c + e]);
     }
-    reinterpret_cast<f32x4*>(dr)[i] = o;
+    Chunk<T>::store(dr + i * N, o);
   }
 }
 
 // derivative of the activation on the non-positive side (1 on the positive side): none 1, ReLU 0, LeakyReLU 0.2
 inline float bn_slope(int act) { return act == NSID_ACT_RELU ? 0.f : (act == NSID_ACT_LEAKY ? 0.2f : 1.f); }
 
-inline int stream_grid(long n4) {
-  long b = (n4 + 255) / 256;
+inline int stream_grid(long nchunks) {
+  long b = (nchunks + 255) / 256;
   return (int)(b > 2048 ? 2048 : (b < 1 ? 1 : b));   // cap and grid-stride (guide §6 G11)
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_atomic_kernel(const T* __restrict__ x, long ld, int M, int C,
+                                                            float* __restrict__ out) {
+  constexpr int N = Chunk<T>::N;
+  constexpr int CQ = CR_CH / N, RG = 256 / CQ, ROWS = NSID_ROW_TILE / RG;
+  __shared__ float red[RG][CR_CH];
+  const int row0 = blockIdx.x * NSID_ROW_TILE;
+  const int t = threadIdx.x, q = t % CQ, rgp = t / CQ;
+  const int c = blockIdx.y * CR_CH + N * q;
+  float s[N];
+#pragma unroll
+  for (int e = 0; e < N; ++e) s[e] = 0.f;
+  if (c < C)
+    for (int i = 0; i < ROWS; ++i) {
+      const int row = row0 + rgp + RG * i;
+      if (row < M) {
+        float d[N];
+        Chunk<T>::load(x + (long)row * ld + c, d);
+#pragma unroll
+        for (int e = 0; e < N; ++e) s[e] += d[e];
+      }
+    }
+#pragma unroll
+  for (int e = 0; e < N; ++e) red[rgp][N * q + e] = s[e];
+  __syncthreads();
+  if (t < CR_CH && blockIdx.y * CR_CH + t < C) {
+    float a = 0.f;
+    for (int g = 0; g < RG; ++g) a += red[g][t];
+    atomicAdd(out + blockIdx.y * CR_CH + t, a);
+  }
 }
 
 }  // namespace
@@ -209,9 +243,9 @@ extern "C" int nsid_bn_finalize(const float* stat, int tiles, int C, int M, cons
   NSID_REQUIRE(stat && gamma && beta && scale && shift && mean && invstd && C > 0 && M > 0);
   NSID_REQUIRE(tiles == nsid_row_tiles(M));
   NSID_REQUIRE((running_mean == nullptr) == (running_var == nullptr));
-  NSID_LAUNCH(bn_finalize_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_TG), 0, static_cast<hipStream_t>(stream), stat,
-                     tiles, C, M, gamma, beta, running_mean, running_var, nbt, momentum, eps, scale, shift, mean,
-                     invstd);
+  NSID_LAUNCH(bn_finalize_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_TG), 0,
+              static_cast<hipStream_t>(stream), stat, tiles, C, M, gamma, beta, running_mean, running_var, nbt,
+              momentum, eps, scale, shift, mean, invstd);
   return nsid_launch_status();
 }
 
@@ -219,91 +253,69 @@ extern "C" int nsid_bn_eval_affine(const float* gamma, const float* beta, const 
                                    const float* running_var, float eps, int C, float* scale, float* shift,
                                    void* stream) {
   NSID_REQUIRE(gamma && beta && running_mean && running_var && scale && shift && C > 0);
-  NSID_LAUNCH(bn_eval_affine_kernel, dim3((C + 127) / 128), dim3(128), 0, static_cast<hipStream_t>(stream),
-                     gamma, beta, running_mean, running_var, eps, C, scale, shift);
+  NSID_LAUNCH(bn_eval_affine_kernel, dim3((C + 127) / 128), dim3(128), 0, static_cast<hipStream_t>(stream), gamma, beta,
+              running_mean, running_var, eps, C, scale, shift);
   return nsid_launch_status();
 }
 
-extern "C" int nsid_bn_apply(const float* r, const float* scale, const float* shift, int act, const float* residual,
-                             float* out, int M, int C, void* stream) {
-  NSID_REQUIRE(r && scale && shift && out && M > 0 && C > 0 && C % 4 == 0);
-  NSID_REQUIRE(nsid_aligned16(r) && nsid_aligned16(out) && nsid_aligned16(scale) && nsid_aligned16(shift));
-  const long n4 = (long)M * C / 4;
-  NSID_LAUNCH(bn_apply_kernel, dim3(stream_grid(n4)), dim3(256), 0, static_cast<hipStream_t>(stream), r, scale,
-                     shift, act, residual, out, n4, C / 4);
+extern "C" int nsid_bn_apply(const void* r, const float* scale, const float* shift, int act, const void* residual,
+                             void* out, int M, int C, int dtype, void* stream) {
+  NSID_REQUIRE(r && scale && shift && out && M > 0 && C > 0 && NSID_DTYPE_OK(dtype));
+  NSID_REQUIRE(C % (dtype == NSID_BF16 ? 8 : 4) == 0 && nsid_aligned16(r) && nsid_aligned16(out));
+  NSID_DISPATCH_DTYPE(dtype, T, {
+    const long nchunks = (long)M * C / Chunk<T>::N;
+    NSID_LAUNCH((bn_apply_kernel<T>), dim3(stream_grid(nchunks)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                static_cast<const T*>(r), scale, shift, act, static_cast<const T*>(residual), static_cast<T*>(out),
+                nchunks, C / Chunk<T>::N);
+  });
   return nsid_launch_status();
 }
 
-extern "C" int nsid_bn_bwd_reduce(const float* dout, const float* r, int M, int C, const float* scale,
+extern "C" int nsid_bn_bwd_reduce(const void* dout, const void* r, int M, int C, const float* scale,
                                   const float* shift, const float* mean, const float* invstd, int act, float* partial,
-                                  void* stream) {
-  NSID_REQUIRE(dout && r && scale && shift && mean && invstd && partial && M > 0 && C > 0 && C % 4 == 0);
-  const int tiles = nsid_row_tiles(M);
+                                  int dtype, void* stream) {
+  NSID_REQUIRE(dout && r && scale && shift && mean && invstd && partial && M > 0 && C > 0 && NSID_DTYPE_OK(dtype));
+  NSID_REQUIRE(C % (dtype == NSID_BF16 ? 8 : 4) == 0);
   NSID_REQUIRE(act == NSID_ACT_NONE || act == NSID_ACT_RELU || act == NSID_ACT_LEAKY);
-  NSID_LAUNCH((col_reduce_kernel<1>), dim3(tiles, (C + CR_CH - 1) / CR_CH), dim3(256), 0,
-              static_cast<hipStream_t>(stream), dout, r, (long)C, M, C, scale, shift, mean, invstd, bn_slope(act),
-              partial, tiles);
+  const int tiles = nsid_row_tiles(M);
+  NSID_DISPATCH_DTYPE(dtype, T, {
+    NSID_LAUNCH((col_reduce_kernel<1, T>), dim3(tiles, (C + CR_CH - 1) / CR_CH), dim3(256), 0,
+                static_cast<hipStream_t>(stream), static_cast<const T*>(dout), static_cast<const T*>(r), (long)C, M, C,
+                scale, shift, mean, invstd, bn_slope(act), partial, tiles);
+  });
   return nsid_launch_status();
 }
 
 extern "C" int nsid_bn_bwd_finalize(const float* partial, int tiles, int C, int M, float* dgamma, float* dbeta,
                                     float* coef, void* stream) {
   NSID_REQUIRE(partial && coef && C > 0 && M > 0 && tiles == nsid_row_tiles(M));
-  NSID_LAUNCH(bn_bwd_finalize_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_TG), 0, static_cast<hipStream_t>(stream),
-                     partial, tiles, C, M, dgamma, dbeta, coef);
+  NSID_LAUNCH(bn_bwd_finalize_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_TG), 0,
+              static_cast<hipStream_t>(stream), partial, tiles, C, M, dgamma, dbeta, coef);
   return nsid_launch_status();
 }
 
-extern "C" int nsid_bn_bwd_apply(const float* dout, const float* r, int M, int C, const float* scale,
+extern "C" int nsid_bn_bwd_apply(const void* dout, const void* r, int M, int C, const float* scale,
                                  const float* shift, const float* mean, const float* invstd, int act,
-                                 const float* coef, float* dr, void* stream) {
-  NSID_REQUIRE(dout && r && scale && shift && mean && invstd && coef && dr && M > 0 && C > 0 && C % 4 == 0);
-  const long n4 = (long)M * C / 4;
+                                 const float* coef, void* dr, int dtype, void* stream) {
+  NSID_REQUIRE(dout && r && scale && shift && mean && invstd && coef && dr && M > 0 && C > 0 && NSID_DTYPE_OK(dtype));
+  NSID_REQUIRE(C % (dtype == NSID_BF16 ? 8 : 4) == 0);
   NSID_REQUIRE(act == NSID_ACT_NONE || act == NSID_ACT_RELU || act == NSID_ACT_LEAKY);
-  NSID_LAUNCH(bn_bwd_apply_kernel, dim3(stream_grid(n4)), dim3(256), 0, static_cast<hipStream_t>(stream), dout,
-                     r, n4, C / 4, scale, shift, mean, invstd, bn_slope(act), coef, dr);
+  NSID_DISPATCH_DTYPE(dtype, T, {
+    const long nchunks = (long)M * C / Chunk<T>::N;
+    NSID_LAUNCH((bn_bwd_apply_kernel<T>), dim3(stream_grid(nchunks)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                static_cast<const T*>(dout), static_cast<const T*>(r), nchunks, C / Chunk<T>::N, scale, shift, mean,
+                invstd, bn_slope(act), coef, static_cast<T*>(dr));
+  });
   return nsid_launch_status();
 }
 
-namespace {
-__global__ __launch_bounds__(256) void colsum_atomic_kernel(const float* __restrict__ x, long ld, int M, int C,
-                                                            float* __restrict__ out) {
-  __shared__ f32x4 red[256];
-  const int row0 = blockIdx.x * NSID_ROW_TILE;
-  const int t = threadIdx.x, q = t % CR_Q, rgp = t / CR_Q;
-  const int c = blockIdx.y * CR_CH + 4 * q;
-  f32x4 s = {0.f, 0.f, 0.f, 0.f};
-  if (c < C)
-    for (int i = 0; i < CR_ROWS; ++i) {
-      const int row = row0 + rgp + CR_RG * i;
-      if (row < M) {
-        const f32x4 d = *reinterpret_cast<const f32x4*>(x + (long)row * ld + c);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) s[e] += d[e];
-      }
-    }
-  red[t] = s;
-  __syncthreads();
-  if (t < CR_Q && c < C) {
-    f32x4 a = red[t];
-    for (int g = 1; g < CR_RG; ++g) {
-      const f32x4 b = red[g * CR_Q + t];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) a[e] += b[e];
-    }
-#pragma unroll
-    for (int e = 0; e < 4; ++e) atomicAdd(out + c + e, a[e]);
-  }
-}
-}  // namespace
-
-// out[c] += sum_m x[m,c]: per-tile partial sums (col_reduce<0>) then a fixed-order fp64 combine; `partial` scratch
-// is the caller's (tiles x C floats) so that nothing is allocated here.
-extern "C" int nsid_colsum_acc(const float* x, int ldx, int M, int C, float* out, void* stream) {
-  NSID_REQUIRE(x && out && M > 0 && C > 0 && C % 4 == 0 && ldx % 4 == 0 && nsid_aligned16(x));
-  // direct atomics per tile keep this entry allocation-free; it only serves the few biases that are not in front of
-  // a BatchNorm (proj, projector: M <= batch), so contention is irrelevant
-  NSID_LAUNCH(colsum_atomic_kernel, dim3(nsid_row_tiles(M), (C + CR_CH - 1) / CR_CH), dim3(256), 0,
-              static_cast<hipStream_t>(stream), x, (long)ldx, M, C, out);
+// out[c] += sum_m x[m,c] (bias gradients of layers that are NOT in front of a BatchNorm: proj, projector).
+extern "C" int nsid_colsum_acc(const void* x, int ldx, int M, int C, float* out, int dtype, void* stream) {
+  NSID_REQUIRE(x && out && M > 0 && C > 0 && NSID_DTYPE_OK(dtype) && nsid_aligned16(x));
+  NSID_REQUIRE(C % (dtype == NSID_BF16 ? 8 : 4) == 0 && ldx % (dtype == NSID_BF16 ? 8 : 4) == 0);
+  NSID_DISPATCH_DTYPE(dtype, T, {
+    NSID_LAUNCH((colsum_atomic_kernel<T>), dim3(nsid_row_tiles(M), (C + CR_CH - 1) / CR_CH), dim3(256), 0,
+                static_cast<hipStream_t>(stream), static_cast<const T*>(x), (long)ldx, M, C, out);
+  });
   return nsid_launch_status();
 }

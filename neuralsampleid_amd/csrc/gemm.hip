@@ -20,15 +20,15 @@ namespace {
 inline float act_slope(int act) { return act == NSID_ACT_RELU ? 0.f : (act == NSID_ACT_LEAKY ? 0.2f : 1.f); }
 
 struct GemmArgs {
-  const float* A; long lda; long a_goff;   // group offset in elements
-  const float* B; long ldb; long b_goff;
-  float* C; long ldc; long c_goff;
+  const void* A; long lda; long a_goff;   // group offset in elements (operand storage: fp32 or bf16, see ST)
+  const void* B; long ldb; long b_goff;
+  void* C; long ldc; long c_goff;
   int I, J, R;
   // operand-load activation as a negative-side slope (1 = none, 0 = ReLU, 0.2 = LeakyReLU): one branch-free select
   const float* a_scale; const float* a_shift; float a_slope; long a_aff_goff;   // per-R affine on A (forward)
   const float* b_scale; const float* b_shift; float b_slope; long b_aff_goff;   // per-j affine on B (backward-wgt)
   const float* bias; long bias_goff;                                        // per-j
-  const float* addend; long ldadd;                                          // same indexing as C
+  const void* addend; long ldadd;                                           // same indexing and storage as C
   float* stat; long stat_plane;    // stat[0*plane + tile*stat_ld + col], stat[1*plane + ...]
   long stat_ld;
   int rsplit;     // number of R-splits (grid.y); >1 => atomic epilogue
@@ -37,113 +37,142 @@ struct GemmArgs {
   int split_major;  // grid = (splits, tiles): the tiles of one split share an XCD (blocks b, b+8 share an L2)
 };
 
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-
 // Precision H = false: fp32 operands, v_mfma_f32_16x16x4_f32, BK = 16 (exact fp32 — the parity path).
 // Precision H = true : operands rounded to bf16 (RNE, v_cvt_pk_bf16_f32) as they are written to LDS, fp32 storage in
 //                      HBM and fp32 accumulation, v_mfma_f32_16x16x32_bf16 (16x the fp32 matrix rate), BK = 32.
 template <bool H> struct Prec { static constexpr int BK = H ? 32 : 16; static constexpr int ESZ = H ? 2 : 4; };
 
-template <int ROWS, bool RMAJOR, bool H>
+template <int ROWS, bool RMAJOR, bool H, bool SRC16 = false>
 struct TileGeom {
   static constexpr int BK = Prec<H>::BK, ESZ = Prec<H>::ESZ;
   // RMAJOR: lds[row][BK elements + 16 B pad] (row = i or j, R contiguous): 80-byte rows in both precisions.
   // else  : lds[BK][ROWS elements + 16 B pad] (R = row, i/j contiguous)
   static constexpr int STRIDE = RMAJOR ? BK * ESZ + 16 : ROWS * ESZ + 16;   // bytes
   static constexpr int BYTES = (RMAJOR ? ROWS : BK) * STRIDE;
-  static constexpr int VEC = ROWS * BK / 4 / 256;   // float4 (of fp32 source) per thread per stage
-  static constexpr int QPR = BK / 4;                // source quads per row of an R-major tile
+  // SRC16: the operand is stored as bf16 in HBM -> one 16-byte load carries 8 elements instead of 4
+  static constexpr int EPC = SRC16 ? 8 : 4;             // elements per 16-byte source chunk
+  static constexpr int SSZ = SRC16 ? 2 : 4;             // source element size
+  static constexpr int VEC = ROWS * BK / EPC / 256;     // 16-byte chunks per thread per stage
+  static constexpr int CPR = BK / EPC;                  // chunks per row of an R-major tile
+  static constexpr int CPC = ROWS / EPC;                // chunks per (reduction) row of an i/j-major tile
+  static_assert(!SRC16 || H, "bf16 storage implies the bf16 MFMA path");
 };
 
 // Staging is split in two so that the global-load latency hides under the MFMA block of the current stage
-// (issue early / write late): stage_load only ISSUES the loads (raw operand quads plus the producer-BatchNorm
-// scale/shift quads they will need); stage_store, which runs after the MFMAs, applies affine + activation, zero-fills
-// out-of-range quads, rounds to bf16 in the H path, and writes LDS.  Nothing consumes a load result before the MFMAs.
-template <int ROWS, bool RMAJOR, bool H>
+// (issue early / write late): stage_load only ISSUES the 16-byte loads; stage_store, which runs after the MFMAs,
+// applies affine + activation, zero-fills out-of-range chunks, rounds to bf16 in the H path, and writes LDS.
+// A bf16-stored operand without affine is copied chunk-for-chunk (its HBM image IS the LDS image).
+template <int ROWS, bool RMAJOR, bool H, bool SRC16>
 struct StageRegs {
-  static constexpr int VEC = TileGeom<ROWS, RMAJOR, H>::VEC;
-  f32x4 v[VEC];
+  static constexpr int VEC = TileGeom<ROWS, RMAJOR, H, SRC16>::VEC;
+  f32x4 v[VEC];      // raw 16-byte chunks (4 fp32 or 8 bf16)
   bool ok[VEC];
 };
 
-template <int ROWS, bool RMAJOR, bool H>
-__device__ __forceinline__ void stage_load(StageRegs<ROWS, RMAJOR, H>& s, const float* __restrict__ base, long ld,
+template <int ROWS, bool RMAJOR, bool H, bool SRC16>
+__device__ __forceinline__ void stage_load(StageRegs<ROWS, RMAJOR, H, SRC16>& s, const char* __restrict__ base, long ld,
                                            int row0, int nrows, int r0, int rend) {
-  using G = TileGeom<ROWS, RMAJOR, H>;
+  using G = TileGeom<ROWS, RMAJOR, H, SRC16>;
   const int t = threadIdx.x;
 #pragma unroll
   for (int q = 0; q < G::VEC; ++q) {
     const int idx = t + 256 * q;
+    long off;
     if (RMAJOR) {
-      const int row = idx / G::QPR, rv = (idx % G::QPR) * 4;
-      const int gi = row0 + row, gr = r0 + rv;
-      s.ok[q] = gi < nrows && gr < rend;              // extents are multiples of 4: a quad is all-in or all-out
-      const long off = s.ok[q] ? (long)gi * ld + gr : 0;   // out-of-range quads read element 0 and are zeroed later
-      s.v[q] = *reinterpret_cast<const f32x4*>(base + off);
+      const int gi = row0 + idx / G::CPR, gr = r0 + (idx % G::CPR) * G::EPC;
+      s.ok[q] = gi < nrows && gr < rend;              // extents are multiples of the chunk: all-in or all-out
+      off = s.ok[q] ? (long)gi * ld + gr : 0;         // out-of-range chunks read element 0 and are zeroed later
     } else {
-      constexpr int V_PER_ROW = ROWS / 4;
-      const int rr = idx / V_PER_ROW, cv = (idx % V_PER_ROW) * 4;
-      const int gr = r0 + rr, gc = row0 + cv;
+      const int gr = r0 + idx / G::CPC, gc = row0 + (idx % G::CPC) * G::EPC;
       s.ok[q] = gr < rend && gc < nrows;
-      const long off = s.ok[q] ? (long)gr * ld + gc : 0;
-      s.v[q] = *reinterpret_cast<const f32x4*>(base + off);
+      off = s.ok[q] ? (long)gr * ld + gc : 0;
+    }
+    s.v[q] = *reinterpret_cast<const f32x4*>(base + off * G::SSZ);
+  }
+}
+
+// reduction-indexed affine (producer BatchNorm) of an R-major operand for the stage that starts at r0. VMEM completes in
+// order, so these small loads must be issued BEFORE the operand loads of a later stage: issued after them, the first
+// use would wait for the whole prefetch (vmcnt is positional) and collapse the pipeline.
+template <int ROWS, bool H, bool SRC16>
+__device__ __forceinline__ void affine_prefetch(f32x4* sc, f32x4* sh, int r0, int rend, const float* scale,
+                                                const float* shift) {
+  using G = TileGeom<ROWS, true, H, SRC16>;
+#pragma unroll
+  for (int q = 0; q < G::VEC; ++q) {
+    const int gr = r0 + ((threadIdx.x + 256 * q) % G::CPR) * G::EPC;
+    const int ga = gr < rend ? gr : 0;
+#pragma unroll
+    for (int e = 0; e < G::EPC; e += 4) {        // raw float4 registers: nothing consumes them before the commit
+      sc[(q * G::EPC + e) >> 2] = *reinterpret_cast<const f32x4*>(scale + ga + e);
+      sh[(q * G::EPC + e) >> 2] = *reinterpret_cast<const f32x4*>(shift + ga + e);
     }
   }
 }
 
 // column-indexed affine of an i/j-major operand is the same for every stage: fetched once per kernel
-template <int ROWS, bool H>
+template <int ROWS, bool H, bool SRC16>
 __device__ __forceinline__ void colaffine_load(f32x4* sc, f32x4* sh, int row0, int nrows, const float* scale,
                                                const float* shift) {
-  constexpr int VEC = TileGeom<ROWS, false, H>::VEC;
-  constexpr int V_PER_ROW = ROWS / 4;
+  using G = TileGeom<ROWS, false, H, SRC16>;
 #pragma unroll
-  for (int q = 0; q < VEC; ++q) {
-    const int cv = ((threadIdx.x + 256 * q) % V_PER_ROW) * 4;
+  for (int q = 0; q < G::VEC; ++q) {
+    const int cv = ((threadIdx.x + 256 * q) % G::CPC) * G::EPC;
     const int gc = row0 + cv < nrows ? row0 + cv : 0;
-    sc[q] = *reinterpret_cast<const f32x4*>(scale + gc);
-    sh[q] = *reinterpret_cast<const f32x4*>(shift + gc);
+#pragma unroll
+    for (int e = 0; e < G::EPC; e += 4) {
+      sc[(q * G::EPC + e) >> 2] = *reinterpret_cast<const f32x4*>(scale + gc + e);
+      sh[(q * G::EPC + e) >> 2] = *reinterpret_cast<const f32x4*>(shift + gc + e);
+    }
   }
 }
 
-template <int ROWS, bool RMAJOR, bool H>
-__device__ __forceinline__ void stage_store(char* lds, const StageRegs<ROWS, RMAJOR, H>& s, bool affine, float slope,
-                                            const f32x4* csc, const f32x4* csh, const float* rscale,
-                                            const float* rshift, int r0, int rend) {
-  using G = TileGeom<ROWS, RMAJOR, H>;
+template <int ROWS, bool RMAJOR, bool H, bool SRC16>
+__device__ __forceinline__ void stage_store(char* lds, const StageRegs<ROWS, RMAJOR, H, SRC16>& s, bool affine,
+                                            float slope, const f32x4* csc, const f32x4* csh) {
+  using G = TileGeom<ROWS, RMAJOR, H, SRC16>;
   const int t = threadIdx.x;
 #pragma unroll
   for (int q = 0; q < G::VEC; ++q) {
     const int idx = t + 256 * q;
-    f32x4 x = s.v[q];
-    if (affine) {
-      f32x4 sc, sh;
-      if (RMAJOR) {   // reduction-indexed affine (producer BatchNorm): tiny cache-hot vectors, fetched at commit time
-        const int gr = r0 + (idx % G::QPR) * 4;
-        const int ga = gr < rend ? gr : 0;
-        sc = *reinterpret_cast<const f32x4*>(rscale + ga);
-        sh = *reinterpret_cast<const f32x4*>(rshift + ga);
-      } else {
-        sc = csc[q];
-        sh = csh[q];
-      }
+    const int lo = RMAJOR ? (idx / G::CPR) * G::STRIDE + (idx % G::CPR) * G::EPC * G::ESZ
+                          : (idx / G::CPC) * G::STRIDE + (idx % G::CPC) * G::EPC * G::ESZ;
+    if (SRC16 && !affine) {           // wave-uniform: bf16 in HBM == bf16 in LDS
+      f32x4 raw = s.v[q];
+      if (!s.ok[q]) raw = f32x4{0.f, 0.f, 0.f, 0.f};
+      *reinterpret_cast<f32x4*>(lds + lo) = raw;
+      continue;
+    }
+    float x[G::EPC];
+    if (SRC16) {
+      const bf16x8 h = __builtin_bit_cast(bf16x8, s.v[q]);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float v = sc[e] * x[e] + sh[e];
+      for (int e = 0; e < 8; ++e) x[e] = (float)h[e];
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) x[e] = s.v[q][e];
+    }
+    if (affine) {
+#pragma unroll
+      for (int e = 0; e < G::EPC; ++e) {
+        // csc/csh: per-chunk affine registers — column-indexed (fetched once per kernel) for i/j-major tiles,
+        // reduction-indexed (prefetched per stage by affine_prefetch, AHEAD of the next operand loads) for R-major ones
+        const float v = csc[(q * G::EPC + e) >> 2][e & 3] * x[e] + csh[(q * G::EPC + e) >> 2][e & 3];
         x[e] = v < 0.f ? v * slope : v;          // NaN compares false and passes through, as torch's activations do
       }
     }
-    if (!s.ok[q]) x = f32x4{0.f, 0.f, 0.f, 0.f};
-    int off;
-    if (RMAJOR) {
-      off = (idx / G::QPR) * G::STRIDE + (idx % G::QPR) * 4 * G::ESZ;
-    } else {
-      constexpr int V_PER_ROW = ROWS / 4;
-      off = (idx / V_PER_ROW) * G::STRIDE + (idx % V_PER_ROW) * 4 * G::ESZ;
+    if (!s.ok[q]) {
+#pragma unroll
+      for (int e = 0; e < G::EPC; ++e) x[e] = 0.f;
     }
-    if (H) *reinterpret_cast<bf16x4*>(lds + off) = __builtin_convertvector(x, bf16x4);
-    else *reinterpret_cast<f32x4*>(lds + off) = x;
+    if (H) {
+#pragma unroll
+      for (int e = 0; e < G::EPC; e += 4)
+        *reinterpret_cast<bf16x4*>(lds + lo + e * 2) =
+            __builtin_convertvector((f32x4{x[e], x[e + 1], x[e + 2], x[e + 3]}), bf16x4);
+    } else {
+      *reinterpret_cast<f32x4*>(lds + lo) = f32x4{x[0], x[1], x[2], x[3]};
+    }
   }
 }
 
@@ -179,10 +208,16 @@ __device__ __forceinline__ bf16x8 frag_read_bf16(const char* lds, int tile_row0,
   }
 }
 
-template <int BM, int BN, bool A_RMAJOR, bool B_RMAJOR, bool H>
+// ST: ACTIVATION tensors are bf16 in HBM. The left operand is always an activation; the right operand is one only in
+// the weight-gradient variant (both i/j-major); the output is an activation in the forward and backward-data variants.
+// AAFF: the left operand carries a reduction-indexed affine (forward GEMM fed by a raw conv output). A template flag,
+// not a runtime one: a runtime branch around the per-stage affine loads makes the compiler's vmcnt bookkeeping
+// conservative at the join and drains the prefetch.
+template <int BM, int BN, bool A_RMAJOR, bool B_RMAJOR, bool H, bool ST, bool AAFF>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {   // >= 2 waves/SIMD: <= 256 VGPR+AGPR
-  using GA = TileGeom<BM, A_RMAJOR, H>;
-  using GB = TileGeom<BN, B_RMAJOR, H>;
+  constexpr bool SA = ST, SB = ST && !A_RMAJOR && !B_RMAJOR, SC = ST && A_RMAJOR;
+  using GA = TileGeom<BM, A_RMAJOR, H, SA>;
+  using GB = TileGeom<BN, B_RMAJOR, H, SB>;
   constexpr int BK = Prec<H>::BK;
   constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 16, TN = WN / 16;
   constexpr int STAGE = GA::BYTES + GB::BYTES;
@@ -208,8 +243,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {   // >
   const int rbeg = split * p.rchunk;
   const int rend = min(p.R, rbeg + p.rchunk);
 
-  const float* A = p.A + g * p.a_goff;
-  const float* B = p.B + g * p.b_goff;
+  const char* A = reinterpret_cast<const char*>(p.A) + g * p.a_goff * GA::SSZ;
+  const char* B = reinterpret_cast<const char*>(p.B) + g * p.b_goff * GB::SSZ;
   const float* a_sc = p.a_scale ? p.a_scale + g * p.a_aff_goff : nullptr;
   const float* a_sh = p.a_shift ? p.a_shift + g * p.a_aff_goff : nullptr;
   const float* b_sc = p.b_scale ? p.b_scale + g * p.b_aff_goff : nullptr;
@@ -227,29 +262,32 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {   // >
 
   // only these operand/affine pairings exist: forward (A reduction-major, affine on the reduction index) and
   // backward-weight (B column-major, affine on the column index)
-  const bool a_aff = A_RMAJOR && a_sc != nullptr;
+  constexpr bool a_aff = AAFF;
   const bool b_aff = !B_RMAJOR && b_sc != nullptr;
-  f32x4 bcs[GB::VEC], bch[GB::VEC];
-  if (b_aff) colaffine_load<BN, H>(bcs, bch, j0, p.J, b_sc, b_sh);
+  f32x4 bcs[GB::VEC * GB::EPC / 4], bch[GB::VEC * GB::EPC / 4];
+  if (b_aff) colaffine_load<BN, H, SB>(bcs, bch, j0, p.J, b_sc, b_sh);
   const int nstage = (rend - rbeg + BK - 1) / BK;
 
   // Register prefetch depth: fp32 MFMA blocks (64 x 32 cycles) cover one memory round trip, so one stage in flight
   // is enough; the bf16 MFMA block (16 x 16 cycles) is far shorter than the round trip, so TWO stages are kept in
   // flight (two register sets, static indices through the 2x unrolled loop body below).
   constexpr int DEPTH = H ? 2 : 1;
-  StageRegs<BM, A_RMAJOR, H> ra[DEPTH];
-  StageRegs<BN, B_RMAJOR, H> rb[DEPTH];
+  StageRegs<BM, A_RMAJOR, H, SA> ra[DEPTH];
+  StageRegs<BN, B_RMAJOR, H, SB> rb[DEPTH];
 
+  f32x4 acs[GA::VEC * GA::EPC / 4], ach[GA::VEC * GA::EPC / 4];   // reduction-indexed affine of the stage being committed
   auto issue = [&](auto& sa, auto& sb, int st) {
     const int r0 = rbeg + st * BK;
-    stage_load<BM, A_RMAJOR, H>(sa, A, p.lda, i0, p.I, r0, rend);
-    stage_load<BN, B_RMAJOR, H>(sb, B, p.ldb, j0, p.J, r0, rend);
+    stage_load<BM, A_RMAJOR, H, SA>(sa, A, p.lda, i0, p.I, r0, rend);
+    stage_load<BN, B_RMAJOR, H, SB>(sb, B, p.ldb, j0, p.J, r0, rend);
+  };
+  auto aff_fetch = [&](int st) {
+    if constexpr (AAFF) affine_prefetch<BM, H, SA>(acs, ach, rbeg + st * BK, rend, a_sc, a_sh);
   };
   auto commit = [&](const auto& sa, const auto& sb, int st) {
     char* dst = lds_raw + (st & 1) * STAGE;
-    const int r0 = rbeg + st * BK;
-    stage_store<BM, A_RMAJOR, H>(dst, sa, a_aff, p.a_slope, nullptr, nullptr, a_sc, a_sh, r0, rend);
-    stage_store<BN, B_RMAJOR, H>(dst + GA::BYTES, sb, b_aff, p.b_slope, bcs, bch, nullptr, nullptr, r0, rend);
+    stage_store<BM, A_RMAJOR, H, SA>(dst, sa, a_aff, p.a_slope, acs, ach);
+    stage_store<BN, B_RMAJOR, H, SB>(dst + GA::BYTES, sb, b_aff, p.b_slope, bcs, bch);
   };
   auto compute = [&](int st) {
     const char* la = lds_raw + (st & 1) * STAGE;
@@ -281,39 +319,56 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {   // >
     }
   };
 
-  if (nstage > 0) {
-    issue(ra[0], rb[0], 0);
-    commit(ra[0], rb[0], 0);
-    if (DEPTH == 2 && nstage > 1) issue(ra[DEPTH - 1], rb[DEPTH - 1], 1);     // stage 1 -> register set 1
-  }
-  __syncthreads();
   if (DEPTH == 1) {
+    if (nstage > 0) {
+      aff_fetch(0);
+      issue(ra[0], rb[0], 0);
+      commit(ra[0], rb[0], 0);
+    }
+    __syncthreads();
     for (int st = 0; st < nstage; ++st) {
       const bool more = st + 1 < nstage;
-      if (more) issue(ra[0], rb[0], st + 1);        // lands under the MFMA block below
+      if (more) {                                   // lands under the MFMA block below
+        aff_fetch(st + 1);
+        issue(ra[0], rb[0], st + 1);
+      }
       compute(st);
       if (more) commit(ra[0], rb[0], st + 1);
       __syncthreads();
     }
   } else {
-    // invariant at the top of iteration st: LDS[st&1] holds stage st; register set (st+1)&1 holds stage st+1 (loads
-    // possibly still in flight); register set st&1 is free. Plain loads stay in flight across __syncthreads().
+    // Two stages in flight, branch-free body. A stage index past the end addresses r0 >= rend: every chunk is out of
+    // range, reads a dummy element and is committed as zeros, so phantom stages add exactly 0 to the accumulators and
+    // the loop can always run an even number of stages with NO control flow between a load and its wait — the
+    // compiler's vmcnt(N) is then exact (a join would force vmcnt(0) and drain the prefetch).
+    // Invariant at the top of an iteration: LDS[st&1] holds stage st, register set 1 holds stage st+1 (in flight),
+    // register set 0 is free. Plain loads stay in flight across __syncthreads(); the scheduling barriers pin the
+    // phase order issue -> MFMA -> commit.
+    aff_fetch(0);
+    issue(ra[0], rb[0], 0);
+    commit(ra[0], rb[0], 0);
+    issue(ra[DEPTH - 1], rb[DEPTH - 1], 1);
+    __syncthreads();
     for (int st = 0; st < nstage; st += 2) {
-      if (st + 2 < nstage) issue(ra[0], rb[0], st + 2);
+      aff_fetch(st + 1);
+      issue(ra[0], rb[0], st + 2);
+      __builtin_amdgcn_sched_barrier(0);
       compute(st);
-      if (st + 1 < nstage) commit(ra[DEPTH - 1], rb[DEPTH - 1], st + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      commit(ra[DEPTH - 1], rb[DEPTH - 1], st + 1);
       __syncthreads();
-      if (st + 1 < nstage) {
-        if (st + 3 < nstage) issue(ra[DEPTH - 1], rb[DEPTH - 1], st + 3);
-        compute(st + 1);
-        if (st + 2 < nstage) commit(ra[0], rb[0], st + 2);
-        __syncthreads();
-      }
+      aff_fetch(st + 2);
+      issue(ra[DEPTH - 1], rb[DEPTH - 1], st + 3);
+      __builtin_amdgcn_sched_barrier(0);
+      compute(st + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      commit(ra[0], rb[0], st + 2);
+      __syncthreads();
     }
   }
 
   // ---------------- epilogue. C/D layout: col = lane&15, row = 4*(lane>>4) + reg.
-  float* C = p.C + g * p.c_goff;
+  float* C = reinterpret_cast<float*>(p.C) + g * p.c_goff;      // fp32 view: the atomic path always writes fp32
   const float* bias = (p.bias && split == 0) ? p.bias + g * p.bias_goff : nullptr;
   float csum[TN], csq[TN];
 #pragma unroll
@@ -338,12 +393,17 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {   // >
     // accumulator layout are store-issue bound). Each wave transposes its own 64 x WN sub-tile, 32 rows at a time.
     constexpr int OLD = WN + 4;                  // staggers rq groups over the banks, keeps rows 16-B aligned
     float* ost = lds + wave * (32 * OLD);        // 4 waves x 32 x (WN+4) floats <= one stage buffer
-    constexpr int Q_PER_ROW = WN / 4, ROWS_PER_PASS = 64 / Q_PER_ROW;
-    const int orow = lane / Q_PER_ROW, oq = (lane % Q_PER_ROW) * 4;
+    constexpr int OE = SC ? 8 : 4;               // output elements per lane per store (16 bytes either way)
+    constexpr int OSZ = SC ? 2 : 4;
+    constexpr int Q_PER_ROW = WN / OE, ROWS_PER_PASS = 64 / Q_PER_ROW;
+    const int orow = lane / Q_PER_ROW, oq = (lane % Q_PER_ROW) * OE;
     const int jq = j0 + wn0 + oq;
-    const bool jqok = jq < p.J;                  // J % 4 == 0: a quad is all-in or all-out
-    f32x4 bq = {0.f, 0.f, 0.f, 0.f};
-    if (bias && jqok) bq = *reinterpret_cast<const f32x4*>(bias + jq);
+    const bool jqok = jq < p.J;                  // J % OE == 0: a chunk is all-in or all-out
+    float bq[OE];
+#pragma unroll
+    for (int e = 0; e < OE; ++e) bq[e] = (bias && jqok) ? bias[jq + e] : 0.f;
+    char* Cb = reinterpret_cast<char*>(p.C) + g * p.c_goff * OSZ;
+    const char* Ab = reinterpret_cast<const char*>(p.addend) + g * p.c_goff * OSZ;
 #pragma unroll
     for (int h = 0; h < TM / 2; ++h) {
 #pragma unroll
@@ -358,15 +418,22 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {   // >
         const int rr = pass * ROWS_PER_PASS + orow;
         const int i = i0 + wm0 + 32 * h + rr;
         if (i < p.I && jqok) {
-          f32x4 v = *reinterpret_cast<const f32x4*>(ost + rr * OLD + oq);
+          float v[OE];
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] += bq[e];
-          if (p.addend) {
-            const f32x4 ad = *reinterpret_cast<const f32x4*>(p.addend + g * p.c_goff + (long)i * p.ldadd + jq);
+          for (int e = 0; e < OE; e += 4) {
+            const f32x4 t4 = *reinterpret_cast<const f32x4*>(ost + rr * OLD + oq + e);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] += ad[e];
+            for (int k4 = 0; k4 < 4; ++k4) v[e + k4] = t4[k4] + bq[e + k4];
           }
-          *reinterpret_cast<f32x4*>(C + (long)i * p.ldc + jq) = v;
+          if (p.addend) {
+            float ad[OE];
+            if (SC) Chunk<__bf16>::load(reinterpret_cast<const __bf16*>(Ab) + (long)i * p.ldadd + jq, ad);
+            else Chunk<float>::load(reinterpret_cast<const float*>(Ab) + (long)i * p.ldadd + jq, ad);
+#pragma unroll
+            for (int e = 0; e < OE; ++e) v[e] += ad[e];
+          }
+          if (SC) Chunk<__bf16>::store(reinterpret_cast<__bf16*>(Cb) + (long)i * p.ldc + jq, v);
+          else Chunk<float>::store(reinterpret_cast<float*>(Cb) + (long)i * p.ldc + jq, v);
         }
       }
       __syncthreads();
@@ -431,9 +498,10 @@ __global__ void elu_inplace_kernel(float* __restrict__ x, long rows, int cols, l
 int g_gemm_precision = NSID_GEMM_FP32;     // process-wide (nsid_set_gemm_precision)
 
 template <int BM, int BN, bool AR, bool BR>
-int launch(GemmArgs p, int groups, hipStream_t s) {
+int launch(GemmArgs p, int groups, hipStream_t s, int act_dtype) {
   const int tiles = ((p.I + BM - 1) / BM) * ((p.J + BN - 1) / BN);
-  const bool half = g_gemm_precision == NSID_GEMM_BF16;
+  const bool st16 = act_dtype == NSID_BF16;
+  const bool half = g_gemm_precision == NSID_GEMM_BF16 || st16;
   const int bk = half ? 32 : 16;
   p.rchunk = (p.rchunk + bk - 1) / bk * bk;            // whole stages per split
   p.rsplit = (p.R + p.rchunk - 1) / p.rchunk;
@@ -441,8 +509,17 @@ int launch(GemmArgs p, int groups, hipStream_t s) {
   // index fastest (and a multiple of 8 of them) consecutive blocks go to different XCDs and one split stays on one L2.
   p.split_major = p.rsplit > 1 && (p.rsplit % 8) == 0;
   dim3 grid(p.split_major ? p.rsplit : tiles, p.split_major ? tiles : p.rsplit, groups);
-  if (half) NSID_LAUNCH((gemm_kernel<BM, BN, AR, BR, true>), grid, dim3(256), 0, s, p);
-  else NSID_LAUNCH((gemm_kernel<BM, BN, AR, BR, false>), grid, dim3(256), 0, s, p);
+  constexpr bool CAN_AFF = AR && BR;                   // only the forward variant takes a reduction-indexed affine
+  const bool aff = CAN_AFF && p.a_scale != nullptr;
+#define NSID_GEMM_GO(HH, SS)                                                                              \
+  do {                                                                                                    \
+    if (aff) NSID_LAUNCH((gemm_kernel<BM, BN, AR, BR, HH, SS, CAN_AFF>), grid, dim3(256), 0, s, p);        \
+    else NSID_LAUNCH((gemm_kernel<BM, BN, AR, BR, HH, SS, false>), grid, dim3(256), 0, s, p);              \
+  } while (0)
+  if (st16) NSID_GEMM_GO(true, true);
+  else if (half) NSID_GEMM_GO(true, false);
+  else NSID_GEMM_GO(false, false);
+#undef NSID_GEMM_GO
   return nsid_launch_status();
 }
 
@@ -457,11 +534,13 @@ extern "C" int nsid_set_gemm_precision(int mode) {
 extern "C" int nsid_get_gemm_precision(void) { return g_gemm_precision; }
 extern "C" int nsid_row_tiles(int M) { return (M + NSID_ROW_TILE - 1) / NSID_ROW_TILE; }
 
-extern "C" int nsid_linear_fwd(const float* x, int ldx, const float* w, const float* bias, float* out, int ldo, int M,
+extern "C" int nsid_linear_fwd(const void* x, int ldx, const float* w, const float* bias, void* out, int ldo, int M,
                                int Nout, int K, int groups, const float* in_scale, const float* in_shift, int act_in,
-                               int act_out, float* stat, int ksplit, void* stream) {
-  NSID_REQUIRE(x && w && out && M > 0 && Nout > 0 && K > 0 && groups > 0 && ksplit >= 1);
-  NSID_REQUIRE(K % 4 == 0 && ldx % 4 == 0 && nsid_aligned16(x) && nsid_aligned16(w));
+                               int act_out, float* stat, int ksplit, int act_dtype, void* stream) {
+  NSID_REQUIRE(x && w && out && M > 0 && Nout > 0 && K > 0 && groups > 0 && ksplit >= 1 && NSID_DTYPE_OK(act_dtype));
+  const int ch = act_dtype == NSID_BF16 ? 8 : 4;     // elements per 16-byte chunk of the activation tensors
+  NSID_REQUIRE(K % ch == 0 && ldx % ch == 0 && nsid_aligned16(x) && nsid_aligned16(w) && K % 4 == 0);
+  NSID_REQUIRE(act_dtype == NSID_F32 || (ksplit == 1 && act_out == NSID_ACT_NONE && Nout % 8 == 0 && ldo % 8 == 0));
   NSID_REQUIRE(ldx >= groups * K && ldo >= groups * Nout);
   NSID_REQUIRE(Nout % 4 == 0 && ldo % 4 == 0 && nsid_aligned16(out) && (bias == nullptr || nsid_aligned16(bias)));
   NSID_REQUIRE((in_scale == nullptr) == (in_shift == nullptr));
@@ -483,19 +562,24 @@ extern "C" int nsid_linear_fwd(const float* x, int ldx, const float* w, const fl
   // bf16 operands make the kernel latency/HBM-bound: when 128-wide tiles would give fewer than two workgroups per CU,
   // halve the tile width to double the loads in flight (the statistics tile stays 128 rows)
   const long t128 = (long)nsid_row_tiles(M) * ((Nout + 127) / 128) * groups;
-  const bool narrow = Nout <= 64 || (g_gemm_precision == NSID_GEMM_BF16 && t128 < 512);
-  const int rc = narrow ? launch<128, 64, true, true>(p, groups, s) : launch<128, 128, true, true>(p, groups, s);
+  const bool half = g_gemm_precision == NSID_GEMM_BF16 || act_dtype == NSID_BF16;
+  const bool narrow = Nout <= 64 || (half && t128 < 512);
+  const int rc = narrow ? launch<128, 64, true, true>(p, groups, s, act_dtype)
+                        : launch<128, 128, true, true>(p, groups, s, act_dtype);
   if (rc != NSID_OK || act_out != NSID_ACT_ELU) return rc;
   const long n = (long)M * groups * Nout;
-  NSID_LAUNCH(elu_inplace_kernel, dim3((int)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256)), dim3(256), 0, s, out,
-              (long)M, groups * Nout, (long)ldo);
+  NSID_LAUNCH(elu_inplace_kernel, dim3((int)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256)), dim3(256), 0, s,
+              static_cast<float*>(out), (long)M, groups * Nout, (long)ldo);
   return nsid_launch_status();
 }
 
-extern "C" int nsid_linear_bwd_data(const float* dout, int ldd, const float* w, const float* addend, int ldadd,
-                                    float* din, int ldi, int M, int Nout, int K, int groups, void* stream) {
-  NSID_REQUIRE(dout && w && din && M > 0 && Nout > 0 && K > 0 && groups > 0);
-  NSID_REQUIRE(Nout % 4 == 0 && K % 4 == 0 && ldd % 4 == 0 && nsid_aligned16(dout) && nsid_aligned16(w));
+extern "C" int nsid_linear_bwd_data(const void* dout, int ldd, const float* w, const void* addend, int ldadd,
+                                    void* din, int ldi, int M, int Nout, int K, int groups, int act_dtype,
+                                    void* stream) {
+  NSID_REQUIRE(dout && w && din && M > 0 && Nout > 0 && K > 0 && groups > 0 && NSID_DTYPE_OK(act_dtype));
+  const int ch = act_dtype == NSID_BF16 ? 8 : 4;
+  NSID_REQUIRE(Nout % ch == 0 && K % ch == 0 && ldd % ch == 0 && ldi % ch == 0 && nsid_aligned16(dout) && nsid_aligned16(w));
+  NSID_REQUIRE(addend == nullptr || ldadd % ch == 0);
   NSID_REQUIRE(ldd >= groups * Nout && ldi >= groups * K && ldi % 4 == 0 && nsid_aligned16(din));
   NSID_REQUIRE(addend == nullptr || (ldadd % 4 == 0 && ldadd >= groups * K && nsid_aligned16(addend)));
   GemmArgs p{};
@@ -507,15 +591,17 @@ extern "C" int nsid_linear_bwd_data(const float* dout, int ldd, const float* w, 
   p.rsplit = 1; p.rchunk = Nout;
   hipStream_t s = static_cast<hipStream_t>(stream);
   const long t128 = (long)nsid_row_tiles(M) * ((K + 127) / 128) * groups;
-  if (K <= 64 || (g_gemm_precision == NSID_GEMM_BF16 && t128 < 512)) return launch<128, 64, true, false>(p, groups, s);
-  return launch<128, 128, true, false>(p, groups, s);
+  const bool half = g_gemm_precision == NSID_GEMM_BF16 || act_dtype == NSID_BF16;
+  if (K <= 64 || (half && t128 < 512)) return launch<128, 64, true, false>(p, groups, s, act_dtype);
+  return launch<128, 128, true, false>(p, groups, s, act_dtype);
 }
 
-extern "C" int nsid_linear_bwd_weight(const float* dout, int ldd, const float* x, int ldx, float* dw, int M, int Nout,
+extern "C" int nsid_linear_bwd_weight(const void* dout, int ldd, const void* x, int ldx, float* dw, int M, int Nout,
                                       int K, int groups, const float* in_scale, const float* in_shift, int act_in,
-                                      void* stream) {
-  NSID_REQUIRE(dout && x && dw && M > 0 && Nout > 0 && K > 0 && groups > 0);
-  NSID_REQUIRE(Nout % 4 == 0 && K % 4 == 0 && ldd % 4 == 0 && ldx % 4 == 0 && nsid_aligned16(dout) && nsid_aligned16(x));
+                                      int act_dtype, void* stream) {
+  NSID_REQUIRE(dout && x && dw && M > 0 && Nout > 0 && K > 0 && groups > 0 && NSID_DTYPE_OK(act_dtype));
+  const int ch = act_dtype == NSID_BF16 ? 8 : 4;
+  NSID_REQUIRE(Nout % ch == 0 && K % ch == 0 && ldd % ch == 0 && ldx % ch == 0 && nsid_aligned16(dout) && nsid_aligned16(x));
   NSID_REQUIRE((in_scale == nullptr) == (in_shift == nullptr));
   GemmArgs p{};
   p.A = dout; p.lda = ldd; p.a_goff = Nout;          // A[R = m][i = n]
@@ -538,6 +624,6 @@ extern "C" int nsid_linear_bwd_weight(const float* dout, int ldd, const float* x
   p.rsplit = rsplit;
   p.rchunk = (M + rsplit - 1) / rsplit;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (small) return launch<64, 64, false, false>(p, groups, s);
-  return launch<128, 128, false, false>(p, groups, s);
+  if (small) return launch<64, 64, false, false>(p, groups, s, act_dtype);
+  return launch<128, 128, false, false>(p, groups, s, act_dtype);
 }

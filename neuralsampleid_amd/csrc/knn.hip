@@ -27,7 +27,8 @@ __device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
   return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
 }
 
-__global__ __launch_bounds__(KNN_THREADS) void knn_kernel(const float* __restrict__ r, long ldr,
+template <typename T>
+__global__ __launch_bounds__(KNN_THREADS) void knn_kernel(const T* __restrict__ r, long ldr,
                                                           const float* __restrict__ scale,
                                                           const float* __restrict__ shift, int N, int C, int k,
                                                           int dilation, int32_t* __restrict__ idx) {
@@ -40,20 +41,21 @@ __global__ __launch_bounds__(KNN_THREADS) void knn_kernel(const float* __restric
 
   const int b = blockIdx.x;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const float* src = r + (long)b * N * ldr;
-  const int C4 = C >> 2;
+  const T* src = r + (long)b * N * ldr;
+  constexpr int NV = Chunk<T>::N;
+  const int CV = C / NV;
 
-  // ---- phase 1a: stage y = scale*r + shift into LDS (coalesced float4)
-  for (int q = t; q < N * C4; q += KNN_THREADS) {
-    const int n = q / C4, c = (q % C4) * 4;
-    f32x4 v = *reinterpret_cast<const f32x4*>(src + (long)n * ldr + c);
+  // ---- phase 1a: stage y = scale*r + shift into LDS as fp32 (coalesced 16-byte chunks of either storage type)
+  for (int q = t; q < N * CV; q += KNN_THREADS) {
+    const int n = q / CV, c = (q % CV) * NV;
+    float v[NV];
+    Chunk<T>::load(src + (long)n * ldr + c, v);
     if (scale != nullptr) {
-      const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + c);
-      const f32x4 sh = *reinterpret_cast<const f32x4*>(shift + c);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = sc[e] * v[e] + sh[e];
+      for (int e = 0; e < NV; ++e) v[e] = scale[c + e] * v[e] + shift[c + e];
     }
-    *reinterpret_cast<f32x4*>(yn + n * LD + c) = v;
+#pragma unroll
+    for (int e = 0; e < NV; e += 4) *reinterpret_cast<f32x4*>(yn + n * LD + c + e) = f32x4{v[e], v[e + 1], v[e + 2], v[e + 3]};
   }
   __syncthreads();
   // ---- phase 1b: F.normalize(p=2, dim=channels, eps=1e-12), then |y^|^2 as the reference recomputes it
@@ -153,9 +155,10 @@ __global__ __launch_bounds__(KNN_THREADS) void knn_kernel(const float* __restric
 
 }  // namespace
 
-extern "C" int nsid_knn_graph(const float* r, int ldr, const float* scale, const float* shift, int B, int N, int C,
-                              int k, int dilation, int32_t* idx, void* stream) {
-  NSID_REQUIRE(r && idx && B > 0 && k > 0 && dilation > 0);
+extern "C" int nsid_knn_graph(const void* r, int ldr, const float* scale, const float* shift, int B, int N, int C,
+                              int k, int dilation, int32_t* idx, int dtype, void* stream) {
+  NSID_REQUIRE(r && idx && B > 0 && k > 0 && dilation > 0 && NSID_DTYPE_OK(dtype));
+  NSID_REQUIRE(ldr % (dtype == NSID_BF16 ? 8 : 4) == 0);
   NSID_REQUIRE(N % 32 == 0 && N <= 256 && C % 16 == 0 && ldr % 4 == 0 && ldr >= C && nsid_aligned16(r));
   NSID_REQUIRE(k * dilation <= N);
   NSID_REQUIRE((scale == nullptr) == (shift == nullptr));
@@ -163,12 +166,16 @@ extern "C" int nsid_knn_graph(const float* r, int ldr, const float* scale, const
   NSID_REQUIRE(bytes <= 160 * 1024);
   static size_t configured = 0;       // raise the dynamic-LDS cap once per size step (not a per-call sync)
   if (bytes > configured) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(knn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            160 * 1024) != hipSuccess)
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(knn_kernel<float>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(knn_kernel<__bf16>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
       return NSID_ELAUNCH;
     configured = 160 * 1024;
   }
-  NSID_LAUNCH(knn_kernel, dim3(B), dim3(KNN_THREADS), bytes, static_cast<hipStream_t>(stream), r, (long)ldr,
-                     scale, shift, N, C, k, dilation, idx);
+  NSID_DISPATCH_DTYPE(dtype, T, {
+    NSID_LAUNCH((knn_kernel<T>), dim3(B), dim3(KNN_THREADS), bytes, static_cast<hipStream_t>(stream),
+                static_cast<const T*>(r), (long)ldr, scale, shift, N, C, k, dilation, idx);
+  });
   return nsid_launch_status();
 }

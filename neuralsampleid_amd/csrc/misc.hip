@@ -10,42 +10,51 @@ inline int grid_for(long n, int cap = 2048) {
 }
 
 // ------------------------------------------------------------------ Downsample (3-tap stride-2 conv along N)
-__global__ __launch_bounds__(256) void im2col3_fwd_kernel(const float* __restrict__ x, int B, int N, int No, int C,
-                                                          float* __restrict__ col) {
-  const int C4 = C >> 2;
-  const long total = (long)B * No * 3 * C4;
+template <typename T>
+__global__ __launch_bounds__(256) void im2col3_fwd_kernel(const T* __restrict__ x, int B, int N, int No, int C,
+                                                          T* __restrict__ col) {
+  constexpr int NV = Chunk<T>::N;
+  const int CV = C / NV;
+  const long total = (long)B * No * 3 * CV;
   for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += (long)gridDim.x * blockDim.x) {
-    const int c4 = (int)(q % C4);
-    const int t = (int)((q / C4) % 3);
-    const long orow = q / (3L * C4);
+    const int cv = (int)(q % CV);
+    const int t = (int)((q / CV) % 3);
+    const long orow = q / (3L * CV);
     const int b = (int)(orow / No), no = (int)(orow % No);
     const int n = 2 * no - 1 + t;
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (n >= 0 && n < N) v = *reinterpret_cast<const f32x4*>(x + ((long)b * N + n) * C + 4 * c4);
-    *reinterpret_cast<f32x4*>(col + orow * (3L * C) + (long)t * C + 4 * c4) = v;
+    float v[NV];
+#pragma unroll
+    for (int e = 0; e < NV; ++e) v[e] = 0.f;
+    if (n >= 0 && n < N) Chunk<T>::load(x + ((long)b * N + n) * C + NV * cv, v);
+    Chunk<T>::store(col + orow * (3L * C) + (long)t * C + NV * cv, v);
   }
 }
 
 // dx[b,n,:] = sum over (n', t) with 2n'-1+t == n of dcol[b,n', t*C:(t+1)*C]   (gather form: no atomics)
-__global__ __launch_bounds__(256) void im2col3_bwd_kernel(const float* __restrict__ dcol, int B, int N, int No, int C,
-                                                          float* __restrict__ dx) {
-  const int C4 = C >> 2;
-  const long total = (long)B * N * C4;
+template <typename T>
+__global__ __launch_bounds__(256) void im2col3_bwd_kernel(const T* __restrict__ dcol, int B, int N, int No, int C,
+                                                          T* __restrict__ dx) {
+  constexpr int NV = Chunk<T>::N;
+  const int CV = C / NV;
+  const long total = (long)B * N * CV;
   for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += (long)gridDim.x * blockDim.x) {
-    const int c4 = (int)(q % C4);
-    const long row = q / C4;
+    const int cv = (int)(q % CV);
+    const long row = q / CV;
     const int b = (int)(row / N), n = (int)(row % N);
-    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    float s[NV];
+#pragma unroll
+    for (int e = 0; e < NV; ++e) s[e] = 0.f;
 #pragma unroll
     for (int t = 0; t < 3; ++t) {
       const int m = n + 1 - t;            // 2n' = n+1-t
       if (m >= 0 && (m & 1) == 0 && (m >> 1) < No) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(dcol + ((long)b * No + (m >> 1)) * (3L * C) + (long)t * C + 4 * c4);
+        float v[NV];
+        Chunk<T>::load(dcol + ((long)b * No + (m >> 1)) * (3L * C) + (long)t * C + NV * cv, v);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) s[e] += v[e];
+        for (int e = 0; e < NV; ++e) s[e] += v[e];
       }
     }
-    *reinterpret_cast<f32x4*>(dx + row * C + 4 * c4) = s;
+    Chunk<T>::store(dx + row * C + NV * cv, s);
   }
 }
 
@@ -73,9 +82,10 @@ __device__ __forceinline__ float linspace01(int i, int steps) {
   return (i < steps / 2) ? (float)i * step : 1.0f - (float)(steps - 1 - i) * step;
 }
 
+template <typename T>
 __global__ __launch_bounds__(256) void patchify_fwd_kernel(const float* __restrict__ spec, const float* __restrict__ w,
                                                            const float* __restrict__ bias, int H, int W, int pb,
-                                                           int pf, int F, float* __restrict__ out, int ldo,
+                                                           int pf, int F, T* __restrict__ out, int ldo,
                                                            float* __restrict__ minmax) {
   extern __shared__ __attribute__((aligned(16))) float sm[];   // weights [F][3][pb][pf] then reduction scratch
   const int b = blockIdx.x, t = threadIdx.x;
@@ -96,7 +106,7 @@ __global__ __launch_bounds__(256) void patchify_fwd_kernel(const float* __restri
   const int Hp = H / pb, Wp = W / pf, NP = Hp * Wp;
   for (int p = t; p < NP; p += blockDim.x) {
     const int ph = p / Wp, pw = p % Wp;
-    float* dst = out + ((long)b * NP + p) * ldo;
+    T* dst = out + ((long)b * NP + p) * ldo;
     for (int f = 0; f < F; ++f) {
       float acc = bias[f];
       const float* wf = wl + f * 3 * pb * pf;
@@ -111,16 +121,17 @@ __global__ __launch_bounds__(256) void patchify_fwd_kernel(const float* __restri
           acc += wf[2 * pb * pf + i * pf + j] * s;
         }
       }
-      dst[f] = acc < 0.f ? 0.f : acc;     // NaN (constant clip: 0/0) propagates, as in the reference
+      dst[f] = (T)(acc < 0.f ? 0.f : acc);     // NaN (constant clip: 0/0) propagates, as in the reference
     }
   }
 }
 
 // dw[f][c][i][j] += sum_{b,p} g[b,p,f] * img_c[b, ph*pb+i, pw*pf+j], g = dout * (out > 0); one block per clip
+template <typename T>
 __global__ __launch_bounds__(256) void patchify_bwd_kernel(const float* __restrict__ spec,
                                                            const float* __restrict__ minmax,
-                                                           const float* __restrict__ out,
-                                                           const float* __restrict__ dout, int ldo, int H, int W,
+                                                           const T* __restrict__ out,
+                                                           const T* __restrict__ dout, int ldo, int H, int W,
                                                            int pb, int pf, int F, float* __restrict__ dw,
                                                            float* __restrict__ dbias) {
   extern __shared__ __attribute__((aligned(16))) float sm[];   // g [NP][F]
@@ -131,7 +142,7 @@ __global__ __launch_bounds__(256) void patchify_bwd_kernel(const float* __restri
   for (int q = t; q < NP * F; q += blockDim.x) {
     const int p = q / F, f = q % F;
     const long o = ((long)b * NP + p) * ldo + f;
-    sm[q] = out[o] > 0.f ? dout[o] : 0.f;
+    sm[q] = (float)out[o] > 0.f ? (float)dout[o] : 0.f;
   }
   __syncthreads();
   const int per_f = 3 * pb * pf;
@@ -154,31 +165,37 @@ __global__ __launch_bounds__(256) void patchify_bwd_kernel(const float* __restri
 }
 
 // ------------------------------------------------------------------ node mean
-__global__ __launch_bounds__(256) void node_mean_fwd_kernel(const float* __restrict__ x, int N, int C,
+template <typename T>
+__global__ __launch_bounds__(256) void node_mean_fwd_kernel(const T* __restrict__ x, int N, int C,
                                                             float* __restrict__ out) {
-  const int b = blockIdx.x, C4 = C >> 2;
-  for (int c4 = blockIdx.y * blockDim.x + threadIdx.x; c4 < C4; c4 += gridDim.y * blockDim.x) {
-    f32x4 s = {0.f, 0.f, 0.f, 0.f};
-    for (int n = 0; n < N; ++n) {
-      const f32x4 v = *reinterpret_cast<const f32x4*>(x + ((long)b * N + n) * C + 4 * c4);
+  constexpr int NV = Chunk<T>::N;
+  const int b = blockIdx.x, CV = C / NV;
+  for (int cv = blockIdx.y * blockDim.x + threadIdx.x; cv < CV; cv += gridDim.y * blockDim.x) {
+    float s[NV];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) s[e] += v[e];
+    for (int e = 0; e < NV; ++e) s[e] = 0.f;
+    for (int n = 0; n < N; ++n) {
+      float v[NV];
+      Chunk<T>::load(x + ((long)b * N + n) * C + NV * cv, v);
+#pragma unroll
+      for (int e = 0; e < NV; ++e) s[e] += v[e];
     }
 #pragma unroll
-    for (int e = 0; e < 4; ++e) s[e] /= (float)N;
-    *reinterpret_cast<f32x4*>(out + (long)b * C + 4 * c4) = s;
+    for (int e = 0; e < NV; ++e) out[(long)b * C + NV * cv + e] = s[e] / (float)N;
   }
 }
-__global__ __launch_bounds__(256) void node_mean_bwd_kernel(const float* __restrict__ dout, int N, int C, long total4,
-                                                            float* __restrict__ dx) {
-  const int C4 = C >> 2;
-  for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < total4; q += (long)gridDim.x * blockDim.x) {
-    const int c4 = (int)(q % C4);
-    const long b = q / ((long)C4 * N);
-    f32x4 v = *reinterpret_cast<const f32x4*>(dout + b * C + 4 * c4);
+template <typename T>
+__global__ __launch_bounds__(256) void node_mean_bwd_kernel(const float* __restrict__ dout, int N, int C,
+                                                            long nchunks, T* __restrict__ dx) {
+  constexpr int NV = Chunk<T>::N;
+  const int CV = C / NV;
+  for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < nchunks; q += (long)gridDim.x * blockDim.x) {
+    const int cv = (int)(q % CV);
+    const long b = q / ((long)CV * N);
+    float v[NV];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] /= (float)N;
-    reinterpret_cast<f32x4*>(dx)[q] = v;
+    for (int e = 0; e < NV; ++e) v[e] = dout[b * C + NV * cv + e] / (float)N;
+    Chunk<T>::store(dx + q * NV, v);
   }
 }
 
@@ -287,8 +304,9 @@ __global__ void adam_tick_kernel(int64_t* step, const float* gnorm) {
 }
 
 // ------------------------------------------------------------------ (B,C,N) <-> rows (B*N, C): 32x32 LDS transpose
-__global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ src, long src_batch, long src_ld,
-                                                        float* __restrict__ dst, long dst_batch, long dst_ld,
+template <typename TS, typename TD>
+__global__ __launch_bounds__(256) void transpose_kernel(const TS* __restrict__ src, long src_batch, long src_ld,
+                                                        TD* __restrict__ dst, long dst_batch, long dst_ld,
                                                         int R, int S) {   // src[b][r][s] -> dst[b][s][r]
   __shared__ float tile[32][33];
   const int b = blockIdx.z;
@@ -296,29 +314,37 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict_
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;    // 32 x 8
   for (int i = ty; i < 32; i += 8) {
     const int rr = r0 + i, ss = s0 + tx;
-    if (rr < R && ss < S) tile[i][tx] = src[b * src_batch + (long)rr * src_ld + ss];
+    if (rr < R && ss < S) tile[i][tx] = (float)src[b * src_batch + (long)rr * src_ld + ss];
   }
   __syncthreads();
   for (int i = ty; i < 32; i += 8) {
     const int ss = s0 + i, rr = r0 + tx;
-    if (rr < R && ss < S) dst[b * dst_batch + (long)ss * dst_ld + rr] = tile[tx][i];
+    if (rr < R && ss < S) dst[b * dst_batch + (long)ss * dst_ld + rr] = (TD)tile[tx][i];
   }
 }
 
 }  // namespace
 
-extern "C" int nsid_im2col3_fwd(const float* x, int B, int N, int C, float* col, void* stream) {
-  NSID_REQUIRE(x && col && B > 0 && N > 0 && C > 0 && C % 4 == 0 && nsid_aligned16(x) && nsid_aligned16(col));
+extern "C" int nsid_im2col3_fwd(const void* x, int B, int N, int C, void* col, int dtype, void* stream) {
+  NSID_REQUIRE(x && col && B > 0 && N > 0 && C > 0 && NSID_DTYPE_OK(dtype) && nsid_aligned16(x) && nsid_aligned16(col));
+  const int nv = dtype == NSID_BF16 ? 8 : 4;
+  NSID_REQUIRE(C % nv == 0);
   const int No = (N - 1) / 2 + 1;
-  NSID_LAUNCH(im2col3_fwd_kernel, dim3(grid_for((long)B * No * 3 * (C / 4))), dim3(256), 0,
-                     static_cast<hipStream_t>(stream), x, B, N, No, C, col);
+  NSID_DISPATCH_DTYPE(dtype, T, {
+    NSID_LAUNCH((im2col3_fwd_kernel<T>), dim3(grid_for((long)B * No * 3 * (C / nv))), dim3(256), 0,
+                static_cast<hipStream_t>(stream), static_cast<const T*>(x), B, N, No, C, static_cast<T*>(col));
+  });
   return nsid_launch_status();
 }
-extern "C" int nsid_im2col3_bwd(const float* dcol, int B, int N, int C, float* dx, void* stream) {
-  NSID_REQUIRE(dcol && dx && B > 0 && N > 0 && C > 0 && C % 4 == 0 && nsid_aligned16(dcol) && nsid_aligned16(dx));
+extern "C" int nsid_im2col3_bwd(const void* dcol, int B, int N, int C, void* dx, int dtype, void* stream) {
+  NSID_REQUIRE(dcol && dx && B > 0 && N > 0 && C > 0 && NSID_DTYPE_OK(dtype) && nsid_aligned16(dcol) && nsid_aligned16(dx));
+  const int nv = dtype == NSID_BF16 ? 8 : 4;
+  NSID_REQUIRE(C % nv == 0);
   const int No = (N - 1) / 2 + 1;
-  NSID_LAUNCH(im2col3_bwd_kernel, dim3(grid_for((long)B * N * (C / 4))), dim3(256), 0,
-                     static_cast<hipStream_t>(stream), dcol, B, N, No, C, dx);
+  NSID_DISPATCH_DTYPE(dtype, T, {
+    NSID_LAUNCH((im2col3_bwd_kernel<T>), dim3(grid_for((long)B * N * (C / nv))), dim3(256), 0,
+                static_cast<hipStream_t>(stream), static_cast<const T*>(dcol), B, N, No, C, static_cast<T*>(dx));
+  });
   return nsid_launch_status();
 }
 extern "C" int nsid_pack_ds_weight(const float* w, int Cout, int Cin, float* wp, void* stream) {
@@ -335,37 +361,50 @@ extern "C" int nsid_unpack_ds_wgrad(const float* dwp, int Cout, int Cin, float* 
 }
 
 extern "C" int nsid_peak_patchify_fwd(const float* spec, const float* w, const float* bias, int B, int H, int W, int pb,
-                                      int pf, int F, float* out, int ldo, float* minmax, void* stream) {
+                                      int pf, int F, void* out, int ldo, float* minmax, int out_dtype, void* stream) {
   NSID_REQUIRE(spec && w && bias && out && B > 0 && H > 1 && W > 1 && pb > 0 && pf > 0 && F > 0);
-  NSID_REQUIRE(H % pb == 0 && W % pf == 0 && ldo >= F);
+  NSID_REQUIRE(H % pb == 0 && W % pf == 0 && ldo >= F && NSID_DTYPE_OK(out_dtype));
   const size_t bytes = ((size_t)F * 3 * pb * pf + 8) * sizeof(float);
   NSID_REQUIRE(bytes <= 48 * 1024);
-  NSID_LAUNCH(patchify_fwd_kernel, dim3(B), dim3(256), bytes, static_cast<hipStream_t>(stream), spec, w, bias,
-                     H, W, pb, pf, F, out, ldo, minmax);
+  NSID_DISPATCH_DTYPE(out_dtype, T, {
+    NSID_LAUNCH((patchify_fwd_kernel<T>), dim3(B), dim3(256), bytes, static_cast<hipStream_t>(stream), spec, w, bias,
+                H, W, pb, pf, F, static_cast<T*>(out), ldo, minmax);
+  });
   return nsid_launch_status();
 }
-extern "C" int nsid_peak_patchify_bwd(const float* spec, const float* minmax, const float* out, const float* dout,
+extern "C" int nsid_peak_patchify_bwd(const float* spec, const float* minmax, const void* out, const void* dout,
                                       int ldo, int B, int H, int W, int pb, int pf, int F, float* dw, float* dbias,
-                                      void* stream) {
+                                      int out_dtype, void* stream) {
   NSID_REQUIRE(spec && minmax && out && dout && dw && dbias && B > 0 && H % pb == 0 && W % pf == 0 && ldo >= F);
+  NSID_REQUIRE(NSID_DTYPE_OK(out_dtype));
   const size_t bytes = (size_t)(H / pb) * (W / pf) * F * sizeof(float);
   NSID_REQUIRE(bytes <= 48 * 1024);
-  NSID_LAUNCH(patchify_bwd_kernel, dim3(B), dim3(256), bytes, static_cast<hipStream_t>(stream), spec, minmax,
-                     out, dout, ldo, H, W, pb, pf, F, dw, dbias);
+  NSID_DISPATCH_DTYPE(out_dtype, T, {
+    NSID_LAUNCH((patchify_bwd_kernel<T>), dim3(B), dim3(256), bytes, static_cast<hipStream_t>(stream), spec, minmax,
+                static_cast<const T*>(out), static_cast<const T*>(dout), ldo, H, W, pb, pf, F, dw, dbias);
+  });
   return nsid_launch_status();
 }
 
-extern "C" int nsid_node_mean_fwd(const float* x, int B, int N, int C, float* out, void* stream) {
-  NSID_REQUIRE(x && out && B > 0 && N > 0 && C > 0 && C % 4 == 0 && nsid_aligned16(x) && nsid_aligned16(out));
-  NSID_LAUNCH(node_mean_fwd_kernel, dim3(B, (C / 4 + 255) / 256), dim3(256), 0,
-                     static_cast<hipStream_t>(stream), x, N, C, out);
+extern "C" int nsid_node_mean_fwd(const void* x, int B, int N, int C, float* out, int x_dtype, void* stream) {
+  NSID_REQUIRE(x && out && B > 0 && N > 0 && C > 0 && NSID_DTYPE_OK(x_dtype) && nsid_aligned16(x));
+  const int nv = x_dtype == NSID_BF16 ? 8 : 4;
+  NSID_REQUIRE(C % nv == 0);
+  NSID_DISPATCH_DTYPE(x_dtype, T, {
+    NSID_LAUNCH((node_mean_fwd_kernel<T>), dim3(B, (C / nv + 255) / 256), dim3(256), 0,
+                static_cast<hipStream_t>(stream), static_cast<const T*>(x), N, C, out);
+  });
   return nsid_launch_status();
 }
-extern "C" int nsid_node_mean_bwd(const float* dout, int B, int N, int C, float* dx, void* stream) {
-  NSID_REQUIRE(dout && dx && B > 0 && N > 0 && C > 0 && C % 4 == 0 && nsid_aligned16(dout) && nsid_aligned16(dx));
-  const long total4 = (long)B * N * (C / 4);
-  NSID_LAUNCH(node_mean_bwd_kernel, dim3(grid_for(total4)), dim3(256), 0, static_cast<hipStream_t>(stream),
-                     dout, N, C, total4, dx);
+extern "C" int nsid_node_mean_bwd(const float* dout, int B, int N, int C, void* dx, int dx_dtype, void* stream) {
+  NSID_REQUIRE(dout && dx && B > 0 && N > 0 && C > 0 && NSID_DTYPE_OK(dx_dtype) && nsid_aligned16(dx));
+  const int nv = dx_dtype == NSID_BF16 ? 8 : 4;
+  NSID_REQUIRE(C % nv == 0);
+  const long nchunks = (long)B * N * (C / nv);
+  NSID_DISPATCH_DTYPE(dx_dtype, T, {
+    NSID_LAUNCH((node_mean_bwd_kernel<T>), dim3(grid_for(nchunks)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                dout, N, C, nchunks, static_cast<T*>(dx));
+  });
   return nsid_launch_status();
 }
 extern "C" int nsid_elu_bwd(const float* dout, const float* out, long n, float* din, void* stream) {
@@ -405,15 +444,21 @@ extern "C" int nsid_adam_step(float* p, const float* g, float* m, float* v, long
   return nsid_launch_status();
 }
 
-extern "C" int nsid_bcn_to_rows(const float* x, int B, int C, int N, float* rows, int ld, void* stream) {
-  NSID_REQUIRE(x && rows && B > 0 && C > 0 && N > 0 && ld >= C);
-  NSID_LAUNCH(transpose_kernel, dim3((N + 31) / 32, (C + 31) / 32, B), dim3(256), 0,
-                     static_cast<hipStream_t>(stream), x, (long)C * N, (long)N, rows, (long)N * ld, (long)ld, C, N);
+extern "C" int nsid_bcn_to_rows(const float* x, int B, int C, int N, void* rows, int ld, int rows_dtype, void* stream) {
+  NSID_REQUIRE(x && rows && B > 0 && C > 0 && N > 0 && ld >= C && NSID_DTYPE_OK(rows_dtype));
+  NSID_DISPATCH_DTYPE(rows_dtype, T, {
+    NSID_LAUNCH((transpose_kernel<float, T>), dim3((N + 31) / 32, (C + 31) / 32, B), dim3(256), 0,
+                static_cast<hipStream_t>(stream), x, (long)C * N, (long)N, static_cast<T*>(rows), (long)N * ld, (long)ld,
+                C, N);
+  });
   return nsid_launch_status();
 }
-extern "C" int nsid_rows_to_bcn(const float* rows, int ld, int B, int C, int N, float* x, void* stream) {
-  NSID_REQUIRE(x && rows && B > 0 && C > 0 && N > 0 && ld >= C);
-  NSID_LAUNCH(transpose_kernel, dim3((C + 31) / 32, (N + 31) / 32, B), dim3(256), 0,
-                     static_cast<hipStream_t>(stream), rows, (long)N * ld, (long)ld, x, (long)C * N, (long)N, N, C);
+extern "C" int nsid_rows_to_bcn(const void* rows, int ld, int B, int C, int N, float* x, int rows_dtype, void* stream) {
+  NSID_REQUIRE(x && rows && B > 0 && C > 0 && N > 0 && ld >= C && NSID_DTYPE_OK(rows_dtype));
+  NSID_DISPATCH_DTYPE(rows_dtype, T, {
+    NSID_LAUNCH((transpose_kernel<T, float>), dim3((C + 31) / 32, (N + 31) / 32, B), dim3(256), 0,
+                static_cast<hipStream_t>(stream), static_cast<const T*>(rows), (long)N * ld, (long)ld, x, (long)C * N,
+                (long)N, N, C);
+  });
   return nsid_launch_status();
 }

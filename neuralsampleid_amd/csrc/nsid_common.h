@@ -7,6 +7,45 @@
 #include "../../include/nsid.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// Activation storage: fp32 or bf16 (include/nsid.h NSID_F32 / NSID_BF16). Streaming kernels move one 16-byte chunk per
+// lane per access in either type: 4 fp32 or 8 bf16; arithmetic is always fp32.
+template <typename T> struct Chunk;
+template <> struct Chunk<float> {
+  static constexpr int N = 4;
+  __device__ static __forceinline__ void load(const float* p, float* v) {
+    const f32x4 x = *reinterpret_cast<const f32x4*>(p);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = x[e];
+  }
+  __device__ static __forceinline__ void store(float* p, const float* v) {
+    *reinterpret_cast<f32x4*>(p) = f32x4{v[0], v[1], v[2], v[3]};
+  }
+};
+template <> struct Chunk<__bf16> {
+  static constexpr int N = 8;
+  __device__ static __forceinline__ void load(const __bf16* p, float* v) {
+    const bf16x8 x = *reinterpret_cast<const bf16x8*>(p);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (float)x[e];
+  }
+  __device__ static __forceinline__ void store(__bf16* p, const float* v) {
+    bf16x8 x;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) x[e] = (__bf16)v[e];      // RNE (v_cvt_pk_bf16_f32), NaN stays NaN
+    *reinterpret_cast<bf16x8*>(p) = x;
+  }
+};
+
+// dispatch a templated launch on the runtime storage code
+#define NSID_DISPATCH_DTYPE(dtype, T, ...)                    \
+  do {                                                        \
+    if ((dtype) == NSID_BF16) { typedef __bf16 T; __VA_ARGS__; } \
+    else { typedef float T; __VA_ARGS__; }                    \
+  } while (0)
+#define NSID_DTYPE_OK(d) ((d) == NSID_F32 || (d) == NSID_BF16)
 
 #define NSID_WAVE 64
 

@@ -48,6 +48,21 @@ EXACT_BIAS_GRAD = _os.environ.get("NSID_EXACT_BIAS_GRAD", "0") == "1"
 # for autograd to add: saves one zero-fill and one add per parameter per view.
 DIRECT_GRADS = False
 
+# Storage type of activation tensors (features, raw conv outputs and their gradients) from the pipeline entry onwards
+# (peak-extractor output / layout conversion). torch.float32 (default, strict parity) or torch.bfloat16 (BASELINE
+# config 2: bf16 storage, fp32 accumulate — halves the HBM traffic of a step). Parameters, statistics, indices and the
+# small head tensors stay fp32 either way. Set through set_activation_dtype().
+ACT_DTYPE = torch.float32
+
+
+def set_activation_dtype(dtype) -> None:
+    global ACT_DTYPE
+    dtype = {"fp32": torch.float32, "bf16": torch.bfloat16}.get(dtype, dtype)
+    if dtype not in (torch.float32, torch.bfloat16):
+        raise ValueError("activation storage is torch.float32 or torch.bfloat16")
+    ACT_DTYPE = dtype
+
+
 # Called at the end of every block backward with the parameter tensors whose gradient contribution has just been
 # enqueued (parallel.GradReducer uses it to overlap the bucketed all-reduce with the rest of backward).
 GRAD_READY_HOOK = None
@@ -202,7 +217,7 @@ def proj_mean_forward(x: Tensor, P, S: Optional[dict], B: int, N: int) -> Tensor
     xm = ops.node_mean_fwd(x, B, N, C)
     h, _ = ops.linear_fwd(xm, ops.w2d(P["weight"]), P["bias"], B, E, C)
     if S is not None:
-        S.update(xm=xm, B=B, N=N, C=C)
+        S.update(xm=xm, B=B, N=N, C=C, xdtype=x.dtype)
     return h
 
 
@@ -212,7 +227,7 @@ def proj_mean_backward(dh: Tensor, P, S, G) -> Tensor:
     ops.linear_bwd_weight(dh, xm, ops.w2d(G["weight"]), B, E, C)
     ops.colsum_acc(dh, G["bias"])
     dxm = ops.linear_bwd_data(dh, ops.w2d(P["weight"]), B, E, C)
-    return ops.node_mean_bwd(dxm, B, N, C)
+    return ops.node_mean_bwd(dxm, B, N, C, S["xdtype"])
 
 
 # ------------------------------------------------------------------------------------------------ projector
@@ -244,7 +259,7 @@ def projector_backward(dz: Tensor, P, S, G) -> Tensor:
 
 # ------------------------------------------------------------------------------------------------ peak extractor
 def patchify_forward(spec: Tensor, P, S: Optional[dict], pb: int, pf: int) -> Tensor:
-    out, minmax = ops.peak_patchify_fwd(spec, P["convs.0.weight"], P["convs.0.bias"], pb, pf)
+    out, minmax = ops.peak_patchify_fwd(spec, P["convs.0.weight"], P["convs.0.bias"], pb, pf, ACT_DTYPE)
     if S is not None:
         S.update(spec=spec, minmax=minmax, out=out, pb=pb, pf=pf)
     return out
@@ -290,9 +305,9 @@ def run_block(fwd, bwd, module_params: Dict[str, Tensor], module_buffers: Dict[s
 
 class _ToRows(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x):           # (B, C, N[,1]) -> (B*N, C)
+    def forward(ctx, x):           # (B, C, N[,1]) fp32 -> (B*N, C) in the activation storage type
         ctx.shape = x.shape
-        return ops.bcn_to_rows(x.contiguous())
+        return ops.bcn_to_rows(x.contiguous(), ACT_DTYPE)
 
     @staticmethod
     def backward(ctx, d):
@@ -302,12 +317,13 @@ class _ToRows(torch.autograd.Function):
 
 class _FromRows(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, rows, B, N):  # (B*N, C) -> (B, C, N)
+    def forward(ctx, rows, B, N):  # (B*N, C) -> (B, C, N) fp32
+        ctx.rows_dtype = rows.dtype
         return ops.rows_to_bcn(rows.contiguous(), B, N)
 
     @staticmethod
     def backward(ctx, d):
-        return ops.bcn_to_rows(d.contiguous()), None, None
+        return ops.bcn_to_rows(d.contiguous(), ctx.rows_dtype), None, None
 
 
 def to_rows(x: Tensor) -> Tensor:

@@ -70,6 +70,7 @@ def _stream():
 
 
 def _chk(*ts):
+    """parameters / statistics / head tensors: contiguous fp32 on the GPU"""
     for t in ts:
         if t is None:
             continue
@@ -77,6 +78,27 @@ def _chk(*ts):
             raise RuntimeError("neuralsampleid_amd ops need tensors on the MI355X (cuda) device; there is no CPU path")
         if t.dtype != torch.float32 or not t.is_contiguous():
             raise RuntimeError(f"expected contiguous float32, got {t.dtype} contiguous={t.is_contiguous()}")
+
+
+F32, BF16 = 0, 1
+
+
+def _act(*ts) -> int:
+    """activation tensors (features, raw conv outputs, their gradients): contiguous fp32 or bf16, all the same type;
+    returns the C ABI dtype code"""
+    code = None
+    for t in ts:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError("neuralsampleid_amd ops need tensors on the MI355X (cuda) device; there is no CPU path")
+        if t.dtype not in (torch.float32, torch.bfloat16) or not t.is_contiguous():
+            raise RuntimeError(f"expected contiguous float32/bfloat16, got {t.dtype} contiguous={t.is_contiguous()}")
+        c = BF16 if t.dtype == torch.bfloat16 else F32
+        if code is not None and c != code:
+            raise RuntimeError("activation tensors of one call must share a storage type")
+        code = c
+    return code
 
 
 GEMM_FP32, GEMM_BF16 = 0, 1
@@ -104,49 +126,55 @@ def w2d(w: torch.Tensor) -> torch.Tensor:
 # ------------------------------------------------------------------------------------------------ linear
 def linear_fwd(x, w, bias, M, Nout, K, groups=1, in_scale=None, in_shift=None, act_in=ACT_NONE, act_out=ACT_NONE,
                want_stat=False, ksplit=1, out=None) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
-    _chk(x, w, bias, in_scale, in_shift)
+    _chk(w, bias, in_scale, in_shift)
+    dt = _act(x, out)
     ldx = x.shape[-1]
     if out is None:
-        out = (torch.zeros if ksplit > 1 else torch.empty)((M, groups * Nout), device=x.device, dtype=torch.float32)
+        out = (torch.zeros if ksplit > 1 else torch.empty)((M, groups * Nout), device=x.device, dtype=x.dtype)
     stat = torch.empty((2, row_tiles(M), groups * Nout), device=x.device, dtype=torch.float32) if want_stat else None
-    narrow = Nout <= 64 or (lib.nsid_get_gemm_precision() == GEMM_BF16
-                            and row_tiles(M) * ((Nout + 127) // 128) * groups < 512)
+    half = dt == BF16 or lib.nsid_get_gemm_precision() == GEMM_BF16
+    narrow = Nout <= 64 or (half and row_tiles(M) * ((Nout + 127) // 128) * groups < 512)
     name = "gemm_kernel<128,%d,true,true>" % (64 if narrow else 128)
-    _timed(name, 2.0 * M * Nout * K * groups, 4.0 * groups * (M * K + Nout * K + M * Nout), lambda: call(
+    esz = x.element_size()
+    _timed(name, 2.0 * M * Nout * K * groups, groups * (esz * M * K + 4.0 * Nout * K + esz * M * Nout), lambda: call(
         "nsid_linear_fwd", _p(x), ldx, _p(w), _p(bias), _p(out), out.shape[-1], M, Nout, K, groups, _p(in_scale),
-        _p(in_shift), act_in, act_out, _p(stat), ksplit, _stream()), (M, Nout, K, groups))
+        _p(in_shift), act_in, act_out, _p(stat), ksplit, dt, _stream()), (M, Nout, K, groups))
     return out, stat
 
 
 def linear_bwd_data(dout, w, M, Nout, K, groups=1, addend=None, out=None) -> torch.Tensor:
-    _chk(dout, w, addend)
+    _chk(w)
+    dt = _act(dout, addend, out)
     if out is None:
-        out = torch.empty((M, groups * K), device=dout.device, dtype=torch.float32)
-    narrow = K <= 64 or (lib.nsid_get_gemm_precision() == GEMM_BF16
-                         and row_tiles(M) * ((K + 127) // 128) * groups < 512)
+        out = torch.empty((M, groups * K), device=dout.device, dtype=dout.dtype)
+    half = dt == BF16 or lib.nsid_get_gemm_precision() == GEMM_BF16
+    narrow = K <= 64 or (half and row_tiles(M) * ((K + 127) // 128) * groups < 512)
     name = "gemm_kernel<128,%d,true,false>" % (64 if narrow else 128)
+    esz = dout.element_size()
     _timed(name, 2.0 * M * Nout * K * groups,
-           4.0 * groups * (M * Nout + Nout * K + M * K * (2 if addend is not None else 1)), lambda: call(
+           groups * (esz * M * Nout + 4.0 * Nout * K + esz * M * K * (2 if addend is not None else 1)), lambda: call(
                "nsid_linear_bwd_data", _p(dout), dout.shape[-1], _p(w), _p(addend),
-               0 if addend is None else addend.shape[-1], _p(out), out.shape[-1], M, Nout, K, groups, _stream()),
+               0 if addend is None else addend.shape[-1], _p(out), out.shape[-1], M, Nout, K, groups, dt, _stream()),
            (M, Nout, K, groups))
     return out
 
 
 def linear_bwd_weight(dout, x, dw, M, Nout, K, groups=1, in_scale=None, in_shift=None, act_in=ACT_NONE) -> None:
     """dw += dout^T f(x)"""
-    _chk(dout, x, dw, in_scale, in_shift)
+    _chk(dw, in_scale, in_shift)
+    dt = _act(dout, x)
     t128 = ((Nout + 127) // 128) * ((K + 127) // 128) * groups
     small = Nout <= 64 or K <= 64 or t128 * ((M + 511) // 512) < 256
     name = "gemm_kernel<%s,false,false>" % ("64,64" if small else "128,128")
-    _timed(name, 2.0 * M * Nout * K * groups, 4.0 * groups * (M * Nout + M * K + Nout * K), lambda: call(
+    esz = x.element_size()
+    _timed(name, 2.0 * M * Nout * K * groups, groups * (esz * M * Nout + esz * M * K + 4.0 * Nout * K), lambda: call(
         "nsid_linear_bwd_weight", _p(dout), dout.shape[-1], _p(x), x.shape[-1], _p(dw), M, Nout, K, groups,
-        _p(in_scale), _p(in_shift), act_in, _stream()), (M, Nout, K, groups))
+        _p(in_scale), _p(in_shift), act_in, dt, _stream()), (M, Nout, K, groups))
 
 
 def colsum_acc(x, out) -> None:
-    _chk(x, out)
-    call("nsid_colsum_acc", _p(x), x.shape[-1], x.shape[0], x.shape[1], _p(out), _stream())
+    _chk(out)
+    call("nsid_colsum_acc", _p(x), x.shape[-1], x.shape[0], x.shape[1], _p(out), _act(x), _stream())
 
 
 # ------------------------------------------------------------------------------------------------ batch norm
@@ -176,55 +204,55 @@ def bn_eval_affine(gamma, beta, running_mean, running_var, eps=BN_EPS) -> BNAffi
 
 
 def bn_apply(r, aff: BNAffine, act=ACT_NONE, residual=None, out=None) -> torch.Tensor:
-    _chk(r, residual)
+    dt = _act(r, residual, out)
     M, C = r.shape
     if out is None:
         out = torch.empty_like(r)
-    call("nsid_bn_apply", _p(r), _p(aff.scale), _p(aff.shift), act, _p(residual), _p(out), M, C, _stream())
+    call("nsid_bn_apply", _p(r), _p(aff.scale), _p(aff.shift), act, _p(residual), _p(out), M, C, dt, _stream())
     return out
 
 
 def bn_backward(dout, r, aff: BNAffine, act, dgamma, dbeta, inplace=False) -> torch.Tensor:
     """Gradient w.r.t. the raw conv output r of y = act(BN(r)), given dL/dy; dgamma/dbeta are accumulated."""
-    _chk(dout, r)
+    dt = _act(dout, r)
     M, C = r.shape
     tiles = row_tiles(M)
     partial = torch.empty((2, tiles, C), device=r.device, dtype=torch.float32)
     coef = torch.empty((2, C), device=r.device, dtype=torch.float32)
     s = _stream()
     call("nsid_bn_bwd_reduce", _p(dout), _p(r), M, C, _p(aff.scale), _p(aff.shift), _p(aff.mean), _p(aff.invstd),
-         act, _p(partial), s)
+         act, _p(partial), dt, s)
     call("nsid_bn_bwd_finalize", _p(partial), tiles, C, M, _p(dgamma), _p(dbeta), _p(coef), s)
     dr = dout if inplace else torch.empty_like(dout)
     call("nsid_bn_bwd_apply", _p(dout), _p(r), M, C, _p(aff.scale), _p(aff.shift), _p(aff.mean), _p(aff.invstd),
-         act, _p(coef), _p(dr), s)
+         act, _p(coef), _p(dr), dt, s)
     return dr
 
 
 # ------------------------------------------------------------------------------------------------ graph ops
 def knn_graph(r, B, N, C, k, dilation=1, aff: Optional[BNAffine] = None) -> torch.Tensor:
     """(B*N, C) features (optionally with a pending BatchNorm affine) -> int32 (B, N, k) clip-local neighbour ids"""
-    _chk(r)
+    dt = _act(r)
     idx = torch.empty((B, N, k), device=r.device, dtype=torch.int32)
     call("nsid_knn_graph", _p(r), r.shape[-1], _p(aff.scale) if aff else None, _p(aff.shift) if aff else None,
-         B, N, C, k, dilation, _p(idx), _stream())
+         B, N, C, k, dilation, _p(idx), dt, _stream())
     return idx
 
 
 def mr_aggregate_fwd(r, idx, B, N, C, aff: Optional[BNAffine] = None, want_argmax=True):
-    _chk(r)
+    dt = _act(r)
     k = idx.shape[-1]
-    u = torch.empty((B * N, 2 * C), device=r.device, dtype=torch.float32)
+    u = torch.empty((B * N, 2 * C), device=r.device, dtype=r.dtype)
     amax = torch.empty((B * N, C), device=r.device, dtype=torch.uint8) if want_argmax else None
     call("nsid_mr_aggregate_fwd", _p(r), r.shape[-1], _p(aff.scale) if aff else None,
-         _p(aff.shift) if aff else None, _p(idx), B, N, C, k, _p(u), _p(amax), _stream())
+         _p(aff.shift) if aff else None, _p(idx), B, N, C, k, _p(u), _p(amax), dt, _stream())
     return u, amax
 
 
 def mr_aggregate_bwd(du, idx, amax, B, N, C) -> torch.Tensor:
-    _chk(du)
-    dy = torch.empty((B * N, C), device=du.device, dtype=torch.float32)
-    call("nsid_mr_aggregate_bwd", _p(du), _p(idx), _p(amax), B, N, C, idx.shape[-1], _p(dy), _stream())
+    dt = _act(du)
+    dy = torch.empty((B * N, C), device=du.device, dtype=du.dtype)
+    call("nsid_mr_aggregate_bwd", _p(du), _p(idx), _p(amax), B, N, C, idx.shape[-1], _p(dy), dt, _stream())
     return dy
 
 
@@ -234,16 +262,16 @@ def ds_out_nodes(N: int) -> int:
 
 
 def im2col3_fwd(x, B, N, C) -> torch.Tensor:
-    _chk(x)
-    col = torch.empty((B * ds_out_nodes(N), 3 * C), device=x.device, dtype=torch.float32)
-    call("nsid_im2col3_fwd", _p(x), B, N, C, _p(col), _stream())
+    dt = _act(x)
+    col = torch.empty((B * ds_out_nodes(N), 3 * C), device=x.device, dtype=x.dtype)
+    call("nsid_im2col3_fwd", _p(x), B, N, C, _p(col), dt, _stream())
     return col
 
 
 def im2col3_bwd(dcol, B, N, C) -> torch.Tensor:
-    _chk(dcol)
-    dx = torch.empty((B * N, C), device=dcol.device, dtype=torch.float32)
-    call("nsid_im2col3_bwd", _p(dcol), B, N, C, _p(dx), _stream())
+    dt = _act(dcol)
+    dx = torch.empty((B * N, C), device=dcol.device, dtype=dcol.dtype)
+    call("nsid_im2col3_bwd", _p(dcol), B, N, C, _p(dx), dt, _stream())
     return dx
 
 
@@ -261,36 +289,36 @@ def unpack_ds_wgrad(dwp, dw) -> None:
 
 
 # ------------------------------------------------------------------------------------------------ peak extractor
-def peak_patchify_fwd(spec, w, bias, pb, pf):
+def peak_patchify_fwd(spec, w, bias, pb, pf, out_dtype=torch.float32):
     _chk(spec, w, bias)
     B, H, W = spec.shape
     F = w.shape[0]
     n = (H // pb) * (W // pf)
-    out = torch.empty((B * n, F), device=spec.device, dtype=torch.float32)
+    out = torch.empty((B * n, F), device=spec.device, dtype=out_dtype)
     minmax = torch.empty((B, 2), device=spec.device, dtype=torch.float32)
-    call("nsid_peak_patchify_fwd", _p(spec), _p(w), _p(bias), B, H, W, pb, pf, F, _p(out), F, _p(minmax), _stream())
+    call("nsid_peak_patchify_fwd", _p(spec), _p(w), _p(bias), B, H, W, pb, pf, F, _p(out), F, _p(minmax), _act(out),
+         _stream())
     return out, minmax
 
 
 def peak_patchify_bwd(spec, minmax, out, dout, pb, pf, dw, dbias) -> None:
-    _chk(spec, minmax, out, dout, dw, dbias)
+    _chk(spec, minmax, dw, dbias)
     B, H, W = spec.shape
     call("nsid_peak_patchify_bwd", _p(spec), _p(minmax), _p(out), _p(dout), out.shape[-1], B, H, W, pb, pf,
-         out.shape[-1], _p(dw), _p(dbias), _stream())
+         out.shape[-1], _p(dw), _p(dbias), _act(out, dout), _stream())
 
 
 # ------------------------------------------------------------------------------------------------ head
 def node_mean_fwd(x, B, N, C) -> torch.Tensor:
-    _chk(x)
     out = torch.empty((B, C), device=x.device, dtype=torch.float32)
-    call("nsid_node_mean_fwd", _p(x), B, N, C, _p(out), _stream())
+    call("nsid_node_mean_fwd", _p(x), B, N, C, _p(out), _act(x), _stream())
     return out
 
 
-def node_mean_bwd(dout, B, N, C) -> torch.Tensor:
+def node_mean_bwd(dout, B, N, C, dtype=torch.float32) -> torch.Tensor:
     _chk(dout)
-    dx = torch.empty((B * N, C), device=dout.device, dtype=torch.float32)
-    call("nsid_node_mean_bwd", _p(dout), B, N, C, _p(dx), _stream())
+    dx = torch.empty((B * N, C), device=dout.device, dtype=dtype)
+    call("nsid_node_mean_bwd", _p(dout), B, N, C, _p(dx), _act(dx), _stream())
     return dx
 
 
@@ -349,18 +377,18 @@ def adam_step(p, g, m, v, hyper, step, partial, gnorm_out) -> None:
 
 
 # ------------------------------------------------------------------------------------------------ layout
-def bcn_to_rows(x) -> torch.Tensor:
-    """(B, C, N[, 1]) reference layout -> node-major (B*N, C)"""
+def bcn_to_rows(x, dtype=torch.float32) -> torch.Tensor:
+    """(B, C, N[, 1]) fp32 reference layout -> node-major (B*N, C) in the activation storage type"""
     _chk(x)
     B, C, N = x.shape[0], x.shape[1], x.shape[2]
-    rows = torch.empty((B * N, C), device=x.device, dtype=torch.float32)
-    call("nsid_bcn_to_rows", _p(x), B, C, N, _p(rows), C, _stream())
+    rows = torch.empty((B * N, C), device=x.device, dtype=dtype)
+    call("nsid_bcn_to_rows", _p(x), B, C, N, _p(rows), C, _act(rows), _stream())
     return rows
 
 
 def rows_to_bcn(rows, B, N) -> torch.Tensor:
-    _chk(rows)
+    """node-major (B*N, C) of either storage type -> (B, C, N) fp32"""
     C = rows.shape[-1]
     x = torch.empty((B, C, N), device=rows.device, dtype=torch.float32)
-    call("nsid_rows_to_bcn", _p(rows), C, B, C, N, _p(x), _stream())
+    call("nsid_rows_to_bcn", _p(rows), C, B, C, N, _p(x), _act(rows), _stream())
     return x

@@ -1,0 +1,210 @@
+"""GPU parity of bf16 ACTIVATION STORAGE (functional.set_activation_dtype('bf16'); BASELINE config 2: bf16 storage, fp32
+accumulate). Every kernel that touches an activation tensor is run on bf16 tensors and compared with the same op on the
+upcast fp32 copy of the SAME bf16 values (so the only differences are the final rounding of the outputs to bf16:
+relative L2 <= 2.5e-3, i.e. bf16's 2^-9 half-ulp rms, and bit-exact for pure data movement / integer outputs)."""
+import numpy as np
+import pytest
+import torch
+
+from synth import GRAFP_CFG, synth_randn, synth_state
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+BF = torch.bfloat16
+
+
+@pytest.fixture()
+def ops():
+    from neuralsampleid_amd import functional as F_
+    from neuralsampleid_amd import ops as o
+    o.set_gemm_precision("bf16")
+    yield o
+    o.set_gemm_precision("fp32")
+    F_.set_activation_dtype("fp32")
+
+
+def relerr(a, b):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+def act_ref(x, act):
+    return {0: x, 1: torch.relu(x), 2: torch.nn.functional.leaky_relu(x, 0.2)}[act]
+
+
+def bfr(x):
+    """fp64 view of the bf16 rounding of x"""
+    return x.to(BF).double()
+
+
+CASES = [(512, 64, 64, 1, False, 0), (200, 256, 64, 1, True, 1), (384, 32, 32, 4, False, 0), (256, 128, 128, 4, True, 2),
+         (640, 64, 8, 1, False, 0), (2048, 1024, 256, 1, True, 1), (136, 192, 384, 1, False, 0)]
+
+
+@pytest.mark.parametrize("M,Nout,K,groups,affine,act", CASES)
+def test_linear_family_bf16_storage(ops, M, Nout, K, groups, affine, act):
+    x = synth_randn(f"sx{M}{K}{groups}", M, groups * K).to(BF)
+    w = synth_randn(f"sw{Nout}{K}{groups}", groups * Nout, K) * K ** -0.5
+    bias = synth_randn(f"sb{Nout}", groups * Nout)
+    dout = synth_randn(f"sd{M}{Nout}", M, groups * Nout).to(BF)
+    add = synth_randn(f"sa{M}{K}", M, groups * K).to(BF)
+    sc = 1 + 0.2 * synth_randn("ssc", groups * K) if affine else None
+    sh = 0.3 * synth_randn("ssh", groups * K) if affine else None
+    xin = act_ref(x.float() * sc + sh, act) if affine else x.float()      # the kernel's fp32 value before bf16 rounding
+    d = lambda t: None if t is None else t.to(DEV)
+    G = range(groups)
+    ref = torch.cat([bfr(xin[:, g * K:(g + 1) * K]) @ bfr(w[g * Nout:(g + 1) * Nout]).t() for g in G], 1) + bias.double()
+    out, stat = ops.linear_fwd(d(x), d(w), d(bias), M, Nout, K, groups, d(sc), d(sh), act, 0, want_stat=True)
+    assert out.dtype == BF and stat.dtype == torch.float32
+    assert relerr(out, ref) < 2.5e-3
+    assert relerr(stat[0].sum(0), ref.sum(0)) < 1e-4                      # statistics come from the fp32 accumulators
+    assert relerr(stat[1].sum(0), (ref * ref).sum(0)) < 1e-4
+    ref = torch.cat([dout.double()[:, g * Nout:(g + 1) * Nout] @ bfr(w[g * Nout:(g + 1) * Nout]) for g in G], 1)
+    got = ops.linear_bwd_data(d(dout), d(w), M, Nout, K, groups, d(add))
+    assert got.dtype == BF and relerr(got, ref + add.double()) < 2.5e-3
+    ref = torch.cat([dout.double()[:, g * Nout:(g + 1) * Nout].t() @ bfr(xin[:, g * K:(g + 1) * K]) for g in G], 0)
+    dw = torch.zeros(groups * Nout, K, device=DEV)
+    ops.linear_bwd_weight(d(dout), d(x), dw, M, Nout, K, groups, d(sc), d(sh), act)
+    assert relerr(dw, ref) < 2e-5                                          # fp32 output: only accumulation order differs
+
+
+@pytest.mark.parametrize("M,C,act", [(512, 64, 0), (300, 256, 1), (1024, 2048, 1), (256, 80, 2)])
+def test_batchnorm_kernels_bf16_storage(ops, M, C, act):
+    r16 = (synth_randn(f"sbn{M}{C}", M, C) * 1.5 + 0.7).to(BF).to(DEV)
+    res16 = synth_randn("sbnres", M, C).to(BF).to(DEV)
+    dout16 = synth_randn("sbndo", M, C).to(BF).to(DEV)
+    r32, res32, dout32 = r16.float(), res16.float(), dout16.float()
+    x64 = r32.double()
+    mean, var = x64.mean(0), x64.var(0, unbiased=False)
+    invstd = 1 / torch.sqrt(var + 1e-5)
+    gamma = (1 + 0.1 * synth_randn("sbng", C)).to(DEV)
+    beta = (0.1 * synth_randn("sbnb", C)).to(DEV)
+    scale = (gamma.double() * invstd).float()
+    shift = (beta.double() - mean * gamma.double() * invstd).float()
+    aff = ops.BNAffine(scale.contiguous(), shift.contiguous(), mean.float().contiguous(), invstd.float().contiguous())
+    y16 = ops.bn_apply(r16, aff, act, res16)
+    y32 = ops.bn_apply(r32, aff, act, res32)
+    assert y16.dtype == BF and relerr(y16, y32) < 2.5e-3
+    g16, b16 = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+    g32, b32 = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+    dr16 = ops.bn_backward(dout16, r16, aff, act, g16, b16)
+    dr32 = ops.bn_backward(dout32, r32, aff, act, g32, b32)
+    assert dr16.dtype == BF and relerr(dr16, dr32) < 2.5e-3
+    assert relerr(g16, g32) < 1e-5 and relerr(b16, b32) < 1e-5           # reductions are fp32 on identical inputs
+    s16, s32 = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+    ops.colsum_acc(dout16, s16)
+    ops.colsum_acc(dout32, s32)
+    assert relerr(s16, s32) < 1e-5
+
+
+def test_graph_kernels_bf16_storage(ops):
+    B, N, C, k = 3, 128, 128, 5
+    r16 = synth_randn("sgr", B * N, C).to(BF).to(DEV)
+    sc, sh = (1 + 0.3 * synth_randn("sgsc", C)).to(DEV), (0.5 * synth_randn("sgsh", C)).to(DEV)
+    aff = ops.BNAffine(sc, sh)
+    idx16 = ops.knn_graph(r16, B, N, C, k, 2, aff)
+    idx32 = ops.knn_graph(r16.float(), B, N, C, k, 2, aff)
+    assert torch.equal(idx16, idx32)                                       # same values in -> same graph out
+    u16, am16 = ops.mr_aggregate_fwd(r16, idx16, B, N, C, aff)
+    u32, am32 = ops.mr_aggregate_fwd(r16.float(), idx16, B, N, C, aff)
+    assert u16.dtype == BF and torch.equal(am16, am32) and torch.equal(u16, u32.to(BF))
+    du16 = synth_randn("sgdu", B * N, 2 * C).to(BF).to(DEV)
+    dy16 = ops.mr_aggregate_bwd(du16, idx16, am16, B, N, C)
+    dy32 = ops.mr_aggregate_bwd(du16.float(), idx16, am16, B, N, C)
+    assert dy16.dtype == BF and relerr(dy16, dy32) < 2.5e-3
+
+
+def test_misc_kernels_bf16_storage(ops):
+    B, N, C = 3, 64, 64
+    x16 = synth_randn("smx", B * N, C).to(BF).to(DEV)
+    col16 = ops.im2col3_fwd(x16, B, N, C)
+    assert col16.dtype == BF and torch.equal(col16, ops.im2col3_fwd(x16.float(), B, N, C).to(BF))
+    dcol16 = synth_randn("smd", B * ops.ds_out_nodes(N), 3 * C).to(BF).to(DEV)
+    assert relerr(ops.im2col3_bwd(dcol16, B, N, C), ops.im2col3_bwd(dcol16.float(), B, N, C)) < 2.5e-3
+    assert relerr(ops.node_mean_fwd(x16, B, N, C), ops.node_mean_fwd(x16.float(), B, N, C)) < 1e-6
+    dm = synth_randn("smm", B, C).to(DEV)
+    assert torch.equal(ops.node_mean_bwd(dm, B, N, C, BF), ops.node_mean_bwd(dm, B, N, C).to(BF))
+    x4 = synth_randn("sml", 2, 40, 24).to(DEV)
+    rows16 = ops.bcn_to_rows(x4, BF)
+    assert rows16.dtype == BF and torch.equal(rows16, ops.bcn_to_rows(x4).to(BF))
+    assert torch.equal(ops.rows_to_bcn(rows16, 2, 24), rows16.float().reshape(2, 24, 40).transpose(1, 2))
+    spec = (synth_randn("sms", 4, 64, 128) * 20 - 40).to(DEV)
+    w, b = synth_randn("smw", 8, 3, 4, 8).to(DEV) * 0.2, synth_randn("smb", 8).to(DEV) * 0.1
+    o16, mm = ops.peak_patchify_fwd(spec, w, b, 4, 8, BF)
+    o32, _ = ops.peak_patchify_fwd(spec, w, b, 4, 8)
+    assert o16.dtype == BF and torch.equal(o16, o32.to(BF))
+    do16 = synth_randn("smdo", 4 * 256, 8).to(BF).to(DEV)
+    dw16, db16 = torch.zeros_like(w), torch.zeros_like(b)
+    dw32, db32 = torch.zeros_like(w), torch.zeros_like(b)
+    ops.peak_patchify_bwd(spec, mm, o16, do16, 4, 8, dw16, db16)
+    ops.peak_patchify_bwd(spec, mm, o16.float(), do16.float(), 4, 8, dw32, db32)
+    assert relerr(dw16, dw32) < 1e-4 and relerr(db16, db32) < 1e-4
+
+
+def build(k=3):
+    from neuralsampleid_amd.encoder.graph_encoder import GraphEncoder
+    from neuralsampleid_amd.simclr.simclr import SimCLR
+    return SimCLR(GRAFP_CFG, GraphEncoder(GRAFP_CFG, in_channels=8, k=k, size="t"))
+
+
+def test_simclr_eval_bf16_storage_vs_reference(ops, golden):
+    """fingerprinting semantics with bf16 activations end to end, against the fp32 REFERENCE goldens"""
+    from neuralsampleid_amd import functional as F_
+    from neuralsampleid_amd.simclr.ntxent import ntxent_loss
+    F_.set_activation_dtype("bf16")
+    g = golden("e2e_b8_k3")
+    model = build()
+    model.load_state_dict(synth_state(model.state_dict()))
+    model.to(DEV).eval()
+    x_i, x_j = g.t("x_i").to(DEV), g.t("x_j").to(DEV)
+    n = len([k for k in g if k.startswith("knn.eval.")])
+    gold_idx = [g.t(f"knn.eval.{c}") for c in range(n)]
+    try:
+        F_.TAPE = F_.KnnTape(replay=gold_idx)
+        with torch.no_grad():
+            h_i, h_j, z_i, z_j = model(x_i, x_j)
+            loss = ntxent_loss(z_i, z_j, GRAFP_CFG)
+    finally:
+        F_.TAPE = None
+    assert h_i.dtype == torch.float32 and z_i.dtype == torch.float32
+    print("bf16 storage eval: rel_h", relerr(h_i, g.t("h_i_eval")), "dloss", abs(float(loss) - float(g["loss_eval"][0])))
+    assert relerr(h_i, g.t("h_i_eval")) < 4e-2 and relerr(h_j, g.t("h_j_eval")) < 4e-2
+    assert abs(float(loss) - float(g["loss_eval"][0])) < 5e-3
+    cos = torch.nn.functional.cosine_similarity(z_i.cpu(), g.t("z_i_eval"), dim=1)
+    assert float(cos.min()) > 0.999
+
+
+def test_training_curve_bf16_storage_tracks_fp32(ops):
+    """same acceptance as tests/test_bf16_gpu.py::test_training_curve_bf16_tracks_fp32, with bf16 activation storage"""
+    import math
+    from neuralsampleid_amd import functional as F_
+    from neuralsampleid_amd.optim import FusedClipAdam
+    from neuralsampleid_amd.simclr.ntxent import ntxent_loss
+    B = 128
+    gi, gj = torch.Generator().manual_seed(0), torch.Generator().manual_seed(1)
+    x_i = torch.randn(B, 64, 128, generator=gi) * 20 - 40
+    x_j = (x_i + 3 * torch.randn(B, 64, 128, generator=gj)).to(DEV)
+    x_i = x_i.to(DEV)
+    curves = {}
+    for mode in ("fp32", "bf16"):
+        ops.set_gemm_precision(mode)
+        F_.set_activation_dtype(mode)
+        torch.manual_seed(42)
+        model = build().to(DEV).train()
+        opt = FusedClipAdam(model.parameters(), lr=8e-5, max_norm=1.0)
+        ls = []
+        for _ in range(30):
+            opt.zero_grad()
+            _, _, z_i, z_j = model(x_i, x_j)
+            loss = ntxent_loss(z_i, z_j, GRAFP_CFG)
+            loss.backward()
+            opt.step()
+            ls.append(float(loss.detach()))
+        curves[mode] = ls
+    ratios = [abs(math.log(a / b)) for a, b in zip(curves["bf16"], curves["fp32"])]
+    worst, mean = max(ratios), sum(ratios) / len(ratios)
+    print("bf16-storage curve:", [round(v, 3) for v in curves["bf16"][::5]], "fp32:", [round(v, 3) for v in curves["fp32"][::5]],
+          "worst", round(worst, 3), "mean", round(mean, 3))
+    # measured at B=128: mean 0.29, worst 1.09 (the worst sits in the tail where both losses are ~0.02-0.05)
+    assert mean < 0.5 and worst < 1.5, (mean, worst, curves)
+    assert curves["bf16"][-1] < 0.1 * curves["bf16"][0]
