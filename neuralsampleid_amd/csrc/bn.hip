@@ -75,10 +75,12 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ r, 
   constexpr int N = Chunk<T>::N;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nchunks; i += (long)gridDim.x * blockDim.x) {
     const int c = (int)(i % CV) * N;
-    float v[N], o[N];
+    float v[N], o[N], sc[N], sh[N];
     Chunk<T>::load(r + i * N, v);
+    load_channels<N>(scale, c, sc);
+    load_channels<N>(shift, c, sh);
 #pragma unroll
-    for (int e = 0; e < N; ++e) o[e] = nsid_act(scale[c + e] * v[e] + shift[c + e], act);
+    for (int e = 0; e < N; ++e) o[e] = nsid_act(sc[e] * v[e] + sh[e], act);
     if (residual != nullptr) {
       float rs[N];
       Chunk<T>::load(residual + i * N, rs);
@@ -124,6 +126,13 @@ __global__ __launch_bounds__(256) void col_reduce_kernel(const T* __restrict__ d
       Chunk<T>::load(dout + off, d[i]);
       if (MODE == 1) Chunk<T>::load(r + off, x[i]);
     }
+    float sc[N], sh[N], mu[N], is[N];
+    if (MODE == 1) {
+      load_channels<N>(scale, c, sc);
+      load_channels<N>(shift, c, sh);
+      load_channels<N>(mean, c, mu);
+      load_channels<N>(invstd, c, is);
+    }
 #pragma unroll
     for (int i = 0; i < ROWS; ++i) {
       if (row0 + rgp + RG * i >= M) continue;
@@ -132,9 +141,9 @@ __global__ __launch_bounds__(256) void col_reduce_kernel(const T* __restrict__ d
         if (MODE == 0) {
           s0[e] += d[i][e];
         } else {
-          const float g = (scale[c + e] * x[i][e] + shift[c + e]) > 0.f ? d[i][e] : d[i][e] * slope;
+          const float g = (sc[e] * x[i][e] + sh[e]) > 0.f ? d[i][e] : d[i][e] * slope;
           s0[e] += g;
-          s1[e] += g * ((x[i][e] - mean[c + e]) * invstd[c + e]);
+          s1[e] += g * ((x[i][e] - mu[e]) * is[e]);
         }
       }
     }
@@ -181,15 +190,20 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
   const int C = CV * N;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nchunks; i += (long)gridDim.x * blockDim.x) {
     const int c = (int)(i % CV) * N;
-    float d[N], x[N], o[N];
+    float d[N], x[N], o[N], sc[N], sh[N], mu[N], is[N], c0[N], c1[N];
     Chunk<T>::load(dout + i * N, d);
     Chunk<T>::load(r + i * N, x);
+    load_channels<N>(scale, c, sc);
+    load_channels<N>(shift, c, sh);
+    load_channels<N>(mean, c, mu);
+    load_channels<N>(invstd, c, is);
+    load_channels<N>(coef, c, c0);
+    load_channels<N>(coef + C, c, c1);
 #pragma unroll
     for (int e = 0; e < N; ++e) {
-      const float sc = scale[c + e];
-      const float g = (sc * x[e] + shift[c + e]) > 0.f ? d[e] : d[e] * slope;
-      const float xh = (x[e] - mean[c + e]) * invstd[c + e];
-      o[e] = sc * (g - coef[c + e] - xh * coef[C + c + e]);
+      const float g = (sc[e] * x[e] + sh[e]) > 0.f ? d[e] : d[e] * slope;
+      const float xh = (x[e] - mu[e]) * is[e];
+      o[e] = sc[e] * (g - c0[e] - xh * c1[e]);
     }
     Chunk<T>::store(dr + i * N, o);
   }

@@ -51,8 +51,11 @@ __global__ __launch_bounds__(KNN_THREADS) void knn_kernel(const T* __restrict__ 
     float v[NV];
     Chunk<T>::load(src + (long)n * ldr + c, v);
     if (scale != nullptr) {
+      float sc[NV], sh[NV];
+      load_channels<NV>(scale, c, sc);
+      load_channels<NV>(shift, c, sh);
 #pragma unroll
-      for (int e = 0; e < NV; ++e) v[e] = scale[c + e] * v[e] + shift[c + e];
+      for (int e = 0; e < NV; ++e) v[e] = sc[e] * v[e] + sh[e];
     }
 #pragma unroll
     for (int e = 0; e < NV; e += 4) *reinterpret_cast<f32x4*>(yn + n * LD + c + e) = f32x4{v[e], v[e + 1], v[e + 2], v[e + 3]};

@@ -22,10 +22,14 @@ __global__ __launch_bounds__(256) void mr_fwd_kernel(const T* __restrict__ r, lo
     int arg[NV];
 #pragma unroll
     for (int e = 0; e < NV; ++e) {
-      sc[e] = scale ? scale[c + e] : 1.f;
-      sh[e] = shift ? shift[c + e] : 0.f;
+      sc[e] = 1.f;
+      sh[e] = 0.f;
       best[e] = -__builtin_inff();
       arg[e] = 0;
+    }
+    if (scale != nullptr) {
+      load_channels<NV>(scale, c, sc);
+      load_channels<NV>(shift, c, sh);
     }
     Chunk<T>::load(r + row * ldr + c, y);
 #pragma unroll

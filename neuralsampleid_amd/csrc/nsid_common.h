@@ -39,6 +39,16 @@ template <> struct Chunk<__bf16> {
   }
 };
 
+// N consecutive per-channel fp32 values (BatchNorm scale/shift/mean/...) as float4 loads; c is a multiple of 4
+template <int N>
+__device__ __forceinline__ void load_channels(const float* __restrict__ p, int c, float* v) {
+#pragma unroll
+  for (int e = 0; e < N; e += 4) {
+    const f32x4 x = *reinterpret_cast<const f32x4*>(p + c + e);
+    v[e] = x[0]; v[e + 1] = x[1]; v[e + 2] = x[2]; v[e + 3] = x[3];
+  }
+}
+
 // dispatch a templated launch on the runtime storage code
 #define NSID_DISPATCH_DTYPE(dtype, T, ...)                    \
   do {                                                        \
