@@ -150,6 +150,7 @@ def main():
     ap.add_argument("--clips", type=int, default=100000, help="infer mode: total clips of the job")
     ap.add_argument("--deep", action="store_true",
                     help="BASELINE config 4: blocks [4,4,12,4], k=18, intended dilation schedule (capped by N)")
+    ap.add_argument("--no-overlap", action="store_true", help="run the two views on one stream instead of two")
     ap.add_argument("--no-graph", action="store_true", help="do not capture the step in a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -178,7 +179,8 @@ def main():
     enc_kw = dict(blocks=[4, 4, 12, 4], use_dilation=True) if args.deep else {}
     if args.deep:
         args.k = 18
-    model = SimCLR(CFG, GraphEncoder(CFG, in_channels=CFG["n_filters"], k=args.k, size="t", **enc_kw)).to(dev).train()
+    model = SimCLR(CFG, GraphEncoder(CFG, in_channels=CFG["n_filters"], k=args.k, size="t", **enc_kw),
+                   overlap_views=not args.no_overlap).to(dev).train()
     if args.mode == "infer":
         return infer_bench(args, model, rank, world, dev, dist)
     opt = FusedClipAdam(model.parameters(), lr=CFG["lr"], max_norm=1.0)
@@ -189,6 +191,8 @@ def main():
     def step():
         opt.zero_grad()
         reducer.start_step()
+        if model._side_stream is not None:
+            reducer.streams = [torch.cuda.current_stream(), model._side_stream]
         _, _, z_i, z_j = model(x_i, x_j)
         loss = parallel.dist_ntxent_loss(z_i, z_j, CFG)      # z all-gather; NT-Xent over the global batch
         loss.backward()                                      # bucketed all-reduce fires as buckets complete
@@ -322,6 +326,7 @@ def main():
                        "gemm_arithmetic": ("bf16 MFMA operands, fp32 accumulate" if args.precision == "bf16"
                                            else "fp32 operands, fp32 accumulate"),
                        "activation_storage": args.storage,
+                       "views": "two HIP streams (parallel graph branches)" if not args.no_overlap else "sequential",
                        "hipgraph": graph is not None, "final_loss": round(final_loss, 5)},
             "roofline": roofline,
             "step_hbm_frac_algorithmic": round(step_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),

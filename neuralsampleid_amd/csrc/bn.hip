@@ -173,8 +173,9 @@ __global__ __launch_bounds__(FIN_CH * FIN_TG) void bn_bwd_finalize_kernel(const 
   double sg, sgx;
   tile_sums(partial, partial + (long)tiles * C, tiles, C, c, tg, c < C, red0, red1, sg, sgx);
   if (tg != 0 || c >= C) return;
-  if (dbeta) dbeta[c] += (float)sg;
-  if (dgamma) dgamma[c] += (float)sgx;
+  // atomic: the two views of a step may run this concurrently on different streams for the same layer
+  if (dbeta) atomicAdd(dbeta + c, (float)sg);
+  if (dgamma) atomicAdd(dgamma + c, (float)sgx);
   coef[c] = (float)(sg / M);
   coef[C + c] = (float)(sgx / M);
 }

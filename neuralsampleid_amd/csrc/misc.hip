@@ -71,7 +71,7 @@ __global__ void unpack_ds_wgrad_kernel(const float* __restrict__ dwp, int Cout, 
   for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += (long)gridDim.x * blockDim.x) {
     const int c = (int)(q % Cin), t = (int)((q / Cin) % 3);
     const long o = q / (3L * Cin);
-    dw[((o * Cin + c) * 3 + t) * 3 + 1] += dwp[q];
+    atomicAdd(dw + ((o * Cin + c) * 3 + t) * 3 + 1, dwp[q]);     // both views may accumulate concurrently
   }
 }
 

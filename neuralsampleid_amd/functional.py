@@ -63,6 +63,32 @@ def set_activation_dtype(dtype) -> None:
     ACT_DTYPE = dtype
 
 
+class ViewOrder:
+    """Two-stream execution of the two views (simclr.SimCLR(overlap_views=True)): the views are independent until
+    NT-Xent, so view j runs on a side stream and its kernels fill the launch gaps / low-occupancy tails of view i's.
+    The only cross-view state in forward is the BatchNorm running statistics, which the reference updates view i
+    first, then view j (simclr.py:36,42): view i RECORDS an event after each bn_finalize, view j WAITS for the event
+    of the same layer before its own. (In backward every shared accumulation is atomic.)"""
+
+    def __init__(self):
+        self.mode, self.events, self.pos = None, [], 0
+
+
+VIEW_ORDER = ViewOrder()
+SIDE_STREAMS = []      # side streams that carry a view's forward AND backward kernels (registered by SimCLR)
+
+
+def join_side_streams() -> None:
+    """Make the current stream wait for everything enqueued on the side streams. With direct gradient accumulation
+    there are no AccumulateGrad nodes, so autograd does not join a side stream at the end of backward: whoever consumes
+    the gradients next (optimiser step, gradient all-reduce) must."""
+    if SIDE_STREAMS:
+        cur = torch.cuda.current_stream()
+        for st in SIDE_STREAMS:
+            if st != cur:
+                cur.wait_stream(st)
+
+
 # Called at the end of every block backward with the parameter tensors whose gradient contribution has just been
 # enqueued (parallel.GradReducer uses it to overlap the bucketed all-reduce with the rest of backward).
 GRAD_READY_HOOK = None
@@ -86,7 +112,15 @@ def conv_bn(x: Tensor, M: int, K: int, Nout: int, w: Tensor, bias: Optional[Tens
                              in_aff.scale if in_aff else None, in_aff.shift if in_aff else None, act_in,
                              ACT_NONE, want_stat=training)
     if training:
+        vo = VIEW_ORDER
+        if vo.mode == "wait":
+            torch.cuda.current_stream().wait_event(vo.events[vo.pos])
+            vo.pos += 1
         aff = ops.bn_finalize(stat, M, gamma, beta, rm, rv, nbt)
+        if vo.mode == "record":
+            ev = torch.cuda.Event()
+            ev.record()
+            vo.events.append(ev)
     else:
         aff = ops.bn_eval_affine(gamma, beta, rm, rv)
     return r, aff

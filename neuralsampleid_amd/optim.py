@@ -41,6 +41,8 @@ class FusedClipAdam:
             functional.DIRECT_GRADS = True
 
     def zero_grad(self, set_to_none: bool = False):
+        from . import functional
+        functional.join_side_streams()
         self.flat_g.zero_()
 
     def set_lr(self, lr: float):
@@ -51,6 +53,8 @@ class FusedClipAdam:
         return float(self.hyper[0])
 
     def step(self):
+        from . import functional
+        functional.join_side_streams()               # a view's backward may still be running on its side stream
         partial = ops.sumsq_partial(self.flat_g)
         ops.adam_step(self.flat_p, self.flat_g, self.exp_avg, self.exp_avg_sq, self.hyper, self.step_count, partial,
                       self.grad_norm)

@@ -128,6 +128,7 @@ class GradReducer:
             self.bounds.append((0, end))
             self.need.append(count * uses_per_step)
         self.remaining, self.works, self.fired = [], [], []
+        self.streams = []                            # extra compute streams (two-stream views), see _fire
 
     def start_step(self):
         self.remaining = list(self.need)
@@ -145,10 +146,16 @@ class GradReducer:
     def _fire(self, b: int):
         self.fired.append(b)
         if _distributed(self.group):
+            cur = torch.cuda.current_stream() if self.flat.is_cuda else None
+            for st in self.streams:                  # contributions may have been enqueued on another view's stream
+                if cur is not None and st != cur:
+                    cur.wait_stream(st)
             s, e = self.bounds[b]
             self.works.append(dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def finish(self):
+        from . import functional
+        functional.join_side_streams()
         for b, r in enumerate(self.remaining):
             if r > 0:                      # a parameter that got fewer contributions than expected this step
                 self.remaining[b] = 0

@@ -350,3 +350,28 @@ def test_graph_encoder_dgl_signature_shim(golden):
     w = model.encoder.proj.weight.reshape(1024, 512)
     ref = (x_nodes.mean(dim=2) @ w.t()) + model.encoder.proj.bias
     assert maxerr(ref, x_emb) < 1e-3
+
+
+def test_two_stream_views_equal_sequential(golden):
+    """SimCLR(overlap_views=True) runs view j on a side stream: same loss, gradients and BN running statistics as the
+    sequential order (running stats must see view i first, then view j — reference simclr.py:36,42)"""
+    from neuralsampleid_amd.optim import FusedClipAdam
+    from neuralsampleid_amd.simclr.ntxent import ntxent_loss
+    g = golden("e2e_b8_k3")
+    x_i, x_j = g.t("x_i").to(DEV), g.t("x_j").to(DEV)
+    res = {}
+    for overlap in (False, True):
+        model = build_model(3).train()
+        model.overlap_views = overlap
+        opt = FusedClipAdam(model.parameters(), lr=8e-5)
+        opt.zero_grad()
+        _, _, z_i, z_j = model(x_i, x_j)
+        loss = ntxent_loss(z_i, z_j, GRAFP_CFG)
+        loss.backward()
+        opt.step()                                   # joins the side stream before reading the gradients
+        res[overlap] = (float(loss), opt.flat_g.clone(), {k: v.clone() for k, v in model.state_dict().items()
+                                                          if k.endswith(("running_mean", "running_var"))})
+    assert abs(res[True][0] - res[False][0]) < 1e-5
+    assert relerr(res[True][1], res[False][1]) < 1e-3                      # atomics order + kNN near-ties only
+    for k, v in res[False][2].items():
+        assert maxerr(res[True][2][k], v) < 1e-5, k
