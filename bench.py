@@ -91,7 +91,7 @@ def infer_bench(args, model, rank, world, dev, dist):
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        t = torch.tensor([elapsed], dtype=torch.float64)          # host-side group (gloo): max over ranks
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t)
     if rank == 0:
@@ -106,7 +106,8 @@ def infer_bench(args, model, rank, world, dev, dist):
                        "parallelism": f"shard{world}"}}))
     if world > 1:
         dist.barrier()
-        dist.destroy_process_group()
+    from neuralsampleid_amd import parallel
+    parallel.shutdown()
 
 
 def measured_traffic(kernel, precision):
@@ -162,7 +163,9 @@ def main():
     from neuralsampleid_amd.optim import FusedClipAdam
     from neuralsampleid_amd.simclr.simclr import SimCLR
 
-    rank, local, world = parallel.init_from_env("nccl")
+    # data-path collectives: direct RCCL communicator (neuralsampleid_amd/rccl.py) on its own HIP stream; the
+    # torch.distributed group (gloo) only carries the ncclUniqueId, the host barriers and the max-over-ranks of the time
+    rank, local, world = parallel.init_from_env("rccl")
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     torch.cuda.set_device(local)
@@ -231,6 +234,11 @@ def main():
             print(f"[bench] hipGraph capture unavailable ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
             graph = None
             torch.cuda.synchronize()
+        if world > 1:                 # replayed collectives must match on every rank: all capture, or none
+            ok = torch.tensor([1 if graph is not None else 0])
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok) == 0:
+                graph = None
     run = graph.replay if graph is not None else step
     for _ in range(max(0, args.warmup - n_eager)):
         run()
@@ -244,16 +252,23 @@ def main():
     if rank == 0:
         log(f"timed {args.steps} steps: {1e3 * elapsed / args.steps:.2f} ms/step")
     if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        t = torch.tensor([elapsed], dtype=torch.float64)             # host-side group (gloo)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t)
     final_loss = float(loss_buf)
 
     roofline, kernels = None, None
+    if not args.no_roofline:
+        # per-launch HIP-event timing of the GEMM family in one instrumented eager step (events on the launch stream).
+        # Every rank runs the step (it contains collectives); only rank 0 instruments and reports.
+        if rank != 0:
+            step()
+            torch.cuda.synchronize()
     if rank == 0 and not args.no_roofline:
-        # per-launch HIP-event timing of the GEMM family in one instrumented eager step (events on the launch stream)
         ops.PROFILE = ops.KernelProfile()
+        model.overlap_views = False          # one stream: a launch's events then bracket that kernel alone
         step()
+        model.overlap_views = not args.no_overlap
         prof = ops.PROFILE.summary()
         if os.environ.get("NSID_BENCH_SHAPES"):
             with open(os.environ["NSID_BENCH_SHAPES"], "w") as f:
@@ -321,7 +336,9 @@ def main():
                                    f"(fwd x2 views + NT-Xent + bwd + clip + Adam), batch={args.batch} synthetic "
                                    f"(64,128) log-mel clip pairs per GPU, random-init weights",
                        "global_batch": args.batch * world, "k": args.k, "parallelism": f"dp{world}",
-                       "collectives": ("z all-gather + bucketed SUM all-reduce of gradients overlapped with backward"
+                       "collectives": ("direct RCCL on a dedicated HIP stream: z all-gather + bucketed SUM all-reduce "
+                                       "of gradients overlapped with backward" + (", captured in the hipGraph"
+                                                                                   if graph is not None else "")
                                        if parallel._distributed() else "none (single process)"),
                        "gemm_arithmetic": ("bf16 MFMA operands, fp32 accumulate" if args.precision == "bf16"
                                            else "fp32 operands, fp32 accumulate"),
@@ -337,7 +354,7 @@ def main():
         print(json.dumps(out))
     if world > 1:
         dist.barrier()
-        dist.destroy_process_group()
+    parallel.shutdown()
 
 
 if __name__ == "__main__":

@@ -11,7 +11,13 @@ The MI355X-native equivalent keeps those semantics with two collectives and no p
      global mean loss through that rank's clips, so they add (no 1/world averaging);
   BatchNorm statistics are per rank (no SyncBN), as under DataParallel.
 
-The collective plumbing is device-agnostic (`gloo` on CPU in tests); the loss rows come from an injected kernel."""
+Two transports behind the same three calls (all-gather, all-reduce, bucketed async all-reduce):
+  * `rccl.RcclComm` (GPU, the product path): direct RCCL on one dedicated HIP stream — capturable in the step's hipGraph,
+    no helper thread (see rccl.py for why ProcessGroupNCCL is not used on the data path). `init_from_env("rccl")`
+    creates it (torch.distributed/gloo only carries the 128-byte ncclUniqueId and the host barrier) and installs it as
+    the module default `COMM`.
+  * torch.distributed collectives on the default group (`gloo` on CPU in tests, where the loss rows come from an
+    injected oracle kernel; also "nccl" if a caller insists)."""
 from typing import Callable, Optional, Tuple
 
 import torch
@@ -26,11 +32,36 @@ def shard_range(global_batch: int, rank: int, world: int) -> Tuple[int, int]:
     return rank * n, n
 
 
+COMM = None      # default rccl.RcclComm of this process (set by init_from_env("rccl") / set_default_comm)
+
+
+def set_default_comm(comm) -> None:
+    global COMM
+    COMM = comm
+
+
+def _comm_for(group):
+    """the RCCL communicator to use, or None -> torch.distributed on `group`"""
+    return COMM if group is None else None
+
+
+def _rank_world(group=None) -> Tuple[int, int]:
+    c = _comm_for(group)
+    if c is not None:
+        return c.rank, c.world
+    if dist.is_initialized():
+        return dist.get_rank(group), dist.get_world_size(group)
+    return 0, 1
+
+
 def gather_embeddings(z: torch.Tensor, group=None) -> torch.Tensor:
     """(B_local, d) -> (B_global, d), rank-major so that global pair p = rank*B_local + local index"""
-    world = dist.get_world_size(group)
-    if world == 1 and not _distributed(group):
+    if not _distributed(group):
         return z
+    c = _comm_for(group)
+    if c is not None:
+        return c.all_gather(z)
+    world = dist.get_world_size(group)
     out = torch.empty((world * z.shape[0], z.shape[1]), device=z.device, dtype=z.dtype)
     dist.all_gather_into_tensor(out, z.contiguous(), group=group)
     return out
@@ -41,14 +72,18 @@ class _DistNtxent(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, z_i, z_j, tau, rows_fn, group):
-        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        rank, world = _rank_world(group)
         zi_all = gather_embeddings(z_i.detach(), group)
         zj_all = gather_embeddings(z_j.detach(), group)
         p0, n = shard_range(zi_all.shape[0], rank, world)
         part, dzi, dzj = rows_fn(zi_all, zj_all, tau, p0, n)        # part = sum of owned rows / (2*B_global)
         loss = part.reshape(()).clone()
-        if _distributed(group):
-            dist.all_reduce(loss, op=dist.ReduceOp.SUM, group=group)   # every rank reports the global loss
+        if _distributed(group):                                        # every rank reports the global loss
+            c = _comm_for(group)
+            if c is not None:
+                c.all_reduce_(loss)
+            else:
+                dist.all_reduce(loss, op=dist.ReduceOp.SUM, group=group)
         ctx.save_for_backward(dzi, dzj)
         return loss
 
@@ -78,6 +113,14 @@ def allreduce_gradients(flat_grad: torch.Tensor, group=None, bucket_bytes: int =
     collective, so early buckets can overlap the rest of backward when launched from a side stream)."""
     if not _distributed(group):
         return []
+    c = _comm_for(group)
+    if c is not None:                      # RCCL: stream-ordered on the comm stream; "works" are joined by wait_async()
+        n = flat_grad.numel() if bucket_bytes <= 0 else max(1, bucket_bytes // flat_grad.element_size())
+        for s in range(0, flat_grad.numel(), n):
+            c.all_reduce_async_(flat_grad[s:s + n])
+        if not async_op:
+            c.wait_async()
+        return [c] if async_op else []
     if bucket_bytes <= 0:
         w = dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
         return [w] if async_op else []
@@ -94,9 +137,13 @@ def _distributed(group=None) -> bool:
     """collectives are issued when a process group exists and has >1 rank (NSID_FORCE_COLLECTIVES=1: also with one
     rank, so that the collective code path — including hipGraph capture of it — can be exercised on a single GPU)"""
     import os
+    force = os.environ.get("NSID_FORCE_COLLECTIVES", "0") == "1"
+    c = _comm_for(group)
+    if c is not None:
+        return c.world > 1 or force
     if not dist.is_initialized():
         return False
-    return dist.get_world_size(group) > 1 or os.environ.get("NSID_FORCE_COLLECTIVES", "0") == "1"
+    return dist.get_world_size(group) > 1 or force
 
 
 class GradReducer:
@@ -146,11 +193,15 @@ class GradReducer:
     def _fire(self, b: int):
         self.fired.append(b)
         if _distributed(self.group):
+            s, e = self.bounds[b]
             cur = torch.cuda.current_stream() if self.flat.is_cuda else None
+            c = _comm_for(self.group)
+            if c is not None:                        # the comm stream forks from every stream that carried contributions
+                c.all_reduce_async_(self.flat[s:e], producers=[cur] + [st for st in self.streams if st != cur])
+                return
             for st in self.streams:                  # contributions may have been enqueued on another view's stream
                 if cur is not None and st != cur:
                     cur.wait_stream(st)
-            s, e = self.bounds[b]
             self.works.append(dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def finish(self):
@@ -163,6 +214,9 @@ class GradReducer:
         for w in self.works:
             w.wait()
         self.works = []
+        c = _comm_for(self.group)
+        if c is not None and _distributed(self.group):
+            c.wait_async()                 # the compute stream waits for the comm stream (no host sync)
 
     def install(self):
         from . import functional
@@ -171,16 +225,34 @@ class GradReducer:
 
 
 def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
-    """torchrun contract: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT. Returns (rank, local, world)."""
+    """torchrun contract: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT. Returns (rank, local, world).
+
+    backend "rccl" (the GPU product path): torch.distributed over gloo for bootstrap + host barriers, and a direct
+    rccl.RcclComm (installed as the default COMM) for every data-path collective. "gloo"/"nccl": torch.distributed only."""
     import os
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    import os as _os
-    if (world > 1 or _os.environ.get("NSID_FORCE_COLLECTIVES", "0") == "1") and not dist.is_initialized():
-        if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
-        if backend == "nccl":
-            torch.cuda.set_device(local)
+    force = os.environ.get("NSID_FORCE_COLLECTIVES", "0") == "1"
+    if backend is None:
+        backend = "rccl" if torch.cuda.is_available() else "gloo"
+    if backend in ("rccl", "nccl"):
+        torch.cuda.set_device(local)
+    if world > 1 and not dist.is_initialized():
+        dist.init_process_group(backend="gloo" if backend == "rccl" else backend, rank=rank, world_size=world)
+    elif force and backend != "rccl" and not dist.is_initialized():
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    if backend == "rccl" and (world > 1 or force) and COMM is None:
+        from . import rccl
+        set_default_comm(rccl.init_comm(rank, world, torch.device("cuda", local)))
     return rank, local, world
+
+
+def shutdown() -> None:
+    """destroy the default communicator and the torch.distributed group (if any)"""
+    global COMM
+    if COMM is not None:
+        COMM.destroy()
+        COMM = None
+    if dist.is_initialized():
+        dist.destroy_process_group()

@@ -175,3 +175,56 @@ def test_single_process_paths_need_no_process_group():
     g = torch.zeros(10)
     assert parallel.allreduce_gradients(g) == []
     assert parallel.shard_range(256, 0, 1) == (0, 256)
+
+
+def _uid_worker(rank, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(WORLD),
+                      LOCAL_RANK=str(rank))
+    from neuralsampleid_amd import parallel, rccl
+    parallel.init_from_env("gloo")
+    seen = {}
+
+    class FakeComm:                                  # stands in for ncclCommInitRank: no GPU in this container
+        def __init__(self, rank, world, uid, device=None):
+            seen.update(rank=rank, world=world, uid=uid)
+    real, rccl.RcclComm = rccl.RcclComm, FakeComm
+    try:
+        rccl.init_comm(rank, WORLD)
+    finally:
+        rccl.RcclComm = real
+    gathered = [None] * WORLD
+    dist.all_gather_object(gathered, (seen["rank"], seen["world"], seen["uid"]))
+    if rank == 0:
+        out.put(gathered)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_rccl_bootstrap_broadcasts_rank0_unique_id():
+    """the direct-RCCL communicator's bootstrap: rank 0's 128-byte ncclUniqueId reaches every rank over gloo"""
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    port = _free_port()
+    procs = [ctx.Process(target=_uid_worker, args=(r, port, q)) for r in range(WORLD)]
+    for p in procs:
+        p.start()
+    deadline = time.time() + 120
+    while q.empty():
+        assert time.time() < deadline and all(p.exitcode in (None, 0) for p in procs)
+        time.sleep(0.2)
+    got = q.get()
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert [g[0] for g in got] == [0, 1] and all(g[1] == WORLD for g in got)
+    assert len(got[0][2]) == 128 and got[0][2] == got[1][2]
+
+
+def test_rccl_library_exports_the_bound_entry_points():
+    from neuralsampleid_amd import rccl
+    L = rccl.lib()
+    for name in ("ncclGetUniqueId", "ncclCommInitRank", "ncclAllReduce", "ncclAllGather", "ncclCommDestroy",
+                 "ncclGetErrorString", "ncclCommGetAsyncError"):
+        assert hasattr(L, name)
+    assert rccl.version() >= 21800
+    assert len(rccl.new_unique_id()) == rccl.NCCL_UNIQUE_ID_BYTES

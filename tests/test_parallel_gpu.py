@@ -1,6 +1,8 @@
 """GPU: the data-parallel code path (RCCL all-gather of z, sharded NT-Xent, bucketed all-reduce overlapped with backward)
-on a 1-rank NCCL group must reproduce the plain single-process step — same loss, same gradients — i.e. no contribution
-is lost to a bucket that fires early, and the collectives compose with the HIP kernels' atomically accumulated grads."""
+on a 1-rank group must reproduce the plain single-process step — same loss, same gradients — i.e. no contribution
+is lost to a bucket that fires early, and the collectives compose with the HIP kernels' atomically accumulated grads.
+Both transports are covered: the direct RCCL communicator (neuralsampleid_amd/rccl.py, the product path — eager, with
+two-stream views, and captured in a hipGraph) and torch.distributed's "nccl" group."""
 import os
 
 import pytest
@@ -27,6 +29,24 @@ def one_rank_group():
             os.environ.pop(k, None)
         else:
             os.environ[k] = v
+
+
+@pytest.fixture()
+def rccl_comm():
+    from neuralsampleid_amd import functional, parallel, rccl
+    old = os.environ.get("NSID_FORCE_COLLECTIVES")
+    os.environ["NSID_FORCE_COLLECTIVES"] = "1"
+    comm = rccl.init_comm(0, 1)
+    parallel.set_default_comm(comm)
+    yield comm
+    torch.cuda.synchronize()
+    parallel.set_default_comm(None)
+    comm.destroy()
+    functional.GRAD_READY_HOOK = None
+    if old is None:
+        os.environ.pop("NSID_FORCE_COLLECTIVES", None)
+    else:
+        os.environ["NSID_FORCE_COLLECTIVES"] = old
 
 
 def build():
@@ -66,3 +86,114 @@ def test_reducer_step_equals_plain_step(one_rank_group):
     assert abs(float(l0) - float(l1)) < 1e-5
     rel = float((o1.flat_g - g0).norm() / g0.norm())
     assert rel < 1e-3, rel                                            # fp32 atomics order + kNN near-ties only
+
+
+def test_rccl_binding_one_rank(rccl_comm):
+    from neuralsampleid_amd import rccl
+    assert rccl.version() >= 21800 and rccl_comm.world == 1 and rccl_comm.async_error() == 0
+    x = torch.arange(1000, device=DEV, dtype=torch.float32)
+    y = rccl_comm.all_reduce_(x.clone())
+    g = rccl_comm.all_gather(x.reshape(10, 100))
+    b = torch.ones(64, device=DEV, dtype=torch.bfloat16)
+    rccl_comm.all_reduce_async_(b)
+    rccl_comm.wait_async()
+    torch.cuda.synchronize()
+    assert torch.equal(y, x) and torch.equal(g, x.reshape(10, 100)) and torch.equal(b, torch.ones_like(b))
+    with pytest.raises(ValueError):
+        rccl_comm.all_reduce_(torch.zeros(4))                          # host tensor
+
+
+@pytest.mark.parametrize("overlap", [False, True])
+def test_rccl_reducer_step_equals_plain_step(rccl_comm, overlap):
+    from neuralsampleid_amd import parallel
+    from neuralsampleid_amd.optim import FusedClipAdam
+    from neuralsampleid_amd.simclr.ntxent import ntxent_loss
+    x_i, x_j = (t.to(DEV) for t in synth_clips(32))
+    m0 = build()
+    o0 = FusedClipAdam(m0.parameters(), lr=8e-5)
+    o0.zero_grad()
+    _, _, z_i, z_j = m0(x_i, x_j)
+    l0 = ntxent_loss(z_i, z_j, GRAFP_CFG)
+    l0.backward()
+    torch.cuda.synchronize()
+    g0 = o0.flat_g.clone()
+    m1 = build()
+    m1.overlap_views = overlap
+    o1 = FusedClipAdam(m1.parameters(), lr=8e-5)
+    red = parallel.GradReducer(o1.params, o1.flat_g, o1.offsets, bucket_bytes=1 << 20).install()
+    calls0 = rccl_comm.calls
+    o1.zero_grad()
+    red.start_step()
+    _, _, z_i, z_j = m1(x_i, x_j)
+    if overlap:
+        red.streams = [torch.cuda.current_stream(), m1._side_stream]
+    l1 = parallel.dist_ntxent_loss(z_i, z_j, GRAFP_CFG)
+    l1.backward()
+    fired_during_backward = len(red.fired)
+    red.finish()
+    torch.cuda.synchronize()
+    assert fired_during_backward == len(red.bounds)
+    assert rccl_comm.calls - calls0 == len(red.bounds) + 3            # buckets + 2 all-gathers + the loss all-reduce
+    assert abs(float(l0) - float(l1)) < 1e-5
+    rel = float((o1.flat_g - g0).norm() / g0.norm())
+    assert rel < 1e-3, rel
+
+
+def test_rccl_step_captured_in_hipgraph(rccl_comm):
+    """the whole step incl. the collectives on the communicator's stream is captured once and replayed: from the same
+    state, one replay must produce the loss, the (all-reduced) gradients and the updated weights of one eager step"""
+    from neuralsampleid_amd import parallel
+    from neuralsampleid_amd.optim import FusedClipAdam
+    x_i, x_j = (t.to(DEV) for t in synth_clips(16))
+    m = build()
+    m.overlap_views = True
+    o = FusedClipAdam(m.parameters(), lr=8e-5)
+    red = parallel.GradReducer(o.params, o.flat_g, o.offsets, bucket_bytes=4 << 20).install()
+    loss_buf = torch.zeros((), device=DEV)
+
+    def step():
+        o.zero_grad()
+        red.start_step()
+        if m._side_stream is not None:
+            red.streams = [torch.cuda.current_stream(), m._side_stream]
+        _, _, z_i, z_j = m(x_i, x_j)
+        loss = parallel.dist_ntxent_loss(z_i, z_j, GRAFP_CFG)
+        loss.backward()
+        red.finish()
+        o.step()
+        loss_buf.copy_(loss.detach())
+
+    def snapshot():
+        return ({k: v.clone() for k, v in m.state_dict().items()}, o.exp_avg.clone(), o.exp_avg_sq.clone(),
+                o.step_count.clone())
+
+    def restore(snap):
+        m.load_state_dict(snap[0])                                     # copies in place: captured pointers stay valid
+        o.exp_avg.copy_(snap[1]); o.exp_avg_sq.copy_(snap[2]); o.step_count.copy_(snap[3])
+
+    init = snapshot()
+    step()                                                             # eager reference step (also the warm-up)
+    torch.cuda.synchronize()
+    ref = (float(loss_buf), o.flat_g.clone(), o.flat_p.clone(), snapshot()[0])
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        step()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    calls = rccl_comm.calls
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        step()
+    assert rccl_comm.calls - calls == len(red.bounds) + 3              # the collectives were enqueued under capture
+    restore(init)
+    loss_buf.zero_(); o.flat_g.fill_(7.0)
+    graph.replay()
+    torch.cuda.synchronize()
+    assert int(o.step_count) == 1 and abs(float(loss_buf) - ref[0]) < 1e-5
+    assert float((o.flat_g - ref[1]).norm() / ref[1].norm()) < 1e-3    # fp32 atomics order + kNN near-ties only
+    assert float((o.flat_p - ref[2]).abs().max()) < 2.1 * 8e-5         # one Adam step: |dp| <= lr per weight
+    assert float((o.flat_p - ref[2]).abs().mean()) < 0.05 * 8e-5
+    for k, v in ref[3].items():
+        if k.endswith(("running_mean", "running_var")):
+            assert float((m.state_dict()[k] - v).abs().max()) < 1e-4, k
