@@ -50,8 +50,10 @@ int nsid_get_gemm_precision(void);
 int nsid_row_tiles(int M);
 
 /* ---- 1x1 convolution / Linear as a row GEMM on MFMA (fp32 accumulate) ------------------------------------
- * act_dtype = NSID_BF16: the activation operands/outputs are bf16 in HBM (weights, bias, statistics, weight gradients
- * stay fp32) and the bf16 MFMA path is used whatever nsid_set_gemm_precision says.
+ * act_dtype = NSID_BF16: the activation operands/outputs are bf16 in HBM (bias, statistics, weight gradients stay
+ * fp32) and the bf16 MFMA path is used whatever nsid_set_gemm_precision says.  w_dtype = NSID_BF16 (only together
+ * with act_dtype = NSID_BF16): `w` points to a bf16 copy of the weight matrix (nsid_f32_to_bf16; the optimiser keeps
+ * one shadow buffer for all parameters) — same values the fp32 weights round to when staged, half the operand bytes.
  * Replaces nn.Conv2d(…,1) / nn.Linear forward+backward at encoder/gcn_lib/torch_vertex.py:152-162,
  * encoder/graph_encoder.py:74-77,151,179, encoder/gcn_lib/torch_nn.py:56 (groups=4), simclr/simclr.py:25-28.
  *
@@ -62,13 +64,13 @@ int nsid_row_tiles(int M);
  *           pre-activation output, the input of nsid_bn_finalize (training-mode BatchNorm statistics).
  *           ksplit > 1 splits K over workgroups and accumulates atomically: `out` must be zeroed, stat == NULL,
  *           act_out == NSID_ACT_NONE. */
-int nsid_linear_fwd(const void* x, int ldx, const float* w, const float* bias, void* out, int ldo, int M, int Nout,
-                    int K, int groups, const float* in_scale, const float* in_shift, int act_in, int act_out,
+int nsid_linear_fwd(const void* x, int ldx, const void* w, int w_dtype, const float* bias, void* out, int ldo, int M,
+                    int Nout, int K, int groups, const float* in_scale, const float* in_shift, int act_in, int act_out,
                     float* stat, int ksplit, int act_dtype /* of x and out */, void* stream);
 /* backward-data: din[m, g*K+k] = addend[m, g*K+k] + sum_n dout[m, g*Nout+n] * w[g*Nout+n, k]   (addend optional) */
-int nsid_linear_bwd_data(const void* dout, int ldd, const float* w, const void* addend, int ldadd, void* din,
-                         int ldi, int M, int Nout, int K, int groups, int act_dtype /* dout, addend, din */,
-                         void* stream);
+int nsid_linear_bwd_data(const void* dout, int ldd, const void* w, int w_dtype, const void* addend, int ldadd,
+                         void* din, int ldi, int M, int Nout, int K, int groups,
+                         int act_dtype /* dout, addend, din */, void* stream);
 /* backward-weight: dw[g*Nout+n, k] += sum_m dout[m, g*Nout+n] * f(x[m, g*K+k])   (f as in forward; atomic) */
 int nsid_linear_bwd_weight(const void* dout, int ldd, const void* x, int ldx, float* dw, int M, int Nout, int K,
                            int groups, const float* in_scale, const float* in_shift, int act_in,
@@ -145,6 +147,10 @@ int nsid_elu_bwd(const float* dout, const float* out, long n, float* din, void* 
 int nsid_l2norm_fwd(const float* p, int B, int d, float eps, float* z, float* norm, void* stream);
 int nsid_l2norm_bwd(const float* dz, const float* z, const float* norm, int B, int d, float eps, float* dp,
                     void* stream);
+
+/* bf16 shadow of fp32 weights: dst[i] = bf16_rne(src[i]), n % 8 == 0, both 16-byte aligned (operand `w` of
+ * nsid_linear_fwd / nsid_linear_bwd_data with w_dtype = NSID_BF16). */
+int nsid_f32_to_bf16(const float* src, void* dst, long n, void* stream);
 
 /* ---- NT-Xent (simclr/ntxent.py:5-30) -------------------------------------------------------------------
  * Row i = 2p+v of the interleaved (2*Bg, d) matrix is view v of pair p: v ? z_j[p] : z_i[p]; positive = i^1.

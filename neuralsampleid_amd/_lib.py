@@ -14,8 +14,8 @@ LIB_PATH = os.path.join(_PKG, "libnsid_hip.so")
 # signature letters: p = device pointer, i = int, l = long, f = float, s = stream (void*)
 SIGNATURES = {
     "nsid_set_gemm_precision": "i",
-    "nsid_linear_fwd": "pipppiiiiippiipiis",
-    "nsid_linear_bwd_data": "pippipiiiiiis",
+    "nsid_linear_fwd": "pipippiiiiippiipiis",
+    "nsid_linear_bwd_data": "pipipipiiiiiis",
     "nsid_linear_bwd_weight": "pipipiiiippiis",
     "nsid_colsum_acc": "piiipis",
     "nsid_bn_finalize": "piiipppppffpppps",
@@ -41,6 +41,7 @@ SIGNATURES = {
     "nsid_ntxent_fwd_bwd": "ppiifiipppps",
     "nsid_sumsq_partial": "plps",
     "nsid_adam_step": "pppplpppips",
+    "nsid_f32_to_bf16": "ppls",
     "nsid_bcn_to_rows": "piiipiis",
     "nsid_rows_to_bcn": "piiiipis",
 }

@@ -13,6 +13,8 @@
 // register-staged double buffer in LDS. Each lane fetches 4 consecutive reduction elements of its fragment row with
 // one ds_read_b128 and feeds them to 4 MFMAs (sub-step s uses element s); A and B use the same permutation
 // r = 4*(lane>>4) + s inside the 16-deep chunk, so the sum is unchanged.
+#include <algorithm>
+#include <cstdlib>
 #include "nsid_common.h"
 
 namespace {
@@ -213,9 +215,12 @@ __device__ __forceinline__ bf16x8 frag_read_bf16(const char* lds, int tile_row0,
 // AAFF: the left operand carries a reduction-indexed affine (forward GEMM fed by a raw conv output). A template flag,
 // not a runtime one: a runtime branch around the per-stage affine loads makes the compiler's vmcnt bookkeeping
 // conservative at the join and drains the prefetch.
-template <int BM, int BN, bool A_RMAJOR, bool B_RMAJOR, bool H, bool ST, bool AAFF>
+// WB: the right operand is a WEIGHT matrix stored as bf16 (the optimiser's shadow copy, optim.py): its HBM image is the
+// LDS image — half the L2->LDS bytes of fp32 weights and no convert pass (forward / backward-data variants only).
+template <int BM, int BN, bool A_RMAJOR, bool B_RMAJOR, bool H, bool ST, bool AAFF, bool WB = false>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {   // >= 2 waves/SIMD: <= 256 VGPR+AGPR
-  constexpr bool SA = ST, SB = ST && !A_RMAJOR && !B_RMAJOR, SC = ST && A_RMAJOR;
+  constexpr bool SA = ST, SB = (ST && !A_RMAJOR && !B_RMAJOR) || WB, SC = ST && A_RMAJOR;
+  static_assert(!WB || (ST && A_RMAJOR), "bf16 weights ride with bf16 activations in the forward/backward-data GEMMs");
   using GA = TileGeom<BM, A_RMAJOR, H, SA>;
   using GB = TileGeom<BN, B_RMAJOR, H, SB>;
   constexpr int BK = Prec<H>::BK;
@@ -498,7 +503,7 @@ __global__ void elu_inplace_kernel(float* __restrict__ x, long rows, int cols, l
 int g_gemm_precision = NSID_GEMM_FP32;     // process-wide (nsid_set_gemm_precision)
 
 template <int BM, int BN, bool AR, bool BR>
-int launch(GemmArgs p, int groups, hipStream_t s, int act_dtype) {
+int launch(GemmArgs p, int groups, hipStream_t s, int act_dtype, bool w_bf16 = false) {
   const int tiles = ((p.I + BM - 1) / BM) * ((p.J + BN - 1) / BN);
   const bool st16 = act_dtype == NSID_BF16;
   const bool half = g_gemm_precision == NSID_GEMM_BF16 || st16;
@@ -516,6 +521,14 @@ int launch(GemmArgs p, int groups, hipStream_t s, int act_dtype) {
     if (aff) NSID_LAUNCH((gemm_kernel<BM, BN, AR, BR, HH, SS, CAN_AFF>), grid, dim3(256), 0, s, p);        \
     else NSID_LAUNCH((gemm_kernel<BM, BN, AR, BR, HH, SS, false>), grid, dim3(256), 0, s, p);              \
   } while (0)
+  if constexpr (AR) {
+    if (st16 && w_bf16) {
+      if (aff) NSID_LAUNCH((gemm_kernel<BM, BN, AR, BR, true, true, CAN_AFF, true>), grid, dim3(256), 0, s, p);
+      else NSID_LAUNCH((gemm_kernel<BM, BN, AR, BR, true, true, false, true>), grid, dim3(256), 0, s, p);
+      return nsid_launch_status();
+    }
+  }
+  if (w_bf16) return NSID_EINVAL;
   if (st16) NSID_GEMM_GO(true, true);
   else if (half) NSID_GEMM_GO(true, false);
   else NSID_GEMM_GO(false, false);
@@ -534,10 +547,11 @@ extern "C" int nsid_set_gemm_precision(int mode) {
 extern "C" int nsid_get_gemm_precision(void) { return g_gemm_precision; }
 extern "C" int nsid_row_tiles(int M) { return (M + NSID_ROW_TILE - 1) / NSID_ROW_TILE; }
 
-extern "C" int nsid_linear_fwd(const void* x, int ldx, const float* w, const float* bias, void* out, int ldo, int M,
-                               int Nout, int K, int groups, const float* in_scale, const float* in_shift, int act_in,
-                               int act_out, float* stat, int ksplit, int act_dtype, void* stream) {
+extern "C" int nsid_linear_fwd(const void* x, int ldx, const void* w, int w_dtype, const float* bias, void* out, int ldo,
+                               int M, int Nout, int K, int groups, const float* in_scale, const float* in_shift,
+                               int act_in, int act_out, float* stat, int ksplit, int act_dtype, void* stream) {
   NSID_REQUIRE(x && w && out && M > 0 && Nout > 0 && K > 0 && groups > 0 && ksplit >= 1 && NSID_DTYPE_OK(act_dtype));
+  NSID_REQUIRE(NSID_DTYPE_OK(w_dtype) && (w_dtype == NSID_F32 || (act_dtype == NSID_BF16 && K % 8 == 0)));
   const int ch = act_dtype == NSID_BF16 ? 8 : 4;     // elements per 16-byte chunk of the activation tensors
   NSID_REQUIRE(K % ch == 0 && ldx % ch == 0 && nsid_aligned16(x) && nsid_aligned16(w) && K % 4 == 0);
   NSID_REQUIRE(act_dtype == NSID_F32 || (ksplit == 1 && act_out == NSID_ACT_NONE && Nout % 8 == 0 && ldo % 8 == 0));
@@ -564,8 +578,9 @@ extern "C" int nsid_linear_fwd(const void* x, int ldx, const float* w, const flo
   const long t128 = (long)nsid_row_tiles(M) * ((Nout + 127) / 128) * groups;
   const bool half = g_gemm_precision == NSID_GEMM_BF16 || act_dtype == NSID_BF16;
   const bool narrow = Nout <= 64 || (half && t128 < 512);
-  const int rc = narrow ? launch<128, 64, true, true>(p, groups, s, act_dtype)
-                        : launch<128, 128, true, true>(p, groups, s, act_dtype);
+  const bool wb = w_dtype == NSID_BF16;
+  const int rc = narrow ? launch<128, 64, true, true>(p, groups, s, act_dtype, wb)
+                        : launch<128, 128, true, true>(p, groups, s, act_dtype, wb);
   if (rc != NSID_OK || act_out != NSID_ACT_ELU) return rc;
   const long n = (long)M * groups * Nout;
   NSID_LAUNCH(elu_inplace_kernel, dim3((int)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256)), dim3(256), 0, s,
@@ -573,10 +588,12 @@ extern "C" int nsid_linear_fwd(const void* x, int ldx, const float* w, const flo
   return nsid_launch_status();
 }
 
-extern "C" int nsid_linear_bwd_data(const void* dout, int ldd, const float* w, const void* addend, int ldadd,
+extern "C" int nsid_linear_bwd_data(const void* dout, int ldd, const void* w, int w_dtype, const void* addend, int ldadd,
                                     void* din, int ldi, int M, int Nout, int K, int groups, int act_dtype,
                                     void* stream) {
   NSID_REQUIRE(dout && w && din && M > 0 && Nout > 0 && K > 0 && groups > 0 && NSID_DTYPE_OK(act_dtype));
+  NSID_REQUIRE(NSID_DTYPE_OK(w_dtype) && (w_dtype == NSID_F32 || (act_dtype == NSID_BF16 && K % 8 == 0)));
+  const bool wb = w_dtype == NSID_BF16;
   const int ch = act_dtype == NSID_BF16 ? 8 : 4;
   NSID_REQUIRE(Nout % ch == 0 && K % ch == 0 && ldd % ch == 0 && ldi % ch == 0 && nsid_aligned16(dout) && nsid_aligned16(w));
   NSID_REQUIRE(addend == nullptr || ldadd % ch == 0);
@@ -592,8 +609,8 @@ extern "C" int nsid_linear_bwd_data(const void* dout, int ldd, const float* w, c
   hipStream_t s = static_cast<hipStream_t>(stream);
   const long t128 = (long)nsid_row_tiles(M) * ((K + 127) / 128) * groups;
   const bool half = g_gemm_precision == NSID_GEMM_BF16 || act_dtype == NSID_BF16;
-  if (K <= 64 || (half && t128 < 512)) return launch<128, 64, true, false>(p, groups, s, act_dtype);
-  return launch<128, 128, true, false>(p, groups, s, act_dtype);
+  if (K <= 64 || (half && t128 < 512)) return launch<128, 64, true, false>(p, groups, s, act_dtype, wb);
+  return launch<128, 128, true, false>(p, groups, s, act_dtype, wb);
 }
 
 extern "C" int nsid_linear_bwd_weight(const void* dout, int ldd, const void* x, int ldx, float* dw, int M, int Nout,
@@ -610,17 +627,25 @@ extern "C" int nsid_linear_bwd_weight(const void* dout, int ldd, const void* x, 
   p.I = Nout; p.J = K; p.R = M;
   p.b_scale = in_scale; p.b_shift = in_shift; p.b_slope = act_slope(act_in); p.b_aff_goff = K;
   p.atomic_out = 1;
-  // 64x64 tiles when the output is narrow, or when 128x128 tiles times the deepest useful split (>= 512 rows each)
-  // would leave most of the 256 CUs idle
+  // Tile and split choice (measured on MI355X, tools/gemm_bench.py): every workgroup ends in a tile-sized burst of fp32
+  // atomics that all XCDs resolve memory-side (~1.3 TB/s chip-wide), so the bytes of atomics = workgroups x tile bytes
+  // decide the kernel: 64x64 tiles (16 KB) beat 128x128 (64 KB) at every shape of the encoder once >= 256 workgroups
+  // are in flight. Splits: >= 1024 rows each, at most ~1024 workgroups, at least ~256.
+  // fp32 arithmetic (16x lower matrix rate) stays MFMA-bound: there the larger tile wins whenever it fills the chip.
+  const bool half = g_gemm_precision == NSID_GEMM_BF16 || act_dtype == NSID_BF16;
   const long t128 = (long)((Nout + 127) / 128) * ((K + 127) / 128) * groups;
-  const bool small = (Nout <= 64 || K <= 64) || t128 * ((M + 511) / 512) < 256;
+  const bool small = half || (Nout <= 64 || K <= 64) || t128 * ((M + 511) / 512) < 256;
   const int bm = small ? 64 : 128;
   const long tiles = (long)((Nout + bm - 1) / bm) * ((K + bm - 1) / bm) * groups;
-  // split the row reduction so that about 2 workgroups per CU are in flight, each reducing >= 512 rows: every split
-  // ends in a tile-sized burst of atomics (~1.3 TB/s chip-wide), so fewer, longer splits beat many short ones
-  long want = (512 + tiles - 1) / tiles;
-  long maxsplit = (M + 511) / 512;
-  int rsplit = (int)(want < 1 ? 1 : (want > maxsplit ? maxsplit : want));
+  long S;
+  if (half) {
+    S = std::min<long>((M + 1023) / 1024, std::max<long>(1, 1024 / tiles));
+    S = std::max<long>(S, (256 + tiles - 1) / tiles);
+    S = std::min<long>(S, (M + 255) / 256);
+  } else {
+    S = std::min<long>((512 + tiles - 1) / tiles, (M + 511) / 512);
+  }
+  int rsplit = (int)std::max<long>(S, 1);
   p.rsplit = rsplit;
   p.rchunk = (M + rsplit - 1) / rsplit;
   hipStream_t s = static_cast<hipStream_t>(stream);

@@ -444,6 +444,22 @@ extern "C" int nsid_adam_step(float* p, const float* g, float* m, float* v, long
   return nsid_launch_status();
 }
 
+// bf16 shadow copy of weights (RNE, the rounding the GEMMs apply when they stage fp32 weights): n % 8 == 0
+__global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float* __restrict__ src, __bf16* __restrict__ dst, long n8) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
+    float v[8];
+    Chunk<float>::load(src + 8 * i, v);
+    Chunk<float>::load(src + 8 * i + 4, v + 4);
+    Chunk<__bf16>::store(dst + 8 * i, v);
+  }
+}
+extern "C" int nsid_f32_to_bf16(const float* src, void* dst, long n, void* stream) {
+  NSID_REQUIRE(src && dst && n > 0 && n % 8 == 0 && nsid_aligned16(src) && nsid_aligned16(dst));
+  NSID_LAUNCH(f32_to_bf16_kernel, dim3(grid_for(n / 8, 4096)), dim3(256), 0, static_cast<hipStream_t>(stream), src,
+              static_cast<__bf16*>(dst), n / 8);
+  return nsid_launch_status();
+}
+
 extern "C" int nsid_bcn_to_rows(const float* x, int B, int C, int N, void* rows, int ld, int rows_dtype, void* stream) {
   NSID_REQUIRE(x && rows && B > 0 && C > 0 && N > 0 && ld >= C && NSID_DTYPE_OK(rows_dtype));
   NSID_DISPATCH_DTYPE(rows_dtype, T, {

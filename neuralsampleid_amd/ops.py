@@ -123,6 +123,64 @@ def w2d(w: torch.Tensor) -> torch.Tensor:
     return w.reshape(w.shape[0], -1)
 
 
+# ------------------------------------------------------------------------------------------------ bf16 weight shadows
+class WeightShadows:
+    """bf16 copies of weight matrices for the bf16-storage GEMMs (forward / backward-data right operand): half the
+    L2->LDS operand bytes and no convert pass in the kernel. Values are the RNE rounding the kernel applies to fp32
+    weights anyway, so results are identical.
+
+    Entries are keyed by the fp32 tensor's data pointer: [shadow, version]. `FusedClipAdam` registers views of ONE flat
+    shadow buffer and refreshes all of it at the start of every step (its update kernel does not bump torch's version
+    counters); torch-side in-place changes (load_state_dict, torch.optim) are caught by the version check. Weights that
+    are not registered are converted on the fly (one small launch per GEMM)."""
+
+    def __init__(self):
+        self.entries = {}
+
+    def register(self, w: torch.Tensor, shadow: torch.Tensor, owner: torch.Tensor) -> None:
+        """`owner` keeps the fp32 memory alive (the optimiser's flat buffer): while it lives the address cannot be
+        reused by another tensor; once it is gone the entry is dropped on its next lookup"""
+        import weakref
+        self.entries[w.data_ptr()] = [shadow, -1, w.numel(), weakref.ref(owner)]
+
+    def clear(self) -> None:
+        self.entries.clear()
+
+    def operand(self, w: torch.Tensor) -> torch.Tensor:
+        e = self.entries.get(w.data_ptr())
+        if e is not None and e[3]() is None:
+            del self.entries[w.data_ptr()]
+            e = None
+        if e is None or e[2] != w.numel():
+            return f32_to_bf16(w)
+        if e[1] != w._version:
+            f32_to_bf16(w, e[0])
+            e[1] = w._version
+        return e[0]
+
+
+SHADOWS = WeightShadows()
+
+
+def f32_to_bf16(src: torch.Tensor, dst: Optional[torch.Tensor] = None) -> torch.Tensor:
+    _chk(src)
+    n = src.numel()
+    if dst is None:
+        dst = torch.empty(((n + 7) // 8 * 8,), device=src.device, dtype=torch.bfloat16)
+    if n % 8:            # tiny odd-sized matrices: let torch round (same RNE)
+        dst[:n].copy_(src.reshape(-1))
+        return dst
+    call("nsid_f32_to_bf16", _p(src), _p(dst), n, _stream())
+    return dst
+
+
+def _weight(w: torch.Tensor, dt: int, K: int):
+    """(pointer-holder tensor, C ABI dtype code) of a GEMM's weight operand"""
+    if dt == BF16 and K % 8 == 0 and w.numel() % 8 == 0:
+        return SHADOWS.operand(w), BF16
+    return w, F32
+
+
 # ------------------------------------------------------------------------------------------------ linear
 def linear_fwd(x, w, bias, M, Nout, K, groups=1, in_scale=None, in_shift=None, act_in=ACT_NONE, act_out=ACT_NONE,
                want_stat=False, ksplit=1, out=None) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
@@ -136,8 +194,10 @@ def linear_fwd(x, w, bias, M, Nout, K, groups=1, in_scale=None, in_shift=None, a
     narrow = Nout <= 64 or (half and row_tiles(M) * ((Nout + 127) // 128) * groups < 512)
     name = "gemm_kernel<128,%d,true,true>" % (64 if narrow else 128)
     esz = x.element_size()
-    _timed(name, 2.0 * M * Nout * K * groups, groups * (esz * M * K + 4.0 * Nout * K + esz * M * Nout), lambda: call(
-        "nsid_linear_fwd", _p(x), ldx, _p(w), _p(bias), _p(out), out.shape[-1], M, Nout, K, groups, _p(in_scale),
+    wop, wdt = _weight(w, dt, K)
+    _timed(name, 2.0 * M * Nout * K * groups,
+           groups * (esz * M * K + float(wop.element_size()) * Nout * K + esz * M * Nout), lambda: call(
+        "nsid_linear_fwd", _p(x), ldx, _p(wop), wdt, _p(bias), _p(out), out.shape[-1], M, Nout, K, groups, _p(in_scale),
         _p(in_shift), act_in, act_out, _p(stat), ksplit, dt, _stream()), (M, Nout, K, groups))
     return out, stat
 
@@ -151,9 +211,11 @@ def linear_bwd_data(dout, w, M, Nout, K, groups=1, addend=None, out=None) -> tor
     narrow = K <= 64 or (half and row_tiles(M) * ((K + 127) // 128) * groups < 512)
     name = "gemm_kernel<128,%d,true,false>" % (64 if narrow else 128)
     esz = dout.element_size()
+    wop, wdt = _weight(w, dt, K)
     _timed(name, 2.0 * M * Nout * K * groups,
-           groups * (esz * M * Nout + 4.0 * Nout * K + esz * M * K * (2 if addend is not None else 1)), lambda: call(
-               "nsid_linear_bwd_data", _p(dout), dout.shape[-1], _p(w), _p(addend),
+           groups * (esz * M * Nout + float(wop.element_size()) * Nout * K
+                     + esz * M * K * (2 if addend is not None else 1)), lambda: call(
+               "nsid_linear_bwd_data", _p(dout), dout.shape[-1], _p(wop), wdt, _p(addend),
                0 if addend is None else addend.shape[-1], _p(out), out.shape[-1], M, Nout, K, groups, dt, _stream()),
            (M, Nout, K, groups))
     return out
@@ -164,7 +226,8 @@ def linear_bwd_weight(dout, x, dw, M, Nout, K, groups=1, in_scale=None, in_shift
     _chk(dw, in_scale, in_shift)
     dt = _act(dout, x)
     t128 = ((Nout + 127) // 128) * ((K + 127) // 128) * groups
-    small = Nout <= 64 or K <= 64 or t128 * ((M + 511) // 512) < 256
+    half = dt == BF16 or lib.nsid_get_gemm_precision() == GEMM_BF16
+    small = half or Nout <= 64 or K <= 64 or t128 * ((M + 511) // 512) < 256
     name = "gemm_kernel<%s,false,false>" % ("64,64" if small else "128,128")
     esz = x.element_size()
     _timed(name, 2.0 * M * Nout * K * groups, groups * (esz * M * Nout + esz * M * K + 4.0 * Nout * K), lambda: call(

@@ -23,22 +23,30 @@ def main():
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--only", default="fwd,bwd_data,bwd_weight")
     ap.add_argument("--shapes", default="")
-    ap.add_argument("--precision", default="fp32")
+    ap.add_argument("--precision", default="bf16")
+    ap.add_argument("--fp32-weights", action="store_true", help="do not use bf16 weight shadows")
+    ap.add_argument("--storage", default="bf16", help="activation storage: bf16 (needs --precision bf16) or fp32")
     args = ap.parse_args()
     dev = "cuda"
     ops.set_gemm_precision(args.precision)
+    adt = torch.bfloat16 if args.storage == "bf16" else torch.float32
     shapes = SHAPES
     if args.shapes:
         shapes = [tuple(int(v) for v in s.split("x")) + (False,) for s in args.shapes.split(",")]
     for M, N, K, G, aff in shapes:
-        x = torch.randn(M, G * K, device=dev)
+        x = torch.randn(M, G * K, device=dev).to(adt)
         w = torch.randn(G * N, K, device=dev) * K ** -0.5
-        dout = torch.randn(M, G * N, device=dev)
+        if args.storage == "bf16" and not args.fp32_weights:
+            ops.SHADOWS.register(w, ops.f32_to_bf16(w), owner=w)
+        dout = torch.randn(M, G * N, device=dev).to(adt)
         sc = (1 + 0.1 * torch.randn(G * K, device=dev)) if aff else None
         sh = (0.1 * torch.randn(G * K, device=dev)) if aff else None
         dw = torch.zeros(G * N, K, device=dev)
-        out = torch.empty(M, G * N, device=dev)
-        din = torch.empty(M, G * K, device=dev)
+        out = torch.empty(M, G * N, device=dev, dtype=adt)
+        din = torch.empty(M, G * K, device=dev, dtype=adt)
+        esz = x.element_size()
+        nbytes = {"fwd": G * (esz * M * K + 4.0 * N * K + esz * M * N), "bwd_data": G * (esz * M * N + 4.0 * N * K + esz * M * K),
+                  "bwd_weight": G * (esz * M * N + esz * M * K + 4.0 * N * K)}
         runs = {
             "fwd": lambda: ops.linear_fwd(x, w, None, M, N, K, G, sc, sh, ops.ACT_RELU if aff else 0, 0, want_stat=True,
                                           out=out),
@@ -58,7 +66,7 @@ def main():
             e1.record()
             torch.cuda.synchronize()
             us = 1e3 * e0.elapsed_time(e1) / args.reps
-            line += f" | {name} {us:7.1f} us {flops / us / 1e6:6.1f} TF"
+            line += f" | {name} {us:6.1f}us {flops / us / 1e6:5.0f}TF {nbytes[name] / us / 1e3:5.0f}GB/s"
         print(line, flush=True)
 
 
