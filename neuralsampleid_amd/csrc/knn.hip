@@ -2,6 +2,7 @@
 // the 't' encoder) is staged once into LDS, BatchNorm-applied and L2-normalised there, the N x N distance matrix
 // is produced 16 rows at a time by fp32 MFMA straight from LDS and consumed by the top-k selection without ever
 // reaching HBM.  Algorithmic HBM traffic = read N*C*4 B, write N*k*4 B per clip.
+#include <cstdlib>
 #include "nsid_common.h"
 
 namespace {
@@ -156,6 +157,227 @@ __global__ __launch_bounds__(KNN_THREADS) void knn_kernel(const T* __restrict__ 
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// Fast path (k*dilation <= 8, C a multiple of 64): 8 waves per clip, no distance strips in LDS, no wave-wide reductions.
+// The MFMA is issued with the operands swapped (A = the COLUMN nodes' rows, B = the ROW nodes' rows), so the C/D layout
+// hands lane (lr, rq) the distances D[i = i0+lr][j = j0 + 4*rq + e]: every row of the 16-row tile is spread over the 4
+// lanes lr, lr+16, lr+32, lr+48, each of which sees a quarter of the columns in increasing order and keeps its own
+// sorted top-KD list in registers (branch-free insertion, ties keep the lower index). The four lists of a row are merged
+// with two butterfly exchanges (ds_bpermute), lexicographic on (distance, index). The products and their accumulation
+// order over channels are those of the strip kernel above, so the distances are bit-identical to it.
+// Small graphs (N < 128) have fewer than 8 row tiles: the column tiles of a row tile are then split over 2 waves and the
+// second wave's lists reach the first through a small LDS buffer.
+constexpr int KNN2_THREADS = 512;
+constexpr int KNN2_WAVES = 8;
+
+template <int KD>
+struct TopList {
+  float key[KD];
+  int id[KD];
+  __device__ __forceinline__ void init() {
+#pragma unroll
+    for (int p = 0; p < KD; ++p) { key[p] = __builtin_inff(); id[p] = 0; }
+  }
+  // candidates arrive in increasing index order: strict < keeps the earlier (lower) index on ties; NaN never enters
+  __device__ __forceinline__ void push_ordered(float d, int j) {
+    bool lt[KD];
+#pragma unroll
+    for (int p = 0; p < KD; ++p) lt[p] = d < key[p];
+#pragma unroll
+    for (int p = KD - 1; p > 0; --p) {
+      key[p] = lt[p] ? (lt[p - 1] ? key[p - 1] : d) : key[p];
+      id[p] = lt[p] ? (lt[p - 1] ? id[p - 1] : j) : id[p];
+    }
+    key[0] = lt[0] ? d : key[0];
+    id[0] = lt[0] ? j : id[0];
+  }
+  // arbitrary arrival order: (distance, index) lexicographic
+  __device__ __forceinline__ void push_any(float d, int j) {
+    bool lt[KD];
+#pragma unroll
+    for (int p = 0; p < KD; ++p) lt[p] = d < key[p] || (d == key[p] && j < id[p]);
+#pragma unroll
+    for (int p = KD - 1; p > 0; --p) {
+      key[p] = lt[p] ? (lt[p - 1] ? key[p - 1] : d) : key[p];
+      id[p] = lt[p] ? (lt[p - 1] ? id[p - 1] : j) : id[p];
+    }
+    key[0] = lt[0] ? d : key[0];
+    id[0] = lt[0] ? j : id[0];
+  }
+};
+
+// sum over the 16 lanes of a DPP row (quad xor-1, xor-2, half mirror, mirror): every lane of the row gets the total
+__device__ __forceinline__ float row16_sum(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));
+  return v;
+}
+
+template <typename T, int KD>
+__global__ __launch_bounds__(KNN2_THREADS) void knn2_kernel(const T* __restrict__ r, long ldr,
+                                                            const float* __restrict__ scale,
+                                                            const float* __restrict__ shift, int N, int C, int k,
+                                                            int dilation, int32_t* __restrict__ idx) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int LD = C + 4;
+  float* yn = smem;                      // [N][LD] normalised features, fp32
+  float* sq = yn + (long)N * LD;         // [N]
+  float* xkey = sq + N;                  // [4 row tiles][16 rows][KD] lists handed over by the second column group
+  int* xid = reinterpret_cast<int*>(xkey + 4 * 16 * KD);
+
+  const int b = blockIdx.x;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const T* src = r + (long)b * N * ldr;
+  constexpr int NV = Chunk<T>::N;
+  const int CV = C / NV;
+
+  // ---- phase 1a: y = scale*r + shift into LDS as fp32
+  for (int q = t; q < N * CV; q += KNN2_THREADS) {
+    const int n = q / CV, c = (q % CV) * NV;
+    float v[NV];
+    Chunk<T>::load(src + (long)n * ldr + c, v);
+    if (scale != nullptr) {
+      float sc[NV], sh[NV];
+      load_channels<NV>(scale, c, sc);
+      load_channels<NV>(shift, c, sh);
+#pragma unroll
+      for (int e = 0; e < NV; ++e) v[e] = sc[e] * v[e] + sh[e];
+    }
+#pragma unroll
+    for (int e = 0; e < NV; e += 4) *reinterpret_cast<f32x4*>(yn + n * LD + c + e) = f32x4{v[e], v[e + 1], v[e + 2], v[e + 3]};
+  }
+  __syncthreads();
+  // ---- phase 1b: F.normalize(p=2, dim=channels, eps=1e-12) and |y^|^2 of the normalised rows; a row is handled by
+  // LPR = min(64, C/4) lanes with one or two float4 each
+  {
+    const int LPR = C / 4 < 64 ? C / 4 : 64;     // 16, 32 or 64
+    const int RPP = 64 / LPR;                     // rows per wave pass
+    const int CPL = C / 4 / LPR;                  // float4 chunks per lane (1 or 2)
+    const int cl = lane % LPR;
+    for (int n0 = wave * RPP; n0 < N; n0 += KNN2_WAVES * RPP) {
+      const int n = n0 + lane / LPR;
+      f32x4 v0 = *reinterpret_cast<const f32x4*>(yn + n * LD + 4 * cl), v1 = {0.f, 0.f, 0.f, 0.f};
+      if (CPL > 1) v1 = *reinterpret_cast<const f32x4*>(yn + n * LD + 4 * (cl + LPR));
+      float ss = (v0[0] * v0[0] + v0[1] * v0[1]) + (v0[2] * v0[2] + v0[3] * v0[3]);
+      ss += (v1[0] * v1[0] + v1[1] * v1[1]) + (v1[2] * v1[2] + v1[3] * v1[3]);
+      ss = row16_sum(ss);
+      if (LPR >= 32) ss += __shfl_xor(ss, 16, 64);
+      if (LPR >= 64) ss += __shfl_xor(ss, 32, 64);
+      const float denom = fmaxf(sqrtf(ss), 1e-12f);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { v0[e] = v0[e] / denom; v1[e] = v1[e] / denom; }
+      float s2 = (v0[0] * v0[0] + v0[1] * v0[1]) + (v0[2] * v0[2] + v0[3] * v0[3]);
+      s2 += (v1[0] * v1[0] + v1[1] * v1[1]) + (v1[2] * v1[2] + v1[3] * v1[3]);
+      s2 = row16_sum(s2);
+      if (LPR >= 32) s2 += __shfl_xor(s2, 16, 64);
+      if (LPR >= 64) s2 += __shfl_xor(s2, 32, 64);
+      *reinterpret_cast<f32x4*>(yn + n * LD + 4 * cl) = v0;
+      if (CPL > 1) *reinterpret_cast<f32x4*>(yn + n * LD + 4 * (cl + LPR)) = v1;
+      if (cl == 0) sq[n] = s2;
+    }
+  }
+  __syncthreads();
+
+  const int lr = lane & 15, rq = lane >> 4;
+  const int RT = N >> 4;                                  // row tiles == column tiles (2, 4, 8 or 16)
+  const int G = RT >= KNN2_WAVES ? 1 : 2;                 // column groups per row tile
+  const int CTG = RT / G;                                 // column tiles per group: 16, 8, 2 or 1
+  const int NT = CTG >= 4 ? 4 : CTG;                      // column tiles per MFMA pass
+  const int cg = RT >= KNN2_WAVES ? 0 : wave / RT;
+  const bool active = cg < G;                             // wave-uniform
+  TopList<KD> top;
+
+  for (int rt = (RT >= KNN2_WAVES ? wave : wave % RT); rt < RT && active; rt += KNN2_WAVES) {
+    top.init();
+    const int i = 16 * rt + lr;                           // this lane's row node
+    const float si = sq[i];
+    const float* arow = yn + i * LD + 4 * rq;
+    for (int ct0 = cg * CTG; ct0 < (cg + 1) * CTG; ct0 += NT) {
+      f32x4 acc[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+      const float* brow = yn + (16 * ct0 + lr) * LD + 4 * rq;
+      for (int ch = 0; ch < C; ch += 16) {
+        const f32x4 fa = *reinterpret_cast<const f32x4*>(arow + ch);
+        f32x4 fb[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (u < NT) fb[u] = *reinterpret_cast<const f32x4*>(brow + u * 16 * LD + ch);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+            if (u < NT) acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(fb[u][e], fa[e], acc[u], 0, 0, 0);
+      }
+      // acc[u][e] = y_j . y_i with j = 16*(ct0+u) + 4*rq + e, i = this lane's row: D = (|i|^2 - 2 i.j) + |j|^2
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (u < NT) {
+          const int j0 = 16 * (ct0 + u) + 4 * rq;
+          const f32x4 sj = *reinterpret_cast<const f32x4*>(sq + j0);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) top.push_ordered((si + (-2.f * acc[u][e])) + sj[e], j0 + e);
+        }
+      }
+    }
+    // ---- merge the four quarter lists of every row (lanes lr + 16q): two butterfly exchanges, after which all four
+    // lanes hold the same top-KD of the union
+#pragma unroll
+    for (int step = 16; step <= 32; step <<= 1) {
+      float ok[KD];
+      int oi[KD];
+#pragma unroll
+      for (int p = 0; p < KD; ++p) { ok[p] = __shfl_xor(top.key[p], step, 64); oi[p] = __shfl_xor(top.id[p], step, 64); }
+#pragma unroll
+      for (int p = 0; p < KD; ++p) top.push_any(ok[p], oi[p]);
+    }
+    if (G > 1 && cg > 0) {                                // hand the list over to the wave that owns the row tile
+      if (rq == 0) {
+#pragma unroll
+        for (int p = 0; p < KD; ++p) { xkey[(rt * 16 + lr) * KD + p] = top.key[p]; xid[(rt * 16 + lr) * KD + p] = top.id[p]; }
+      }
+    } else if (G == 1 && rq == 0) {
+      int32_t* out = idx + ((long)b * N + i) * k;
+#pragma unroll
+      for (int p = 0; p < KD; ++p)
+        if (p % dilation == 0 && p / dilation < k) out[p / dilation] = top.id[p];
+    }
+  }
+  if (G > 1) {                                            // uniform over the workgroup
+    __syncthreads();
+    if (active && cg == 0) {
+      const int rt = wave % RT;
+#pragma unroll
+      for (int p = 0; p < KD; ++p) top.push_any(xkey[(rt * 16 + lr) * KD + p], xid[(rt * 16 + lr) * KD + p]);
+      if (rq == 0) {
+        int32_t* out = idx + ((long)b * N + 16 * rt + lr) * k;
+#pragma unroll
+        for (int p = 0; p < KD; ++p)
+          if (p % dilation == 0 && p / dilation < k) out[p / dilation] = top.id[p];
+      }
+    }
+  }
+}
+
+template <typename T, int KD>
+int launch_knn2(const void* r, int ldr, const float* scale, const float* shift, int B, int N, int C, int k, int dilation,
+                int32_t* idx, hipStream_t s) {
+  const size_t bytes = ((size_t)N * (C + 4) + N + 2 * 4 * 16 * KD) * sizeof(float);
+  static bool configured = false;      // raise the dynamic-LDS cap once per instantiation (not a per-call sync)
+  if (!configured) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(knn2_kernel<T, KD>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+      return NSID_ELAUNCH;
+    configured = true;
+  }
+  NSID_LAUNCH((knn2_kernel<T, KD>), dim3(B), dim3(KNN2_THREADS), bytes, s, static_cast<const T*>(r), (long)ldr, scale,
+              shift, N, C, k, dilation, idx);
+  return nsid_launch_status();
+}
+
 }  // namespace
 
 extern "C" int nsid_knn_graph(const void* r, int ldr, const float* scale, const float* shift, int B, int N, int C,
@@ -165,6 +387,19 @@ extern "C" int nsid_knn_graph(const void* r, int ldr, const float* scale, const 
   NSID_REQUIRE(N % 32 == 0 && N <= 256 && C % 16 == 0 && ldr % 4 == 0 && ldr >= C && nsid_aligned16(r));
   NSID_REQUIRE(k * dilation <= N);
   NSID_REQUIRE((scale == nullptr) == (shift == nullptr));
+  const int kd = k * dilation;
+  static const bool use_fast = getenv("NSID_KNN_STRIPS") == nullptr;
+  if (use_fast && kd <= 8 && C >= 64 && C <= 512 && (C & (C - 1)) == 0 && N >= 32 && (N & (N - 1)) == 0) {
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (dtype == NSID_BF16) {
+      if (kd <= 3) return launch_knn2<__bf16, 3>(r, ldr, scale, shift, B, N, C, k, dilation, idx, s);
+      if (kd <= 5) return launch_knn2<__bf16, 5>(r, ldr, scale, shift, B, N, C, k, dilation, idx, s);
+      return launch_knn2<__bf16, 8>(r, ldr, scale, shift, B, N, C, k, dilation, idx, s);
+    }
+    if (kd <= 3) return launch_knn2<float, 3>(r, ldr, scale, shift, B, N, C, k, dilation, idx, s);
+    if (kd <= 5) return launch_knn2<float, 5>(r, ldr, scale, shift, B, N, C, k, dilation, idx, s);
+    return launch_knn2<float, 8>(r, ldr, scale, shift, B, N, C, k, dilation, idx, s);
+  }
   const size_t bytes = ((size_t)N * (C + 4) + N + (size_t)KNN_WAVES * 16 * (N + 4)) * sizeof(float);
   NSID_REQUIRE(bytes <= 160 * 1024);
   static size_t configured = 0;       // raise the dynamic-LDS cap once per size step (not a per-call sync)
