@@ -62,44 +62,99 @@ __global__ __launch_bounds__(256) void mr_fwd_kernel(const T* __restrict__ r, lo
   }
 }
 
+// backward as a GATHER over the reversed graph (LDS float atomics cost ~3 cycles per lane: the scatter form spent 2/3 of
+// its time in 16 K ds_add_f32 per clip). Per clip:
+//   A. stage the odd half of du (the max-relative gradient, in its storage type) and the arg-max bytes in LDS;
+//   B. reverse the neighbour lists with N*k INTEGER atomics: in-degree count, wave scan, fill -> CSR (start, src);
+//   C. every thread owns NV channels of one node n: dy = du_even - du_odd (own row) + sum over the edges (m, j) that
+//      point at n of du_odd[m, c] where argmax[m, c] == j.
+// The order of a node's incoming edges depends on the fill race, so the fp32 sum order is not fixed (neither was the
+// atomic scatter's); a node's incoming values are few (k on average).
+constexpr int MRB_THREADS = 1024;
+
 template <typename T>
-__global__ __launch_bounds__(256) void mr_bwd_kernel(const T* __restrict__ du, const int32_t* __restrict__ idx,
-                                                     const uint8_t* __restrict__ argmax, int N, int C, int k,
-                                                     T* __restrict__ dy) {
-  extern __shared__ __attribute__((aligned(16))) float acc[];   // [N][C] fp32 accumulator for the whole clip
-  constexpr int NV = Chunk<T>::N;          // du elements per chunk = NV/2 channel pairs (even, odd)
-  const int b = blockIdx.x;
+__global__ __launch_bounds__(MRB_THREADS) void mr_bwd_kernel(const T* __restrict__ du, const int32_t* __restrict__ idx,
+                                                             const uint8_t* __restrict__ argmax, int N, int C, int k,
+                                                             T* __restrict__ dy) {
+  extern __shared__ __attribute__((aligned(16))) char mrb_smem[];
+  constexpr int NV = Chunk<T>::N;          // dy channels per thread; the matching du run is 2*NV elements (32 B)
+  T* odd = reinterpret_cast<T*>(mrb_smem);                          // [N][C]
+  uint8_t* am = reinterpret_cast<uint8_t*>(odd + (long)N * C);      // [N][C]
+  int* cnt = reinterpret_cast<int*>(am + (long)N * C);              // [N]   in-degree, then fill cursor
+  int* start = cnt + N;                                             // [N+1]
+  int* src = start + N + 1;                                         // [N*k] (m << 8) | j
+  const int b = blockIdx.x, t = threadIdx.x;
   const long row0 = (long)b * N;
-  const int CH = C / (NV / 2);             // chunks of du per node row
-  const int total = N * CH;
-  // pass 1: dy = du_even - du_odd (pass-through of the interleave, and the -1 on the centre of the max-relative)
-  for (int q = threadIdx.x; q < total; q += blockDim.x) {
-    const int n = q / CH, c = (q % CH) * (NV / 2);
-    float g[NV];
-    Chunk<T>::load(du + (row0 + n) * (2L * C) + 2 * c, g);
+  const int CV = C / NV;
+  const int total = N * CV;
+  const T* dub = du + row0 * (2L * C);
+  const uint8_t* amb = argmax + row0 * C;
+  const int32_t* nbb = idx + row0 * k;
+  const int E = N * k;
+
+  for (int n = t; n < N; n += MRB_THREADS) cnt[n] = 0;
+  // ---- A: stage du_odd and argmax
+  for (int q = t; q < total; q += MRB_THREADS) {
+    float g0[NV], g1[NV], o[NV];
+    Chunk<T>::load(dub + (long)q * 2 * NV, g0);
+    Chunk<T>::load(dub + (long)q * 2 * NV + NV, g1);
 #pragma unroll
-    for (int e = 0; e < NV / 2; ++e) acc[n * C + c + e] = g[2 * e] - g[2 * e + 1];
+    for (int e = 0; e < NV / 2; ++e) { o[e] = g0[2 * e + 1]; o[NV / 2 + e] = g1[2 * e + 1]; }
+    Chunk<T>::store(odd + (long)q * NV, o);                  // exact: a copy in the storage type
+#pragma unroll
+    for (int e = 0; e < NV; e += 4)
+      *reinterpret_cast<uint32_t*>(am + (long)q * NV + e) = *reinterpret_cast<const uint32_t*>(amb + (long)q * NV + e);
   }
   __syncthreads();
-  // pass 2: +du_odd to the arg-max neighbour of every (node, channel)
-  for (int q = threadIdx.x; q < total; q += blockDim.x) {
-    const int n = q / CH, c = (q % CH) * (NV / 2);
-    float g[NV];
-    Chunk<T>::load(du + (row0 + n) * (2L * C) + 2 * c, g);
-    const uint8_t* am = argmax + (row0 + n) * C + c;
-    const int32_t* nb = idx + (row0 + n) * k;
+  // ---- B: reversed graph
+  for (int e = t; e < E; e += MRB_THREADS) atomicAdd(&cnt[min(max(nbb[e], 0), N - 1)], 1);
+  __syncthreads();
+  if (t < 64) {                                              // exclusive scan of cnt[0..N) by one wave
+    const int per = (N + 63) / 64;
+    int loc = 0;
+    for (int i2 = 0; i2 < per; ++i2) { const int n = t * per + i2; if (n < N) loc += cnt[n]; }
+    int inc = loc;
+#pragma unroll
+    for (int o2 = 1; o2 < 64; o2 <<= 1) { const int v = __shfl_up(inc, o2, 64); if (t >= o2) inc += v; }
+    int run = inc - loc;
+    for (int i2 = 0; i2 < per; ++i2) {
+      const int n = t * per + i2;
+      if (n < N) { start[n] = run; const int c2 = cnt[n]; cnt[n] = run; run += c2; }
+    }
+    if (t == 63) start[N] = inc;
+  }
+  __syncthreads();
+  for (int e = t; e < E; e += MRB_THREADS) {
+    const int tg = min(max(nbb[e], 0), N - 1);
+    const int p = atomicAdd(&cnt[tg], 1);
+    src[p] = ((e / k) << 8) | (e % k);
+  }
+  __syncthreads();
+  // ---- C: gather
+  for (int q = t; q < total; q += MRB_THREADS) {
+    const int n = q / CV, c = (q % CV) * NV;
+    float g0[NV], g1[NV], v[NV];
+    Chunk<T>::load(dub + (long)q * 2 * NV, g0);             // second read of du: L2
+    Chunk<T>::load(dub + (long)q * 2 * NV + NV, g1);
 #pragma unroll
     for (int e = 0; e < NV / 2; ++e) {
-      const int tgt = min(max(nb[min((int)am[e], k - 1)], 0), N - 1);
-      atomicAdd(&acc[tgt * C + c + e], g[2 * e + 1]);
+      v[e] = g0[2 * e] - g0[2 * e + 1];
+      v[NV / 2 + e] = g1[2 * e] - g1[2 * e + 1];
     }
-  }
-  __syncthreads();
-  const int CV = C / NV;
-  for (int q = threadIdx.x; q < N * CV; q += blockDim.x) {
-    float v[NV];
+    const int p1 = start[n + 1];
+    for (int p = start[n]; p < p1; ++p) {
+      const int s2 = src[p];
+      const int m = s2 >> 8, jj = s2 & 255;
+      float o[NV];
+      Chunk<T>::load(odd + (long)m * C + c, o);
+      const uint8_t* a = am + (long)m * C + c;
 #pragma unroll
-    for (int e = 0; e < NV; ++e) v[e] = acc[q * NV + e];
+      for (int e = 0; e < NV; e += 4) {
+        const uint32_t a4 = *reinterpret_cast<const uint32_t*>(a + e);
+#pragma unroll
+        for (int x = 0; x < 4; ++x) v[e + x] += (int)((a4 >> (8 * x)) & 255u) == jj ? o[e + x] : 0.f;
+      }
+    }
     Chunk<T>::store(dy + row0 * C + (long)q * NV, v);
   }
 }
@@ -127,8 +182,9 @@ extern "C" int nsid_mr_aggregate_bwd(const void* du, const int32_t* idx, const u
                                      int k, void* dy, int dtype, void* stream) {
   NSID_REQUIRE(du && idx && argmax && dy && B > 0 && N > 0 && C > 0 && k > 0 && k <= 255 && NSID_DTYPE_OK(dtype));
   NSID_REQUIRE(C % (dtype == NSID_BF16 ? 8 : 4) == 0 && nsid_aligned16(du) && nsid_aligned16(dy));
-  const size_t bytes = (size_t)N * C * sizeof(float);
-  NSID_REQUIRE(bytes <= 160 * 1024);
+  const size_t esz = dtype == NSID_BF16 ? 2 : 4;
+  const size_t bytes = (size_t)N * C * (esz + 1) + ((size_t)2 * N + 1 + (size_t)N * k) * sizeof(int) + 16;
+  NSID_REQUIRE(bytes <= 160 * 1024 && C % 4 == 0 && ((size_t)N * C * (esz + 1)) % 4 == 0);
   static bool configured = false;
   if (!configured) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(mr_bwd_kernel<float>),
@@ -139,7 +195,7 @@ extern "C" int nsid_mr_aggregate_bwd(const void* du, const int32_t* idx, const u
     configured = true;
   }
   NSID_DISPATCH_DTYPE(dtype, T, {
-    NSID_LAUNCH((mr_bwd_kernel<T>), dim3(B), dim3(256), bytes, static_cast<hipStream_t>(stream),
+    NSID_LAUNCH((mr_bwd_kernel<T>), dim3(B), dim3(MRB_THREADS), bytes, static_cast<hipStream_t>(stream),
                 static_cast<const T*>(du), idx, argmax, N, C, k, static_cast<T*>(dy));
   });
   return nsid_launch_status();

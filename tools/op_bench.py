@@ -14,12 +14,23 @@ STAGES = [(256, 64), (128, 128), (64, 256), (32, 512)]
 
 
 def timeit(fn, reps):
+    """average device time per call: `reps` calls captured in one hipGraph (no host launch cost between them)"""
     for _ in range(3):
         fn()
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        fn()
+    torch.cuda.current_stream().wait_stream(side)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(reps):
+            fn()
+    g.replay()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(reps):
-        fn()
+    g.replay()
     e1.record()
     torch.cuda.synchronize()
     return 1e3 * e0.elapsed_time(e1) / reps
