@@ -82,20 +82,32 @@ __device__ __forceinline__ float linspace01(int i, int steps) {
   return (i < steps / 2) ? (float)i * step : 1.0f - (float)(steps - 1 - i) * step;
 }
 
+// Both kernels stage the whole clip in LDS first (H*W fp32 = 32 KB, vectorised coalesced loads, the min-max
+// normalisation applied once): the per-patch loops then read LDS instead of issuing dependent strided global loads (the
+// first versions were pure load-latency chains: 85 us forward, 214 us backward for a 2 MFLOP op).
+constexpr int PATCH_PAD = 8;     // row stride W+8 floats: the pb rows of a patch fall on different banks
+
 template <typename T>
 __global__ __launch_bounds__(256) void patchify_fwd_kernel(const float* __restrict__ spec, const float* __restrict__ w,
                                                            const float* __restrict__ bias, int H, int W, int pb,
                                                            int pf, int F, T* __restrict__ out, int ldo,
                                                            float* __restrict__ minmax) {
-  extern __shared__ __attribute__((aligned(16))) float sm[];   // weights [F][3][pb][pf] then reduction scratch
+  extern __shared__ __attribute__((aligned(16))) float sm[];   // weights [F][3][pb][pf], scratch [8], clip [H][W+pad]
   const int b = blockIdx.x, t = threadIdx.x;
   const float* x = spec + (long)b * H * W;
-  const int wn = F * 3 * pb * pf;
+  const int wn = F * 3 * pb * pf, LDW = W + PATCH_PAD;
   float* wl = sm;
   float* red = sm + wn;      // [2][4 waves]
+  float* xs = red + 8;
   for (int i = t; i < wn; i += blockDim.x) wl[i] = w[i];
   float lo = __builtin_inff(), hi = -__builtin_inff();
-  for (int i = t; i < H * W; i += blockDim.x) { const float v = x[i]; lo = fminf(lo, v); hi = fmaxf(hi, v); }
+  for (int i = t; i < H * W / 4; i += blockDim.x) {             // W % 4 == 0: a float4 never straddles a row
+    const f32x4 v = *reinterpret_cast<const f32x4*>(x + 4 * i);
+    const int hh = (4 * i) / W, ww = (4 * i) % W;
+    *reinterpret_cast<f32x4*>(xs + hh * LDW + ww) = v;
+    lo = fminf(fminf(lo, v[0]), fminf(v[1], fminf(v[2], v[3])));
+    hi = fmaxf(fmaxf(hi, v[0]), fmaxf(v[1], fmaxf(v[2], v[3])));
+  }
   lo = wave_min(lo); hi = wave_max(hi);
   if ((t & 63) == 0) { red[t >> 6] = lo; red[4 + (t >> 6)] = hi; }
   __syncthreads();
@@ -115,7 +127,7 @@ __global__ __launch_bounds__(256) void patchify_fwd_kernel(const float* __restri
         const float fr = linspace01(hh, H);
         for (int j = 0; j < pf; ++j) {
           const int ww = pw * pf + j;
-          const float s = (x[hh * W + ww] - lo) / range;
+          const float s = (xs[hh * LDW + ww] - lo) / range;
           acc += wf[i * pf + j] * linspace01(ww, W);
           acc += wf[pb * pf + i * pf + j] * fr;
           acc += wf[2 * pb * pf + i * pf + j] * s;
@@ -131,37 +143,64 @@ template <typename T>
 __global__ __launch_bounds__(256) void patchify_bwd_kernel(const float* __restrict__ spec,
                                                            const float* __restrict__ minmax,
                                                            const T* __restrict__ out,
-                                                           const T* __restrict__ dout, int ldo, int H, int W,
-                                                           int pb, int pf, int F, float* __restrict__ dw,
+                                                           const T* __restrict__ dout, int ldo, int B, int H,
+                                                           int W, int pb, int pf, int F, float* __restrict__ dw,
                                                            float* __restrict__ dbias) {
-  extern __shared__ __attribute__((aligned(16))) float sm[];   // g [NP][F]
-  const int b = blockIdx.x, t = threadIdx.x;
+  extern __shared__ __attribute__((aligned(16))) float sm[];   // g [NP][F], then the normalised clip [H][W+pad]
+  const int t = threadIdx.x;
   const int Hp = H / pb, Wp = W / pf, NP = Hp * Wp;
-  const float* x = spec + (long)b * H * W;
-  const float lo = minmax[2 * b], range = minmax[2 * b + 1] - lo;
-  for (int q = t; q < NP * F; q += blockDim.x) {
-    const int p = q / F, f = q % F;
-    const long o = ((long)b * NP + p) * ldo + f;
-    sm[q] = (float)out[o] > 0.f ? (float)dout[o] : 0.f;
-  }
-  __syncthreads();
-  const int per_f = 3 * pb * pf;
-  for (int q = t; q < F * per_f; q += blockDim.x) {
-    const int f = q / per_f, rem = q % per_f;
-    const int c = rem / (pb * pf), i = (rem / pf) % pb, j = rem % pf;
-    float acc = 0.f;
-    for (int p = 0; p < NP; ++p) {
-      const int hh = (p / Wp) * pb + i, ww = (p % Wp) * pf + j;
-      const float v = c == 0 ? linspace01(ww, W) : (c == 1 ? linspace01(hh, H) : (x[hh * W + ww] - lo) / range);
-      acc += sm[p * F + f] * v;
+  const int per_f = 3 * pb * pf, LDW = W + PATCH_PAD;
+  float* xs = sm + NP * F;
+  // A workgroup walks clips b, b + grid, ... with its sums in registers: one atomic per workgroup and output
+  constexpr int MAXQ = 4;                                      // outputs per thread: F*per_f <= 4*256
+  float wacc[MAXQ] = {0.f, 0.f, 0.f, 0.f}, bacc = 0.f;
+  for (int b = blockIdx.x; b < B; b += gridDim.x) {
+    const float* x = spec + (long)b * H * W;
+    const float lo = minmax[2 * b], range = minmax[2 * b + 1] - lo;
+    __syncthreads();                                           // previous clip's readers are done with sm
+    for (int q = t; q < NP * F; q += blockDim.x) {
+      const int p = q / F, f = q % F;
+      const long o = ((long)b * NP + p) * ldo + f;
+      sm[q] = (float)out[o] > 0.f ? (float)dout[o] : 0.f;
     }
-    atomicAdd(dw + q, acc);
+    for (int i = t; i < H * W / 4; i += blockDim.x) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(x + 4 * i);
+      const int hh = (4 * i) / W, ww = (4 * i) % W;
+      *reinterpret_cast<f32x4*>(xs + hh * LDW + ww) =
+          f32x4{(v[0] - lo) / range, (v[1] - lo) / range, (v[2] - lo) / range, (v[3] - lo) / range};
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < MAXQ; ++u) {
+      const int q = t + u * 256;
+      if (q < F * per_f) {
+        const int f = q / per_f, rem = q % per_f;
+        const int c = rem / (pb * pf), i = (rem / pf) % pb, j = rem % pf;
+        float acc = 0.f;
+        if (c == 2) {
+          for (int ph = 0; ph < Hp; ++ph)
+            for (int pw = 0; pw < Wp; ++pw)
+              acc += sm[(ph * Wp + pw) * F + f] * xs[(ph * pb + i) * LDW + pw * pf + j];
+        } else {
+          for (int ph = 0; ph < Hp; ++ph)
+            for (int pw = 0; pw < Wp; ++pw)
+              acc += sm[(ph * Wp + pw) * F + f] * (c == 0 ? linspace01(pw * pf + j, W) : linspace01(ph * pb + i, H));
+        }
+        wacc[u] += acc;
+      }
+    }
+    if (t < F) {
+      float acc = 0.f;
+      for (int p = 0; p < NP; ++p) acc += sm[p * F + t];
+      bacc += acc;
+    }
   }
-  for (int f = t; f < F; f += blockDim.x) {
-    float acc = 0.f;
-    for (int p = 0; p < NP; ++p) acc += sm[p * F + f];
-    atomicAdd(dbias + f, acc);
+#pragma unroll
+  for (int u = 0; u < MAXQ; ++u) {
+    const int q = t + u * 256;
+    if (q < F * per_f) atomicAdd(dw + q, wacc[u]);
   }
+  if (t < F) atomicAdd(dbias + t, bacc);
 }
 
 // ------------------------------------------------------------------ node mean
@@ -364,8 +403,8 @@ extern "C" int nsid_peak_patchify_fwd(const float* spec, const float* w, const f
                                       int pf, int F, void* out, int ldo, float* minmax, int out_dtype, void* stream) {
   NSID_REQUIRE(spec && w && bias && out && B > 0 && H > 1 && W > 1 && pb > 0 && pf > 0 && F > 0);
   NSID_REQUIRE(H % pb == 0 && W % pf == 0 && ldo >= F && NSID_DTYPE_OK(out_dtype));
-  const size_t bytes = ((size_t)F * 3 * pb * pf + 8) * sizeof(float);
-  NSID_REQUIRE(bytes <= 48 * 1024);
+  const size_t bytes = ((size_t)F * 3 * pb * pf + 8 + (size_t)H * (W + 8)) * sizeof(float);
+  NSID_REQUIRE(bytes <= 64 * 1024 && W % 4 == 0 && (F * 3 * pb * pf) % 4 == 0 && nsid_aligned16(spec));
   NSID_DISPATCH_DTYPE(out_dtype, T, {
     NSID_LAUNCH((patchify_fwd_kernel<T>), dim3(B), dim3(256), bytes, static_cast<hipStream_t>(stream), spec, w, bias,
                 H, W, pb, pf, F, static_cast<T*>(out), ldo, minmax);
@@ -377,11 +416,12 @@ extern "C" int nsid_peak_patchify_bwd(const float* spec, const float* minmax, co
                                       int out_dtype, void* stream) {
   NSID_REQUIRE(spec && minmax && out && dout && dw && dbias && B > 0 && H % pb == 0 && W % pf == 0 && ldo >= F);
   NSID_REQUIRE(NSID_DTYPE_OK(out_dtype));
-  const size_t bytes = (size_t)(H / pb) * (W / pf) * F * sizeof(float);
-  NSID_REQUIRE(bytes <= 48 * 1024);
+  const size_t bytes = ((size_t)(H / pb) * (W / pf) * F + (size_t)H * (W + 8)) * sizeof(float);
+  NSID_REQUIRE(bytes <= 64 * 1024 && (long)F * 3 * pb * pf <= 4 * 256 && F <= 256 && W % 4 == 0 && nsid_aligned16(spec));
+  NSID_REQUIRE(((H / pb) * (W / pf) * F) % 4 == 0);
   NSID_DISPATCH_DTYPE(out_dtype, T, {
-    NSID_LAUNCH((patchify_bwd_kernel<T>), dim3(B), dim3(256), bytes, static_cast<hipStream_t>(stream), spec, minmax,
-                static_cast<const T*>(out), static_cast<const T*>(dout), ldo, H, W, pb, pf, F, dw, dbias);
+    NSID_LAUNCH((patchify_bwd_kernel<T>), dim3(B < 256 ? B : 256), dim3(256), bytes, static_cast<hipStream_t>(stream),
+                spec, minmax, static_cast<const T*>(out), static_cast<const T*>(dout), ldo, B, H, W, pb, pf, F, dw, dbias);
   });
   return nsid_launch_status();
 }
