@@ -71,7 +71,9 @@ struct StageRegs {
   bool ok[VEC];
 };
 
-template <int ROWS, bool RMAJOR, bool H, bool SRC16>
+// FULL: the tile and every stage lie inside the operand (host-checked), so there is no predication at all — the bounds
+// logic (compare, select, zero-fill per chunk) is a third of the instructions of a K = 256 tile otherwise.
+template <int ROWS, bool RMAJOR, bool H, bool SRC16, bool FULL>
 __device__ __forceinline__ void stage_load(StageRegs<ROWS, RMAJOR, H, SRC16>& s, const char* __restrict__ base, long ld,
                                            int row0, int nrows, int r0, int rend) {
   using G = TileGeom<ROWS, RMAJOR, H, SRC16>;
@@ -82,11 +84,11 @@ __device__ __forceinline__ void stage_load(StageRegs<ROWS, RMAJOR, H, SRC16>& s,
     long off;
     if (RMAJOR) {
       const int gi = row0 + idx / G::CPR, gr = r0 + (idx % G::CPR) * G::EPC;
-      s.ok[q] = gi < nrows && gr < rend;              // extents are multiples of the chunk: all-in or all-out
+      s.ok[q] = FULL || (gi < nrows && gr < rend);    // extents are multiples of the chunk: all-in or all-out
       off = s.ok[q] ? (long)gi * ld + gr : 0;         // out-of-range chunks read element 0 and are zeroed later
     } else {
       const int gr = r0 + idx / G::CPC, gc = row0 + (idx % G::CPC) * G::EPC;
-      s.ok[q] = gr < rend && gc < nrows;
+      s.ok[q] = FULL || (gr < rend && gc < nrows);
       off = s.ok[q] ? (long)gr * ld + gc : 0;
     }
     s.v[q] = *reinterpret_cast<const f32x4*>(base + off * G::SSZ);
@@ -217,7 +219,7 @@ __device__ __forceinline__ bf16x8 frag_read_bf16(const char* lds, int tile_row0,
 // conservative at the join and drains the prefetch.
 // WB: the right operand is a WEIGHT matrix stored as bf16 (the optimiser's shadow copy, optim.py): its HBM image is the
 // LDS image — half the L2->LDS bytes of fp32 weights and no convert pass (forward / backward-data variants only).
-template <int BM, int BN, bool A_RMAJOR, bool B_RMAJOR, bool H, bool ST, bool AAFF, bool WB = false>
+template <int BM, int BN, bool A_RMAJOR, bool B_RMAJOR, bool H, bool ST, bool AAFF, bool WB = false, bool FULL = false>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {   // >= 2 waves/SIMD: <= 256 VGPR+AGPR
   constexpr bool SA = ST, SB = (ST && !A_RMAJOR && !B_RMAJOR) || WB, SC = ST && A_RMAJOR;
   static_assert(!WB || (ST && A_RMAJOR), "bf16 weights ride with bf16 activations in the forward/backward-data GEMMs");
@@ -282,9 +284,10 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {   // >
 
   f32x4 acs[GA::VEC * GA::EPC / 4], ach[GA::VEC * GA::EPC / 4];   // reduction-indexed affine of the stage being committed
   auto issue = [&](auto& sa, auto& sb, int st) {
-    const int r0 = rbeg + st * BK;
-    stage_load<BM, A_RMAJOR, H, SA>(sa, A, p.lda, i0, p.I, r0, rend);
-    stage_load<BN, B_RMAJOR, H, SB>(sb, B, p.ldb, j0, p.J, r0, rend);
+    int r0 = rbeg + st * BK;
+    if (FULL) r0 = min(r0, rend - BK);      // the two prefetches past the last stage re-read it (never computed on)
+    stage_load<BM, A_RMAJOR, H, SA, FULL>(sa, A, p.lda, i0, p.I, r0, rend);
+    stage_load<BN, B_RMAJOR, H, SB, FULL>(sb, B, p.ldb, j0, p.J, r0, rend);
   };
   auto aff_fetch = [&](int st) {
     if constexpr (AAFF) affine_prefetch<BM, H, SA>(acs, ach, rbeg + st * BK, rend, a_sc, a_sh);
@@ -383,14 +386,14 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {   // >
 #pragma unroll
     for (int b = 0; b < TN; ++b) {
       const int j = j0 + wn0 + 16 * b + lr;
-      const bool jok = j < p.J;
+      const bool jok = FULL || j < p.J;
       const float bj = (bias && jok) ? bias[j] : 0.f;
 #pragma unroll
       for (int a = 0; a < TM; ++a)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int i = i0 + wm0 + 16 * a + 4 * rq + r;
-          if (i < p.I && jok) atomicAdd(C + (long)i * p.ldc + j, acc[a][b][r] + bj);
+          if ((FULL || i < p.I) && jok) atomicAdd(C + (long)i * p.ldc + j, acc[a][b][r] + bj);
         }
     }
   } else {
@@ -403,10 +406,11 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {   // >
     constexpr int Q_PER_ROW = WN / OE, ROWS_PER_PASS = 64 / Q_PER_ROW;
     const int orow = lane / Q_PER_ROW, oq = (lane % Q_PER_ROW) * OE;
     const int jq = j0 + wn0 + oq;
-    const bool jqok = jq < p.J;                  // J % OE == 0: a chunk is all-in or all-out
+    const bool jqok = FULL || jq < p.J;          // J % OE == 0: a chunk is all-in or all-out
+    const bool has_bias = bias != nullptr;       // wave-uniform
     float bq[OE];
 #pragma unroll
-    for (int e = 0; e < OE; ++e) bq[e] = (bias && jqok) ? bias[jq + e] : 0.f;
+    for (int e = 0; e < OE; ++e) bq[e] = (has_bias && jqok) ? bias[jq + e] : 0.f;
     char* Cb = reinterpret_cast<char*>(p.C) + g * p.c_goff * OSZ;
     const char* Ab = reinterpret_cast<const char*>(p.addend) + g * p.c_goff * OSZ;
 #pragma unroll
@@ -422,13 +426,17 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {   // >
       for (int pass = 0; pass < 32 / ROWS_PER_PASS; ++pass) {
         const int rr = pass * ROWS_PER_PASS + orow;
         const int i = i0 + wm0 + 32 * h + rr;
-        if (i < p.I && jqok) {
+        if ((FULL || i < p.I) && jqok) {
           float v[OE];
 #pragma unroll
           for (int e = 0; e < OE; e += 4) {
             const f32x4 t4 = *reinterpret_cast<const f32x4*>(ost + rr * OLD + oq + e);
 #pragma unroll
-            for (int k4 = 0; k4 < 4; ++k4) v[e + k4] = t4[k4] + bq[e + k4];
+            for (int k4 = 0; k4 < 4; ++k4) v[e + k4] = t4[k4];
+          }
+          if (has_bias) {
+#pragma unroll
+            for (int e = 0; e < OE; ++e) v[e] += bq[e];
           }
           if (p.addend) {
             float ad[OE];
@@ -448,15 +456,15 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {   // >
 #pragma unroll
       for (int b = 0; b < TN; ++b) {
         const int j = j0 + wn0 + 16 * b + lr;
-        const bool jok = j < p.J;
+        const bool jok = FULL || j < p.J;
         const float bj = (bias && jok) ? bias[j] : 0.f;
 #pragma unroll
         for (int a = 0; a < TM; ++a)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int i = i0 + wm0 + 16 * a + 4 * rq + r;
-            if (i < p.I && jok) {
-              const float v = acc[a][b][r] + bj;
+            if ((FULL || i < p.I) && jok) {
+              const float v = has_bias ? acc[a][b][r] + bj : acc[a][b][r];
               csum[b] += v;
               csq[b] += v * v;
             }
@@ -480,7 +488,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {   // >
     __syncthreads();
     if (threadIdx.x < BN) {
       const int j = j0 + threadIdx.x;
-      if (j < p.J) {
+      if (FULL || j < p.J) {
         const long col = g * p.c_goff + j;     // forward: c_goff == Nout per group == column offset
         p.stat[(long)ti * p.stat_ld + col] = red[0 * BN + threadIdx.x] + red[1 * BN + threadIdx.x];
         p.stat[p.stat_plane + (long)ti * p.stat_ld + col] = red[2 * BN + threadIdx.x] + red[3 * BN + threadIdx.x];
@@ -521,10 +529,22 @@ int launch(GemmArgs p, int groups, hipStream_t s, int act_dtype, bool w_bf16 = f
     if (aff) NSID_LAUNCH((gemm_kernel<BM, BN, AR, BR, HH, SS, CAN_AFF>), grid, dim3(256), 0, s, p);        \
     else NSID_LAUNCH((gemm_kernel<BM, BN, AR, BR, HH, SS, false>), grid, dim3(256), 0, s, p);              \
   } while (0)
+  // FULL: whole tiles and an even number of whole stages per split -> the predication-free instantiation
+  const bool full = st16 && p.I % BM == 0 && p.J % BN == 0 && p.rchunk % (2 * bk) == 0 && p.R % p.rchunk == 0;
   if constexpr (AR) {
     if (st16 && w_bf16) {
-      if (aff) NSID_LAUNCH((gemm_kernel<BM, BN, AR, BR, true, true, CAN_AFF, true>), grid, dim3(256), 0, s, p);
-      else NSID_LAUNCH((gemm_kernel<BM, BN, AR, BR, true, true, false, true>), grid, dim3(256), 0, s, p);
+      if (full) {
+        if (aff) NSID_LAUNCH((gemm_kernel<BM, BN, AR, BR, true, true, CAN_AFF, true, true>), grid, dim3(256), 0, s, p);
+        else NSID_LAUNCH((gemm_kernel<BM, BN, AR, BR, true, true, false, true, true>), grid, dim3(256), 0, s, p);
+      } else {
+        if (aff) NSID_LAUNCH((gemm_kernel<BM, BN, AR, BR, true, true, CAN_AFF, true>), grid, dim3(256), 0, s, p);
+        else NSID_LAUNCH((gemm_kernel<BM, BN, AR, BR, true, true, false, true>), grid, dim3(256), 0, s, p);
+      }
+      return nsid_launch_status();
+    }
+  } else {
+    if (st16 && full) {            // weight gradient, bf16 operands
+      NSID_LAUNCH((gemm_kernel<BM, BN, AR, BR, true, true, false, false, true>), grid, dim3(256), 0, s, p);
       return nsid_launch_status();
     }
   }
