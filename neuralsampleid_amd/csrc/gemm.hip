@@ -597,7 +597,12 @@ extern "C" int nsid_linear_fwd(const void* x, int ldx, const void* w, int w_dtyp
   // halve the tile width to double the loads in flight (the statistics tile stays 128 rows)
   const long t128 = (long)nsid_row_tiles(M) * ((Nout + 127) / 128) * groups;
   const bool half = g_gemm_precision == NSID_GEMM_BF16 || act_dtype == NSID_BF16;
-  const bool narrow = Nout <= 64 || (half && t128 < 512);
+  static const int force_narrow = getenv("NSID_FWD_NARROW") ? atoi(getenv("NSID_FWD_NARROW")) : -1;
+  // measured (tools/gemm_bench.py, bf16 path): the 128-wide tile wins from 256 output columns on, and always when the
+  // left operand carries the producer's BatchNorm (every column tile re-applies it: fewer, wider tiles = less VALU)
+  bool narrow = half ? (Nout <= 64 || (Nout <= 128 && K <= 256 && in_scale == nullptr)) : Nout <= 64;
+  (void)t128;
+  if (force_narrow >= 0 && Nout > 64) narrow = force_narrow != 0;
   const bool wb = w_dtype == NSID_BF16;
   const int rc = narrow ? launch<128, 64, true, true>(p, groups, s, act_dtype, wb)
                         : launch<128, 128, true, true>(p, groups, s, act_dtype, wb);
@@ -629,7 +634,11 @@ extern "C" int nsid_linear_bwd_data(const void* dout, int ldd, const void* w, in
   hipStream_t s = static_cast<hipStream_t>(stream);
   const long t128 = (long)nsid_row_tiles(M) * ((K + 127) / 128) * groups;
   const bool half = g_gemm_precision == NSID_GEMM_BF16 || act_dtype == NSID_BF16;
-  if (K <= 64 || (half && t128 < 512)) return launch<128, 64, true, false>(p, groups, s, act_dtype, wb);
+  static const int force_narrow = getenv("NSID_BWD_NARROW") ? atoi(getenv("NSID_BWD_NARROW")) : -1;
+  bool narrow = half ? (K <= 64 || (K <= 128 && Nout <= 256)) : K <= 64;
+  (void)t128;
+  if (force_narrow >= 0 && K > 64) narrow = force_narrow != 0;
+  if (narrow) return launch<128, 64, true, false>(p, groups, s, act_dtype, wb);
   return launch<128, 128, true, false>(p, groups, s, act_dtype, wb);
 }
 

@@ -59,10 +59,20 @@ def main():
             fn = runs[name]
             for _ in range(3):
                 fn()
+            torch.cuda.synchronize()
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                fn()
+            torch.cuda.current_stream().wait_stream(side)
+            g = torch.cuda.CUDAGraph()               # device time per call: no host launch cost between the reps
+            with torch.cuda.graph(g):
+                for _ in range(args.reps):
+                    fn()
+            g.replay()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            for _ in range(args.reps):
-                fn()
+            g.replay()
             e1.record()
             torch.cuda.synchronize()
             us = 1e3 * e0.elapsed_time(e1) / args.reps
