@@ -15,11 +15,26 @@ __device__ __forceinline__ void tile_sums(const float* __restrict__ p0, const fl
                                           int C, int c, int tg, bool ok, double* red0, double* red1, double& sum,
                                           double& sq) {
   double a = 0.0, b = 0.0;
-  if (ok)
-    for (int t = tg; t < tiles; t += FIN_TG) {
+  if (ok) {
+    // all loads of a batch are issued before the first add (the fp64 chain would otherwise serialise one L2 round trip
+    // per tile: this kernel is pure latency); the summation order is unchanged
+    constexpr int UB = 8;
+    int t = tg;
+    for (; t + (UB - 1) * FIN_TG < tiles; t += UB * FIN_TG) {
+      float va[UB], vb[UB];
+#pragma unroll
+      for (int u = 0; u < UB; ++u) {
+        va[u] = p0[(long)(t + u * FIN_TG) * C + c];
+        vb[u] = p1[(long)(t + u * FIN_TG) * C + c];
+      }
+#pragma unroll
+      for (int u = 0; u < UB; ++u) { a += (double)va[u]; b += (double)vb[u]; }
+    }
+    for (; t < tiles; t += FIN_TG) {
       a += (double)p0[(long)t * C + c];
       b += (double)p1[(long)t * C + c];
     }
+  }
   red0[threadIdx.x] = a;
   red1[threadIdx.x] = b;
   __syncthreads();

@@ -87,7 +87,7 @@ __device__ __forceinline__ float linspace01(int i, int steps) {
 // first versions were pure load-latency chains: 85 us forward, 214 us backward for a 2 MFLOP op).
 constexpr int PATCH_PAD = 8;     // row stride W+8 floats: the pb rows of a patch fall on different banks
 
-template <typename T>
+template <typename T, int MAXPATCH>
 __global__ __launch_bounds__(256) void patchify_fwd_kernel(const float* __restrict__ spec, const float* __restrict__ w,
                                                            const float* __restrict__ bias, int H, int W, int pb,
                                                            int pf, int F, T* __restrict__ out, int ldo,
@@ -101,12 +101,24 @@ __global__ __launch_bounds__(256) void patchify_fwd_kernel(const float* __restri
   float* xs = red + 8;
   for (int i = t; i < wn; i += blockDim.x) wl[i] = w[i];
   float lo = __builtin_inff(), hi = -__builtin_inff();
-  for (int i = t; i < H * W / 4; i += blockDim.x) {             // W % 4 == 0: a float4 never straddles a row
-    const f32x4 v = *reinterpret_cast<const f32x4*>(x + 4 * i);
-    const int hh = (4 * i) / W, ww = (4 * i) % W;
-    *reinterpret_cast<f32x4*>(xs + hh * LDW + ww) = v;
-    lo = fminf(fminf(lo, v[0]), fminf(v[1], fminf(v[2], v[3])));
-    hi = fmaxf(fmaxf(hi, v[0]), fmaxf(v[1], fmaxf(v[2], v[3])));
+  constexpr int XB = 8;                                          // loads of a batch are issued before the first use
+  for (int i0 = t; i0 < H * W / 4; i0 += XB * blockDim.x) {      // W % 4 == 0: a float4 never straddles a row
+    f32x4 v[XB];
+#pragma unroll
+    for (int u = 0; u < XB; ++u) {
+      const int i = i0 + u * blockDim.x;
+      if (i < H * W / 4) v[u] = *reinterpret_cast<const f32x4*>(x + 4 * i);
+    }
+#pragma unroll
+    for (int u = 0; u < XB; ++u) {
+      const int i = i0 + u * blockDim.x;
+      if (i < H * W / 4) {
+        const int hh = (4 * i) / W, ww = (4 * i) % W;
+        *reinterpret_cast<f32x4*>(xs + hh * LDW + ww) = v[u];
+        lo = fminf(fminf(lo, v[u][0]), fminf(v[u][1], fminf(v[u][2], v[u][3])));
+        hi = fmaxf(fmaxf(hi, v[u][0]), fmaxf(v[u][1], fmaxf(v[u][2], v[u][3])));
+      }
+    }
   }
   lo = wave_min(lo); hi = wave_max(hi);
   if ((t & 63) == 0) { red[t >> 6] = lo; red[4 + (t >> 6)] = hi; }
@@ -116,21 +128,30 @@ __global__ __launch_bounds__(256) void patchify_fwd_kernel(const float* __restri
   if (t == 0 && minmax != nullptr) { minmax[2 * b] = lo; minmax[2 * b + 1] = hi; }
   const float range = hi - lo;
   const int Hp = H / pb, Wp = W / pf, NP = Hp * Wp;
+  // MAXPATCH >= pb*pf (host-checked; the instantiation with MAXPATCH == pb*pf has no predicates): the patch's three
+  // input planes sit in registers, one division per spectrogram value
   for (int p = t; p < NP; p += blockDim.x) {
     const int ph = p / Wp, pw = p % Wp;
     T* dst = out + ((long)b * NP + p) * ldo;
+    float sv[MAXPATCH], lw[MAXPATCH], lh[MAXPATCH];
+#pragma unroll
+    for (int q = 0; q < MAXPATCH; ++q) {
+      if (q < pb * pf) {
+        const int i = q / pf, j = q % pf;
+        sv[q] = (xs[(ph * pb + i) * LDW + pw * pf + j] - lo) / range;
+        lw[q] = linspace01(pw * pf + j, W);
+        lh[q] = linspace01(ph * pb + i, H);
+      }
+    }
     for (int f = 0; f < F; ++f) {
       float acc = bias[f];
       const float* wf = wl + f * 3 * pb * pf;
-      for (int i = 0; i < pb; ++i) {
-        const int hh = ph * pb + i;
-        const float fr = linspace01(hh, H);
-        for (int j = 0; j < pf; ++j) {
-          const int ww = pw * pf + j;
-          const float s = (xs[hh * LDW + ww] - lo) / range;
-          acc += wf[i * pf + j] * linspace01(ww, W);
-          acc += wf[pb * pf + i * pf + j] * fr;
-          acc += wf[2 * pb * pf + i * pf + j] * s;
+#pragma unroll
+      for (int q = 0; q < MAXPATCH; ++q) {
+        if (q < pb * pf) {                       // accumulation order: (i, j) row-major, planes time/freq/spec
+          acc += wf[q] * lw[q];
+          acc += wf[pb * pf + q] * lh[q];
+          acc += wf[2 * pb * pf + q] * sv[q];
         }
       }
       dst[f] = (T)(acc < 0.f ? 0.f : acc);     // NaN (constant clip: 0/0) propagates, as in the reference
@@ -154,20 +175,48 @@ __global__ __launch_bounds__(256) void patchify_bwd_kernel(const float* __restri
   // A workgroup walks clips b, b + grid, ... with its sums in registers: one atomic per workgroup and output
   constexpr int MAXQ = 4;                                      // outputs per thread: F*per_f <= 4*256
   float wacc[MAXQ] = {0.f, 0.f, 0.f, 0.f}, bacc = 0.f;
+  constexpr int NV = Chunk<T>::N;
+  const bool vec = (F % NV == 0) && (ldo % NV == 0);          // 16-byte rows of out / dout (F = 8 bf16: one chunk a patch)
   for (int b = blockIdx.x; b < B; b += gridDim.x) {
     const float* x = spec + (long)b * H * W;
     const float lo = minmax[2 * b], range = minmax[2 * b + 1] - lo;
     __syncthreads();                                           // previous clip's readers are done with sm
-    for (int q = t; q < NP * F; q += blockDim.x) {
-      const int p = q / F, f = q % F;
-      const long o = ((long)b * NP + p) * ldo + f;
-      sm[q] = (float)out[o] > 0.f ? (float)dout[o] : 0.f;
+    // staging: every global load of a batch is issued before its first use (these loops were serial round trips)
+    if (vec) {
+      const int FC = F / NV;
+      for (int q = t; q < NP * FC; q += blockDim.x) {
+        const int p = q / FC, f = (q % FC) * NV;
+        const long o = ((long)b * NP + p) * ldo + f;
+        float ov[NV], dv[NV];
+        Chunk<T>::load(out + o, ov);
+        Chunk<T>::load(dout + o, dv);
+#pragma unroll
+        for (int e = 0; e < NV; ++e) sm[p * F + f + e] = ov[e] > 0.f ? dv[e] : 0.f;
+      }
+    } else {
+      for (int q = t; q < NP * F; q += blockDim.x) {
+        const int p = q / F, f = q % F;
+        const long o = ((long)b * NP + p) * ldo + f;
+        sm[q] = (float)out[o] > 0.f ? (float)dout[o] : 0.f;
+      }
     }
-    for (int i = t; i < H * W / 4; i += blockDim.x) {
-      const f32x4 v = *reinterpret_cast<const f32x4*>(x + 4 * i);
-      const int hh = (4 * i) / W, ww = (4 * i) % W;
-      *reinterpret_cast<f32x4*>(xs + hh * LDW + ww) =
-          f32x4{(v[0] - lo) / range, (v[1] - lo) / range, (v[2] - lo) / range, (v[3] - lo) / range};
+    constexpr int XB = 8;
+    for (int i0 = t; i0 < H * W / 4; i0 += XB * blockDim.x) {
+      f32x4 v[XB];
+#pragma unroll
+      for (int u = 0; u < XB; ++u) {
+        const int i = i0 + u * blockDim.x;
+        if (i < H * W / 4) v[u] = *reinterpret_cast<const f32x4*>(x + 4 * i);
+      }
+#pragma unroll
+      for (int u = 0; u < XB; ++u) {
+        const int i = i0 + u * blockDim.x;
+        if (i < H * W / 4) {
+          const int hh = (4 * i) / W, ww = (4 * i) % W;
+          *reinterpret_cast<f32x4*>(xs + hh * LDW + ww) =
+              f32x4{(v[u][0] - lo) / range, (v[u][1] - lo) / range, (v[u][2] - lo) / range, (v[u][3] - lo) / range};
+        }
+      }
     }
     __syncthreads();
 #pragma unroll
@@ -176,17 +225,26 @@ __global__ __launch_bounds__(256) void patchify_bwd_kernel(const float* __restri
       if (q < F * per_f) {
         const int f = q / per_f, rem = q % per_f;
         const int c = rem / (pb * pf), i = (rem / pf) % pb, j = rem % pf;
-        float acc = 0.f;
-        if (c == 2) {
-          for (int ph = 0; ph < Hp; ++ph)
-            for (int pw = 0; pw < Wp; ++pw)
-              acc += sm[(ph * Wp + pw) * F + f] * xs[(ph * pb + i) * LDW + pw * pf + j];
-        } else {
-          for (int ph = 0; ph < Hp; ++ph)
-            for (int pw = 0; pw < Wp; ++pw)
-              acc += sm[(ph * Wp + pw) * F + f] * (c == 0 ? linspace01(pw * pf + j, W) : linspace01(ph * pb + i, H));
+        // one partial sum per patch COLUMN group (pw % UB): independent LDS chains instead of one 256-long chain, and
+        // no division in the loops
+        constexpr int UB = 4;
+        float part[UB] = {0.f, 0.f, 0.f, 0.f};
+        for (int ph = 0; ph < Hp; ++ph) {
+          const float lh = linspace01(ph * pb + i, H);
+          const float* srow = sm + (ph * Wp) * F + f;
+          const float* xrow = xs + (ph * pb + i) * LDW + j;
+          for (int pw0 = 0; pw0 < Wp; pw0 += UB) {
+#pragma unroll
+            for (int v = 0; v < UB; ++v) {
+              const int pw = pw0 + v;
+              if (pw < Wp) {
+                const float img = c == 2 ? xrow[pw * pf] : (c == 0 ? linspace01(pw * pf + j, W) : lh);
+                part[v] += srow[pw * F] * img;
+              }
+            }
+          }
         }
-        wacc[u] += acc;
+        wacc[u] += (part[0] + part[1]) + (part[2] + part[3]);
       }
     }
     if (t < F) {
@@ -404,10 +462,14 @@ extern "C" int nsid_peak_patchify_fwd(const float* spec, const float* w, const f
   NSID_REQUIRE(spec && w && bias && out && B > 0 && H > 1 && W > 1 && pb > 0 && pf > 0 && F > 0);
   NSID_REQUIRE(H % pb == 0 && W % pf == 0 && ldo >= F && NSID_DTYPE_OK(out_dtype));
   const size_t bytes = ((size_t)F * 3 * pb * pf + 8 + (size_t)H * (W + 8)) * sizeof(float);
-  NSID_REQUIRE(bytes <= 64 * 1024 && W % 4 == 0 && (F * 3 * pb * pf) % 4 == 0 && nsid_aligned16(spec));
+  NSID_REQUIRE(bytes <= 64 * 1024 && W % 4 == 0 && (F * 3 * pb * pf) % 4 == 0 && nsid_aligned16(spec) && pb * pf <= 64);
   NSID_DISPATCH_DTYPE(out_dtype, T, {
-    NSID_LAUNCH((patchify_fwd_kernel<T>), dim3(B), dim3(256), bytes, static_cast<hipStream_t>(stream), spec, w, bias,
-                H, W, pb, pf, F, static_cast<T*>(out), ldo, minmax);
+    if (pb * pf == 32)
+      NSID_LAUNCH((patchify_fwd_kernel<T, 32>), dim3(B), dim3(256), bytes, static_cast<hipStream_t>(stream), spec, w,
+                  bias, H, W, pb, pf, F, static_cast<T*>(out), ldo, minmax);
+    else
+      NSID_LAUNCH((patchify_fwd_kernel<T, 64>), dim3(B), dim3(256), bytes, static_cast<hipStream_t>(stream), spec, w,
+                  bias, H, W, pb, pf, F, static_cast<T*>(out), ldo, minmax);
   });
   return nsid_launch_status();
 }
