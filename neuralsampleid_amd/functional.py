@@ -237,7 +237,7 @@ def downsample_backward(dout: Tensor, P, S, G) -> Tensor:
     dr = ops.bn_backward(dout, r, aff, ACT_NONE, G["conv.1.weight"], G["conv.1.bias"])
     _bias_grad_before_bn(dr, G["conv.0.bias"])
     dwp = torch.zeros_like(wp)
-    ops.linear_bwd_weight(dr, col, dwp, Mo, Co, 3 * C)
+    ops.linear_bwd_weight(dr, col, dwp, Mo, Co, 3 * C, offload=False)      # unpacked right below, same stream
     ops.unpack_ds_wgrad(dwp, G["conv.0.weight"])
     dcol = ops.linear_bwd_data(dr, wp, Mo, Co, 3 * C)
     return ops.im2col3_bwd(dcol, B, N, C)

@@ -196,10 +196,12 @@ class GradReducer:
             s, e = self.bounds[b]
             cur = torch.cuda.current_stream() if self.flat.is_cuda else None
             c = _comm_for(self.group)
+            from . import functional
+            others = [st for st in list(self.streams) + list(functional.SIDE_STREAMS) if st != cur]
             if c is not None:                        # the comm stream forks from every stream that carried contributions
-                c.all_reduce_async_(self.flat[s:e], producers=[cur] + [st for st in self.streams if st != cur])
+                c.all_reduce_async_(self.flat[s:e], producers=[cur] + others)
                 return
-            for st in self.streams:                  # contributions may have been enqueued on another view's stream
+            for st in others:                        # contributions may have been enqueued on another view's stream
                 if cur is not None and st != cur:
                     cur.wait_stream(st)
             self.works.append(dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
