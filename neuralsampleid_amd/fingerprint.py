@@ -24,6 +24,9 @@ def extract_fingerprints(model, specs: torch.Tensor, batch: int = 1024, out: tor
     The model is run in eval mode (restored afterwards)."""
     was_training = model.training
     model.eval()
+    from . import functional, ops
+    if functional.ACT_DTYPE == torch.bfloat16:
+        ops.register_weight_shadows(model)          # bf16 copies of the weights, converted once (version-checked)
     try:
         S = specs.shape[0]
         d = model.projector[-1].out_features

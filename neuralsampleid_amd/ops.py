@@ -162,6 +162,17 @@ class WeightShadows:
 SHADOWS = WeightShadows()
 
 
+def register_weight_shadows(module) -> int:
+    """Give every not-yet-registered GEMM weight of `module` a persistent bf16 shadow (inference: no optimiser keeps one).
+    Shadows follow torch-side weight changes through the version check. Returns the number of new shadows."""
+    n = 0
+    for p in module.parameters():
+        if p.is_cuda and p.dim() >= 2 and p.numel() % 8 == 0 and p.data_ptr() not in SHADOWS.entries:
+            SHADOWS.register(p.data, torch.empty(p.numel(), device=p.device, dtype=torch.bfloat16), owner=p)
+            n += 1
+    return n
+
+
 def f32_to_bf16(src: torch.Tensor, dst: Optional[torch.Tensor] = None) -> torch.Tensor:
     _chk(src)
     n = src.numel()
