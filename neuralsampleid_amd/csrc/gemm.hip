@@ -660,6 +660,13 @@ extern "C" int nsid_linear_bwd_weight(const void* dout, int ldd, const void* x, 
   // atomics that all XCDs resolve memory-side (~1.3 TB/s chip-wide), so the bytes of atomics = workgroups x tile bytes
   // decide the kernel: 64x64 tiles (16 KB) beat 128x128 (64 KB) at every shape of the encoder once >= 256 workgroups
   // are in flight. Splits: >= 1024 rows each, at most ~1024 workgroups, at least ~256.
+  static const bool use_wide = getenv("NSID_WGRAD_V1") == nullptr;
+  if (use_wide && act_dtype == NSID_BF16 && nsid_aligned16(dout) && nsid_aligned16(x) &&
+      (in_scale == nullptr || (nsid_aligned16(in_scale) && nsid_aligned16(in_shift)))) {
+    const int rc = nsid_wgrad2_launch(dout, ldd, x, ldx, dw, M, Nout, K, groups, in_scale, in_shift, act_slope(act_in),
+                                      static_cast<hipStream_t>(stream));
+    if (rc != 1) return rc;                  // 1 = shape outside the fast form's preconditions
+  }
   // fp32 arithmetic (16x lower matrix rate) stays MFMA-bound: there the larger tile wins whenever it fills the chip.
   const bool half = g_gemm_precision == NSID_GEMM_BF16 || act_dtype == NSID_BF16;
   const long t128 = (long)((Nout + 127) / 128) * ((K + 127) / 128) * groups;

@@ -125,3 +125,7 @@ static inline bool nsid_aligned16(const void* p) { return (reinterpret_cast<uint
   do {                     \
     if (!(cond)) return NSID_EINVAL; \
   } while (0)
+
+// wgrad.hip: 128x128-tile form of the bf16 weight-gradient GEMM; returns 1 when the shape is outside its preconditions
+int nsid_wgrad2_launch(const void* dout, int ldd, const void* x, int ldx, float* dw, int M, int Nout, int K, int groups,
+                       const float* in_scale, const float* in_shift, float slope, hipStream_t stream);

@@ -273,6 +273,8 @@ def _linear_bwd_weight(dout, x, dw, M, Nout, K, groups=1, in_scale=None, in_shif
     half = dt == BF16 or lib.nsid_get_gemm_precision() == GEMM_BF16
     small = half or Nout <= 64 or K <= 64 or t128 * ((M + 511) // 512) < 256
     name = "gemm_kernel<%s,false,false>" % ("64,64" if small else "128,128")
+    if dt == BF16 and Nout % 128 == 0 and K % 128 == 0 and M % 128 == 0 and (Nout // 128) * (K // 128) * groups >= 64:
+        name = "wgrad3_kernel"              # csrc/wgrad.hip: 128x128 tiles, 8 waves
     esz = x.element_size()
     _timed(name, 2.0 * M * Nout * K * groups, groups * (esz * M * Nout + esz * M * K + 4.0 * Nout * K), lambda: call(
         "nsid_linear_bwd_weight", _p(dout), dout.shape[-1], _p(x), x.shape[-1], _p(dw), M, Nout, K, groups,
