@@ -71,9 +71,21 @@ def infer_bench(args, model, rank, world, dev, dist):
     from neuralsampleid_amd import fingerprint
     lo, hi = fingerprint.shard_bounds(args.clips, rank, world)
     mb = 1024
-    pool, _ = synth_clips(4 * mb, 77 + rank, dev)                 # synthetic clips, reused round-robin
     n_mb = (hi - lo + mb - 1) // mb
     out = torch.empty((mb, CFG["d"]), device=dev)
+    front, waves = None, None
+    if args.from_wave:                                            # 4 waveforms of exactly `mb` segments each
+        from neuralsampleid_amd.frontend import LogMelFrontEnd
+        fcfg = {"fs": 16000, "n_fft": 1024, "win_len": 1024, "hop_len": 512, "n_mels": CFG["n_mels"],
+                "n_frames": CFG["n_frames"], "overlap": 0.875}
+        front = LogMelFrontEnd(fcfg, dev)
+        frames = (mb - 1) * front.step + CFG["n_frames"]
+        g = torch.Generator().manual_seed(99 + rank)
+        waves = [(0.1 * torch.randn((frames - 1) * 512 + 8, generator=g)).to(dev) for _ in range(4)]
+        pool = torch.cat([front(w) for w in waves])
+        assert pool.shape[0] == 4 * mb
+    else:
+        pool, _ = synth_clips(4 * mb, 77 + rank, dev)             # synthetic clips, reused round-robin
     for i in range(max(1, args.warmup)):
         fingerprint.extract_fingerprints(model, pool[:mb], mb, out)
     torch.cuda.synchronize()
@@ -84,6 +96,11 @@ def infer_bench(args, model, rank, world, dev, dist):
     for i in range(n_mb):
         n = min(mb, hi - lo - done)
         s = (i % 4) * mb
+        if front is not None:                                     # waveform -> log-mel segments inside the timed region
+            segs = front(waves[i % 4])
+            fingerprint.extract_fingerprints(model, segs[:n], mb, out[:n])
+            done += n
+            continue
         fingerprint.extract_fingerprints(model, pool[s:s + n], mb, out[:n])
         done += n
     torch.cuda.synchronize()
@@ -101,7 +118,9 @@ def infer_bench(args, model, rank, world, dev, dist):
             "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / n_mb, 3), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f32" if args.precision == "fp32" else "bf16",
             "data": "synthetic",
-            "config": {"workload": f"fingerprint inference, {args.clips} synthetic clips, eval-mode BN, micro-batch {mb}, "
+            "config": {"workload": f"fingerprint inference, {args.clips} synthetic clips"
+                                   f"{' from 16 kHz waveforms (log-mel front end on the GPU)' if args.from_wave else ''}"
+                                   f", eval-mode BN, micro-batch {mb}, "
                                    f"GraphEncoder('t', k={args.k}{', deep' if args.deep else ''})",
                        "parallelism": f"shard{world}"}}))
     if world > 1:
@@ -149,6 +168,8 @@ def main():
                     help="train: contrastive step (BASELINE config 2/3, default); infer: forward-only fingerprint "
                          "extraction in eval mode (config 5), --clips per job sharded over the ranks")
     ap.add_argument("--clips", type=int, default=100000, help="infer mode: total clips of the job")
+    ap.add_argument("--from-wave", action="store_true",
+                    help="infer mode: start from synthetic 16 kHz waveforms (log-mel front end on the GPU, SURVEY 8f-4)")
     ap.add_argument("--deep", action="store_true",
                     help="BASELINE config 4: blocks [4,4,12,4], k=18, intended dilation schedule (capped by N)")
     ap.add_argument("--no-overlap", action="store_true", help="run the two views on one stream instead of two")

@@ -148,6 +148,16 @@ int nsid_l2norm_fwd(const float* p, int B, int d, float eps, float* z, float* no
 int nsid_l2norm_bwd(const float* dz, const float* z, const float* norm, int B, int d, float eps, float* dp,
                     void* stream);
 
+/* ---- log-mel front end (modules/transformations.py:27-34 MelSpectrogram + AmplitudeToDB, :94-105 unfold) -------
+ * waveform -> reflect pad (n_fft/2 each side, torch.stft center=True) -> STFT as a fp32 GEMM through nsid_linear_fwd
+ * (x = padded waveform with ldx = hop: overlapping frames; w = [window*cos ; -window*sin] rows, (2*n_freq) x n_fft) ->
+ * power, HTK-mel filterbank (fb dense [n_mels][n_freq], band[m] = [first, last+1) non-zero bins), 10*log10(max(.,1e-10))
+ * -> logmel (n_mels, T) -> segments (S, n_mels, n_frames) with hop `step` frames. */
+int nsid_reflect_pad(const float* x, long L, int pad, float* out, void* stream);
+int nsid_power_mel_db(const float* spec, long ld, int n_freq, const float* fb, const int* band, int n_mels, int T,
+                      float* out, void* stream);
+int nsid_unfold_segments(const float* logmel, int n_mels, int T, int n_frames, int step, int S, float* out, void* stream);
+
 /* bf16 shadow of fp32 weights: dst[i] = bf16_rne(src[i]), n % 8 == 0, both 16-byte aligned (operand `w` of
  * nsid_linear_fwd / nsid_linear_bwd_data with w_dtype = NSID_BF16). */
 int nsid_f32_to_bf16(const float* src, void* dst, long n, void* stream);

@@ -42,6 +42,9 @@ SIGNATURES = {
     "nsid_sumsq_partial": "plps",
     "nsid_adam_step": "pppplpppips",
     "nsid_f32_to_bf16": "ppls",
+    "nsid_reflect_pad": "plips",
+    "nsid_power_mel_db": "plippiips",
+    "nsid_unfold_segments": "piiiiips",
     "nsid_bcn_to_rows": "piiipiis",
     "nsid_rows_to_bcn": "piiiipis",
 }

@@ -575,7 +575,8 @@ extern "C" int nsid_linear_fwd(const void* x, int ldx, const void* w, int w_dtyp
   const int ch = act_dtype == NSID_BF16 ? 8 : 4;     // elements per 16-byte chunk of the activation tensors
   NSID_REQUIRE(K % ch == 0 && ldx % ch == 0 && nsid_aligned16(x) && nsid_aligned16(w) && K % 4 == 0);
   NSID_REQUIRE(act_dtype == NSID_F32 || (ksplit == 1 && act_out == NSID_ACT_NONE && Nout % 8 == 0 && ldo % 8 == 0));
-  NSID_REQUIRE(ldx >= groups * K && ldo >= groups * Nout);
+  // ldx < K (overlapping rows of x, read-only) is allowed for one group: the STFT front end frames a waveform that way
+  NSID_REQUIRE((ldx >= groups * K || (groups == 1 && ldx > 0)) && ldo >= groups * Nout);
   NSID_REQUIRE(Nout % 4 == 0 && ldo % 4 == 0 && nsid_aligned16(out) && (bias == nullptr || nsid_aligned16(bias)));
   NSID_REQUIRE((in_scale == nullptr) == (in_shift == nullptr));
   NSID_REQUIRE(ksplit == 1 || (stat == nullptr && act_out == NSID_ACT_NONE));

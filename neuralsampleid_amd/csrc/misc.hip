@@ -546,6 +546,73 @@ extern "C" int nsid_adam_step(float* p, const float* g, float* m, float* v, long
   return nsid_launch_status();
 }
 
+// ------------------------------------------------------------------ log-mel front end (modules/transformations.py:27-34,
+// :94-105 = torchaudio MelSpectrogram(n_fft, win_length, hop, n_mels; center=True reflect, Hann periodic, power 2, HTK mel,
+// norm None) + AmplitudeToDB(power, top_db None) + unfold(size=n_frames, step=n_frames*(1-overlap)))
+// The STFT itself is a fp32 MFMA GEMM: frames (row stride = hop, overlapping) x [window*cos | -window*sin] (nsid_linear_fwd).
+__global__ void reflect_pad_kernel(const float* __restrict__ x, long L, int pad, float* __restrict__ out) {
+  const long n = L + 2L * pad;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    long j = i - pad;
+    if (j < 0) j = -j;                           // torch 'reflect': no edge repeat
+    if (j >= L) j = 2 * (L - 1) - j;
+    out[i] = x[j];
+  }
+}
+
+// one block per frame: power spectrum of the frame into LDS, then one thread per mel band sums its (contiguous) non-zero
+// filter range; out is (n_mels, T) like torchaudio
+__global__ __launch_bounds__(256) void power_mel_db_kernel(const float* __restrict__ spec, long ld, int n_freq,
+                                                           const float* __restrict__ fb, const int* __restrict__ band,
+                                                           int n_mels, int T, float* __restrict__ out) {
+  extern __shared__ float pw[];                  // [n_freq]
+  const int t = blockIdx.x;
+  const float* row = spec + (long)t * ld;
+  for (int f = threadIdx.x; f < n_freq; f += blockDim.x) {
+    const float re = row[f], im = row[n_freq + f];
+    pw[f] = re * re + im * im;
+  }
+  __syncthreads();
+  for (int m = threadIdx.x; m < n_mels; m += blockDim.x) {
+    float acc = 0.f;
+    for (int f = band[2 * m]; f < band[2 * m + 1]; ++f) acc += fb[(long)m * n_freq + f] * pw[f];
+    out[(long)m * T + t] = 10.0f * log10f(fmaxf(acc, 1e-10f));          // AmplitudeToDB: amin 1e-10, ref 1.0
+  }
+}
+
+// (n_mels, T) -> (S, n_mels, n_frames): segment s covers frames [s*step, s*step + n_frames)
+__global__ void unfold_segments_kernel(const float* __restrict__ lm, int n_mels, int T, int n_frames, int step, int S,
+                                       float* __restrict__ out) {
+  const long n = (long)S * n_mels * n_frames;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int f = (int)(i % n_frames), m = (int)((i / n_frames) % n_mels);
+    const long s = i / ((long)n_frames * n_mels);
+    out[i] = lm[(long)m * T + s * step + f];
+  }
+}
+
+extern "C" int nsid_reflect_pad(const float* x, long L, int pad, float* out, void* stream) {
+  NSID_REQUIRE(x && out && L > 1 && pad >= 0 && pad < L);
+  NSID_LAUNCH(reflect_pad_kernel, dim3(grid_for(L + 2L * pad)), dim3(256), 0, static_cast<hipStream_t>(stream), x, L, pad,
+              out);
+  return nsid_launch_status();
+}
+extern "C" int nsid_power_mel_db(const float* spec, long ld, int n_freq, const float* fb, const int* band, int n_mels,
+                                 int T, float* out, void* stream) {
+  NSID_REQUIRE(spec && fb && band && out && n_freq > 0 && n_mels > 0 && T > 0 && ld >= 2L * n_freq);
+  NSID_REQUIRE((size_t)n_freq * sizeof(float) <= 48 * 1024);
+  NSID_LAUNCH(power_mel_db_kernel, dim3(T), dim3(256), (size_t)n_freq * sizeof(float), static_cast<hipStream_t>(stream),
+              spec, ld, n_freq, fb, band, n_mels, T, out);
+  return nsid_launch_status();
+}
+extern "C" int nsid_unfold_segments(const float* logmel, int n_mels, int T, int n_frames, int step, int S, float* out,
+                                    void* stream) {
+  NSID_REQUIRE(logmel && out && n_mels > 0 && n_frames > 0 && step > 0 && S > 0 && (long)(S - 1) * step + n_frames <= T);
+  NSID_LAUNCH(unfold_segments_kernel, dim3(grid_for((long)S * n_mels * n_frames)), dim3(256), 0,
+              static_cast<hipStream_t>(stream), logmel, n_mels, T, n_frames, step, S, out);
+  return nsid_launch_status();
+}
+
 // bf16 shadow copy of weights (RNE, the rounding the GEMMs apply when they stage fp32 weights): n % 8 == 0
 __global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float* __restrict__ src, __bf16* __restrict__ dst, long n8) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {

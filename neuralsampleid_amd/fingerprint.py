@@ -39,3 +39,13 @@ def extract_fingerprints(model, specs: torch.Tensor, batch: int = 1024, out: tor
         return out
     finally:
         model.train(was_training)
+
+
+@torch.no_grad()
+def fingerprints_from_waveform(model, front, wave: torch.Tensor, batch: int = 1024) -> torch.Tensor:
+    """mono fp32 waveform on the GPU -> (S, d) fingerprints: log-mel front end (frontend.LogMelFrontEnd, the reference's
+    MelSpectrogram + AmplitudeToDB + 87.5 %-overlap unfold) fused ahead of the encoder — SURVEY.md §8f-4."""
+    segs = front(wave)
+    if segs.shape[0] == 0:
+        return torch.empty((0, model.projector[-1].out_features), device=wave.device)
+    return extract_fingerprints(model, segs, batch)

@@ -15,7 +15,7 @@ import torch.nn as nn
 
 from conftest import GOLDEN, from_rows, to_rows
 from oracle import ref_torch as R
-from synth import GRAFP_CFG, synth_state, synth_tensor
+from synth import GRAFP_CFG, synth_clips, synth_state, synth_tensor
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
@@ -375,3 +375,27 @@ def test_two_stream_views_equal_sequential(golden):
     assert relerr(res[True][1], res[False][1]) < 1e-3                      # atomics order + kNN near-ties only
     for k, v in res[False][2].items():
         assert maxerr(res[True][2][k], v) < 1e-5, k
+
+
+def test_fingerprint_db_files(tmp_path):
+    """fpdb.build_fp_db: fingerprints from the HIP path land in the reference's DB format (test_fp.py:120-133); two ranks
+    writing their row ranges into the shared memmap give the same file as one rank"""
+    from neuralsampleid_amd import fpdb
+    from neuralsampleid_amd.fingerprint import extract_fingerprints
+    from oracle import ref_fpdb
+    model = build_model(3).eval()
+    x, _ = synth_clips(11)
+    x = x.to(DEV)
+    songs = [("a", x[:4]), ("b", x[4:5]), ("c", x[5:11])]
+    n, d = fpdb.build_fp_db(model, songs, str(tmp_path / "one"), "ref_db", batch=4)
+    ref = extract_fingerprints(model, x, 16).cpu().numpy()
+    data, shape = ref_fpdb.load_memmap_data(str(tmp_path / "one"), "ref_db")      # the reference's reader
+    assert (n, d) == (11, 128) and tuple(shape) == (11, 128)
+    assert np.abs(np.asarray(data) - ref).max() < 1e-5
+    assert fpdb.load_lookup(str(tmp_path / "one"), "ref_db") == ["a"] * 4 + ["b"] + ["c"] * 6
+    for r in range(2):
+        fpdb.build_fp_db(model, songs, str(tmp_path / "two"), "query_db", query_style=True, batch=4, rank=r, world=2,
+                         barrier=lambda: None)
+    data2, _ = ref_fpdb.load_memmap_data(str(tmp_path / "two"), "query_db")
+    assert np.abs(np.asarray(data2) - ref).max() < 1e-5
+    assert fpdb.load_lookup(str(tmp_path / "two"), "query_db")[4] == "b_1"
