@@ -9,8 +9,8 @@
 
 namespace {
 
-constexpr int RB = 64;   // rows i per workgroup (16 per wave)
-constexpr int CBK = 32;  // rows j per staged column block
+constexpr int RB = 16;   // rows i per workgroup (one MFMA row tile, shared by the 4 waves)
+constexpr int CBK = 128; // rows j per staged column block (64 KB of LDS: one staging latency + two barriers per 128 columns)
 
 __device__ __forceinline__ const float* zrow(const float* z_i, const float* z_j, int row, int d) {
   return ((row & 1) ? z_j : z_i) + (long)(row >> 1) * d;
@@ -19,27 +19,51 @@ __device__ __forceinline__ const float* zrow(const float* z_i, const float* z_j,
 __device__ __forceinline__ void stage_rows(float* dst, int ld, const float* z_i, const float* z_j, int row0, int nrows,
                                            int M, int d) {
   const int d4 = d >> 2;
-  for (int q = threadIdx.x; q < nrows * d4; q += blockDim.x) {
-    const int rr = q / d4, c = (q % d4) * 4;
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (row0 + rr < M) v = *reinterpret_cast<const f32x4*>(zrow(z_i, z_j, row0 + rr, d) + c);
-    *reinterpret_cast<f32x4*>(dst + rr * ld + c) = v;
+  constexpr int UB = 8;          // all loads of a batch are issued before the first LDS store (the plain loop was one
+  //                                global round trip per iteration: 16 serial trips per 128-row block)
+  for (int q0 = threadIdx.x; q0 < nrows * d4; q0 += UB * blockDim.x) {
+    f32x4 v[UB];
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+      const int q = q0 + u * blockDim.x;
+      const int rr = q / d4, c = (q % d4) * 4;
+      v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (q < nrows * d4 && row0 + rr < M) v[u] = *reinterpret_cast<const f32x4*>(zrow(z_i, z_j, row0 + rr, d) + c);
+    }
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+      const int q = q0 + u * blockDim.x;
+      const int rr = q / d4, c = (q % d4) * 4;
+      if (q < nrows * d4) *reinterpret_cast<f32x4*>(dst + rr * ld + c) = v[u];
+    }
   }
 }
 
-// T tile for this wave's 16 rows i against 16 column rows j: acc[reg] = z_{j=4*rq+reg} . z_{i=lr}
-__device__ __forceinline__ f32x4 sim_tile(const float* zi_w, const float* zj_t, int ld, int d, int lr, int rq) {
-  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  const float* pa = zj_t + lr * ld + 4 * rq;     // A: row j = lr
+// NT T-tiles at once (column rows j .. j+16*NT-1): independent accumulator chains keep the matrix pipe issuing
+template <int NT>
+__device__ __forceinline__ void sim_tiles(const float* zi_w, const float* zj_t, int ld, int d, int lr, int rq,
+                                          f32x4 (&acc)[NT]) {
+#pragma unroll
+  for (int u = 0; u < NT; ++u) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const float* pa = zj_t + lr * ld + 4 * rq;     // A: row j = lr of tile u
   const float* pb = zi_w + lr * ld + 4 * rq;     // B: column i = lr
   for (int ch = 0; ch < d; ch += 16) {
-    const f32x4 fa = *reinterpret_cast<const f32x4*>(pa + ch);
     const f32x4 fb = *reinterpret_cast<const f32x4*>(pb + ch);
+    f32x4 fa[NT];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[e], fb[e], acc, 0, 0, 0);
+    for (int u = 0; u < NT; ++u) fa[u] = *reinterpret_cast<const f32x4*>(pa + u * 16 * ld + ch);
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int u = 0; u < NT; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[u][e], fb[e], acc[u], 0, 0, 0);
   }
-  return acc;
 }
+
+// Work decomposition of both passes: a workgroup owns ONE 16-row tile (RB rows i); its 4 waves split every staged block of
+// CBK column rows j into quarters (CBK/64 tiles each), so the exp/log work of a row tile — the long pole of these kernels
+// (dependent VALU chains, one wave per SIMD) — is spread over 4x the waves and 4x the CUs of the 64-row form, and the
+// global batch of the 8-GPU run (M = 4096 rows on every rank) gets 256 workgroups. The partial results of the 4 waves
+// meet in LDS at the end.
 
 // pass 1: lse[i] = logsumexp_{j != i} a_ij and rowloss[i] = lse[i] - a_{i, i^1}, for every row i < M
 __global__ __launch_bounds__(256) void ntxent_lse_kernel(const float* __restrict__ z_i, const float* __restrict__ z_j,
@@ -49,22 +73,25 @@ __global__ __launch_bounds__(256) void ntxent_lse_kernel(const float* __restrict
   const int ld = d + 4;
   float* zi_s = sm;                 // [RB][ld]
   float* zj_s = sm + RB * ld;       // [CBK][ld]
+  float* part = zj_s + CBK * ld;    // [4 waves][3][16]
   const int i0 = blockIdx.x * RB;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lr = lane & 15, rq = lane >> 4;
   stage_rows(zi_s, ld, z_i, z_j, i0, RB, M, d);
-  const int i = i0 + 16 * wave + lr;
+  const int i = i0 + lr;
   float mrun = -__builtin_inff(), srun = 0.f, pos = 0.f;
+  constexpr int TPW = CBK / 16 / 4;                   // column tiles per wave per block
   for (int j0 = 0; j0 < M; j0 += CBK) {
     __syncthreads();
     stage_rows(zj_s, ld, z_i, z_j, j0, CBK, M, d);
     __syncthreads();
+    f32x4 acc[TPW];
+    sim_tiles<TPW>(zi_s, zj_s + 16 * (wave * TPW) * ld, ld, d, lr, rq, acc);
 #pragma unroll
-    for (int jt = 0; jt < CBK / 16; ++jt) {
-      const f32x4 acc = sim_tile(zi_s + 16 * wave * ld, zj_s + 16 * jt * ld, ld, d, lr, rq);
+    for (int u = 0; u < TPW; ++u) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const int j = j0 + 16 * jt + 4 * rq + e;
-        const float a = acc[e] / tau;
+        const int j = j0 + 16 * (wave * TPW + u) + 4 * rq + e;
+        const float a = acc[u][e] / tau;
         if (j < M && j != i) {
           if (j == (i ^ 1)) pos = a;
           const float mn = fmaxf(mrun, a);
@@ -74,7 +101,7 @@ __global__ __launch_bounds__(256) void ntxent_lse_kernel(const float* __restrict
       }
     }
   }
-  // merge the four lanes (rq = 0..3) that share row i
+  // merge the four lanes (rq = 0..3) that share row i, then the four waves
 #pragma unroll
   for (int o = 16; o <= 32; o <<= 1) {
     const float m2 = __shfl_xor(mrun, o, 64), s2 = __shfl_xor(srun, o, 64), p2 = __shfl_xor(pos, o, 64);
@@ -85,10 +112,23 @@ __global__ __launch_bounds__(256) void ntxent_lse_kernel(const float* __restrict
     mrun = mn;
     pos += p2;
   }
-  if (rq == 0 && i < M) {
-    const float l = mrun + logf(srun);
-    lse[i] = l;
-    rowloss[i] = l - pos;
+  if (rq == 0) { part[(wave * 3 + 0) * 16 + lr] = mrun; part[(wave * 3 + 1) * 16 + lr] = srun; part[(wave * 3 + 2) * 16 + lr] = pos; }
+  __syncthreads();
+  if (threadIdx.x < 16 && i0 + (int)threadIdx.x < M) {
+    float m = -__builtin_inff(), sacc = 0.f, p = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const float m2 = part[(w * 3 + 0) * 16 + threadIdx.x], s2 = part[(w * 3 + 1) * 16 + threadIdx.x];
+      const float mn = fmaxf(m, m2);
+      const float e1 = m == -__builtin_inff() ? 0.f : expf(m - mn);
+      const float e2 = m2 == -__builtin_inff() ? 0.f : expf(m2 - mn);
+      sacc = sacc * e1 + s2 * e2;
+      m = mn;
+      p += part[(w * 3 + 2) * 16 + threadIdx.x];
+    }
+    const float l = m + logf(sacc);
+    lse[i0 + threadIdx.x] = l;
+    rowloss[i0 + threadIdx.x] = l - p;
   }
 }
 
@@ -101,30 +141,33 @@ __global__ __launch_bounds__(256) void ntxent_grad_kernel(const float* __restric
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int ld = d + 4;
   float* zi_s = sm;
-  float* zj_s = sm + RB * ld;
+  float* zj_s = sm + RB * ld;       // also the [4 waves][16][ld] reduction scratch of the epilogue (CBK >= 64)
   const int i0 = row0 + blockIdx.x * RB;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lr = lane & 15, rq = lane >> 4;
   stage_rows(zi_s, ld, z_i, z_j, i0, RB, M, d);
-  const int i = i0 + 16 * wave + lr;
+  const int i = i0 + lr;
   const bool iok = i < row0 + nrows && i < M;
   const float lse_i = iok ? lse[i] : 0.f;
   f32x4 out[DT];
 #pragma unroll
   for (int c = 0; c < DT; ++c) out[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+  constexpr int TPW = CBK / 16 / 4;
   for (int j0 = 0; j0 < M; j0 += CBK) {
     __syncthreads();
     stage_rows(zj_s, ld, z_i, z_j, j0, CBK, M, d);
     __syncthreads();
+    f32x4 acc[TPW];
+    sim_tiles<TPW>(zi_s, zj_s + 16 * (wave * TPW) * ld, ld, d, lr, rq, acc);
 #pragma unroll
-    for (int jt = 0; jt < CBK / 16; ++jt) {
-      const f32x4 acc = sim_tile(zi_s + 16 * wave * ld, zj_s + 16 * jt * ld, ld, d, lr, rq);
+    for (int u = 0; u < TPW; ++u) {
+      const int jt = wave * TPW + u;
       f32x4 q;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int j = j0 + 16 * jt + 4 * rq + e;
         float v = 0.f;
         if (iok && j < M && j != i) {
-          const float a = acc[e] / tau;
+          const float a = acc[u][e] / tau;
           v = expf(a - lse_i) + expf(a - lse[j]);
           if (j == (i ^ 1)) v -= 2.f;
         }
@@ -139,15 +182,23 @@ __global__ __launch_bounds__(256) void ntxent_grad_kernel(const float* __restric
           out[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(q[e], zb[e * ld + 16 * c], out[c], 0, 0, 0);
     }
   }
+  // the 4 waves hold partial sums over disjoint column sets: add them through LDS.
   // C/D layout of out[c]: column = feature 16*c + lr, row = local row 4*rq + reg
+  __syncthreads();
+  float* red = zj_s;                                       // [4][16][ld]
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+#pragma unroll
+    for (int c = 0; c < DT; ++c) red[(wave * 16 + 4 * rq + e) * ld + 16 * c + lr] = out[c][e];
+  __syncthreads();
   const float sc = 1.f / ((float)M * tau);
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const int row = i0 + 16 * wave + 4 * rq + e;
+  for (int q = threadIdx.x; q < RB * d; q += blockDim.x) {
+    const int rr = q / d, c = q % d;
+    const int row = i0 + rr;
     if (row < row0 + nrows && row < M) {
+      const float v = (red[rr * ld + c] + red[(16 + rr) * ld + c]) + (red[(32 + rr) * ld + c] + red[(48 + rr) * ld + c]);
       float* dst = ((row & 1) ? dz_j : dz_i) + (long)((row >> 1) - (row0 >> 1)) * d;
-#pragma unroll
-      for (int c = 0; c < DT; ++c) dst[16 * c + lr] = out[c][e] * sc;
+      dst[c] = v * sc;
     }
   }
 }
@@ -183,7 +234,7 @@ extern "C" int nsid_ntxent_fwd_bwd(const float* z_i, const float* z_j, int Bg, i
   float* lse = ws;
   float* rowloss = ws + M;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  const size_t bytes = (size_t)(RB + CBK) * (d + 4) * sizeof(float);
+  const size_t bytes = ((size_t)(RB + CBK) * (d + 4) + 4 * 3 * 16) * sizeof(float);
   if (raise_lds(ntxent_lse_kernel, bytes) != NSID_OK) return NSID_ELAUNCH;
   NSID_LAUNCH(ntxent_lse_kernel, dim3((M + RB - 1) / RB), dim3(256), bytes, s, z_i, z_j, M, d, tau, lse,
                      rowloss);
