@@ -234,20 +234,33 @@ __global__ __launch_bounds__(KNN2_THREADS) void knn2_kernel(const T* __restrict_
   constexpr int NV = Chunk<T>::N;
   const int CV = C / NV;
 
-  // ---- phase 1a: y = scale*r + shift into LDS as fp32
-  for (int q = t; q < N * CV; q += KNN2_THREADS) {
-    const int n = q / CV, c = (q % CV) * NV;
-    float v[NV];
-    Chunk<T>::load(src + (long)n * ldr + c, v);
-    if (scale != nullptr) {
-      float sc[NV], sh[NV];
-      load_channels<NV>(scale, c, sc);
-      load_channels<NV>(shift, c, sh);
+  // ---- phase 1a: y = scale*r + shift into LDS as fp32; the loads of a batch are all issued before the first use (a clip
+  // is 4 chunks per thread at bf16: as a plain loop that was 4 serial HBM round trips at one workgroup per CU)
+  constexpr int UB = 4;
+  for (int q0 = t; q0 < N * CV; q0 += UB * KNN2_THREADS) {
+    float v[UB][NV];
 #pragma unroll
-      for (int e = 0; e < NV; ++e) v[e] = sc[e] * v[e] + sh[e];
+    for (int u = 0; u < UB; ++u) {
+      const int q = q0 + u * KNN2_THREADS;
+      if (q < N * CV) Chunk<T>::load(src + (long)(q / CV) * ldr + (q % CV) * NV, v[u]);
     }
 #pragma unroll
-    for (int e = 0; e < NV; e += 4) *reinterpret_cast<f32x4*>(yn + n * LD + c + e) = f32x4{v[e], v[e + 1], v[e + 2], v[e + 3]};
+    for (int u = 0; u < UB; ++u) {
+      const int q = q0 + u * KNN2_THREADS;
+      if (q < N * CV) {
+        const int n = q / CV, c = (q % CV) * NV;
+        if (scale != nullptr) {
+          float sc[NV], sh[NV];
+          load_channels<NV>(scale, c, sc);
+          load_channels<NV>(shift, c, sh);
+#pragma unroll
+          for (int e = 0; e < NV; ++e) v[u][e] = sc[e] * v[u][e] + sh[e];
+        }
+#pragma unroll
+        for (int e = 0; e < NV; e += 4)
+          *reinterpret_cast<f32x4*>(yn + n * LD + c + e) = f32x4{v[u][e], v[u][e + 1], v[u][e + 2], v[u][e + 3]};
+      }
+    }
   }
   __syncthreads();
   // ---- phase 1b: F.normalize(p=2, dim=channels, eps=1e-12) and |y^|^2 of the normalised rows; a row is handled by

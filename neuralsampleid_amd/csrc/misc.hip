@@ -172,6 +172,7 @@ __global__ __launch_bounds__(256) void patchify_bwd_kernel(const float* __restri
   const int Hp = H / pb, Wp = W / pf, NP = Hp * Wp;
   const int per_f = 3 * pb * pf, LDW = W + PATCH_PAD;
   float* xs = sm + NP * F;
+  float* red = xs + H * LDW;                                   // [(Wp + Hp)][F] partial sums of g
   // A workgroup walks clips b, b + grid, ... with its sums in registers: one atomic per workgroup and output
   constexpr int MAXQ = 4;                                      // outputs per thread: F*per_f <= 4*256
   float wacc[MAXQ] = {0.f, 0.f, 0.f, 0.f}, bacc = 0.f;
@@ -219,32 +220,42 @@ __global__ __launch_bounds__(256) void patchify_bwd_kernel(const float* __restri
       }
     }
     __syncthreads();
+    // the two ramp planes depend on the patch column (time ramp) or row (frequency ramp) only: reduce g over the other
+    // patch index first (Wp*F + Hp*F sums), so only the spectrogram plane walks all NP patches
+    for (int q = t; q < (Wp + Hp) * F; q += blockDim.x) {
+      const int f = q % F, k2 = q / F;
+      float a = 0.f;
+      if (k2 < Wp) { for (int ph = 0; ph < Hp; ++ph) a += sm[(ph * Wp + k2) * F + f]; }
+      else { for (int pw = 0; pw < Wp; ++pw) a += sm[((k2 - Wp) * Wp + pw) * F + f]; }
+      red[q] = a;                                              // [Wp][F] column sums, then [Hp][F] row sums
+    }
+    __syncthreads();
 #pragma unroll
     for (int u = 0; u < MAXQ; ++u) {
       const int q = t + u * 256;
       if (q < F * per_f) {
         const int f = q / per_f, rem = q % per_f;
         const int c = rem / (pb * pf), i = (rem / pf) % pb, j = rem % pf;
-        // one partial sum per patch COLUMN group (pw % UB): independent LDS chains instead of one 256-long chain, and
-        // no division in the loops
-        constexpr int UB = 4;
-        float part[UB] = {0.f, 0.f, 0.f, 0.f};
-        for (int ph = 0; ph < Hp; ++ph) {
-          const float lh = linspace01(ph * pb + i, H);
-          const float* srow = sm + (ph * Wp) * F + f;
-          const float* xrow = xs + (ph * pb + i) * LDW + j;
-          for (int pw0 = 0; pw0 < Wp; pw0 += UB) {
+        float acc = 0.f;
+        if (c == 0) {
+          for (int pw = 0; pw < Wp; ++pw) acc += red[pw * F + f] * linspace01(pw * pf + j, W);
+        } else if (c == 1) {
+          for (int ph = 0; ph < Hp; ++ph) acc += red[(Wp + ph) * F + f] * linspace01(ph * pb + i, H);
+        } else {
+          constexpr int UB = 4;                                // independent LDS chains, no division in the loops
+          float part[UB] = {0.f, 0.f, 0.f, 0.f};
+          for (int ph = 0; ph < Hp; ++ph) {
+            const float* srow = sm + (ph * Wp) * F + f;
+            const float* xrow = xs + (ph * pb + i) * LDW + j;
+            for (int pw0 = 0; pw0 < Wp; pw0 += UB) {
 #pragma unroll
-            for (int v = 0; v < UB; ++v) {
-              const int pw = pw0 + v;
-              if (pw < Wp) {
-                const float img = c == 2 ? xrow[pw * pf] : (c == 0 ? linspace01(pw * pf + j, W) : lh);
-                part[v] += srow[pw * F] * img;
-              }
+              for (int v = 0; v < UB; ++v)
+                if (pw0 + v < Wp) part[v] += srow[(pw0 + v) * F] * xrow[(pw0 + v) * pf];
             }
           }
+          acc = (part[0] + part[1]) + (part[2] + part[3]);
         }
-        wacc[u] += (part[0] + part[1]) + (part[2] + part[3]);
+        wacc[u] += acc;
       }
     }
     if (t < F) {
@@ -478,7 +489,7 @@ extern "C" int nsid_peak_patchify_bwd(const float* spec, const float* minmax, co
                                       int out_dtype, void* stream) {
   NSID_REQUIRE(spec && minmax && out && dout && dw && dbias && B > 0 && H % pb == 0 && W % pf == 0 && ldo >= F);
   NSID_REQUIRE(NSID_DTYPE_OK(out_dtype));
-  const size_t bytes = ((size_t)(H / pb) * (W / pf) * F + (size_t)H * (W + 8)) * sizeof(float);
+  const size_t bytes = ((size_t)(H / pb) * (W / pf) * F + (size_t)H * (W + 8) + (size_t)(H / pb + W / pf) * F) * sizeof(float);
   NSID_REQUIRE(bytes <= 64 * 1024 && (long)F * 3 * pb * pf <= 4 * 256 && F <= 256 && W % 4 == 0 && nsid_aligned16(spec));
   NSID_REQUIRE(((H / pb) * (W / pf) * F) % 4 == 0);
   NSID_DISPATCH_DTYPE(out_dtype, T, {
