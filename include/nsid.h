@@ -71,6 +71,14 @@ int nsid_linear_fwd(const void* x, int ldx, const void* w, int w_dtype, const fl
 int nsid_linear_bwd_data(const void* dout, int ldd, const void* w, int w_dtype, const void* addend, int ldadd,
                          void* din, int ldi, int M, int Nout, int K, int groups,
                          int act_dtype /* dout, addend, din */, void* stream);
+/* backward-data whose output din IS dL/dy of a BatchNorm(+activation) layer y = act(BN(r)), r (M x groups*K, bf16, same
+ * layout as din) being that layer's raw input: additionally writes bn_partial[2][nsid_row_tiles(M)][groups*K], the
+ * per-row-tile column sums of g = din*act'(scale*r+shift) and g*xhat — exactly what nsid_bn_bwd_reduce(din, r, ...) would
+ * produce from the stored din (one launch and two tensor reads less per layer). bf16 storage only, ldi == groups*K. */
+int nsid_linear_bwd_data_bn(const void* dout, int ldd, const void* w, int w_dtype, const void* addend, int ldadd,
+                            void* din, int ldi, int M, int Nout, int K, int groups, int act_dtype, const void* bn_r,
+                            const float* bn_scale, const float* bn_shift, const float* bn_mean, const float* bn_invstd,
+                            int bn_act, float* bn_partial, void* stream);
 /* backward-weight: dw[g*Nout+n, k] += sum_m dout[m, g*Nout+n] * f(x[m, g*K+k])   (f as in forward; atomic) */
 int nsid_linear_bwd_weight(const void* dout, int ldd, const void* x, int ldx, float* dw, int M, int Nout, int K,
                            int groups, const float* in_scale, const float* in_shift, int act_in,

@@ -16,6 +16,7 @@ SIGNATURES = {
     "nsid_set_gemm_precision": "i",
     "nsid_linear_fwd": "pipippiiiiippiipiis",
     "nsid_linear_bwd_data": "pipipipiiiiiis",
+    "nsid_linear_bwd_data_bn": "pipipipiiiiiipppppips",
     "nsid_linear_bwd_weight": "pipipiiiippiis",
     "nsid_colsum_acc": "piiipis",
     "nsid_bn_finalize": "piiipppppffpppps",

@@ -37,6 +37,11 @@ struct GemmArgs {
   int rchunk;     // R elements per split (multiple of 16)
   int atomic_out;
   int split_major;  // grid = (splits, tiles): the tiles of one split share an XCD (blocks b, b+8 share an L2)
+  // backward-data only: the output is dL/dy of a BatchNorm(+activation) layer whose raw input r is given; the epilogue
+  // also emits that layer's backward column sums (what nsid_bn_bwd_reduce would compute from the stored output)
+  const void* bn_r; long bn_ldr;
+  const float* bn_scale; const float* bn_shift; const float* bn_mean; const float* bn_invstd; float bn_slope;
+  float* bn_partial; long bn_plane; long bn_ld;
 };
 
 // Precision H = false: fp32 operands, v_mfma_f32_16x16x4_f32, BK = 16 (exact fp32 — the parity path).
@@ -413,6 +418,21 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {   // >
     for (int e = 0; e < OE; ++e) bq[e] = (has_bias && jqok) ? bias[jq + e] : 0.f;
     char* Cb = reinterpret_cast<char*>(p.C) + g * p.c_goff * OSZ;
     const char* Ab = reinterpret_cast<const char*>(p.addend) + g * p.c_goff * OSZ;
+    // fused BatchNorm-backward column sums (backward-data, bf16 output): g = dy * act'(scale*r+shift), xhat = (r-mean)*invstd
+    constexpr bool CAN_BNRED = A_RMAJOR && !B_RMAJOR && SC;
+    const bool bnred = CAN_BNRED && p.bn_r != nullptr;        // wave-uniform
+    float bsc[OE], bsh[OE], bmu[OE], bis[OE], s0[OE], s1[OE];
+    if (CAN_BNRED) {
+#pragma unroll
+      for (int e = 0; e < OE; ++e) { s0[e] = 0.f; s1[e] = 0.f; bsc[e] = bsh[e] = bmu[e] = bis[e] = 0.f; }
+      if (bnred && jqok) {
+        const long ch = g * p.c_goff + jq;
+        load_channels<OE>(p.bn_scale, (int)ch, bsc);
+        load_channels<OE>(p.bn_shift, (int)ch, bsh);
+        load_channels<OE>(p.bn_mean, (int)ch, bmu);
+        load_channels<OE>(p.bn_invstd, (int)ch, bis);
+      }
+    }
 #pragma unroll
     for (int h = 0; h < TM / 2; ++h) {
 #pragma unroll
@@ -447,9 +467,49 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {   // >
           }
           if (SC) Chunk<__bf16>::store(reinterpret_cast<__bf16*>(Cb) + (long)i * p.ldc + jq, v);
           else Chunk<float>::store(reinterpret_cast<float*>(Cb) + (long)i * p.ldc + jq, v);
+          if (CAN_BNRED) {
+            if (bnred) {
+              float x[OE];
+              Chunk<__bf16>::load(reinterpret_cast<const __bf16*>(p.bn_r) + (long)i * p.bn_ldr + g * p.c_goff + jq, x);
+#pragma unroll
+              for (int e = 0; e < OE; ++e) {
+                const float dy = (float)(__bf16)v[e];          // the value a separate reduce pass would read back
+                const float gg = (bsc[e] * x[e] + bsh[e]) > 0.f ? dy : dy * p.bn_slope;
+                s0[e] += gg;
+                s1[e] += gg * ((x[e] - bmu[e]) * bis[e]);
+              }
+            }
+          }
         }
       }
       __syncthreads();
+    }
+    if (CAN_BNRED) {
+      if (bnred) {                  // uniform; the stage / transpose buffers are free (the loop ended on a barrier)
+        float* red2 = lds;          // [2][4 waves][ROWS_PER_PASS][WN]
+#pragma unroll
+        for (int e = 0; e < OE; ++e) {
+          red2[((0 * 4 + wave) * ROWS_PER_PASS + orow) * WN + oq + e] = s0[e];
+          red2[((1 * 4 + wave) * ROWS_PER_PASS + orow) * WN + oq + e] = s1[e];
+        }
+        __syncthreads();
+        if (threadIdx.x < BN) {
+          const int c = threadIdx.x, half = c / WN, cw = c % WN;
+          const int j = j0 + c;
+          if (FULL || j < p.J) {
+            float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+            for (int wr = 0; wr < 2; ++wr)
+              for (int o = 0; o < ROWS_PER_PASS; ++o) {
+                a0 += red2[((0 * 4 + (2 * wr + half)) * ROWS_PER_PASS + o) * WN + cw];
+                a1 += red2[((1 * 4 + (2 * wr + half)) * ROWS_PER_PASS + o) * WN + cw];
+              }
+            const long col = g * p.c_goff + j;
+            p.bn_partial[(long)ti * p.bn_ld + col] = a0;
+            p.bn_partial[p.bn_plane + (long)ti * p.bn_ld + col] = a1;
+          }
+        }
+      }
     }
     if (p.stat != nullptr) {
       // BatchNorm partial statistics of (acc + bias), from the accumulator registers
@@ -614,9 +674,34 @@ extern "C" int nsid_linear_fwd(const void* x, int ldx, const void* w, int w_dtyp
   return nsid_launch_status();
 }
 
+static int linear_bwd_data_impl(const void* dout, int ldd, const void* w, int w_dtype, const void* addend, int ldadd,
+                                void* din, int ldi, int M, int Nout, int K, int groups, int act_dtype, void* stream,
+                                const void* bn_r, const float* bn_scale, const float* bn_shift, const float* bn_mean,
+                                const float* bn_invstd, int bn_act, float* bn_partial);
+
 extern "C" int nsid_linear_bwd_data(const void* dout, int ldd, const void* w, int w_dtype, const void* addend, int ldadd,
                                     void* din, int ldi, int M, int Nout, int K, int groups, int act_dtype,
                                     void* stream) {
+  return linear_bwd_data_impl(dout, ldd, w, w_dtype, addend, ldadd, din, ldi, M, Nout, K, groups, act_dtype, stream,
+                              nullptr, nullptr, nullptr, nullptr, nullptr, NSID_ACT_NONE, nullptr);
+}
+
+extern "C" int nsid_linear_bwd_data_bn(const void* dout, int ldd, const void* w, int w_dtype, const void* addend,
+                                       int ldadd, void* din, int ldi, int M, int Nout, int K, int groups, int act_dtype,
+                                       const void* bn_r, const float* bn_scale, const float* bn_shift,
+                                       const float* bn_mean, const float* bn_invstd, int bn_act, float* bn_partial,
+                                       void* stream) {
+  NSID_REQUIRE(bn_r && bn_scale && bn_shift && bn_mean && bn_invstd && bn_partial && act_dtype == NSID_BF16);
+  NSID_REQUIRE(ldi == groups * K && (groups * K) % 8 == 0 && nsid_aligned16(bn_r));
+  NSID_REQUIRE(bn_act == NSID_ACT_NONE || bn_act == NSID_ACT_RELU || bn_act == NSID_ACT_LEAKY);
+  return linear_bwd_data_impl(dout, ldd, w, w_dtype, addend, ldadd, din, ldi, M, Nout, K, groups, act_dtype, stream,
+                              bn_r, bn_scale, bn_shift, bn_mean, bn_invstd, bn_act, bn_partial);
+}
+
+static int linear_bwd_data_impl(const void* dout, int ldd, const void* w, int w_dtype, const void* addend, int ldadd,
+                                void* din, int ldi, int M, int Nout, int K, int groups, int act_dtype, void* stream,
+                                const void* bn_r, const float* bn_scale, const float* bn_shift, const float* bn_mean,
+                                const float* bn_invstd, int bn_act, float* bn_partial) {
   NSID_REQUIRE(dout && w && din && M > 0 && Nout > 0 && K > 0 && groups > 0 && NSID_DTYPE_OK(act_dtype));
   NSID_REQUIRE(NSID_DTYPE_OK(w_dtype) && (w_dtype == NSID_F32 || (act_dtype == NSID_BF16 && K % 8 == 0)));
   const bool wb = w_dtype == NSID_BF16;
@@ -632,6 +717,10 @@ extern "C" int nsid_linear_bwd_data(const void* dout, int ldd, const void* w, in
   p.I = M; p.J = K; p.R = Nout;
   p.addend = addend; p.ldadd = ldadd;
   p.rsplit = 1; p.rchunk = Nout;
+  p.bn_r = bn_r; p.bn_ldr = (long)groups * K;
+  p.bn_scale = bn_scale; p.bn_shift = bn_shift; p.bn_mean = bn_mean; p.bn_invstd = bn_invstd;
+  p.bn_slope = act_slope(bn_act);
+  p.bn_partial = bn_partial; p.bn_ld = (long)groups * K; p.bn_plane = (long)nsid_row_tiles(M) * groups * K;
   hipStream_t s = static_cast<hipStream_t>(stream);
   const long t128 = (long)nsid_row_tiles(M) * ((K + 127) / 128) * groups;
   const bool half = g_gemm_precision == NSID_GEMM_BF16 || act_dtype == NSID_BF16;

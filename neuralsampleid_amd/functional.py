@@ -178,9 +178,10 @@ def grapher_backward(dx1: Tensor, P, S, G) -> Tensor:
     dr3 = ops.bn_backward(dx1, r3, a3, ACT_NONE, G["fc2.1.weight"], G["fc2.1.bias"])
     _bias_grad_before_bn(dr3, G["fc2.0.bias"])
     ops.linear_bwd_weight(dr3, r2, ops.w2d(G["fc2.0.weight"]), M, C, 2 * C, 1, a2.scale, a2.shift, ACT_RELU)
-    dv = ops.linear_bwd_data(dr3, ops.w2d(P["fc2.0.weight"]), M, C, 2 * C)
+    # dv is dL/d(relu(BN(r2))): the GEMM that writes it also emits that BatchNorm's backward column sums
+    dv, part2 = ops.linear_bwd_data(dr3, ops.w2d(P["fc2.0.weight"]), M, C, 2 * C, bn=(r2, a2, ACT_RELU))
     # grouped conv (+BN+ReLU), input = u
-    dr2 = ops.bn_backward(dv, r2, a2, ACT_RELU, G[pre + "1.weight"], G[pre + "1.bias"], inplace=True)
+    dr2 = ops.bn_backward(dv, r2, a2, ACT_RELU, G[pre + "1.weight"], G[pre + "1.bias"], inplace=True, partial=part2)
     _bias_grad_before_bn(dr2, G[pre + "0.bias"])
     ops.linear_bwd_weight(dr2, u, ops.w2d(G[pre + "0.weight"]), M, C // 2, C // 2, 4)
     du = ops.linear_bwd_data(dr2, ops.w2d(P[pre + "0.weight"]), M, C // 2, C // 2, 4)
@@ -211,8 +212,8 @@ def ffn_backward(dx2: Tensor, P, S, G) -> Tensor:
     H = r4.shape[1]
     dr5 = ops.bn_backward(dx2, r5, a5, ACT_NONE, G["fc2.1.weight"], G["fc2.1.bias"])
     ops.linear_bwd_weight(dr5, r4, ops.w2d(G["fc2.0.weight"]), M, C, H, 1, a4.scale, a4.shift, ACT_RELU)
-    dh = ops.linear_bwd_data(dr5, ops.w2d(P["fc2.0.weight"]), M, C, H)
-    dr4 = ops.bn_backward(dh, r4, a4, ACT_RELU, G["fc1.1.weight"], G["fc1.1.bias"], inplace=True)
+    dh, part4 = ops.linear_bwd_data(dr5, ops.w2d(P["fc2.0.weight"]), M, C, H, bn=(r4, a4, ACT_RELU))
+    dr4 = ops.bn_backward(dh, r4, a4, ACT_RELU, G["fc1.1.weight"], G["fc1.1.bias"], inplace=True, partial=part4)
     ops.linear_bwd_weight(dr4, x1, ops.w2d(G["fc1.0.weight"]), M, H, C)
     return ops.linear_bwd_data(dr4, ops.w2d(P["fc1.0.weight"]), M, H, C, 1, addend=dx2)
 

@@ -213,7 +213,12 @@ def linear_fwd(x, w, bias, M, Nout, K, groups=1, in_scale=None, in_shift=None, a
     return out, stat
 
 
-def linear_bwd_data(dout, w, M, Nout, K, groups=1, addend=None, out=None) -> torch.Tensor:
+FUSE_BN_BWD_REDUCE = True     # backward-data GEMMs emit the next BatchNorm-backward's column sums (bf16 storage only)
+
+
+def linear_bwd_data(dout, w, M, Nout, K, groups=1, addend=None, out=None, bn=None):
+    """din = addend + dout @ w.  bn = (r, BNAffine, act): din is dL/dy of the layer y = act(BN(r)); then the call returns
+    (din, partial) with partial[2][tiles][groups*K] = that layer's backward column sums (see bn_backward(partial=...))."""
     _chk(w)
     dt = _act(dout, addend, out)
     if out is None:
@@ -223,13 +228,24 @@ def linear_bwd_data(dout, w, M, Nout, K, groups=1, addend=None, out=None) -> tor
     name = "gemm_kernel<128,%d,true,false>" % (64 if narrow else 128)
     esz = dout.element_size()
     wop, wdt = _weight(w, dt, K)
-    _timed(name, 2.0 * M * Nout * K * groups,
-           groups * (esz * M * Nout + float(wop.element_size()) * Nout * K
-                     + esz * M * K * (2 if addend is not None else 1)), lambda: call(
-               "nsid_linear_bwd_data", _p(dout), dout.shape[-1], _p(wop), wdt, _p(addend),
-               0 if addend is None else addend.shape[-1], _p(out), out.shape[-1], M, Nout, K, groups, dt, _stream()),
-           (M, Nout, K, groups))
-    return out
+    fuse = bn is not None and FUSE_BN_BWD_REDUCE and dt == BF16 and out.shape[-1] == groups * K and (groups * K) % 8 == 0
+    nbytes = groups * (esz * M * Nout + float(wop.element_size()) * Nout * K
+                       + esz * M * K * ((2 if addend is not None else 1) + (1 if fuse else 0)))
+    if fuse:
+        r, aff, act = bn
+        _act(r, out)
+        partial = torch.empty((2, row_tiles(M), groups * K), device=dout.device, dtype=torch.float32)
+        _timed(name, 2.0 * M * Nout * K * groups, nbytes, lambda: call(
+            "nsid_linear_bwd_data_bn", _p(dout), dout.shape[-1], _p(wop), wdt, _p(addend),
+            0 if addend is None else addend.shape[-1], _p(out), out.shape[-1], M, Nout, K, groups, dt, _p(r),
+            _p(aff.scale), _p(aff.shift), _p(aff.mean), _p(aff.invstd), act, _p(partial), _stream()),
+            (M, Nout, K, groups))
+        return out, partial
+    _timed(name, 2.0 * M * Nout * K * groups, nbytes, lambda: call(
+        "nsid_linear_bwd_data", _p(dout), dout.shape[-1], _p(wop), wdt, _p(addend),
+        0 if addend is None else addend.shape[-1], _p(out), out.shape[-1], M, Nout, K, groups, dt, _stream()),
+        (M, Nout, K, groups))
+    return (out, None) if bn is not None else out
 
 
 # Weight-gradient GEMMs feed nothing but the optimiser: with WGRAD_OFFLOAD they are enqueued on an auxiliary stream per
@@ -321,16 +337,18 @@ def bn_apply(r, aff: BNAffine, act=ACT_NONE, residual=None, out=None) -> torch.T
     return out
 
 
-def bn_backward(dout, r, aff: BNAffine, act, dgamma, dbeta, inplace=False) -> torch.Tensor:
-    """Gradient w.r.t. the raw conv output r of y = act(BN(r)), given dL/dy; dgamma/dbeta are accumulated."""
+def bn_backward(dout, r, aff: BNAffine, act, dgamma, dbeta, inplace=False, partial=None) -> torch.Tensor:
+    """Gradient w.r.t. the raw conv output r of y = act(BN(r)), given dL/dy; dgamma/dbeta are accumulated.
+    partial: the column sums already produced by the GEMM that wrote dout (linear_bwd_data(bn=...)): skips the reduce."""
     dt = _act(dout, r)
     M, C = r.shape
     tiles = row_tiles(M)
-    partial = torch.empty((2, tiles, C), device=r.device, dtype=torch.float32)
     coef = torch.empty((2, C), device=r.device, dtype=torch.float32)
     s = _stream()
-    call("nsid_bn_bwd_reduce", _p(dout), _p(r), M, C, _p(aff.scale), _p(aff.shift), _p(aff.mean), _p(aff.invstd),
-         act, _p(partial), dt, s)
+    if partial is None:
+        partial = torch.empty((2, tiles, C), device=r.device, dtype=torch.float32)
+        call("nsid_bn_bwd_reduce", _p(dout), _p(r), M, C, _p(aff.scale), _p(aff.shift), _p(aff.mean), _p(aff.invstd),
+             act, _p(partial), dt, s)
     call("nsid_bn_bwd_finalize", _p(partial), tiles, C, M, _p(dgamma), _p(dbeta), _p(coef), s)
     dr = dout if inplace else torch.empty_like(dout)
     call("nsid_bn_bwd_apply", _p(dout), _p(r), M, C, _p(aff.scale), _p(aff.shift), _p(aff.mean), _p(aff.invstd),

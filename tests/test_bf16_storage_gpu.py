@@ -209,3 +209,27 @@ def test_training_curve_bf16_storage_tracks_fp32(ops):
     # measured at B=128: mean 0.29, worst 1.09 (the worst sits in the tail where both losses are ~0.02-0.05)
     assert mean < 0.5 and worst < 1.5, (mean, worst, curves)
     assert curves["bf16"][-1] < 0.1 * curves["bf16"][0]
+
+
+@pytest.mark.parametrize("M,Nout,K,groups,act,add", [(512, 256, 1024, 1, 1, False), (640, 64, 128, 1, 1, True),
+                                                       (384, 128, 64, 1, 0, False), (200, 64, 256, 1, 2, True),
+                                                       (256, 32, 32, 4, 1, False)])
+def test_bwd_data_emits_bn_backward_sums(ops, M, Nout, K, groups, act, add):
+    """linear_bwd_data(bn=...) = the plain GEMM plus the column sums nsid_bn_bwd_reduce computes from its stored output"""
+    C = groups * K
+    dout = synth_randn(f"fd{M}{Nout}", M, groups * Nout).to(BF).to(DEV)
+    w = (synth_randn(f"fw{Nout}{K}", groups * Nout, K) * Nout ** -0.5).to(DEV)
+    r = (synth_randn(f"fr{M}{C}", M, C) * 1.3 + 0.2).to(BF).to(DEV)
+    addend = synth_randn(f"fa{M}{C}", M, C).to(BF).to(DEV) if add else None
+    mean, var = r.float().mean(0), r.float().var(0, unbiased=False)
+    invstd = 1 / torch.sqrt(var + 1e-5)
+    gamma, beta = (1 + 0.2 * synth_randn("fg", C)).to(DEV), (0.1 * synth_randn("fb", C)).to(DEV)
+    aff = ops.BNAffine(gamma * invstd, beta - mean * gamma * invstd, mean, invstd)
+    plain = ops.linear_bwd_data(dout, w, M, Nout, K, groups, addend)
+    fused, partial = ops.linear_bwd_data(dout, w, M, Nout, K, groups, addend, bn=(r, aff, act))
+    assert torch.equal(fused, plain) and partial.shape == (2, ops.row_tiles(M), C)
+    dg0, db0, dg1, db1 = (torch.zeros(C, device=DEV) for _ in range(4))
+    ref = ops.bn_backward(plain, r, aff, act, dg0, db0)
+    got = ops.bn_backward(fused, r, aff, act, dg1, db1, partial=partial)
+    assert relerr(dg1, dg0) < 2e-5 and relerr(db1, db0) < 2e-5          # same inputs, different summation order
+    assert relerr(got.float(), ref.float()) < 1e-5
