@@ -241,6 +241,8 @@ def main():
         if rank == 0:
             log(f"eager warm-up step {i} done, loss {float(loss_buf):.4f}")
     graph = None
+    if world > 1 and os.environ.get("NSID_DP_GRAPH", "1") == "0":      # escape hatch: eager collectives, no capture
+        args.no_graph = True
     if not args.no_graph:
         try:
             side = torch.cuda.Stream()

@@ -662,7 +662,7 @@ extern "C" int nsid_linear_fwd(const void* x, int ldx, const void* w, int w_dtyp
   // measured (tools/gemm_bench.py, bf16 path): the 128-wide tile wins from 256 output columns on, and always when the
   // left operand carries the producer's BatchNorm (every column tile re-applies it: fewer, wider tiles = less VALU)
   bool narrow = half ? (Nout <= 64 || (Nout <= 128 && K <= 256 && in_scale == nullptr)) : Nout <= 64;
-  (void)t128;
+  if (half && t128 < 128) narrow = true;        // few row tiles (the projector head, M = batch): more, narrower workgroups
   if (force_narrow >= 0 && Nout > 64) narrow = force_narrow != 0;
   const bool wb = w_dtype == NSID_BF16;
   const int rc = narrow ? launch<128, 64, true, true>(p, groups, s, act_dtype, wb)
@@ -726,7 +726,7 @@ static int linear_bwd_data_impl(const void* dout, int ldd, const void* w, int w_
   const bool half = g_gemm_precision == NSID_GEMM_BF16 || act_dtype == NSID_BF16;
   static const int force_narrow = getenv("NSID_BWD_NARROW") ? atoi(getenv("NSID_BWD_NARROW")) : -1;
   bool narrow = half ? (K <= 64 || (K <= 128 && Nout <= 256)) : K <= 64;
-  (void)t128;
+  if (half && t128 < 128) narrow = true;        // few row tiles (the projector head, M = batch)
   if (force_narrow >= 0 && K > 64) narrow = force_narrow != 0;
   if (narrow) return launch<128, 64, true, false>(p, groups, s, act_dtype, wb);
   return launch<128, 128, true, false>(p, groups, s, act_dtype, wb);

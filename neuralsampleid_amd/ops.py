@@ -203,6 +203,8 @@ def linear_fwd(x, w, bias, M, Nout, K, groups=1, in_scale=None, in_shift=None, a
     stat = torch.empty((2, row_tiles(M), groups * Nout), device=x.device, dtype=torch.float32) if want_stat else None
     half = dt == BF16 or lib.nsid_get_gemm_precision() == GEMM_BF16
     narrow = (Nout <= 64 or (Nout <= 128 and K <= 256 and in_scale is None)) if half else Nout <= 64
+    if half and row_tiles(M) * ((Nout + 127) // 128) * groups < 128:
+        narrow = True
     name = "gemm_kernel<128,%d,true,true>" % (64 if narrow else 128)
     esz = x.element_size()
     wop, wdt = _weight(w, dt, K)
@@ -225,6 +227,8 @@ def linear_bwd_data(dout, w, M, Nout, K, groups=1, addend=None, out=None, bn=Non
         out = torch.empty((M, groups * K), device=dout.device, dtype=dout.dtype)
     half = dt == BF16 or lib.nsid_get_gemm_precision() == GEMM_BF16
     narrow = (K <= 64 or (K <= 128 and Nout <= 256)) if half else K <= 64
+    if half and row_tiles(M) * ((K + 127) // 128) * groups < 128:
+        narrow = True
     name = "gemm_kernel<128,%d,true,false>" % (64 if narrow else 128)
     esz = dout.element_size()
     wop, wdt = _weight(w, dt, K)
