@@ -22,7 +22,6 @@ struct WgArgs {
   int R;                                       // rows (M)
   int rchunk;                                  // rows per workgroup (multiple of 256)
   int tiles_j;                                 // K / tile
-  int dbg_no_store;                            // experiments only: skip the atomic epilogue
   const float* b_scale; const float* b_shift; float b_slope; long b_aff_goff;
 };
 
@@ -154,7 +153,7 @@ __global__ __launch_bounds__(W3_THREADS, 2) void wgrad3_kernel(const WgArgs p) {
         for (int r = 0; r < 4; ++r) scratch[(quad * 64 + a * 16 + b * 4 + r) * 64 + lane] = acc[a][b][r];
   }
   __syncthreads();
-  if (half == 0 && !p.dbg_no_store) {
+  if (half == 0) {
     float* C = p.C + g * p.c_goff;
 #pragma unroll
     for (int a = 0; a < 4; ++a)
@@ -193,8 +192,6 @@ int nsid_wgrad2_launch(const void* dout, int ldd, const void* x, int ldx, float*
       p.C = dw; p.ldc = K; p.c_goff = (long)Nout * K;
       p.R = M; p.rchunk = rc3; p.tiles_j = K / W3_T;
       p.b_scale = in_scale; p.b_shift = in_shift; p.b_slope = slope; p.b_aff_goff = K;
-      static const int no_store = getenv("NSID_W3_NOSTORE") ? 1 : 0;
-      p.dbg_no_store = no_store;
       dim3 grid(M / rc3, (Nout / W3_T) * (K / W3_T), groups);
       if (in_scale != nullptr) NSID_LAUNCH((wgrad3_kernel<true>), grid, dim3(W3_THREADS), 0, stream, p);
       else NSID_LAUNCH((wgrad3_kernel<false>), grid, dim3(W3_THREADS), 0, stream, p);

@@ -1,6 +1,10 @@
 #!/usr/bin/env python3
 """GEMM-family microbench on the shapes of the 't' encoder at B=256 (one view): per shape and direction, average
-launch time from HIP events, TFLOP/s and algorithmic GB/s.  Usage: python tools/gemm_bench.py [--reps 20] [--only fwd]"""
+device time (the repetitions are captured in one hipGraph), TFLOP/s and algorithmic GB/s.
+Usage: python tools/gemm_bench.py [--reps 20] [--only fwd] [--shapes MxNxKxG,...]
+Tuning knobs read by the kernel library (experiments; the defaults are the measured winners): NSID_FWD_NARROW=0/1,
+NSID_BWD_NARROW=0/1 (64- vs 128-wide tiles), NSID_WGRAD_V1=1 (never use the 8-wave 128x128 weight-gradient form),
+NSID_W3_WGS / NSID_W3_MIN_TILES (its workgroup target / smallest layer), NSID_KNN_STRIPS=1 (strip kNN kernel)."""
 import argparse
 import os
 import sys
