@@ -375,6 +375,154 @@ __global__ __launch_bounds__(KNN2_THREADS) void knn2_kernel(const T* __restrict_
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Large k*dilation on small graphs (N <= 128; the deep configuration: k = 18 with dilation 2-3 asks for the 36 or 54
+// nearest of 128 or 64 nodes, nearly a full sort): selection by RANK COUNTING. A wave computes a 16-row distance strip
+// into LDS (4 MFMA accumulator chains), then every lane takes (row, j) pairs and counts the entries of that row that
+// precede D[row][j] in (distance, index) order — N compares on LDS broadcasts, no dependent reductions, no rounds. The
+// element of rank p*dilation is neighbour p. The strip kernel's k*d rounds of wave-wide arg-min took 330 us per call here.
+template <typename T>
+__global__ __launch_bounds__(KNN2_THREADS) void knn_rank_kernel(const T* __restrict__ r, long ldr,
+                                                                const float* __restrict__ scale,
+                                                                const float* __restrict__ shift, int N, int C, int k,
+                                                                int dilation, int32_t* __restrict__ idx) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int LD = C + 4, SLD = N + 4;
+  float* yn = smem;                      // [N][LD]
+  float* sq = yn + (long)N * LD;         // [N]
+  float* strips = sq + N;                // [8 waves][16][SLD]
+  const int b = blockIdx.x;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const T* src = r + (long)b * N * ldr;
+  constexpr int NV = Chunk<T>::N;
+  const int CV = C / NV;
+  constexpr int UB = 4;
+  for (int q0 = t; q0 < N * CV; q0 += UB * KNN2_THREADS) {
+    float v[UB][NV];
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+      const int q = q0 + u * KNN2_THREADS;
+      if (q < N * CV) Chunk<T>::load(src + (long)(q / CV) * ldr + (q % CV) * NV, v[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+      const int q = q0 + u * KNN2_THREADS;
+      if (q < N * CV) {
+        const int n = q / CV, c = (q % CV) * NV;
+        if (scale != nullptr) {
+          float sc[NV], sh[NV];
+          load_channels<NV>(scale, c, sc);
+          load_channels<NV>(shift, c, sh);
+#pragma unroll
+          for (int e = 0; e < NV; ++e) v[u][e] = sc[e] * v[u][e] + sh[e];
+        }
+#pragma unroll
+        for (int e = 0; e < NV; e += 4)
+          *reinterpret_cast<f32x4*>(yn + n * LD + c + e) = f32x4{v[u][e], v[u][e + 1], v[u][e + 2], v[u][e + 3]};
+      }
+    }
+  }
+  __syncthreads();
+  {  // F.normalize + |y^|^2 (same arithmetic as knn2_kernel)
+    const int LPR = C / 4 < 64 ? C / 4 : 64, RPP = 64 / LPR, CPL = C / 4 / LPR, cl = lane % LPR;
+    for (int n0 = wave * RPP; n0 < N; n0 += KNN2_WAVES * RPP) {
+      const int n = n0 + lane / LPR;
+      f32x4 v0 = *reinterpret_cast<const f32x4*>(yn + n * LD + 4 * cl), v1 = {0.f, 0.f, 0.f, 0.f};
+      if (CPL > 1) v1 = *reinterpret_cast<const f32x4*>(yn + n * LD + 4 * (cl + LPR));
+      float ss = (v0[0] * v0[0] + v0[1] * v0[1]) + (v0[2] * v0[2] + v0[3] * v0[3]);
+      ss += (v1[0] * v1[0] + v1[1] * v1[1]) + (v1[2] * v1[2] + v1[3] * v1[3]);
+      ss = row16_sum(ss);
+      if (LPR >= 32) ss += __shfl_xor(ss, 16, 64);
+      if (LPR >= 64) ss += __shfl_xor(ss, 32, 64);
+      const float denom = fmaxf(sqrtf(ss), 1e-12f);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { v0[e] = v0[e] / denom; v1[e] = v1[e] / denom; }
+      float s2 = (v0[0] * v0[0] + v0[1] * v0[1]) + (v0[2] * v0[2] + v0[3] * v0[3]);
+      s2 += (v1[0] * v1[0] + v1[1] * v1[1]) + (v1[2] * v1[2] + v1[3] * v1[3]);
+      s2 = row16_sum(s2);
+      if (LPR >= 32) s2 += __shfl_xor(s2, 16, 64);
+      if (LPR >= 64) s2 += __shfl_xor(s2, 32, 64);
+      *reinterpret_cast<f32x4*>(yn + n * LD + 4 * cl) = v0;
+      if (CPL > 1) *reinterpret_cast<f32x4*>(yn + n * LD + 4 * (cl + LPR)) = v1;
+      if (cl == 0) sq[n] = s2;
+    }
+  }
+  __syncthreads();
+
+  const int lr = lane & 15, rq = lane >> 4;
+  const int NS = N >> 4;
+  const int NT = NS >= 4 ? 4 : NS;                  // column tiles per MFMA pass (2 for N = 32)
+  const int kd = k * dilation;
+  float* strip = strips + wave * 16 * SLD;
+  for (int s = wave; s < NS; s += KNN2_WAVES) {      // no workgroup barrier below: a wave owns its strip buffer
+    const float* arow = yn + (16 * s + lr) * LD + 4 * rq;
+    for (int tn = 0; tn < NS; tn += NT) {
+      f32x4 acc[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+      const float* brow = yn + (16 * tn + lr) * LD + 4 * rq;
+      for (int ch = 0; ch < C; ch += 16) {
+        const f32x4 fa = *reinterpret_cast<const f32x4*>(arow + ch);
+        f32x4 fb[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (u < NT) fb[u] = *reinterpret_cast<const f32x4*>(brow + u * 16 * LD + ch);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+            if (u < NT) acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[e], fb[u][e], acc[u], 0, 0, 0);
+      }
+      // C/D layout: column (node j) = lane&15, row (node i) = 4*(lane>>4) + reg
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (u < NT) {
+          const float sj = sq[16 * (tn + u) + lr];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float si = sq[16 * s + 4 * rq + e];
+            strip[(4 * rq + e) * SLD + 16 * (tn + u) + lr] = (si + (-2.f * acc[u][e])) + sj;
+          }
+        }
+      }
+    }
+    // rank counting over the strip (LDS operations of one wave are ordered: no barrier needed)
+    for (int p = lane; p < 16 * N; p += 64) {
+      const int row = p / N, j = p % N;
+      const float* drow = strip + row * SLD;
+      const float dj = drow[j];
+      int rank = 0;
+      for (int m = 0; m < N; m += 4) {
+        const f32x4 dm = *reinterpret_cast<const f32x4*>(drow + m);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) rank += (dm[e] < dj || (dm[e] == dj && m + e < j)) ? 1 : 0;
+      }
+      int32_t* out = idx + ((long)b * N + 16 * s + row) * k;
+      if (dj != dj) {                                  // NaN distances: every entry ranks 0 — emit valid ids anyway
+        if (j < k) out[j] = j;
+      } else if (rank < kd && rank % dilation == 0) {
+        out[rank / dilation] = j;
+      }
+    }
+  }
+}
+
+template <typename T>
+int launch_knn_rank(const void* r, int ldr, const float* scale, const float* shift, int B, int N, int C, int k,
+                    int dilation, int32_t* idx, hipStream_t s) {
+  const size_t bytes = ((size_t)N * (C + 4) + N + (size_t)KNN2_WAVES * 16 * (N + 4)) * sizeof(float);
+  static bool configured = false;
+  if (!configured) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(knn_rank_kernel<T>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+      return NSID_ELAUNCH;
+    configured = true;
+  }
+  NSID_LAUNCH((knn_rank_kernel<T>), dim3(B), dim3(KNN2_THREADS), bytes, s, static_cast<const T*>(r), (long)ldr, scale,
+              shift, N, C, k, dilation, idx);
+  return nsid_launch_status();
+}
+
 template <typename T, int KD>
 int launch_knn2(const void* r, int ldr, const float* scale, const float* shift, int B, int N, int C, int k, int dilation,
                 int32_t* idx, hipStream_t s) {
@@ -402,7 +550,13 @@ extern "C" int nsid_knn_graph(const void* r, int ldr, const float* scale, const 
   NSID_REQUIRE((scale == nullptr) == (shift == nullptr));
   const int kd = k * dilation;
   static const bool use_fast = getenv("NSID_KNN_STRIPS") == nullptr;
-  if (use_fast && kd <= 8 && C >= 64 && C <= 512 && (C & (C - 1)) == 0 && N >= 32 && (N & (N - 1)) == 0) {
+  const bool pow2 = C >= 64 && C <= 512 && (C & (C - 1)) == 0 && N >= 32 && (N & (N - 1)) == 0;
+  if (use_fast && pow2 && kd > 8 && N <= 128) {              // deep configuration, small graphs: rank counting
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    return dtype == NSID_BF16 ? launch_knn_rank<__bf16>(r, ldr, scale, shift, B, N, C, k, dilation, idx, s)
+                              : launch_knn_rank<float>(r, ldr, scale, shift, B, N, C, k, dilation, idx, s);
+  }
+  if (use_fast && kd <= 8 && pow2) {
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (dtype == NSID_BF16) {
       if (kd <= 3) return launch_knn2<__bf16, 3>(r, ldr, scale, shift, B, N, C, k, dilation, idx, s);
