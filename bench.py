@@ -252,7 +252,10 @@ def main():
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            # world > 1: RCCL's helper threads may touch the HIP runtime while we capture; only calls made by the
+            # capturing thread may invalidate the capture ("thread_local"), not theirs
+            mode = "thread_local" if world > 1 else "global"
+            with torch.cuda.graph(graph, capture_error_mode=mode):
                 step()
             if rank == 0:
                 log("step captured in a hipGraph")

@@ -283,7 +283,9 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {   // >
   // Register prefetch depth: fp32 MFMA blocks (64 x 32 cycles) cover one memory round trip, so one stage in flight
   // is enough; the bf16 MFMA block (16 x 16 cycles) is far shorter than the round trip, so TWO stages are kept in
   // flight (two register sets, static indices through the 2x unrolled loop body below).
-  constexpr int DEPTH = H ? 2 : 1;
+  // Exception: the full-tile forward kernel with bf16 weights and no operand affine fits 128 VGPRs with ONE stage in flight
+  // -> 4 workgroups per CU instead of 3 (1 024 tiles in one round): measured 7-10 % faster than the deeper prefetch.
+  constexpr int DEPTH = (H && !(FULL && WB && !AAFF && BN == 128 && A_RMAJOR && B_RMAJOR)) ? 2 : 1;
   StageRegs<BM, A_RMAJOR, H, SA> ra[DEPTH];
   StageRegs<BN, B_RMAJOR, H, SB> rb[DEPTH];
 
