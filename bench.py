@@ -254,7 +254,7 @@ def main():
             graph = torch.cuda.CUDAGraph()
             # world > 1: RCCL's helper threads may touch the HIP runtime while we capture; only calls made by the
             # capturing thread may invalidate the capture ("thread_local"), not theirs
-            mode = "thread_local" if world > 1 else "global"
+            mode = os.environ.get("NSID_CAPTURE_MODE", "thread_local" if world > 1 else "global")
             with torch.cuda.graph(graph, capture_error_mode=mode):
                 step()
             if rank == 0:
