@@ -111,14 +111,19 @@ class GraphEncoder(nn.Module):
         """nodes (B*N, in_channels) node-major -> (B, emb_dims); with return_nodes also the pre-projection node
         matrix as (rows (B*N_last, C_last), N_last, emb)"""
         params, buffers = _split(self.stem)
-        x = F_.run_block(F_.stem_forward, F_.stem_backward, params, buffers, nodes, self.training)
-        for entry in self.backbone:
-            if isinstance(entry, Downsample):
-                x = entry.forward_rows(x, B, N)
-                N = (N - 1) // 2 + 1
-            else:
-                x = entry[0].forward_rows(x, B, N)
-                x = entry[1].forward_rows(x)
+        prev_chain = F_.CHAIN
+        F_.CHAIN = F_.BwdChain() if (self.training and torch.is_grad_enabled()) else None
+        try:
+            x = F_.run_block(F_.stem_forward, F_.stem_backward, params, buffers, nodes, self.training)
+            for entry in self.backbone:
+                if isinstance(entry, Downsample):
+                    x = entry.forward_rows(x, B, N)
+                    N = (N - 1) // 2 + 1
+                else:
+                    x = entry[0].forward_rows(x, B, N)
+                    x = entry[1].forward_rows(x)
+        finally:
+            F_.CHAIN = prev_chain
         params, buffers = _split(self.proj)
         emb = F_.run_block(F_.proj_mean_forward, F_.proj_mean_backward, params, buffers, x, B, N)
         return (x, N, emb) if return_nodes else emb

@@ -89,6 +89,54 @@ def join_side_streams() -> None:
                 cur.wait_stream(st)
 
 
+class BwdLink:
+    """Hand-over between two consecutive blocks of one view: the producer block materialised its output with
+    bn_apply(r, aff, act) (+ residual); the consumer block's LAST backward GEMM writes the gradient of that output, i.e. the
+    dL/dy of the producer's BatchNorm — so it also emits that BatchNorm-backward's column sums (ops.linear_bwd_data(bn=...))
+    and the producer's backward skips its reduce launch."""
+    __slots__ = ("bn", "partial")
+
+    def __init__(self, bn):
+        self.bn, self.partial = bn, None
+
+
+class BwdChain:
+    """links of the blocks of one encoder forward, in forward order (set by GraphEncoder.forward_rows while it runs)"""
+
+    def __init__(self):
+        self.last = None
+
+    def produce(self, S, r, aff, act):
+        if S is not None:
+            S["link_out"] = self.last = BwdLink((r, aff, act))
+
+    def consume(self, S):
+        if S is not None:
+            S["link_in"] = self.last
+
+
+CHAIN = None          # BwdChain of the encoder forward in progress (None: blocks run stand-alone, nothing is linked)
+
+
+def _link_in(S):
+    link = S.get("link_in")
+    return link.bn if link is not None else None
+
+
+def _link_partial(S):
+    link = S.get("link_out")
+    if link is None:
+        return None
+    part, link.partial = link.partial, None
+    return part
+
+
+def _store_partial(S, part):
+    link = S.get("link_in")
+    if link is not None:
+        link.partial = part
+
+
 # Called at the end of every block backward with the parameter tensors whose gradient contribution has just been
 # enqueued (parallel.GradReducer uses it to overlap the bucketed all-reduce with the rest of backward).
 GRAD_READY_HOOK = None
@@ -134,6 +182,8 @@ def stem_forward(nodes: Tensor, P: Dict[str, Tensor], S: Optional[dict], trainin
     x0 = ops.bn_apply(r, aff, ACT_LEAKY)
     if S is not None:
         S.update(nodes=nodes, r=r, aff=aff)
+        if CHAIN is not None:
+            CHAIN.produce(S, r, aff, ACT_LEAKY)
     return x0
 
 
@@ -141,7 +191,7 @@ def stem_backward(dx0: Tensor, P, S, G, need_input_grad: bool = True) -> Optiona
     nodes, r, aff = S["nodes"], S["r"], S["aff"]
     M, K = nodes.shape
     C = r.shape[1]
-    dr = ops.bn_backward(dx0, r, aff, ACT_LEAKY, G["1.weight"], G["1.bias"])
+    dr = ops.bn_backward(dx0, r, aff, ACT_LEAKY, G["1.weight"], G["1.bias"], partial=_link_partial(S))
     ops.linear_bwd_weight(dr, nodes, ops.w2d(G["0.weight"]), M, C, K)
     return ops.linear_bwd_data(dr, ops.w2d(P["0.weight"]), M, C, K) if need_input_grad else None
 
@@ -165,6 +215,9 @@ def grapher_forward(x0: Tensor, P, S: Optional[dict], B: int, N: int, k: int, di
     x1 = ops.bn_apply(r3, a3, ACT_NONE, residual=x0)
     if S is not None:
         S.update(x0=x0, r1=r1, a1=a1, idx=idx, amax=amax, u=u, r2=r2, a2=a2, r3=r3, a3=a3, B=B, N=N)
+        if CHAIN is not None:
+            CHAIN.consume(S)                       # x0 was materialised by the previous block's BatchNorm
+            CHAIN.produce(S, r3, a3, ACT_NONE)
     return x1
 
 
@@ -175,7 +228,7 @@ def grapher_backward(dx1: Tensor, P, S, G) -> Tensor:
     M, C = x0.shape
     pre = "graph_conv.gconv.nn."
     # fc2 (+BN), input = relu(BN(r2))
-    dr3 = ops.bn_backward(dx1, r3, a3, ACT_NONE, G["fc2.1.weight"], G["fc2.1.bias"])
+    dr3 = ops.bn_backward(dx1, r3, a3, ACT_NONE, G["fc2.1.weight"], G["fc2.1.bias"], partial=_link_partial(S))
     _bias_grad_before_bn(dr3, G["fc2.0.bias"])
     ops.linear_bwd_weight(dr3, r2, ops.w2d(G["fc2.0.weight"]), M, C, 2 * C, 1, a2.scale, a2.shift, ACT_RELU)
     # dv is dL/d(relu(BN(r2))): the GEMM that writes it also emits that BatchNorm's backward column sums
@@ -191,7 +244,9 @@ def grapher_backward(dx1: Tensor, P, S, G) -> Tensor:
     dr1 = ops.bn_backward(dy, r1, a1, ACT_NONE, G["fc1.1.weight"], G["fc1.1.bias"], inplace=True)
     _bias_grad_before_bn(dr1, G["fc1.0.bias"])
     ops.linear_bwd_weight(dr1, x0, ops.w2d(G["fc1.0.weight"]), M, C, C)
-    return ops.linear_bwd_data(dr1, ops.w2d(P["fc1.0.weight"]), M, C, C, 1, addend=dx1)
+    dx0, part = ops.linear_bwd_data(dr1, ops.w2d(P["fc1.0.weight"]), M, C, C, 1, addend=dx1, bn=_link_in(S) or False)
+    _store_partial(S, part)
+    return dx0
 
 
 # ------------------------------------------------------------------------------------------------ FFN
@@ -203,6 +258,9 @@ def ffn_forward(x1: Tensor, P, S: Optional[dict], training: bool) -> Tensor:
     x2 = ops.bn_apply(r5, a5, ACT_NONE, residual=x1)
     if S is not None:
         S.update(x1=x1, r4=r4, a4=a4, r5=r5, a5=a5)
+        if CHAIN is not None:
+            CHAIN.consume(S)
+            CHAIN.produce(S, r5, a5, ACT_NONE)
     return x2
 
 
@@ -210,12 +268,14 @@ def ffn_backward(dx2: Tensor, P, S, G) -> Tensor:
     x1, r4, a4, r5, a5 = S["x1"], S["r4"], S["a4"], S["r5"], S["a5"]
     M, C = x1.shape
     H = r4.shape[1]
-    dr5 = ops.bn_backward(dx2, r5, a5, ACT_NONE, G["fc2.1.weight"], G["fc2.1.bias"])
+    dr5 = ops.bn_backward(dx2, r5, a5, ACT_NONE, G["fc2.1.weight"], G["fc2.1.bias"], partial=_link_partial(S))
     ops.linear_bwd_weight(dr5, r4, ops.w2d(G["fc2.0.weight"]), M, C, H, 1, a4.scale, a4.shift, ACT_RELU)
     dh, part4 = ops.linear_bwd_data(dr5, ops.w2d(P["fc2.0.weight"]), M, C, H, bn=(r4, a4, ACT_RELU))
     dr4 = ops.bn_backward(dh, r4, a4, ACT_RELU, G["fc1.1.weight"], G["fc1.1.bias"], inplace=True, partial=part4)
     ops.linear_bwd_weight(dr4, x1, ops.w2d(G["fc1.0.weight"]), M, H, C)
-    return ops.linear_bwd_data(dr4, ops.w2d(P["fc1.0.weight"]), M, H, C, 1, addend=dx2)
+    dx1, part = ops.linear_bwd_data(dr4, ops.w2d(P["fc1.0.weight"]), M, H, C, 1, addend=dx2, bn=_link_in(S) or False)
+    _store_partial(S, part)
+    return dx1
 
 
 # ------------------------------------------------------------------------------------------------ Downsample
@@ -229,13 +289,15 @@ def downsample_forward(x: Tensor, P, S: Optional[dict], B: int, N: int, training
     out = ops.bn_apply(r, aff, ACT_NONE)
     if S is not None:
         S.update(col=col, wp=wp, r=r, aff=aff, B=B, N=N, C=C)
+        if CHAIN is not None:
+            CHAIN.produce(S, r, aff, ACT_NONE)      # (its own input gradient comes from im2col3_bwd: nothing to fuse)
     return out
 
 
 def downsample_backward(dout: Tensor, P, S, G) -> Tensor:
     col, wp, r, aff, B, N, C = (S[k_] for k_ in ("col", "wp", "r", "aff", "B", "N", "C"))
     Mo, Co = r.shape
-    dr = ops.bn_backward(dout, r, aff, ACT_NONE, G["conv.1.weight"], G["conv.1.bias"])
+    dr = ops.bn_backward(dout, r, aff, ACT_NONE, G["conv.1.weight"], G["conv.1.bias"], partial=_link_partial(S))
     _bias_grad_before_bn(dr, G["conv.0.bias"])
     dwp = torch.zeros_like(wp)
     ops.linear_bwd_weight(dr, col, dwp, Mo, Co, 3 * C, offload=False)      # unpacked right below, same stream

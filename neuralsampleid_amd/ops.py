@@ -232,7 +232,11 @@ def linear_bwd_data(dout, w, M, Nout, K, groups=1, addend=None, out=None, bn=Non
     name = "gemm_kernel<128,%d,true,false>" % (64 if narrow else 128)
     esz = dout.element_size()
     wop, wdt = _weight(w, dt, K)
+    want_pair = bn is not None            # bn=False: "return a pair, nothing to fuse"
+    bn = bn or None
     fuse = bn is not None and FUSE_BN_BWD_REDUCE and dt == BF16 and out.shape[-1] == groups * K and (groups * K) % 8 == 0
+    if fuse and tuple(bn[0].shape) != (M, groups * K):
+        fuse = False
     nbytes = groups * (esz * M * Nout + float(wop.element_size()) * Nout * K
                        + esz * M * K * ((2 if addend is not None else 1) + (1 if fuse else 0)))
     if fuse:
@@ -249,7 +253,7 @@ def linear_bwd_data(dout, w, M, Nout, K, groups=1, addend=None, out=None, bn=Non
         "nsid_linear_bwd_data", _p(dout), dout.shape[-1], _p(wop), wdt, _p(addend),
         0 if addend is None else addend.shape[-1], _p(out), out.shape[-1], M, Nout, K, groups, dt, _stream()),
         (M, Nout, K, groups))
-    return (out, None) if bn is not None else out
+    return (out, None) if want_pair else out
 
 
 # Weight-gradient GEMMs feed nothing but the optimiser: with WGRAD_OFFLOAD they are enqueued on an auxiliary stream per
