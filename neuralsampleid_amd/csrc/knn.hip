@@ -486,16 +486,22 @@ __global__ __launch_bounds__(KNN2_THREADS) void knn_rank_kernel(const T* __restr
         }
       }
     }
-    // rank counting over the strip (LDS operations of one wave are ordered: no barrier needed)
+    // rank counting over the strip (LDS operations of one wave are ordered: no barrier needed).
+    // rank(j) = #{m : D[m] < D[j]} + #{m < j : D[m] == D[j]}; the tie term needs a second pass only for lanes whose value
+    // occurs more than once in the row (duplicated nodes), which is rare: the common pass is one compare + add per entry.
     for (int p = lane; p < 16 * N; p += 64) {
       const int row = p / N, j = p % N;
       const float* drow = strip + row * SLD;
       const float dj = drow[j];
-      int rank = 0;
+      int rank = 0, same = 0;
       for (int m = 0; m < N; m += 4) {
         const f32x4 dm = *reinterpret_cast<const f32x4*>(drow + m);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) rank += (dm[e] < dj || (dm[e] == dj && m + e < j)) ? 1 : 0;
+        for (int e = 0; e < 4; ++e) { rank += dm[e] < dj ? 1 : 0; same += dm[e] == dj ? 1 : 0; }
+      }
+      if (__any(same > 1)) {                           // wave-uniform
+        if (same > 1)
+          for (int m = 0; m < j; ++m) rank += drow[m] == dj ? 1 : 0;
       }
       int32_t* out = idx + ((long)b * N + 16 * s + row) * k;
       if (dj != dj) {                                  // NaN distances: every entry ranks 0 — emit valid ids anyway
