@@ -513,6 +513,194 @@ __global__ __launch_bounds__(KNN2_THREADS) void knn_rank_kernel(const T* __restr
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Large k*dilation on the 256-node graphs (deep configuration, stage 0: the 18 nearest of 256): THRESHOLD SELECT.
+// A pair of waves computes a 16-row distance strip into LDS; then a wave takes a row at a time, 4 values per lane:
+//   1. every lane's minimum, and the rank of that minimum among the 64 lane minima (64 compares on an LDS broadcast);
+//   2. T = the (k*d)-th smallest lane minimum: at least k*d entries are <= T, so every wanted neighbour is <= T;
+//   3. the entries <= T (about k*d .. 4*k*d of them) are compacted into LDS with ballots;
+//   4. each candidate's exact rank among the candidates, (distance, index) order -> neighbour rank/dilation.
+// ~500 instructions per row instead of k*d rounds of a dependent 64-lane arg-min (the strip kernel: 480 us per call here).
+constexpr int KSEL_STRIPS = 4;            // strip buffers per workgroup (8 waves = 4 pairs)
+
+template <typename T>
+__global__ __launch_bounds__(KNN2_THREADS) void knn_sel_kernel(const T* __restrict__ r, long ldr,
+                                                               const float* __restrict__ scale,
+                                                               const float* __restrict__ shift, int N, int C, int k,
+                                                               int dilation, int32_t* __restrict__ idx) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int LD = C + 4, SLD = N + 4;
+  float* yn = smem;                                  // [N][LD]
+  float* sq = yn + (long)N * LD;                     // [N]
+  float* strips = sq + N;                            // [KSEL_STRIPS][16][SLD]
+  float* scratch = strips + KSEL_STRIPS * 16 * SLD;  // [8 waves][64 lane minima + 2*N candidate (value, index)]
+  const int b = blockIdx.x;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const T* src = r + (long)b * N * ldr;
+  constexpr int NV = Chunk<T>::N;
+  const int CV = C / NV;
+  constexpr int UB = 4;
+  for (int q0 = t; q0 < N * CV; q0 += UB * KNN2_THREADS) {
+    float v[UB][NV];
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+      const int q = q0 + u * KNN2_THREADS;
+      if (q < N * CV) Chunk<T>::load(src + (long)(q / CV) * ldr + (q % CV) * NV, v[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+      const int q = q0 + u * KNN2_THREADS;
+      if (q < N * CV) {
+        const int n = q / CV, c = (q % CV) * NV;
+        if (scale != nullptr) {
+          float sc[NV], sh[NV];
+          load_channels<NV>(scale, c, sc);
+          load_channels<NV>(shift, c, sh);
+#pragma unroll
+          for (int e = 0; e < NV; ++e) v[u][e] = sc[e] * v[u][e] + sh[e];
+        }
+#pragma unroll
+        for (int e = 0; e < NV; e += 4)
+          *reinterpret_cast<f32x4*>(yn + n * LD + c + e) = f32x4{v[u][e], v[u][e + 1], v[u][e + 2], v[u][e + 3]};
+      }
+    }
+  }
+  __syncthreads();
+  {  // F.normalize + |y^|^2 (same arithmetic as knn2_kernel)
+    const int LPR = C / 4 < 64 ? C / 4 : 64, RPP = 64 / LPR, CPL = C / 4 / LPR, cl = lane % LPR;
+    for (int n0 = wave * RPP; n0 < N; n0 += KNN2_WAVES * RPP) {
+      const int n = n0 + lane / LPR;
+      f32x4 v0 = *reinterpret_cast<const f32x4*>(yn + n * LD + 4 * cl), v1 = {0.f, 0.f, 0.f, 0.f};
+      if (CPL > 1) v1 = *reinterpret_cast<const f32x4*>(yn + n * LD + 4 * (cl + LPR));
+      float ss = (v0[0] * v0[0] + v0[1] * v0[1]) + (v0[2] * v0[2] + v0[3] * v0[3]);
+      ss += (v1[0] * v1[0] + v1[1] * v1[1]) + (v1[2] * v1[2] + v1[3] * v1[3]);
+      ss = row16_sum(ss);
+      if (LPR >= 32) ss += __shfl_xor(ss, 16, 64);
+      if (LPR >= 64) ss += __shfl_xor(ss, 32, 64);
+      const float denom = fmaxf(sqrtf(ss), 1e-12f);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { v0[e] = v0[e] / denom; v1[e] = v1[e] / denom; }
+      float s2 = (v0[0] * v0[0] + v0[1] * v0[1]) + (v0[2] * v0[2] + v0[3] * v0[3]);
+      s2 += (v1[0] * v1[0] + v1[1] * v1[1]) + (v1[2] * v1[2] + v1[3] * v1[3]);
+      s2 = row16_sum(s2);
+      if (LPR >= 32) s2 += __shfl_xor(s2, 16, 64);
+      if (LPR >= 64) s2 += __shfl_xor(s2, 32, 64);
+      *reinterpret_cast<f32x4*>(yn + n * LD + 4 * cl) = v0;
+      if (CPL > 1) *reinterpret_cast<f32x4*>(yn + n * LD + 4 * (cl + LPR)) = v1;
+      if (cl == 0) sq[n] = s2;
+    }
+  }
+  __syncthreads();
+
+  const int lr = lane & 15, rq = lane >> 4;
+  const int NS = N >> 4;                             // strips == column tiles (a multiple of 8 here: N % 128 == 0)
+  const int kd = k * dilation;
+  const int pair = wave >> 1, hw = wave & 1;         // two waves per strip: column halves in phase A, row halves in phase B
+  float* strip = strips + pair * 16 * SLD;
+  float* lmins = scratch + wave * (64 + 2 * N);
+  float* cval = lmins + 64;
+  int* cidx = reinterpret_cast<int*>(cval + N);
+  const int NE = N >> 6;                             // entries per lane (2 or 4)
+  for (int s0 = 0; s0 < NS; s0 += KSEL_STRIPS) {     // uniform trip count: workgroup barriers inside
+    const int s = s0 + pair;
+    {  // ---- phase A: this wave's half of the column tiles of strip s
+      const float* arow = yn + (16 * s + lr) * LD + 4 * rq;
+      for (int tn = hw * (NS / 2); tn < (hw + 1) * (NS / 2); tn += 4) {
+        f32x4 acc[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const float* brow = yn + (16 * tn + lr) * LD + 4 * rq;
+        for (int ch = 0; ch < C; ch += 16) {
+          const f32x4 fa = *reinterpret_cast<const f32x4*>(arow + ch);
+          f32x4 fb[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) fb[u] = *reinterpret_cast<const f32x4*>(brow + u * 16 * LD + ch);
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[e], fb[u][e], acc[u], 0, 0, 0);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const float sj = sq[16 * (tn + u) + lr];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float si = sq[16 * s + 4 * rq + e];
+            strip[(4 * rq + e) * SLD + 16 * (tn + u) + lr] = (si + (-2.f * acc[u][e])) + sj;
+          }
+        }
+      }
+    }
+    __syncthreads();
+    // ---- phase B: rows 8*hw .. 8*hw+7 of the strip, one row at a time
+    for (int rr = 8 * hw; rr < 8 * hw + 8; ++rr) {
+      const float* drow = strip + rr * SLD;
+      float v[4];
+      float lmin = __builtin_inff();
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        v[e] = e < NE ? drow[lane + 64 * e] : __builtin_inff();
+        lmin = (v[e] < lmin) ? v[e] : lmin;                    // NaN never becomes the minimum
+      }
+      lmins[lane] = lmin;
+      int mrank = 0;                                           // rank of this lane's minimum among the 64 minima
+      for (int m = 0; m < 64; m += 4) {
+        const f32x4 o = *reinterpret_cast<const f32x4*>(lmins + m);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) mrank += (o[e] < lmin || (o[e] == lmin && m + e < lane)) ? 1 : 0;
+      }
+      const unsigned long long pick = __ballot(mrank == kd - 1);
+      const int src_lane = pick ? (__ffsll((long long)pick) - 1) : 0;
+      const float T_ = __shfl(lmin, src_lane, 64);             // (k*d)-th smallest lane minimum
+      int base = 0;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const bool cand = e < NE && v[e] <= T_;
+        const unsigned long long mask = __ballot(cand);
+        if (cand) {
+          const int pos = base + __popcll(mask & ((1ull << lane) - 1ull));
+          cval[pos] = v[e];
+          cidx[pos] = lane + 64 * e;
+        }
+        base += __popcll(mask);
+      }
+      int32_t* out = idx + ((long)b * N + 16 * s + rr) * k;
+      if (base < kd) {                                         // NaN-poisoned row: fewer finite entries than wanted
+        if (lane < k) out[lane] = lane;
+      }
+      for (int c0 = lane; c0 < base; c0 += 64) {
+        const float dv = cval[c0];
+        const int di = cidx[c0];
+        int rank = 0;
+        for (int m = 0; m < base; ++m) {
+          const float ov = cval[m];
+          rank += (ov < dv || (ov == dv && cidx[m] < di)) ? 1 : 0;
+        }
+        if (rank < kd && rank % dilation == 0) out[rank / dilation] = di;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+template <typename T>
+int launch_knn_sel(const void* r, int ldr, const float* scale, const float* shift, int B, int N, int C, int k,
+                   int dilation, int32_t* idx, hipStream_t s) {
+  const size_t bytes = ((size_t)N * (C + 4) + N + (size_t)KSEL_STRIPS * 16 * (N + 4) + (size_t)KNN2_WAVES * (64 + 2 * N)) *
+                       sizeof(float);
+  if (bytes > 160 * 1024) return 1;
+  static bool configured = false;
+  if (!configured) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(knn_sel_kernel<T>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+      return NSID_ELAUNCH;
+    configured = true;
+  }
+  NSID_LAUNCH((knn_sel_kernel<T>), dim3(B), dim3(KNN2_THREADS), bytes, s, static_cast<const T*>(r), (long)ldr, scale,
+              shift, N, C, k, dilation, idx);
+  return nsid_launch_status();
+}
+
 template <typename T>
 int launch_knn_rank(const void* r, int ldr, const float* scale, const float* shift, int B, int N, int C, int k,
                     int dilation, int32_t* idx, hipStream_t s) {
@@ -561,6 +749,12 @@ extern "C" int nsid_knn_graph(const void* r, int ldr, const float* scale, const 
     hipStream_t s = static_cast<hipStream_t>(stream);
     return dtype == NSID_BF16 ? launch_knn_rank<__bf16>(r, ldr, scale, shift, B, N, C, k, dilation, idx, s)
                               : launch_knn_rank<float>(r, ldr, scale, shift, B, N, C, k, dilation, idx, s);
+  }
+  if (use_fast && pow2 && kd > 8 && kd <= 64 && N == 256) {   // deep configuration, stage 0: threshold select
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int rc = dtype == NSID_BF16 ? launch_knn_sel<__bf16>(r, ldr, scale, shift, B, N, C, k, dilation, idx, s)
+                                      : launch_knn_sel<float>(r, ldr, scale, shift, B, N, C, k, dilation, idx, s);
+    if (rc != 1) return rc;
   }
   if (use_fast && kd <= 8 && pow2) {
     hipStream_t s = static_cast<hipStream_t>(stream);
