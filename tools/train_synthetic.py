@@ -36,6 +36,7 @@ def main():
     ap.add_argument("--batch", type=int, default=CFG["bsz_train"])
     ap.add_argument("--k", type=int, default=3)
     ap.add_argument("--fused", action="store_true", help="FusedClipAdam instead of clip_grad_norm_ + torch.optim.Adam")
+    ap.add_argument("--graph", action="store_true", help="capture the step in a hipGraph (graphs.GraphedTrainStep; needs --fused)")
     ap.add_argument("--bf16", action="store_true", help="bf16 activation storage + bf16 MFMA operands (BASELINE config 2)")
     args = ap.parse_args()
     device = torch.device("cuda")
@@ -50,6 +51,19 @@ def main():
         optimizer = FusedClipAdam(model.parameters(), lr=CFG["lr"], max_norm=1.0)
     else:
         optimizer = torch.optim.Adam(model.parameters(), lr=CFG["lr"])                    # train.py:126
+    if args.graph:
+        from neuralsampleid_amd.graphs import GraphedTrainStep
+        data = list(batches(args.steps, args.batch, device))
+        step = GraphedTrainStep(model, optimizer, CFG, *data[0])
+        torch.cuda.synchronize()
+        t0 = time.time()
+        for idx, (x_i, x_j) in enumerate(data):
+            loss = step(x_i, x_j)
+            if idx % 10 == 0:
+                print(f"Step [{idx}/{args.steps}]\t Loss: {loss.item():.4f}")
+        torch.cuda.synchronize()
+        print(f"{args.steps} graph replays in {time.time() - t0:.2f} s")
+        return
     t0 = time.time()
     for idx, (x_i, x_j) in enumerate(batches(args.steps, args.batch, device)):           # train.py:53
         optimizer.zero_grad()                                                             # :58
