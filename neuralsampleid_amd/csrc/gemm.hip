@@ -420,6 +420,37 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {   // >
     for (int e = 0; e < OE; ++e) bq[e] = (has_bias && jqok) ? bias[jq + e] : 0.f;
     char* Cb = reinterpret_cast<char*>(p.C) + g * p.c_goff * OSZ;
     const char* Ab = reinterpret_cast<const char*>(p.addend) + g * p.c_goff * OSZ;
+    if (p.stat != nullptr) {
+      // BatchNorm partial statistics of (acc + bias) from the accumulator registers, parked in LDS behind the transpose
+      // buffers BEFORE the store loop: its barriers publish them and the stores hide the shuffle/LDS latency (as a
+      // separate tail after the stores this cost 2.5 us per GEMM)
+      float* red = lds + 4 * 32 * OLD;       // [2][2 wave-rows][BN]
+#pragma unroll
+      for (int b = 0; b < TN; ++b) {
+        const int j = j0 + wn0 + 16 * b + lr;
+        const bool jok = FULL || j < p.J;
+        const float bj = (bias && jok) ? bias[j] : 0.f;
+        float s = 0.f, q = 0.f;
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int i = i0 + wm0 + 16 * a + 4 * rq + r;
+            if ((FULL || i < p.I) && jok) {
+              const float v = has_bias ? acc[a][b][r] + bj : acc[a][b][r];
+              s += v;
+              q += v * v;
+            }
+          }
+        s += __shfl_xor(s, 16, 64); s += __shfl_xor(s, 32, 64);
+        q += __shfl_xor(q, 16, 64); q += __shfl_xor(q, 32, 64);
+        if (rq == 0) {
+          const int c = wn0 + 16 * b + lr;
+          red[(0 * 2 + (wave >> 1)) * BN + c] = s;
+          red[(1 * 2 + (wave >> 1)) * BN + c] = q;
+        }
+      }
+    }
     // fused BatchNorm-backward column sums (backward-data, bf16 output): g = dy * act'(scale*r+shift), xhat = (r-mean)*invstd
     constexpr bool CAN_BNRED = A_RMAJOR && !B_RMAJOR && SC;
     const bool bnred = CAN_BNRED && p.bn_r != nullptr;        // wave-uniform
@@ -513,41 +544,9 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {   // >
         }
       }
     }
-    if (p.stat != nullptr) {
-      // BatchNorm partial statistics of (acc + bias), from the accumulator registers
-#pragma unroll
-      for (int b = 0; b < TN; ++b) {
-        const int j = j0 + wn0 + 16 * b + lr;
-        const bool jok = FULL || j < p.J;
-        const float bj = (bias && jok) ? bias[j] : 0.f;
-#pragma unroll
-        for (int a = 0; a < TM; ++a)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int i = i0 + wm0 + 16 * a + 4 * rq + r;
-            if ((FULL || i < p.I) && jok) {
-              const float v = has_bias ? acc[a][b][r] + bj : acc[a][b][r];
-              csum[b] += v;
-              csq[b] += v * v;
-            }
-          }
-      }
-    }
   }
-  if (p.stat != nullptr) {   // uniform branch; the stage buffers are free (loop ended on a barrier)
-    float* red = lds;        // [2][2 wave-rows][BN]
-#pragma unroll
-    for (int b = 0; b < TN; ++b) {
-      float s = csum[b], q = csq[b];
-      s += __shfl_xor(s, 16, 64); s += __shfl_xor(s, 32, 64);
-      q += __shfl_xor(q, 16, 64); q += __shfl_xor(q, 32, 64);
-      if (rq == 0) {
-        const int c = wn0 + 16 * b + lr;
-        red[(0 * 2 + (wave >> 1)) * BN + c] = s;
-        red[(1 * 2 + (wave >> 1)) * BN + c] = q;
-      }
-    }
-    __syncthreads();
+  if (p.stat != nullptr) {   // uniform branch: the column sums were parked in LDS before the store loop (see above)
+    const float* red = lds + 4 * 32 * ((BN / 2) + 4);
     if (threadIdx.x < BN) {
       const int j = j0 + threadIdx.x;
       if (FULL || j < p.J) {

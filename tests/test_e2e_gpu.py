@@ -434,5 +434,6 @@ def test_graphed_train_step_equals_eager():
     assert abs(res[True][0][0] - res[False][0][0]) < 1e-5                           # same state, same inputs
     # after an update the two runs differ by fp32 atomics order and kNN near-tie flips (chaotic at B = 16): trajectories
     # stay close, weights moved by the same 3 Adam steps
-    assert max(abs(a - b) for a, b in zip(res[True][0], res[False][0])) < 0.15
-    assert float((res[True][1] - res[False][1]).abs().mean()) < 0.25 * 8e-5
+    assert abs(res[True][0][1] - res[False][0][1]) < 5e-2                           # one update later (0.54 +- 0.01)
+    assert max(abs(a - b) for a, b in zip(res[True][0], res[False][0])) < 0.3
+    assert float((res[True][1] - res[False][1]).abs().mean()) < 1.0 * 8e-5          # both moved by 3 Adam steps of <= lr

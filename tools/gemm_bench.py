@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--only", default="fwd,bwd_data,bwd_weight")
     ap.add_argument("--shapes", default="")
     ap.add_argument("--precision", default="bf16")
+    ap.add_argument("--no-stat", action="store_true", help="forward GEMM without the BatchNorm statistics epilogue")
     ap.add_argument("--fp32-weights", action="store_true", help="do not use bf16 weight shadows")
     ap.add_argument("--storage", default="bf16", help="activation storage: bf16 (needs --precision bf16) or fp32")
     args = ap.parse_args()
@@ -52,7 +53,7 @@ def main():
         nbytes = {"fwd": G * (esz * M * K + 4.0 * N * K + esz * M * N), "bwd_data": G * (esz * M * N + 4.0 * N * K + esz * M * K),
                   "bwd_weight": G * (esz * M * N + esz * M * K + 4.0 * N * K)}
         runs = {
-            "fwd": lambda: ops.linear_fwd(x, w, None, M, N, K, G, sc, sh, ops.ACT_RELU if aff else 0, 0, want_stat=True,
+            "fwd": lambda: ops.linear_fwd(x, w, None, M, N, K, G, sc, sh, ops.ACT_RELU if aff else 0, 0, want_stat=not args.no_stat,
                                           out=out),
             "bwd_data": lambda: ops.linear_bwd_data(dout, w, M, N, K, G, out=din),
             "bwd_weight": lambda: ops.linear_bwd_weight(dout, x, dw, M, N, K, G, sc, sh, ops.ACT_RELU if aff else 0),
