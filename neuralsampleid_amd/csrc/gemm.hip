@@ -474,7 +474,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {   // >
         for (int b = 0; b < TN; ++b)
 #pragma unroll
           for (int r = 0; r < 4; ++r) ost[(16 * a2 + 4 * rq + r) * OLD + 16 * b + lr] = acc[2 * h + a2][b][r];
-      __syncthreads();
+      // no workgroup barrier: a wave reads back only its own transpose buffer, and the LDS operations of one wave execute in
+      // issue order (four barriers per tile were pure skew)
 #pragma unroll
       for (int pass = 0; pass < 32 / ROWS_PER_PASS; ++pass) {
         const int rr = pass * ROWS_PER_PASS + orow;
@@ -515,10 +516,10 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {   // >
           }
         }
       }
-      __syncthreads();
     }
+    __syncthreads();                // every wave is done with its transpose buffer; publishes the parked statistics
     if (CAN_BNRED) {
-      if (bnred) {                  // uniform; the stage / transpose buffers are free (the loop ended on a barrier)
+      if (bnred) {                  // uniform; the stage / transpose buffers are free (barrier above)
         float* red2 = lds;          // [2][4 waves][ROWS_PER_PASS][WN]
 #pragma unroll
         for (int e = 0; e < OE; ++e) {
