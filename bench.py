@@ -303,10 +303,20 @@ def main():
             with open(os.environ["NSID_BENCH_SHAPES"], "w") as f:
                 json.dump(ops.PROFILE.by_shape(), f, indent=0)
         ops.PROFILE = None
-        kernels = {n: {"launches": d["launches"], "avg_us": round(1e3 * d["ms"] / d["launches"], 2),
-                       "tflops": round(d["flops"] / (d["ms"] * 1e-3) / 1e12, 2),
-                       "share_of_step": round(d["ms"] / (1e3 * elapsed / args.steps), 3)} for n, d in prof.items()}
-        dom = max(prof, key=lambda n: prof[n]["ms"])
+        mfma_peak = BF16_MFMA_PEAK_TFLOPS if args.precision == "bf16" else FP32_MFMA_PEAK_TFLOPS
+        kernels = {}
+        for n, d in prof.items():
+            tf = d["flops"] / (d["ms"] * 1e-3) / 1e12
+            gbs = d["bytes"] / (d["ms"] * 1e-3) / 1e9
+            # GEMM family: MFMA utilisation against the dense peak of the operand type; kNN: fp32 matrix pipe (exact
+            # distances); gather kernels: algorithmic HBM bytes only
+            peak = FP32_MFMA_PEAK_TFLOPS if n.startswith("knn") else mfma_peak
+            kernels[n] = {"launches": d["launches"], "avg_us": round(1e3 * d["ms"] / d["launches"], 2),
+                          "tflops": round(tf, 2), "mfma_frac": round(tf / peak, 4) if d["flops"] > 0 else None,
+                          "alg_GBps": round(gbs, 1), "hbm_frac": round(gbs / HBM_PEAK_GBPS, 4),
+                          "share_of_step": round(d["ms"] / (1e3 * elapsed / args.steps), 3)}
+        gemms = {n: d for n, d in prof.items() if n.startswith(("gemm_kernel", "wgrad3"))}
+        dom = max(gemms or prof, key=lambda n: prof[n]["ms"])
         d = prof[dom]
         tr = measured_traffic(dom, args.precision)
         common = {"kernel": dom, "traffic": tr[0] if tr else None,

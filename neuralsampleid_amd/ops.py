@@ -369,8 +369,12 @@ def knn_graph(r, B, N, C, k, dilation=1, aff: Optional[BNAffine] = None) -> torc
     """(B*N, C) features (optionally with a pending BatchNorm affine) -> int32 (B, N, k) clip-local neighbour ids"""
     dt = _act(r)
     idx = torch.empty((B, N, k), device=r.device, dtype=torch.int32)
-    call("nsid_knn_graph", _p(r), r.shape[-1], _p(aff.scale) if aff else None, _p(aff.shift) if aff else None,
-         B, N, C, k, dilation, _p(idx), dt, _stream())
+    kd = k * dilation
+    name = "knn2_kernel" if kd <= 8 else ("knn_rank_kernel" if N <= 128 else ("knn_sel_kernel" if kd <= 64 else "knn_kernel"))
+    # SURVEY 8d K1: read the features once, write int32 ids; 2*N^2*C flop on the fp32 matrix pipe
+    _timed(name, 2.0 * B * N * N * C, float(B) * (N * C * r.element_size() + N * k * 4), lambda: call(
+        "nsid_knn_graph", _p(r), r.shape[-1], _p(aff.scale) if aff else None, _p(aff.shift) if aff else None,
+        B, N, C, k, dilation, _p(idx), dt, _stream()), (B * N, N, C, 1))
     return idx
 
 
@@ -379,15 +383,21 @@ def mr_aggregate_fwd(r, idx, B, N, C, aff: Optional[BNAffine] = None, want_argma
     k = idx.shape[-1]
     u = torch.empty((B * N, 2 * C), device=r.device, dtype=r.dtype)
     amax = torch.empty((B * N, C), device=r.device, dtype=torch.uint8) if want_argmax else None
-    call("nsid_mr_aggregate_fwd", _p(r), r.shape[-1], _p(aff.scale) if aff else None,
-         _p(aff.shift) if aff else None, _p(idx), B, N, C, k, _p(u), _p(amax), dt, _stream())
+    # read x once, write the interleaved (x, max-relative) pair, read idx (+ the arg-max bytes for backward)
+    nbytes = float(B) * N * (3 * C * r.element_size() + k * 4 + (C if want_argmax else 0))
+    _timed("mr_fwd_kernel", 0.0, nbytes, lambda: call(
+        "nsid_mr_aggregate_fwd", _p(r), r.shape[-1], _p(aff.scale) if aff else None,
+        _p(aff.shift) if aff else None, _p(idx), B, N, C, k, _p(u), _p(amax), dt, _stream()), (B * N, 2 * C, C, 1))
     return u, amax
 
 
 def mr_aggregate_bwd(du, idx, amax, B, N, C) -> torch.Tensor:
     dt = _act(du)
     dy = torch.empty((B * N, C), device=du.device, dtype=du.dtype)
-    call("nsid_mr_aggregate_bwd", _p(du), _p(idx), _p(amax), B, N, C, idx.shape[-1], _p(dy), dt, _stream())
+    nbytes = float(B) * N * (3 * C * du.element_size() + idx.shape[-1] * 4 + C)
+    _timed("mr_bwd_kernel", 0.0, nbytes, lambda: call(
+        "nsid_mr_aggregate_bwd", _p(du), _p(idx), _p(amax), B, N, C, idx.shape[-1], _p(dy), dt, _stream()),
+        (B * N, C, 2 * C, 1))
     return dy
 
 
