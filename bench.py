@@ -173,8 +173,6 @@ def main():
     ap.add_argument("--deep", action="store_true",
                     help="BASELINE config 4: blocks [4,4,12,4], k=18, intended dilation schedule (capped by N)")
     ap.add_argument("--no-overlap", action="store_true", help="run the two views on one stream instead of two")
-    ap.add_argument("--wgrad-offload", action="store_true",
-                    help="experiment: weight-gradient GEMMs on auxiliary streams (slower on MI355X: graph edge cost)")
     ap.add_argument("--no-graph", action="store_true", help="do not capture the step in a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -207,7 +205,6 @@ def main():
         args.k = 18
     model = SimCLR(CFG, GraphEncoder(CFG, in_channels=CFG["n_filters"], k=args.k, size="t", **enc_kw),
                    overlap_views=not args.no_overlap).to(dev).train()
-    model.offload_wgrad = model.overlap_views and args.wgrad_offload
     if args.mode == "infer":
         return infer_bench(args, model, rank, world, dev, dist)
     opt = FusedClipAdam(model.parameters(), lr=CFG["lr"], max_norm=1.0)

@@ -300,7 +300,7 @@ def downsample_backward(dout: Tensor, P, S, G) -> Tensor:
     dr = ops.bn_backward(dout, r, aff, ACT_NONE, G["conv.1.weight"], G["conv.1.bias"], partial=_link_partial(S))
     _bias_grad_before_bn(dr, G["conv.0.bias"])
     dwp = torch.zeros_like(wp)
-    ops.linear_bwd_weight(dr, col, dwp, Mo, Co, 3 * C, offload=False)      # unpacked right below, same stream
+    ops.linear_bwd_weight(dr, col, dwp, Mo, Co, 3 * C)
     ops.unpack_ds_wgrad(dwp, G["conv.0.weight"])
     dcol = ops.linear_bwd_data(dr, wp, Mo, Co, 3 * C)
     return ops.im2col3_bwd(dcol, B, N, C)

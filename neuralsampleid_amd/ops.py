@@ -256,41 +256,8 @@ def linear_bwd_data(dout, w, M, Nout, K, groups=1, addend=None, out=None, bn=Non
     return (out, None) if want_pair else out
 
 
-# Weight-gradient GEMMs feed nothing but the optimiser: with WGRAD_OFFLOAD they are enqueued on an auxiliary stream per
-# compute stream (forked by an event after their operands are ready), so the backward-data chain — the critical path of
-# backward — does not wait for them. Whoever consumes the gradients joins the auxiliary streams
-# (functional.join_side_streams: optimiser step, gradient all-reduce).
-WGRAD_OFFLOAD = False
-_WGRAD_AUX = {}
-
-
-def wgrad_stream(cur: "torch.cuda.Stream") -> "torch.cuda.Stream":
-    aux = _WGRAD_AUX.get(cur.cuda_stream)
-    if aux is None:
-        aux = torch.cuda.Stream(device=cur.device)
-        _WGRAD_AUX[cur.cuda_stream] = aux
-        from . import functional
-        functional.SIDE_STREAMS.append(aux)
-    return aux
-
-
-def linear_bwd_weight(dout, x, dw, M, Nout, K, groups=1, in_scale=None, in_shift=None, act_in=ACT_NONE,
-                      offload=True) -> None:
-    """dw += dout^T f(x)   (offload=False: keep it on the current stream — the caller reads dw right after)"""
-    if offload and WGRAD_OFFLOAD and PROFILE is None and dout.is_cuda:
-        cur = torch.cuda.current_stream()
-        aux = wgrad_stream(cur)
-        if aux != cur:
-            aux.wait_stream(cur)
-            for t_ in (dout, x, in_scale, in_shift):          # the caching allocator must not recycle them early
-                if t_ is not None:
-                    t_.record_stream(aux)
-            with torch.cuda.stream(aux):
-                return _linear_bwd_weight(dout, x, dw, M, Nout, K, groups, in_scale, in_shift, act_in)
-    return _linear_bwd_weight(dout, x, dw, M, Nout, K, groups, in_scale, in_shift, act_in)
-
-
-def _linear_bwd_weight(dout, x, dw, M, Nout, K, groups=1, in_scale=None, in_shift=None, act_in=ACT_NONE) -> None:
+def linear_bwd_weight(dout, x, dw, M, Nout, K, groups=1, in_scale=None, in_shift=None, act_in=ACT_NONE) -> None:
+    """dw += dout^T f(x)"""
     _chk(dw, in_scale, in_shift)
     dt = _act(dout, x)
     t128 = ((Nout + 127) // 128) * ((K + 127) // 128) * groups

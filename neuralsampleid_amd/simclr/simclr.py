@@ -15,8 +15,6 @@ class SimCLR(nn.Module):
         self.encoder = encoder
         self.cfg = cfg
         self.overlap_views = overlap_views
-        self.offload_wgrad = False                   # measured on MI355X: the extra cross-stream graph edges cost more
-        #                                              than the overlap buys (13.3 vs 9.7 ms/step) — kept as an option
         self._side_stream = None
         d, h, u = cfg["d"], cfg["h"], cfg["u"]
         if cfg["arch"] != "grafp":
@@ -40,15 +38,11 @@ class SimCLR(nn.Module):
     def forward(self, x_i, x_j):
         if self.overlap_views and x_i.is_cuda and self.training:
             return self._forward_two_streams(x_i, x_j)
-        from .. import ops
-        ops.WGRAD_OFFLOAD = False
         h_i, z_i = self._embed(x_i)     # the encoder runs once per view: BatchNorm statistics are per view
         h_j, z_j = self._embed(x_j)
         return h_i, h_j, z_i, z_j
 
     def _forward_two_streams(self, x_i, x_j):
-        from .. import ops
-        ops.WGRAD_OFFLOAD = self.offload_wgrad       # weight-gradient GEMMs leave the backward critical path
         main = torch.cuda.current_stream()
         if self._side_stream is None:
             self._side_stream = torch.cuda.Stream(device=x_i.device)
@@ -59,8 +53,7 @@ class SimCLR(nn.Module):
         vo.mode, vo.events, vo.pos = "record", [], 0
         try:
             h_i, z_i = self._embed(x_i)
-            import os as _os
-            vo.mode = None if _os.environ.get("NSID_EXP_NO_BN_ORDER") else "wait"
+            vo.mode = "wait"
             with torch.cuda.stream(side):
                 h_j, z_j = self._embed(x_j)
         finally:
