@@ -146,6 +146,13 @@ class WeightShadows:
     def clear(self) -> None:
         self.entries.clear()
 
+    def purge(self) -> int:
+        """drop the entries whose fp32 memory is gone (their shadows would otherwise stay alive with the registry)"""
+        dead = [k for k, e in self.entries.items() if e[3]() is None]
+        for k in dead:
+            del self.entries[k]
+        return len(dead)
+
     def operand(self, w: torch.Tensor) -> torch.Tensor:
         e = self.entries.get(w.data_ptr())
         if e is not None and e[3]() is None:

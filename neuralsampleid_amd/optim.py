@@ -36,6 +36,7 @@ class FusedClipAdam:
         # bf16 shadow of every parameter for the bf16-storage GEMMs (ops.WeightShadows): one flat buffer, refreshed by
         # one launch at the start of each step (zero_grad) — 18.4 M parameters = 110 MB of traffic, ~0.2 % of a step
         self.flat_p16 = torch.zeros(total, device=dev, dtype=torch.bfloat16)
+        ops.SHADOWS.purge()
         for p, off in zip(self.params, self.offsets):
             if p.numel() % 8 == 0:
                 ops.SHADOWS.register(p.data, self.flat_p16[off:off + p.numel()], owner=self.flat_p)
