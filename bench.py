@@ -292,6 +292,7 @@ def main():
             torch.cuda.synchronize()
     if rank == 0 and not args.no_roofline:
         ops.PROFILE = ops.KernelProfile()
+        bracket_us = 1e3 * ops.PROFILE.bracket_ms
         model.overlap_views = False          # one stream: a launch's events then bracket that kernel alone
         step()
         model.overlap_views = not args.no_overlap
@@ -322,7 +323,9 @@ def main():
                   "avg_launch_us": round(1e3 * d["ms"] / d["launches"], 2),
                   "flops_per_launch": round(d["flops"] / d["launches"]),
                   "alg_bytes_per_launch": round(d["bytes"] / d["launches"]),
-                  "method": "HIP events around every launch in one instrumented eager step after the timed region"}
+                  "event_bracket_us": round(bracket_us, 2),
+                  "method": "HIP events around every launch in one instrumented eager step after the timed region, "
+                            "minus the median duration of an empty event bracket (event_bracket_us)"}
         if args.precision == "fp32":      # fp32 MFMA runs at 1/16 of the bf16 rate: the GEMMs are matrix-pipe bound
             ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
             roofline = {"bound": "mfma", "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",

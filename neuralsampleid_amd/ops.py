@@ -19,6 +19,25 @@ class KernelProfile:
 
     def __init__(self):
         self.records = []          # (kernel, flops, algorithmic bytes, start event, end event, shape)
+        self.bracket_ms = self._empty_bracket_ms()
+
+    @staticmethod
+    def _empty_bracket_ms(n: int = 64) -> float:
+        """median elapsed time of an EMPTY event bracket on the current stream: two timed events cost a marker each, and
+        that cost sits inside every per-launch measurement of an eager step; it is subtracted in summary()/by_shape()"""
+        torch.cuda.synchronize()
+        evs = []
+        for _ in range(n):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            e1.record()
+            evs.append((e0, e1))
+        torch.cuda.synchronize()
+        ts = sorted(a.elapsed_time(b) for a, b in evs)
+        return ts[len(ts) // 2]
+
+    def _ms(self, e0, e1) -> float:
+        return max(e0.elapsed_time(e1) - self.bracket_ms, 1e-4)
 
     def summary(self):
         torch.cuda.synchronize()
@@ -26,7 +45,7 @@ class KernelProfile:
         for name, flops, nbytes, e0, e1, shape in self.records:
             d = out.setdefault(name, {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
             d["launches"] += 1
-            d["ms"] += e0.elapsed_time(e1)
+            d["ms"] += self._ms(e0, e1)
             d["flops"] += flops
             d["bytes"] += nbytes
         return out
@@ -38,7 +57,7 @@ class KernelProfile:
         for name, flops, nbytes, e0, e1, shape in self.records:
             d = out.setdefault((name,) + shape, [0, 0.0, flops, nbytes])
             d[0] += 1
-            d[1] += e0.elapsed_time(e1)
+            d[1] += self._ms(e0, e1)
         rows = []
         for key, (n, ms, flops, nbytes) in out.items():
             us = 1e3 * ms / n
