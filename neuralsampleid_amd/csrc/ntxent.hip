@@ -39,6 +39,34 @@ __device__ __forceinline__ void stage_rows(float* dst, int ld, const float* z_i,
   }
 }
 
+// Column blocks are double-buffered through registers: the loads of block j0+CBK are issued before the MFMA / exp work on
+// block j0 and written to LDS after it (one staging latency per block was ~2/3 of these kernels at the 8-GPU global batch:
+// 32 blocks of 128 rows per workgroup). PF chunks of 16 bytes per thread: CBK*d/4/256 <= 16 (d <= 128).
+constexpr int PF_MAX = 16;
+struct Prefetch { f32x4 v[PF_MAX]; };
+
+__device__ __forceinline__ void prefetch_rows(Prefetch& pf, const float* z_i, const float* z_j, int row0, int nrows, int M,
+                                              int d) {
+  const int d4 = d >> 2;
+#pragma unroll
+  for (int u = 0; u < PF_MAX; ++u) {
+    const int q = threadIdx.x + u * 256;
+    const int rr = q / d4, c = (q % d4) * 4;
+    pf.v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (q < nrows * d4 && row0 + rr < M) pf.v[u] = *reinterpret_cast<const f32x4*>(zrow(z_i, z_j, row0 + rr, d) + c);
+  }
+}
+
+__device__ __forceinline__ void commit_rows(float* dst, int ld, const Prefetch& pf, int nrows, int d) {
+  const int d4 = d >> 2;
+#pragma unroll
+  for (int u = 0; u < PF_MAX; ++u) {
+    const int q = threadIdx.x + u * 256;
+    const int rr = q / d4, c = (q % d4) * 4;
+    if (q < nrows * d4) *reinterpret_cast<f32x4*>(dst + rr * ld + c) = pf.v[u];
+  }
+}
+
 // NT T-tiles at once (column rows j .. j+16*NT-1): independent accumulator chains keep the matrix pipe issuing
 template <int NT>
 __device__ __forceinline__ void sim_tiles(const float* zi_w, const float* zj_t, int ld, int d, int lr, int rq,
@@ -80,10 +108,22 @@ __global__ __launch_bounds__(256) void ntxent_lse_kernel(const float* __restrict
   const int i = i0 + lr;
   float mrun = -__builtin_inff(), srun = 0.f, pos = 0.f;
   constexpr int TPW = CBK / 16 / 4;                   // column tiles per wave per block
+  const bool pipelined = CBK * (d >> 2) <= PF_MAX * 256;     // uniform
+  Prefetch pf;
+  if (pipelined) {
+    prefetch_rows(pf, z_i, z_j, 0, CBK, M, d);
+    __syncthreads();                                          // zi_s staged, nobody reads zj_s yet
+    commit_rows(zj_s, ld, pf, CBK, d);
+  }
   for (int j0 = 0; j0 < M; j0 += CBK) {
-    __syncthreads();
-    stage_rows(zj_s, ld, z_i, z_j, j0, CBK, M, d);
-    __syncthreads();
+    if (pipelined) {
+      __syncthreads();                                        // block j0 is in LDS
+      prefetch_rows(pf, z_i, z_j, j0 + CBK, CBK, M, d);       // next block: in flight under the work below (zeros past M)
+    } else {
+      __syncthreads();
+      stage_rows(zj_s, ld, z_i, z_j, j0, CBK, M, d);
+      __syncthreads();
+    }
     f32x4 acc[TPW];
     sim_tiles<TPW>(zi_s, zj_s + 16 * (wave * TPW) * ld, ld, d, lr, rq, acc);
 #pragma unroll
@@ -99,6 +139,10 @@ __global__ __launch_bounds__(256) void ntxent_lse_kernel(const float* __restrict
           mrun = mn;
         }
       }
+    }
+    if (pipelined) {
+      __syncthreads();                                        // every wave is done with block j0
+      commit_rows(zj_s, ld, pf, CBK, d);
     }
   }
   // merge the four lanes (rq = 0..3) that share row i, then the four waves
@@ -152,10 +196,22 @@ __global__ __launch_bounds__(256) void ntxent_grad_kernel(const float* __restric
 #pragma unroll
   for (int c = 0; c < DT; ++c) out[c] = f32x4{0.f, 0.f, 0.f, 0.f};
   constexpr int TPW = CBK / 16 / 4;
+  const bool pipelined = CBK * (d >> 2) <= PF_MAX * 256;     // uniform
+  Prefetch pf;
+  if (pipelined) {
+    prefetch_rows(pf, z_i, z_j, 0, CBK, M, d);
+    __syncthreads();                                          // zi_s staged, nobody reads zj_s yet
+    commit_rows(zj_s, ld, pf, CBK, d);
+  }
   for (int j0 = 0; j0 < M; j0 += CBK) {
-    __syncthreads();
-    stage_rows(zj_s, ld, z_i, z_j, j0, CBK, M, d);
-    __syncthreads();
+    if (pipelined) {
+      __syncthreads();                                        // block j0 is in LDS
+      prefetch_rows(pf, z_i, z_j, j0 + CBK, CBK, M, d);       // next block: in flight under the work below (zeros past M)
+    } else {
+      __syncthreads();
+      stage_rows(zj_s, ld, z_i, z_j, j0, CBK, M, d);
+      __syncthreads();
+    }
     f32x4 acc[TPW];
     sim_tiles<TPW>(zi_s, zj_s + 16 * (wave * TPW) * ld, ld, d, lr, rq, acc);
 #pragma unroll
@@ -180,6 +236,10 @@ __global__ __launch_bounds__(256) void ntxent_grad_kernel(const float* __restric
 #pragma unroll
         for (int e = 0; e < 4; ++e)
           out[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(q[e], zb[e * ld + 16 * c], out[c], 0, 0, 0);
+    }
+    if (pipelined) {
+      __syncthreads();
+      commit_rows(zj_s, ld, pf, CBK, d);
     }
   }
   // the 4 waves hold partial sums over disjoint column sets: add them through LDS.
