@@ -94,9 +94,12 @@ __device__ __forceinline__ void sim_tiles(const float* zi_w, const float* zj_t, 
 // meet in LDS at the end.
 
 // pass 1: lse[i] = logsumexp_{j != i} a_ij and rowloss[i] = lse[i] - a_{i, i^1}, for every row i < M
+// grid.y > 1: the columns are split over workgroups and every workgroup writes its partial (max, sum, positive) of a row to
+// part_out[group][3][M]; ntxent_lse_merge_kernel combines them (online-softmax merge).
 __global__ __launch_bounds__(256) void ntxent_lse_kernel(const float* __restrict__ z_i, const float* __restrict__ z_j,
-                                                         int M, int d, float tau, float* __restrict__ lse,
-                                                         float* __restrict__ rowloss) {
+                                                         int M, int d, float tau, int cols_per_group,
+                                                         float* __restrict__ lse, float* __restrict__ rowloss,
+                                                         float* __restrict__ part_out) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int ld = d + 4;
   float* zi_s = sm;                 // [RB][ld]
@@ -110,12 +113,13 @@ __global__ __launch_bounds__(256) void ntxent_lse_kernel(const float* __restrict
   constexpr int TPW = CBK / 16 / 4;                   // column tiles per wave per block
   const bool pipelined = CBK * (d >> 2) <= PF_MAX * 256;     // uniform
   Prefetch pf;
+  const int jbeg = blockIdx.y * cols_per_group, jend = min(M, jbeg + cols_per_group);
   if (pipelined) {
-    prefetch_rows(pf, z_i, z_j, 0, CBK, M, d);
+    prefetch_rows(pf, z_i, z_j, jbeg, CBK, M, d);
     __syncthreads();                                          // zi_s staged, nobody reads zj_s yet
     commit_rows(zj_s, ld, pf, CBK, d);
   }
-  for (int j0 = 0; j0 < M; j0 += CBK) {
+  for (int j0 = jbeg; j0 < jend; j0 += CBK) {
     if (pipelined) {
       __syncthreads();                                        // block j0 is in LDS
       prefetch_rows(pf, z_i, z_j, j0 + CBK, CBK, M, d);       // next block: in flight under the work below (zeros past M)
@@ -170,18 +174,44 @@ __global__ __launch_bounds__(256) void ntxent_lse_kernel(const float* __restrict
       m = mn;
       p += part[(w * 3 + 2) * 16 + threadIdx.x];
     }
-    const float l = m + logf(sacc);
-    lse[i0 + threadIdx.x] = l;
-    rowloss[i0 + threadIdx.x] = l - p;
+    if (gridDim.y > 1) {
+      float* po = part_out + (long)blockIdx.y * 3 * M + i0 + threadIdx.x;
+      po[0] = m; po[M] = sacc; po[2 * M] = p;
+    } else {
+      const float l = m + logf(sacc);
+      lse[i0 + threadIdx.x] = l;
+      rowloss[i0 + threadIdx.x] = l - p;
+    }
   }
+}
+
+__global__ void ntxent_lse_merge_kernel(const float* __restrict__ part, int groups, int M, float* __restrict__ lse,
+                                        float* __restrict__ rowloss) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= M) return;
+  float m = -__builtin_inff(), sacc = 0.f, p = 0.f;
+  for (int g = 0; g < groups; ++g) {
+    const float m2 = part[(long)g * 3 * M + i], s2 = part[(long)g * 3 * M + M + i];
+    const float mn = fmaxf(m, m2);
+    const float e1 = m == -__builtin_inff() ? 0.f : expf(m - mn);
+    const float e2 = m2 == -__builtin_inff() ? 0.f : expf(m2 - mn);
+    sacc = sacc * e1 + s2 * e2;
+    m = mn;
+    p += part[(long)g * 3 * M + 2 * M + i];
+  }
+  const float l = m + logf(sacc);
+  lse[i] = l;
+  rowloss[i] = l - p;
 }
 
 // pass 2: dz[i] = (1/(M tau)) * sum_j Q_ij z_j,  Q_ij = exp(a_ij - lse_i) + exp(a_ij - lse_j) - 2[j == i^1], Q_ii = 0
 template <int DT>   // d / 16 column tiles of the output
 __global__ __launch_bounds__(256) void ntxent_grad_kernel(const float* __restrict__ z_i, const float* __restrict__ z_j,
                                                           int M, int d, float tau, const float* __restrict__ lse,
-                                                          int row0, int nrows, float* __restrict__ dz_i,
-                                                          float* __restrict__ dz_j) {
+                                                          int row0, int nrows, int cols_per_group,
+                                                          float* __restrict__ dz_i, float* __restrict__ dz_j) {
+  // grid.y > 1: the column blocks are split over workgroups (few own rows against a large global batch: 32 row tiles at the
+  // 8-GPU batch would leave 7/8 of the chip idle); the partial dZ rows are then added atomically into zeroed dz_i / dz_j
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int ld = d + 4;
   float* zi_s = sm;
@@ -198,12 +228,13 @@ __global__ __launch_bounds__(256) void ntxent_grad_kernel(const float* __restric
   constexpr int TPW = CBK / 16 / 4;
   const bool pipelined = CBK * (d >> 2) <= PF_MAX * 256;     // uniform
   Prefetch pf;
+  const int jbeg = blockIdx.y * cols_per_group, jend = min(M, jbeg + cols_per_group);
   if (pipelined) {
-    prefetch_rows(pf, z_i, z_j, 0, CBK, M, d);
+    prefetch_rows(pf, z_i, z_j, jbeg, CBK, M, d);
     __syncthreads();                                          // zi_s staged, nobody reads zj_s yet
     commit_rows(zj_s, ld, pf, CBK, d);
   }
-  for (int j0 = 0; j0 < M; j0 += CBK) {
+  for (int j0 = jbeg; j0 < jend; j0 += CBK) {
     if (pipelined) {
       __syncthreads();                                        // block j0 is in LDS
       prefetch_rows(pf, z_i, z_j, j0 + CBK, CBK, M, d);       // next block: in flight under the work below (zeros past M)
@@ -258,7 +289,8 @@ __global__ __launch_bounds__(256) void ntxent_grad_kernel(const float* __restric
     if (row < row0 + nrows && row < M) {
       const float v = (red[rr * ld + c] + red[(16 + rr) * ld + c]) + (red[(32 + rr) * ld + c] + red[(48 + rr) * ld + c]);
       float* dst = ((row & 1) ? dz_j : dz_i) + (long)((row >> 1) - (row0 >> 1)) * d;
-      dst[c] = v * sc;
+      if (gridDim.y > 1) atomicAdd(dst + c, v * sc);
+      else dst[c] = v * sc;
     }
   }
 }
@@ -283,7 +315,8 @@ int raise_lds(K kernel, size_t bytes) {
 
 }  // namespace
 
-extern "C" size_t nsid_ntxent_ws_floats(int Bg) { return (size_t)4 * Bg + 8; }
+constexpr int LSE_MAX_GROUPS = 16;
+extern "C" size_t nsid_ntxent_ws_floats(int Bg) { return (size_t)4 * Bg + 8 + (size_t)LSE_MAX_GROUPS * 3 * 2 * Bg; }
 
 extern "C" int nsid_ntxent_fwd_bwd(const float* z_i, const float* z_j, int Bg, int d, float tau, int p0, int np,
                                    float* ws, float* loss_out, float* dz_i, float* dz_j, void* stream) {
@@ -296,17 +329,37 @@ extern "C" int nsid_ntxent_fwd_bwd(const float* z_i, const float* z_j, int Bg, i
   hipStream_t s = static_cast<hipStream_t>(stream);
   const size_t bytes = ((size_t)(RB + CBK) * (d + 4) + 4 * 3 * 16) * sizeof(float);
   if (raise_lds(ntxent_lse_kernel, bytes) != NSID_OK) return NSID_ELAUNCH;
-  NSID_LAUNCH(ntxent_lse_kernel, dim3((M + RB - 1) / RB), dim3(256), bytes, s, z_i, z_j, M, d, tau, lse,
-                     rowloss);
+  {
+    const int row_tiles = (M + RB - 1) / RB, nblocks = (M + CBK - 1) / CBK;
+    int cg = row_tiles >= 512 ? 1 : (512 + row_tiles - 1) / row_tiles;        // ~512 workgroups
+    if (cg > nblocks) cg = nblocks;
+    if (cg > LSE_MAX_GROUPS) cg = LSE_MAX_GROUPS;
+    const int cols_per_group = (nblocks + cg - 1) / cg * CBK;
+    cg = (M + cols_per_group - 1) / cols_per_group;
+    float* part = ws + 2 * M + 8;
+    NSID_LAUNCH(ntxent_lse_kernel, dim3(row_tiles, cg), dim3(256), bytes, s, z_i, z_j, M, d, tau, cols_per_group, lse,
+                rowloss, part);
+    if (cg > 1) NSID_LAUNCH(ntxent_lse_merge_kernel, dim3((M + 255) / 256), dim3(256), 0, s, part, cg, M, lse, rowloss);
+  }
   NSID_LAUNCH(ntxent_loss_kernel, dim3(1), dim3(256), 0, s, rowloss, 2 * p0, 2 * np, M, loss_out);
   if (dz_i != nullptr) {
     const int row0 = 2 * p0, nrows = 2 * np;
-    dim3 grid((nrows + RB - 1) / RB);
+    const int row_tiles = (nrows + RB - 1) / RB, nblocks = (M + CBK - 1) / CBK;
+    int cg = row_tiles >= 128 ? 1 : (256 + row_tiles - 1) / row_tiles;       // ~256 workgroups
+    if (cg > nblocks) cg = nblocks;
+    const int cols_per_group = (nblocks + cg - 1) / cg * CBK;
+    cg = (M + cols_per_group - 1) / cols_per_group;
+    if (cg > 1) {          // partial rows are accumulated atomically: zero the outputs first (a memset node when captured)
+      if (hipMemsetAsync(dz_i, 0, (size_t)np * d * sizeof(float), s) != hipSuccess ||
+          hipMemsetAsync(dz_j, 0, (size_t)np * d * sizeof(float), s) != hipSuccess)
+        return NSID_ELAUNCH;
+    }
+    dim3 grid(row_tiles, cg);
 #define NSID_NTX_CASE(DTV)                                                                                   \
   case DTV:                                                                                                  \
     if (raise_lds(ntxent_grad_kernel<DTV>, bytes) != NSID_OK) return NSID_ELAUNCH;                           \
     NSID_LAUNCH((ntxent_grad_kernel<DTV>), grid, dim3(256), bytes, s, z_i, z_j, M, d, tau, lse, row0, \
-                       nrows, dz_i, dz_j);                                                                   \
+                       nrows, cols_per_group, dz_i, dz_j);                                                                   \
     break;
     switch (d / 16) {
       NSID_NTX_CASE(1) NSID_NTX_CASE(2) NSID_NTX_CASE(4) NSID_NTX_CASE(8) NSID_NTX_CASE(16)
