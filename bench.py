@@ -211,6 +211,7 @@ def main():
     x_i, x_j = synth_clips(args.batch, 1000 + 2 * rank, dev)   # each rank owns different clips
     loss_buf = torch.zeros((), device=dev)
     reducer = parallel.GradReducer(opt.params, opt.flat_g, opt.offsets, bucket_bytes=16 << 20).install()
+    parallel.ASYNC_LOSS_REDUCE = True        # reducer.finish() joins the communicator's stream before the loss is read
 
     def step():
         opt.zero_grad()

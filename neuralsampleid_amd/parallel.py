@@ -67,20 +67,45 @@ def gather_embeddings(z: torch.Tensor, group=None) -> torch.Tensor:
     return out
 
 
+# The all-reduce of the scalar loss only serves reporting (every rank logs the global loss). With ASYNC_LOSS_REDUCE it is
+# left running on the communicator's stream instead of being joined before backward; the caller must then join that stream
+# before reading the loss on the host — GradReducer.finish() and allreduce_gradients(async_op=False) both do.
+ASYNC_LOSS_REDUCE = False
+
+
+def gather_pair(z_i: torch.Tensor, z_j: torch.Tensor, group=None):
+    """both views' embeddings of every rank, rank-major: ONE all-gather of the stacked (2, B, d) block on the RCCL path
+    (each collective is a latency on the critical path between forward and backward)"""
+    c = _comm_for(group)
+    if c is None or not _distributed(group):
+        return gather_embeddings(z_i, group), gather_embeddings(z_j, group)
+    B, d = z_i.shape
+    allz = c.all_gather(torch.stack((z_i, z_j)))                       # (world*2, B, d)
+    return _split_views(allz, c.world)
+
+
+def _split_views(allz: torch.Tensor, world: int):
+    """(world*2, B, d) rank-major stacked views -> (world*B, d) per view, global pair p = rank*B + b (as gather_embeddings)"""
+    _, B, d = allz.shape
+    allz = allz.view(world, 2, B, d).transpose(0, 1).reshape(2, world * B, d)
+    return allz[0], allz[1]
+
+
 class _DistNtxent(torch.autograd.Function):
     """loss = global-mean NT-Xent; backward hands back d loss / d z_local from the sharded kernel (no collective)."""
 
     @staticmethod
     def forward(ctx, z_i, z_j, tau, rows_fn, group):
         rank, world = _rank_world(group)
-        zi_all = gather_embeddings(z_i.detach(), group)
-        zj_all = gather_embeddings(z_j.detach(), group)
+        zi_all, zj_all = gather_pair(z_i.detach(), z_j.detach(), group)
         p0, n = shard_range(zi_all.shape[0], rank, world)
         part, dzi, dzj = rows_fn(zi_all, zj_all, tau, p0, n)        # part = sum of owned rows / (2*B_global)
         loss = part.reshape(()).clone()
         if _distributed(group):                                        # every rank reports the global loss
             c = _comm_for(group)
-            if c is not None:
+            if c is not None and ASYNC_LOSS_REDUCE:
+                c.all_reduce_async_(loss)
+            elif c is not None:
                 c.all_reduce_(loss)
             else:
                 dist.all_reduce(loss, op=dist.ReduceOp.SUM, group=group)

@@ -228,3 +228,14 @@ def test_rccl_library_exports_the_bound_entry_points():
         assert hasattr(L, name)
     assert rccl.version() >= 21800
     assert len(rccl.new_unique_id()) == rccl.NCCL_UNIQUE_ID_BYTES
+
+
+def test_stacked_view_gather_keeps_rank_major_pair_order():
+    """the single all-gather of both views (RCCL path) must hand NT-Xent the same row order as two separate gathers"""
+    from neuralsampleid_amd import parallel
+    world, B, d = 3, 4, 5
+    zi = [torch.randn(B, d) for _ in range(world)]
+    zj = [torch.randn(B, d) for _ in range(world)]
+    gathered = torch.cat([torch.stack((a, b)) for a, b in zip(zi, zj)])            # what ncclAllGather returns
+    gi, gj = parallel._split_views(gathered, world)
+    assert torch.equal(gi, torch.cat(zi)) and torch.equal(gj, torch.cat(zj))

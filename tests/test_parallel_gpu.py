@@ -133,7 +133,7 @@ def test_rccl_reducer_step_equals_plain_step(rccl_comm, overlap):
     red.finish()
     torch.cuda.synchronize()
     assert fired_during_backward == len(red.bounds)
-    assert rccl_comm.calls - calls0 == len(red.bounds) + 3            # buckets + 2 all-gathers + the loss all-reduce
+    assert rccl_comm.calls - calls0 == len(red.bounds) + 2            # buckets + ONE all-gather of both views + the loss all-reduce
     assert abs(float(l0) - float(l1)) < 1e-5
     rel = float((o1.flat_g - g0).norm() / g0.norm())
     assert rel < 1e-3, rel
@@ -185,7 +185,7 @@ def test_rccl_step_captured_in_hipgraph(rccl_comm):
     graph = torch.cuda.CUDAGraph()
     with torch.cuda.graph(graph):
         step()
-    assert rccl_comm.calls - calls == len(red.bounds) + 3              # the collectives were enqueued under capture
+    assert rccl_comm.calls - calls == len(red.bounds) + 2              # the collectives were enqueued under capture
     restore(init)
     loss_buf.zero_(); o.flat_g.fill_(7.0)
     graph.replay()
