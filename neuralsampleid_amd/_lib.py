@@ -9,7 +9,7 @@ import torch  # noqa: F401  -- must come first: torch bundles its own libamdhip6
 #                              would bind the system HIP runtime and leave two runtimes in one process
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "libnsid_hip.so")
+LIB_PATH = os.environ.get("NSID_LIB") or os.path.join(_PKG, "libnsid_hip.so")     # NSID_LIB: an alternative build (kernel A/B experiments)
 
 # signature letters: p = device pointer, i = int, l = long, f = float, s = stream (void*)
 SIGNATURES = {
@@ -64,6 +64,8 @@ def _load():
         fn.argtypes = [_CT[c] for c in sig]
         fn.restype = ctypes.c_int
     lib.nsid_version.restype = ctypes.c_int
+    lib.nsid_debug_gemm_trace.argtypes = [ctypes.c_void_p]
+    lib.nsid_debug_gemm_trace.restype = ctypes.c_int
     lib.nsid_get_gemm_precision.restype = ctypes.c_int
     lib.nsid_row_tiles.argtypes = [ctypes.c_int]
     lib.nsid_row_tiles.restype = ctypes.c_int
@@ -75,7 +77,7 @@ def _load():
 
 
 lib = _load()
-EXPORTS = list(SIGNATURES) + ["nsid_version", "nsid_get_gemm_precision", "nsid_row_tiles", "nsid_sumsq_blocks", "nsid_ntxent_ws_floats"]
+EXPORTS = list(SIGNATURES) + ["nsid_version", "nsid_debug_gemm_trace", "nsid_get_gemm_precision", "nsid_row_tiles", "nsid_sumsq_blocks", "nsid_ntxent_ws_floats"]
 
 _ERR = {-1: "NSID_EINVAL (unsupported shape, misaligned pointer or bad argument)",
         -2: "NSID_ELAUNCH (HIP runtime refused the launch)"}

@@ -33,10 +33,13 @@ struct WgArgs {
 // splits x Nout x K x 4) the workgroup has 8 waves: quadrant = wave & 3 (64x64 each), and the two wave groups take the
 // two 32-row halves of every 64-row stage; their partial tiles meet in LDS at the end.
 constexpr int W3_T = 128, W3_BK = 64, W3_THREADS = 512;
-constexpr int W3_STRIDE = W3_T * 2 + 32;                 // 288 B rows: the 4 rows of a transposed read hit disjoint banks
-constexpr int W3_OP_BYTES = W3_BK * W3_STRIDE;           // 18432
+// 288 B rows + 128 B more per block of 8 rows: ds_read_b64_tr_b16 serves 32 lanes together = rows {0-3} and {8-11} of the
+// 16 a fragment spans; row starts r*288 + (r>>3)*128 put those 8 rows on 8 disjoint 32-byte bank ranges (gemm.hip TileGeom)
+constexpr int W3_STRIDE = W3_T * 2 + 32;
+constexpr int W3_SHIFT8 = 128;
+constexpr int W3_OP_BYTES = W3_BK * W3_STRIDE + (W3_BK / 8) * W3_SHIFT8;   // 19456
 constexpr int W3_STAGE = 2 * W3_OP_BYTES;                // A + B
-constexpr int W3_LDS = 2 * W3_STAGE;                     // double buffer: 73728 B (>= the 64 KB epilogue scratch)
+constexpr int W3_LDS = 2 * W3_STAGE;                     // double buffer: 77824 B (>= the 64 KB epilogue scratch)
 constexpr int W3_CHUNKS = W3_BK * W3_T * 2 / 16 / W3_THREADS;   // 2 chunks per thread per operand per stage
 
 struct W3Stage { f32x4 a[W3_CHUNKS], b[W3_CHUNKS]; };
@@ -55,7 +58,8 @@ __device__ __forceinline__ void w3_commit(char* lds, const W3Stage& s, float slo
 #pragma unroll
   for (int q = 0; q < W3_CHUNKS; ++q) {
     const int idx = threadIdx.x + W3_THREADS * q, row = idx >> 4, ch = idx & 15;
-    *reinterpret_cast<f32x4*>(lds + row * W3_STRIDE + ch * 16) = s.a[q];
+    const int ro = row * W3_STRIDE + (row >> 3) * W3_SHIFT8;
+    *reinterpret_cast<f32x4*>(lds + ro + ch * 16) = s.a[q];
     f32x4 raw = s.b[q];
     if (BAFF) {
       const bf16x8 h = __builtin_bit_cast(bf16x8, raw);
@@ -67,13 +71,13 @@ __device__ __forceinline__ void w3_commit(char* lds, const W3Stage& s, float slo
       }
       raw = __builtin_bit_cast(f32x4, o);
     }
-    *reinterpret_cast<f32x4*>(lds + W3_OP_BYTES + row * W3_STRIDE + ch * 16) = raw;
+    *reinterpret_cast<f32x4*>(lds + W3_OP_BYTES + ro + ch * 16) = raw;
   }
 }
 
 __device__ __forceinline__ bf16x8 w3_frag(const char* lds, int row0, int col0, int lr, int rq) {
   typedef bf16x4 __attribute__((address_space(3))) * lds_bf16x4_ptr;
-  const char* base = lds + (row0 + 8 * rq + (lr >> 2)) * W3_STRIDE + (col0 + 4 * (lr & 3)) * 2;
+  const char* base = lds + (row0 + 8 * rq + (lr >> 2)) * W3_STRIDE + ((row0 >> 3) + rq) * W3_SHIFT8 + (col0 + 4 * (lr & 3)) * 2;
   const bf16x4 t0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(base));
   const bf16x4 t1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(base + 4 * W3_STRIDE));
   return __builtin_shufflevector(t0, t1, 0, 1, 2, 3, 4, 5, 6, 7);

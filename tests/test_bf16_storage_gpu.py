@@ -234,3 +234,4 @@ def test_bwd_data_emits_bn_backward_sums(ops, M, Nout, K, groups, act, add):
     got = ops.bn_backward(fused, r, aff, act, dg1, db1, partial=partial)
     assert relerr(dg1, dg0) < 2e-5 and relerr(db1, db0) < 2e-5          # same inputs, different summation order
     assert relerr(got.float(), ref.float()) < 1e-5
+
