@@ -195,33 +195,53 @@ __global__ __launch_bounds__(FIN_CH * FIN_TG) void bn_bwd_finalize_kernel(const 
   coef[C + c] = (float)(sgx / M);
 }
 
-template <typename T>
+// Every thread keeps ONE column chunk for the whole kernel (the launch makes the thread count a multiple of the chunks per
+// row), so the six per-channel vectors are loaded once and U rows are in flight per iteration. With the parameters re-read
+// for every 16-byte chunk the kernel moved 4x more bytes through the L1 path than through HBM and ran at half the rate of
+// bn_apply for the same traffic (10.2 us against 5 us per launch).
+template <typename T, int U>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ dout, const T* __restrict__ r,
-                                                           long nchunks, int CV, const float* __restrict__ scale,
+                                                           long rows, int CV, const float* __restrict__ scale,
                                                            const float* __restrict__ shift,
                                                            const float* __restrict__ mean,
                                                            const float* __restrict__ invstd, float slope,
                                                            const float* __restrict__ coef, T* __restrict__ dr) {
   constexpr int N = Chunk<T>::N;
   const int C = CV * N;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nchunks; i += (long)gridDim.x * blockDim.x) {
-    const int c = (int)(i % CV) * N;
-    float d[N], x[N], o[N], sc[N], sh[N], mu[N], is[N], c0[N], c1[N];
-    Chunk<T>::load(dout + i * N, d);
-    Chunk<T>::load(r + i * N, x);
-    load_channels<N>(scale, c, sc);
-    load_channels<N>(shift, c, sh);
-    load_channels<N>(mean, c, mu);
-    load_channels<N>(invstd, c, is);
-    load_channels<N>(coef, c, c0);
-    load_channels<N>(coef + C, c, c1);
+  const long t = (long)blockIdx.x * blockDim.x + threadIdx.x, total = (long)gridDim.x * blockDim.x;
+  const int cq = (int)(t % CV), c = cq * N;
+  const long rstep = total / CV;                  // total % CV == 0 (host)
+  float sc[N], sh[N], mu[N], is[N], c0[N], c1[N];
+  load_channels<N>(scale, c, sc);
+  load_channels<N>(shift, c, sh);
+  load_channels<N>(mean, c, mu);
+  load_channels<N>(invstd, c, is);
+  load_channels<N>(coef, c, c0);
+  load_channels<N>(coef + C, c, c1);
+  for (long row = t / CV; row < rows; row += U * rstep) {
+    float d[U][N], x[U][N];
 #pragma unroll
-    for (int e = 0; e < N; ++e) {
-      const float g = (sc[e] * x[e] + sh[e]) > 0.f ? d[e] : d[e] * slope;
-      const float xh = (x[e] - mu[e]) * is[e];
-      o[e] = sc[e] * (g - c0[e] - xh * c1[e]);
+    for (int u = 0; u < U; ++u) {
+      const long rr = row + u * rstep;
+      if (rr < rows) {
+        Chunk<T>::load(dout + (rr * CV + cq) * N, d[u]);
+        Chunk<T>::load(r + (rr * CV + cq) * N, x[u]);
+      }
     }
-    Chunk<T>::store(dr + i * N, o);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const long rr = row + u * rstep;
+      if (rr < rows) {
+        float o[N];
+#pragma unroll
+        for (int e = 0; e < N; ++e) {
+          const float g = (sc[e] * x[u][e] + sh[e]) > 0.f ? d[u][e] : d[u][e] * slope;
+          const float xh = (x[u][e] - mu[e]) * is[e];
+          o[e] = sc[e] * (g - c0[e] - xh * c1[e]);
+        }
+        Chunk<T>::store(dr + (rr * CV + cq) * N, o);
+      }
+    }
   }
 }
 
@@ -331,9 +351,17 @@ extern "C" int nsid_bn_bwd_apply(const void* dout, const void* r, int M, int C, 
   NSID_REQUIRE(C % (dtype == NSID_BF16 ? 8 : 4) == 0);
   NSID_REQUIRE(act == NSID_ACT_NONE || act == NSID_ACT_RELU || act == NSID_ACT_LEAKY);
   NSID_DISPATCH_DTYPE(dtype, T, {
-    const long nchunks = (long)M * C / Chunk<T>::N;
-    NSID_LAUNCH((bn_bwd_apply_kernel<T>), dim3(stream_grid(nchunks)), dim3(256), 0, static_cast<hipStream_t>(stream),
-                static_cast<const T*>(dout), static_cast<const T*>(r), nchunks, C / Chunk<T>::N, scale, shift, mean,
+    constexpr int U = 4;
+    const int CV = C / Chunk<T>::N;
+    const long nchunks = (long)M * CV;
+    // thread count: a multiple of the chunks per row (a thread keeps its column chunk), about one thread per U chunks
+    int g0 = CV, d256 = 256;
+    while (d256 % 2 == 0 && g0 % 2 == 0) { d256 /= 2; g0 /= 2; }          // g0 = CV / gcd(CV, 256)
+    long want = (nchunks + 256L * U - 1) / (256L * U);
+    if (want > 2048) want = 2048;
+    const long grid = (want + g0 - 1) / g0 * g0;
+    NSID_LAUNCH((bn_bwd_apply_kernel<T, U>), dim3((int)grid), dim3(256), 0, static_cast<hipStream_t>(stream),
+                static_cast<const T*>(dout), static_cast<const T*>(r), (long)M, CV, scale, shift, mean,
                 invstd, bn_slope(act), coef, static_cast<T*>(dr));
   });
   return nsid_launch_status();
