@@ -46,6 +46,8 @@ int nsid_version(void);
 /* debug: install (or clear with NULL) a device buffer of 4 x uint64 per workgroup; the GEMM kernels then record
    {start, end of main loop, end} on the 100 MHz clock and (XCC_ID << 32 | HW_ID). tools/gemm_trace.py reads it. */
 int nsid_debug_gemm_trace(void* device_buf);
+/* same for the kNN kernel: {start, features staged, normalised, end} per workgroup (= clip) */
+int nsid_debug_knn_trace(void* device_buf);
 /* process-wide arithmetic of the nsid_linear_* GEMMs (BASELINE config 2 names bf16 compute); returns NSID_OK/EINVAL */
 int nsid_set_gemm_precision(int mode);
 int nsid_get_gemm_precision(void);

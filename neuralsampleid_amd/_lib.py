@@ -66,6 +66,8 @@ def _load():
     lib.nsid_version.restype = ctypes.c_int
     lib.nsid_debug_gemm_trace.argtypes = [ctypes.c_void_p]
     lib.nsid_debug_gemm_trace.restype = ctypes.c_int
+    lib.nsid_debug_knn_trace.argtypes = [ctypes.c_void_p]
+    lib.nsid_debug_knn_trace.restype = ctypes.c_int
     lib.nsid_get_gemm_precision.restype = ctypes.c_int
     lib.nsid_row_tiles.argtypes = [ctypes.c_int]
     lib.nsid_row_tiles.restype = ctypes.c_int
@@ -77,7 +79,7 @@ def _load():
 
 
 lib = _load()
-EXPORTS = list(SIGNATURES) + ["nsid_version", "nsid_debug_gemm_trace", "nsid_get_gemm_precision", "nsid_row_tiles", "nsid_sumsq_blocks", "nsid_ntxent_ws_floats"]
+EXPORTS = list(SIGNATURES) + ["nsid_version", "nsid_debug_gemm_trace", "nsid_debug_knn_trace", "nsid_get_gemm_precision", "nsid_row_tiles", "nsid_sumsq_blocks", "nsid_ntxent_ws_floats"]
 
 _ERR = {-1: "NSID_EINVAL (unsupported shape, misaligned pointer or bad argument)",
         -2: "NSID_ELAUNCH (HIP runtime refused the launch)"}

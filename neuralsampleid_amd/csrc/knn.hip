@@ -7,6 +7,17 @@
 
 namespace {
 
+// F.normalize divides every channel of a row by the same norm: 16 384 IEEE divisions per clip (~10 instructions each, three
+// of them quarter rate) were 6.5 us of a 20 us kernel. One IEEE reciprocal per row, then per element the product and ONE
+// residual correction: q = v*r, q += (v - q*d)*r with fused multiply-adds. With r the correctly rounded 1/d this is the
+// correctly rounded quotient v/d (Markstein's theorem; the lone exception, a divisor whose significand is all ones, is off
+// by at most one ulp). |v| <= d here, so nothing overflows.
+__device__ __forceinline__ float div_shared(float v, float d, float r) {
+  const float q = v * r;
+  return fmaf(fmaf(-q, d, v), r, q);
+}
+
+
 constexpr int KNN_THREADS = 256;   // 4 waves, one 16-row strip each per pass
 constexpr int KNN_WAVES = 4;
 
@@ -67,10 +78,10 @@ __global__ __launch_bounds__(KNN_THREADS) void knn_kernel(const T* __restrict__ 
     float ss = 0.f;
     for (int c = lane; c < C; c += 64) { const float v = yn[n * LD + c]; ss += v * v; }
     ss = wave_sum(ss);
-    const float denom = fmaxf(sqrtf(ss), 1e-12f);
+    const float denom = fmaxf(sqrtf(ss), 1e-12f), rden = 1.f / denom;
     float s2 = 0.f;
     for (int c = lane; c < C; c += 64) {
-      const float v = yn[n * LD + c] / denom;
+      const float v = div_shared(yn[n * LD + c], denom, rden);
       yn[n * LD + c] = v;
       s2 += v * v;
     }
@@ -216,7 +227,12 @@ __device__ __forceinline__ float row16_sum(float v) {
   return v;
 }
 
-template <typename T, int KD>
+// debug timeline, as in gemm.hip: {start, features staged, normalised, end} on the 100 MHz clock per workgroup
+__device__ unsigned long long* g_knn_trace = nullptr;
+
+// NT = column tiles per MFMA pass (4 for N >= 128, 2 for N = 64, 1 for N = 32) is a template parameter: as a run-time
+// value every MFMA sat behind its own scalar branch (tools/asm_profile.py: 187 branches, one MFMA per basic block).
+template <typename T, int KD, int NT>
 __global__ __launch_bounds__(KNN2_THREADS) void knn2_kernel(const T* __restrict__ r, long ldr,
                                                             const float* __restrict__ scale,
                                                             const float* __restrict__ shift, int N, int C, int k,
@@ -227,6 +243,9 @@ __global__ __launch_bounds__(KNN2_THREADS) void knn2_kernel(const T* __restrict_
   float* sq = yn + (long)N * LD;         // [N]
   float* xkey = sq + N;                  // [4 row tiles][16 rows][KD] lists handed over by the second column group
   int* xid = reinterpret_cast<int*>(xkey + 4 * 16 * KD);
+  unsigned long long* const trace = g_knn_trace;
+  unsigned long long tt[3] = {0, 0, 0};
+  if (trace) tt[0] = __builtin_amdgcn_s_memrealtime();
 
   const int b = blockIdx.x;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -263,6 +282,7 @@ __global__ __launch_bounds__(KNN2_THREADS) void knn2_kernel(const T* __restrict_
     }
   }
   __syncthreads();
+  if (trace) tt[1] = __builtin_amdgcn_s_memrealtime();
   // ---- phase 1b: F.normalize(p=2, dim=channels, eps=1e-12) and |y^|^2 of the normalised rows; a row is handled by
   // LPR = min(64, C/4) lanes with one or two float4 each
   {
@@ -270,35 +290,69 @@ __global__ __launch_bounds__(KNN2_THREADS) void knn2_kernel(const T* __restrict_
     const int RPP = 64 / LPR;                     // rows per wave pass
     const int CPL = C / 4 / LPR;                  // float4 chunks per lane (1 or 2)
     const int cl = lane % LPR;
-    for (int n0 = wave * RPP; n0 < N; n0 += KNN2_WAVES * RPP) {
-      const int n = n0 + lane / LPR;
-      f32x4 v0 = *reinterpret_cast<const f32x4*>(yn + n * LD + 4 * cl), v1 = {0.f, 0.f, 0.f, 0.f};
-      if (CPL > 1) v1 = *reinterpret_cast<const f32x4*>(yn + n * LD + 4 * (cl + LPR));
-      float ss = (v0[0] * v0[0] + v0[1] * v0[1]) + (v0[2] * v0[2] + v0[3] * v0[3]);
-      ss += (v1[0] * v1[0] + v1[1] * v1[1]) + (v1[2] * v1[2] + v1[3] * v1[3]);
-      ss = row16_sum(ss);
-      if (LPR >= 32) ss += __shfl_xor(ss, 16, 64);
-      if (LPR >= 64) ss += __shfl_xor(ss, 32, 64);
-      const float denom = fmaxf(sqrtf(ss), 1e-12f);
+    // RU independent rows per lane group and iteration: the chain load -> reduce -> sqrt -> 8 divisions -> reduce ->
+    // store is ~2 000 cycles of latency per row at two waves per SIMD (this phase took 7 of the kernel's 20 us)
+    constexpr int RU = 4;
+    for (int n0 = wave * RPP; n0 < N; n0 += RU * KNN2_WAVES * RPP) {
+      f32x4 v0[RU], v1[RU];
+      float ss[RU];
+      int nn[RU];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { v0[e] = v0[e] / denom; v1[e] = v1[e] / denom; }
-      float s2 = (v0[0] * v0[0] + v0[1] * v0[1]) + (v0[2] * v0[2] + v0[3] * v0[3]);
-      s2 += (v1[0] * v1[0] + v1[1] * v1[1]) + (v1[2] * v1[2] + v1[3] * v1[3]);
-      s2 = row16_sum(s2);
-      if (LPR >= 32) s2 += __shfl_xor(s2, 16, 64);
-      if (LPR >= 64) s2 += __shfl_xor(s2, 32, 64);
-      *reinterpret_cast<f32x4*>(yn + n * LD + 4 * cl) = v0;
-      if (CPL > 1) *reinterpret_cast<f32x4*>(yn + n * LD + 4 * (cl + LPR)) = v1;
-      if (cl == 0) sq[n] = s2;
+      for (int u = 0; u < RU; ++u) {
+        const int n = n0 + u * KNN2_WAVES * RPP + lane / LPR;
+        nn[u] = n < N ? n : -1;                  // surplus lane groups read row N-1 and store nothing
+        const int nr = n < N ? n : N - 1;
+        v0[u] = *reinterpret_cast<const f32x4*>(yn + nr * LD + 4 * cl);
+        v1[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (CPL > 1) v1[u] = *reinterpret_cast<const f32x4*>(yn + nr * LD + 4 * (cl + LPR));
+      }
+#pragma unroll
+      for (int u = 0; u < RU; ++u) {
+        ss[u] = (v0[u][0] * v0[u][0] + v0[u][1] * v0[u][1]) + (v0[u][2] * v0[u][2] + v0[u][3] * v0[u][3]);
+        ss[u] += (v1[u][0] * v1[u][0] + v1[u][1] * v1[u][1]) + (v1[u][2] * v1[u][2] + v1[u][3] * v1[u][3]);
+        ss[u] = row16_sum(ss[u]);
+      }
+      if (LPR >= 32) {
+#pragma unroll
+        for (int u = 0; u < RU; ++u) ss[u] += __shfl_xor(ss[u], 16, 64);
+      }
+      if (LPR >= 64) {
+#pragma unroll
+        for (int u = 0; u < RU; ++u) ss[u] += __shfl_xor(ss[u], 32, 64);
+      }
+#pragma unroll
+      for (int u = 0; u < RU; ++u) {
+        const float denom = fmaxf(sqrtf(ss[u]), 1e-12f), rden = 1.f / denom;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v0[u][e] = div_shared(v0[u][e], denom, rden); v1[u][e] = div_shared(v1[u][e], denom, rden); }
+        ss[u] = (v0[u][0] * v0[u][0] + v0[u][1] * v0[u][1]) + (v0[u][2] * v0[u][2] + v0[u][3] * v0[u][3]);
+        ss[u] += (v1[u][0] * v1[u][0] + v1[u][1] * v1[u][1]) + (v1[u][2] * v1[u][2] + v1[u][3] * v1[u][3]);
+        ss[u] = row16_sum(ss[u]);
+      }
+      if (LPR >= 32) {
+#pragma unroll
+        for (int u = 0; u < RU; ++u) ss[u] += __shfl_xor(ss[u], 16, 64);
+      }
+      if (LPR >= 64) {
+#pragma unroll
+        for (int u = 0; u < RU; ++u) ss[u] += __shfl_xor(ss[u], 32, 64);
+      }
+#pragma unroll
+      for (int u = 0; u < RU; ++u) {
+        if (nn[u] < 0) continue;
+        *reinterpret_cast<f32x4*>(yn + nn[u] * LD + 4 * cl) = v0[u];
+        if (CPL > 1) *reinterpret_cast<f32x4*>(yn + nn[u] * LD + 4 * (cl + LPR)) = v1[u];
+        if (cl == 0) sq[nn[u]] = ss[u];
+      }
     }
   }
   __syncthreads();
 
+  if (trace) tt[2] = __builtin_amdgcn_s_memrealtime();
   const int lr = lane & 15, rq = lane >> 4;
   const int RT = N >> 4;                                  // row tiles == column tiles (2, 4, 8 or 16)
   const int G = RT >= KNN2_WAVES ? 1 : 2;                 // column groups per row tile
-  const int CTG = RT / G;                                 // column tiles per group: 16, 8, 2 or 1
-  const int NT = CTG >= 4 ? 4 : CTG;                      // column tiles per MFMA pass
+  const int CTG = RT / G;                                 // column tiles per group: 16, 8, 2 or 1 (a multiple of NT)
   const int cg = RT >= KNN2_WAVES ? 0 : wave / RT;
   const bool active = cg < G;                             // wave-uniform
   TopList<KD> top;
@@ -309,31 +363,35 @@ __global__ __launch_bounds__(KNN2_THREADS) void knn2_kernel(const T* __restrict_
     const float si = sq[i];
     const float* arow = yn + i * LD + 4 * rq;
     for (int ct0 = cg * CTG; ct0 < (cg + 1) * CTG; ct0 += NT) {
-      f32x4 acc[4];
+      f32x4 acc[NT];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int u = 0; u < NT; ++u) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
       const float* brow = yn + (16 * ct0 + lr) * LD + 4 * rq;
-      for (int ch = 0; ch < C; ch += 16) {
-        const f32x4 fa = *reinterpret_cast<const f32x4*>(arow + ch);
-        f32x4 fb[4];
+      // the fragments of the next 16 channels are read while the MFMAs of the current ones run
+      f32x4 fa = *reinterpret_cast<const f32x4*>(arow), fb[NT];
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
-          if (u < NT) fb[u] = *reinterpret_cast<const f32x4*>(brow + u * 16 * LD + ch);
+      for (int u = 0; u < NT; ++u) fb[u] = *reinterpret_cast<const f32x4*>(brow + u * 16 * LD);
+      for (int ch = 0; ch < C; ch += 16) {
+        const int chn = ch + 16 < C ? ch + 16 : ch;       // the last prefetch re-reads the current chunk (unused)
+        const f32x4 na = *reinterpret_cast<const f32x4*>(arow + chn);
+        f32x4 nb[NT];
+#pragma unroll
+        for (int u = 0; u < NT; ++u) nb[u] = *reinterpret_cast<const f32x4*>(brow + u * 16 * LD + chn);
 #pragma unroll
         for (int e = 0; e < 4; ++e)
 #pragma unroll
-          for (int u = 0; u < 4; ++u)
-            if (u < NT) acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(fb[u][e], fa[e], acc[u], 0, 0, 0);
+          for (int u = 0; u < NT; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(fb[u][e], fa[e], acc[u], 0, 0, 0);
+        fa = na;
+#pragma unroll
+        for (int u = 0; u < NT; ++u) fb[u] = nb[u];
       }
       // acc[u][e] = y_j . y_i with j = 16*(ct0+u) + 4*rq + e, i = this lane's row: D = (|i|^2 - 2 i.j) + |j|^2
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        if (u < NT) {
-          const int j0 = 16 * (ct0 + u) + 4 * rq;
-          const f32x4 sj = *reinterpret_cast<const f32x4*>(sq + j0);
+      for (int u = 0; u < NT; ++u) {
+        const int j0 = 16 * (ct0 + u) + 4 * rq;
+        const f32x4 sj = *reinterpret_cast<const f32x4*>(sq + j0);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) top.push_ordered((si + (-2.f * acc[u][e])) + sj[e], j0 + e);
-        }
+        for (int e = 0; e < 4; ++e) top.push_ordered((si + (-2.f * acc[u][e])) + sj[e], j0 + e);
       }
     }
     // ---- merge the four quarter lists of every row (lanes lr + 16q): two butterfly exchanges, after which all four
@@ -372,6 +430,12 @@ __global__ __launch_bounds__(KNN2_THREADS) void knn2_kernel(const T* __restrict_
           if (p % dilation == 0 && p / dilation < k) out[p / dilation] = top.id[p];
       }
     }
+  }
+  if (trace && threadIdx.x == 0) {
+    trace[4 * blockIdx.x + 0] = tt[0];
+    trace[4 * blockIdx.x + 1] = tt[1];
+    trace[4 * blockIdx.x + 2] = tt[2];
+    trace[4 * blockIdx.x + 3] = __builtin_amdgcn_s_memrealtime();
   }
 }
 
@@ -434,9 +498,9 @@ __global__ __launch_bounds__(KNN2_THREADS) void knn_rank_kernel(const T* __restr
       ss = row16_sum(ss);
       if (LPR >= 32) ss += __shfl_xor(ss, 16, 64);
       if (LPR >= 64) ss += __shfl_xor(ss, 32, 64);
-      const float denom = fmaxf(sqrtf(ss), 1e-12f);
+      const float denom = fmaxf(sqrtf(ss), 1e-12f), rden = 1.f / denom;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { v0[e] = v0[e] / denom; v1[e] = v1[e] / denom; }
+      for (int e = 0; e < 4; ++e) { v0[e] = div_shared(v0[e], denom, rden); v1[e] = div_shared(v1[e], denom, rden); }
       float s2 = (v0[0] * v0[0] + v0[1] * v0[1]) + (v0[2] * v0[2] + v0[3] * v0[3]);
       s2 += (v1[0] * v1[0] + v1[1] * v1[1]) + (v1[2] * v1[2] + v1[3] * v1[3]);
       s2 = row16_sum(s2);
@@ -577,9 +641,9 @@ __global__ __launch_bounds__(KNN2_THREADS) void knn_sel_kernel(const T* __restri
       ss = row16_sum(ss);
       if (LPR >= 32) ss += __shfl_xor(ss, 16, 64);
       if (LPR >= 64) ss += __shfl_xor(ss, 32, 64);
-      const float denom = fmaxf(sqrtf(ss), 1e-12f);
+      const float denom = fmaxf(sqrtf(ss), 1e-12f), rden = 1.f / denom;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { v0[e] = v0[e] / denom; v1[e] = v1[e] / denom; }
+      for (int e = 0; e < 4; ++e) { v0[e] = div_shared(v0[e], denom, rden); v1[e] = div_shared(v1[e], denom, rden); }
       float s2 = (v0[0] * v0[0] + v0[1] * v0[1]) + (v0[2] * v0[2] + v0[3] * v0[3]);
       s2 += (v1[0] * v1[0] + v1[1] * v1[1]) + (v1[2] * v1[2] + v1[3] * v1[3]);
       s2 = row16_sum(s2);
@@ -717,23 +781,35 @@ int launch_knn_rank(const void* r, int ldr, const float* scale, const float* shi
   return nsid_launch_status();
 }
 
-template <typename T, int KD>
-int launch_knn2(const void* r, int ldr, const float* scale, const float* shift, int B, int N, int C, int k, int dilation,
-                int32_t* idx, hipStream_t s) {
+template <typename T, int KD, int NT>
+int launch_knn2_nt(const void* r, int ldr, const float* scale, const float* shift, int B, int N, int C, int k,
+                   int dilation, int32_t* idx, hipStream_t s) {
   const size_t bytes = ((size_t)N * (C + 4) + N + 2 * 4 * 16 * KD) * sizeof(float);
   static bool configured = false;      // raise the dynamic-LDS cap once per instantiation (not a per-call sync)
   if (!configured) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(knn2_kernel<T, KD>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(knn2_kernel<T, KD, NT>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
       return NSID_ELAUNCH;
     configured = true;
   }
-  NSID_LAUNCH((knn2_kernel<T, KD>), dim3(B), dim3(KNN2_THREADS), bytes, s, static_cast<const T*>(r), (long)ldr, scale,
+  NSID_LAUNCH((knn2_kernel<T, KD, NT>), dim3(B), dim3(KNN2_THREADS), bytes, s, static_cast<const T*>(r), (long)ldr, scale,
               shift, N, C, k, dilation, idx);
   return nsid_launch_status();
 }
+template <typename T, int KD>
+int launch_knn2(const void* r, int ldr, const float* scale, const float* shift, int B, int N, int C, int k, int dilation,
+                int32_t* idx, hipStream_t s) {
+  const int RT = N >> 4, CTG = RT / (RT >= KNN2_WAVES ? 1 : 2);      // column tiles per wave and row tile (kernel: G, CTG)
+  if (CTG >= 4) return launch_knn2_nt<T, KD, 4>(r, ldr, scale, shift, B, N, C, k, dilation, idx, s);
+  if (CTG == 2) return launch_knn2_nt<T, KD, 2>(r, ldr, scale, shift, B, N, C, k, dilation, idx, s);
+  return launch_knn2_nt<T, KD, 1>(r, ldr, scale, shift, B, N, C, k, dilation, idx, s);
+}
 
 }  // namespace
+
+extern "C" int nsid_debug_knn_trace(void* buf) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_knn_trace), &buf, sizeof(buf)) == hipSuccess ? NSID_OK : NSID_EINVAL;
+}
 
 extern "C" int nsid_knn_graph(const void* r, int ldr, const float* scale, const float* shift, int B, int N, int C,
                               int k, int dilation, int32_t* idx, int dtype, void* stream) {
