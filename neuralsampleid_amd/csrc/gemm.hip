@@ -227,6 +227,19 @@ __device__ __forceinline__ bf16x8 frag_read_bf16(const char* lds, int tile_row0,
   }
 }
 
+// a raw 16-byte chunk as floats: 8 bf16 (BF) or 4 fp32
+template <bool BF>
+__device__ __forceinline__ void chunk_to_float(const f32x4& raw, float* v) {
+  if constexpr (BF) {
+    const bf16x8 h = __builtin_bit_cast(bf16x8, raw);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (float)h[e];
+  } else {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = raw[e];
+  }
+}
+
 // ST: ACTIVATION tensors are bf16 in HBM. The left operand is always an activation; the right operand is one only in
 // the weight-gradient variant (both i/j-major); the output is an activation in the forward and backward-data variants.
 // AAFF: the left operand carries a reduction-indexed affine (forward GEMM fed by a raw conv output). A template flag,
@@ -240,7 +253,8 @@ __device__ __forceinline__ bf16x8 frag_read_bf16(const char* lds, int tile_row0,
 __device__ unsigned long long* g_gemm_trace = nullptr;
 
 template <int BM, int BN, bool A_RMAJOR, bool B_RMAJOR, bool H, bool ST, bool AAFF, bool WB = false, bool FULL = false>
-__global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {   // >= 2 waves/SIMD: <= 256 VGPR+AGPR
+__global__ __launch_bounds__(256, (FULL && WB && BM == 128 && BN == 128 && !AAFF) ? 3 : 2)   // 3 waves/SIMD: <= 168 registers
+void gemm_kernel(const GemmArgs p) {
   unsigned long long* const trace = g_gemm_trace;
   unsigned long long t_start = 0, t_loop = 0;
   if (trace) t_start = __builtin_amdgcn_s_memrealtime();
@@ -530,6 +544,33 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {   // >
     const unsigned lo_c = (unsigned)((orow * (int)p.ldc + oq) * OSZ);
     const unsigned lo_a = (unsigned)((orow * (int)p.ldadd + oq) * OSZ);
     const unsigned lo_r = (unsigned)((orow * (int)p.bn_ldr + oq) * 2);
+    // Backward-data only: the residual-gradient addend and the BatchNorm input of every store pass are fetched NOW, all at
+    // once. Loaded inside the pass they were two dependent HBM round trips per pass: 8 passes, one workgroup per CU and cold
+    // caches made that epilogue 12.6 us behind a 19 us main loop (tools/gemm_trace.py --addend --bn 1 --cold).
+    constexpr bool CAN_ADD = A_RMAJOR && !B_RMAJOR;
+    constexpr int PPH = 32 / ROWS_PER_PASS, NPASS = (TM / 2) * PPH;
+    f32x4 pre_a[CAN_ADD ? NPASS : 1], pre_r[CAN_BNRED ? NPASS : 1];
+    if constexpr (CAN_ADD) {
+      if (p.addend) {
+#pragma unroll
+        for (int q = 0; q < NPASS; ++q) {
+          const int ib = i0 + wm0 + 32 * (q / PPH) + (q % PPH) * ROWS_PER_PASS;
+          const bool ok = (FULL || ib + orow < p.I) && jqok;
+          pre_a[q] = *reinterpret_cast<const f32x4*>(Ab + (ok ? ((long)ib * p.ldadd + (j0 + wn0)) * OSZ + lo_a : 0));
+        }
+      }
+    }
+    if constexpr (CAN_BNRED) {
+      if (bnred) {
+#pragma unroll
+        for (int q = 0; q < NPASS; ++q) {
+          const int ib = i0 + wm0 + 32 * (q / PPH) + (q % PPH) * ROWS_PER_PASS;
+          const bool ok = (FULL || ib + orow < p.I) && jqok;
+          pre_r[q] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(p.bn_r) +
+                                                     (ok ? ((long)ib * p.bn_ldr + g * p.c_goff + (j0 + wn0)) * 2 + lo_r : 0));
+        }
+      }
+    }
 #pragma unroll
     for (int h = 0; h < TM / 2; ++h) {
 #pragma unroll
@@ -552,13 +593,13 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {   // >
 #pragma unroll
             for (int k4 = 0; k4 < 4; ++k4) v[e + k4] = t4[k4];
           }
-          if (p.addend) {
-            float ad[OE];
-            const char* ap = Ab + ((long)ib * p.ldadd + (j0 + wn0)) * OSZ + lo_a;
-            if (SC) Chunk<__bf16>::load(reinterpret_cast<const __bf16*>(ap), ad);
-            else Chunk<float>::load(reinterpret_cast<const float*>(ap), ad);
+          if constexpr (CAN_ADD) {
+            if (p.addend) {
+              float ad[OE];
+              chunk_to_float<SC>(pre_a[h * PPH + pass], ad);
 #pragma unroll
-            for (int e = 0; e < OE; ++e) v[e] += ad[e];
+              for (int e = 0; e < OE; ++e) v[e] += ad[e];
+            }
           }
           char* cp = Cb + ((long)ib * p.ldc + (j0 + wn0)) * OSZ + lo_c;
           if (SC) Chunk<__bf16>::store(reinterpret_cast<__bf16*>(cp), v);
@@ -566,8 +607,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {   // >
           if (CAN_BNRED) {
             if (bnred) {
               float x[OE];
-              Chunk<__bf16>::load(reinterpret_cast<const __bf16*>(reinterpret_cast<const char*>(p.bn_r) +
-                                  ((long)ib * p.bn_ldr + g * p.c_goff + (j0 + wn0)) * 2 + lo_r), x);
+              chunk_to_float<true>(pre_r[h * PPH + pass], x);
 #pragma unroll
               for (int e = 0; e < OE; e += 2) {
                 // dy: the value a separate reduce pass would read back (bf16-rounded)

@@ -13,6 +13,9 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--shape", default="16384x1024x256")
 ap.add_argument("--dir", default="fwd")
 ap.add_argument("--no-stat", action="store_true")
+ap.add_argument("--bn", type=int, default=-1, help="bwd_data: also emit the BatchNorm-backward sums (activation code 0/1/2)")
+ap.add_argument("--addend", action="store_true", help="bwd_data: add a residual gradient in the epilogue")
+ap.add_argument("--cold", action="store_true", help="flush caches with a 1 GiB write before the traced launch")
 args = ap.parse_args()
 M, N, K = (int(v) for v in args.shape.split("x"))
 ops.set_gemm_precision("bf16")
@@ -24,14 +27,25 @@ dout = torch.randn(M, N, device=dev).bfloat16()
 dw = torch.zeros(N, K, device=dev)
 out = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
 din = torch.empty(M, K, device=dev, dtype=torch.bfloat16)
+addend = torch.randn(M, K, device=dev).bfloat16() if args.addend else None
+bn = None
+if args.bn >= 0:
+    r_ = torch.randn(M, K, device=dev).bfloat16()
+    aff = ops.BNAffine(torch.rand(K, device=dev) + 0.5, torch.randn(K, device=dev) * 0.1, torch.zeros(K, device=dev),
+                       torch.ones(K, device=dev))
+    bn = (r_, aff, args.bn)
 run = {"fwd": lambda: ops.linear_fwd(x, w, None, M, N, K, 1, None, None, 0, 0, want_stat=not args.no_stat, out=out),
-       "bwd_data": lambda: ops.linear_bwd_data(dout, w, M, N, K, 1, out=din),
+       "bwd_data": lambda: ops.linear_bwd_data(dout, w, M, N, K, 1, addend, out=din, bn=bn),
        "bwd_weight": lambda: ops.linear_bwd_weight(dout, x, dw, M, N, K, 1)}[args.dir]
 for _ in range(5):
     run()
 torch.cuda.synchronize()
 buf = torch.zeros(1 << 20, dtype=torch.int64, device=dev)
 assert lib.nsid_debug_gemm_trace(buf.data_ptr()) == 0
+if args.cold:
+    junk = torch.empty(1 << 28, dtype=torch.float32, device=dev)
+    junk.fill_(1.0)
+    torch.cuda.synchronize()
 run()
 torch.cuda.synchronize()
 lib.nsid_debug_gemm_trace(None)
