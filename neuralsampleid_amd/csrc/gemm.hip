@@ -173,11 +173,15 @@ __device__ __forceinline__ void stage_store(char* lds, const StageRegs<ROWS, RMA
     }
     if (affine) {
 #pragma unroll
-      for (int e = 0; e < G::EPC; ++e) {
+      for (int e = 0; e < G::EPC; e += 2) {
         // csc/csh: per-chunk affine registers — column-indexed (fetched once per kernel) for i/j-major tiles,
-        // reduction-indexed (prefetched per stage by affine_prefetch, AHEAD of the next operand loads) for R-major ones
-        const float v = csc[(q * G::EPC + e) >> 2][e & 3] * x[e] + csh[(q * G::EPC + e) >> 2][e & 3];
-        x[e] = v < 0.f ? v * slope : v;          // NaN compares false and passes through, as torch's activations do
+        // reduction-indexed (prefetched per stage by affine_prefetch, AHEAD of the next operand loads) for R-major ones.
+        // Packed fp32 math (v_pk_fma / v_pk_mul); slope in [0, 1]: v < 0 ? v*slope : v == max(v, v*slope), NaN stays NaN
+        const f32x4 c4 = csc[(q * G::EPC + e) >> 2], h4 = csh[(q * G::EPC + e) >> 2];
+        const f32x2 v = f32x2{c4[e & 3], c4[(e & 3) + 1]} * f32x2{x[e], x[e + 1]} + f32x2{h4[e & 3], h4[(e & 3) + 1]};
+        const f32x2 w = v * slope;
+        x[e] = fmaxf(v[0], w[0]);
+        x[e + 1] = fmaxf(v[1], w[1]);
       }
     }
     if (!s.ok[q]) {

@@ -65,9 +65,12 @@ __device__ __forceinline__ void w3_commit(char* lds, const W3Stage& s, float slo
       const bf16x8 h = __builtin_bit_cast(bf16x8, raw);
       bf16x8 o;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const float v = csc[e >> 2][e & 3] * (float)h[e] + csh[e >> 2][e & 3];
-        o[e] = (__bf16)(v < 0.f ? v * slope : v);
+      for (int e = 0; e < 8; e += 2) {           // packed fp32 math; slope in [0, 1]: max(v, v*slope) == (v < 0 ? v*slope : v)
+        const f32x2 v = f32x2{csc[e >> 2][e & 3], csc[e >> 2][(e & 3) + 1]} * f32x2{(float)h[e], (float)h[e + 1]} +
+                        f32x2{csh[e >> 2][e & 3], csh[e >> 2][(e & 3) + 1]};
+        const f32x2 w = v * slope;
+        o[e] = (__bf16)fmaxf(v[0], w[0]);
+        o[e + 1] = (__bf16)fmaxf(v[1], w[1]);
       }
       raw = __builtin_bit_cast(f32x4, o);
     }

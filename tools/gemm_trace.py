@@ -13,6 +13,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--shape", default="16384x1024x256")
 ap.add_argument("--dir", default="fwd")
 ap.add_argument("--no-stat", action="store_true")
+ap.add_argument("--aff", action="store_true", help="fwd / bwd_weight: the input carries a BatchNorm affine + ReLU applied on load")
 ap.add_argument("--bn", type=int, default=-1, help="bwd_data: also emit the BatchNorm-backward sums (activation code 0/1/2)")
 ap.add_argument("--addend", action="store_true", help="bwd_data: add a residual gradient in the epilogue")
 ap.add_argument("--cold", action="store_true", help="flush caches with a 1 GiB write before the traced launch")
@@ -34,9 +35,12 @@ if args.bn >= 0:
     aff = ops.BNAffine(torch.rand(K, device=dev) + 0.5, torch.randn(K, device=dev) * 0.1, torch.zeros(K, device=dev),
                        torch.ones(K, device=dev))
     bn = (r_, aff, args.bn)
-run = {"fwd": lambda: ops.linear_fwd(x, w, None, M, N, K, 1, None, None, 0, 0, want_stat=not args.no_stat, out=out),
+sc = (1 + 0.1 * torch.randn(K, device=dev)) if args.aff else None
+sh = (0.1 * torch.randn(K, device=dev)) if args.aff else None
+run = {"fwd": lambda: ops.linear_fwd(x, w, None, M, N, K, 1, sc, sh, ops.ACT_RELU if args.aff else 0, 0,
+                                     want_stat=not args.no_stat, out=out),
        "bwd_data": lambda: ops.linear_bwd_data(dout, w, M, N, K, 1, addend, out=din, bn=bn),
-       "bwd_weight": lambda: ops.linear_bwd_weight(dout, x, dw, M, N, K, 1)}[args.dir]
+       "bwd_weight": lambda: ops.linear_bwd_weight(dout, x, dw, M, N, K, 1, sc, sh, ops.ACT_RELU if args.aff else 0)}[args.dir]
 for _ in range(5):
     run()
 torch.cuda.synchronize()
