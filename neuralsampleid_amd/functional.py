@@ -285,6 +285,10 @@ def downsample_forward(x: Tensor, P, S: Optional[dict], B: int, N: int, training
     No = ops.ds_out_nodes(N)
     col = ops.im2col3_fwd(x, B, N, C)
     wp = ops.pack_ds_weight(P["conv.0.weight"])
+    if ACT_DTYPE == torch.bfloat16 and S is not None:
+        # the packed weight lives until this block's backward: one bf16 conversion serves the forward and the backward-data
+        # GEMM (an unregistered weight is converted at every use)
+        ops.SHADOWS.register(wp, ops.f32_to_bf16(wp), owner=wp, fresh=True)
     r, aff = conv_bn(col, B * No, 3 * C, Co, wp, P["conv.0.bias"], _bn(P, S, "conv.1."), training)
     out = ops.bn_apply(r, aff, ACT_NONE)
     if S is not None:

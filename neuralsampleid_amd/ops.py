@@ -156,11 +156,12 @@ class WeightShadows:
     def __init__(self):
         self.entries = {}
 
-    def register(self, w: torch.Tensor, shadow: torch.Tensor, owner: torch.Tensor) -> None:
+    def register(self, w: torch.Tensor, shadow: torch.Tensor, owner: torch.Tensor, fresh: bool = False) -> None:
         """`owner` keeps the fp32 memory alive (the optimiser's flat buffer): while it lives the address cannot be
-        reused by another tensor; once it is gone the entry is dropped on its next lookup"""
+        reused by another tensor; once it is gone the entry is dropped on its next lookup. fresh: `shadow` already holds
+        the conversion of the current contents of w"""
         import weakref
-        self.entries[w.data_ptr()] = [shadow, -1, w.numel(), weakref.ref(owner)]
+        self.entries[w.data_ptr()] = [shadow, w._version if fresh else -1, w.numel(), weakref.ref(owner)]
 
     def clear(self) -> None:
         self.entries.clear()
