@@ -158,6 +158,22 @@ def knn_mismatch(idx, gold_idx, gap, tol=1e-4):
     return int((bad & (np.asarray(gap) >= tol)).sum()), int(bad.sum())
 
 
+def test_batchnorm_eval_affine_is_cached_until_a_tensor_changes(ops):
+    """eval-mode scale/shift are computed once per layer and follow in-place updates of any of the four tensors"""
+    C = 96
+    g, b = (1 + 0.1 * synth_randn("eg", C)).to(DEV), (0.1 * synth_randn("eb", C)).to(DEV)
+    rm, rv = synth_randn("erm", C).to(DEV), (0.5 + synth_randn("erv", C).abs()).to(DEV)
+    ref = lambda: (g / torch.sqrt(rv + 1e-5), b - rm * g / torch.sqrt(rv + 1e-5))
+    a1 = ops.bn_eval_affine(g, b, rm, rv)
+    assert torch.allclose(a1.scale, ref()[0], rtol=1e-6, atol=1e-7) and torch.allclose(a1.shift, ref()[1], rtol=1e-6, atol=1e-6)
+    a2 = ops.bn_eval_affine(g, b, rm, rv)
+    assert a2.scale.data_ptr() == a1.scale.data_ptr()                 # served from the cache
+    rv.mul_(2.0)                                                      # e.g. load_state_dict / a training step
+    a3 = ops.bn_eval_affine(g, b, rm, rv)
+    assert a3.scale.data_ptr() != a1.scale.data_ptr()
+    assert torch.allclose(a3.scale, ref()[0], rtol=1e-6, atol=1e-7) and torch.allclose(a3.shift, ref()[1], rtol=1e-6, atol=1e-6)
+
+
 @pytest.mark.parametrize("tag,kds", [("c64n256", [(3, 1), (5, 1), (4, 2), (18, 3)]),
                                      ("c128n128", [(3, 1), (18, 2)]),
                                      ("c512n32", [(3, 1), (5, 2), (18, 1)])])
