@@ -649,7 +649,8 @@ void gemm_kernel(const GemmArgs p) {
             float a0 = 0.f, a1 = 0.f;
 #pragma unroll
             for (int wr = 0; wr < 2; ++wr)
-              for (int o = 0; o < ROWS_PER_PASS; ++o) {
+#pragma unroll
+              for (int o = 0; o < ROWS_PER_PASS; ++o) {     // unrolled: the LDS reads pipeline instead of one round trip each
                 a0 += red2[((0 * 4 + (2 * wr + half)) * ROWS_PER_PASS + o) * WN + cw];
                 a1 += red2[((1 * 4 + (2 * wr + half)) * ROWS_PER_PASS + o) * WN + cw];
               }
