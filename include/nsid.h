@@ -72,6 +72,12 @@ int nsid_row_tiles(int M);
 int nsid_linear_fwd(const void* x, int ldx, const void* w, int w_dtype, const float* bias, void* out, int ldo, int M,
                     int Nout, int K, int groups, const float* in_scale, const float* in_shift, int act_in, int act_out,
                     float* stat, int ksplit, int act_dtype /* of x and out */, void* stream);
+/* the same GEMM with `addend` (same storage type and row layout as out, row stride ldadd) added in the epilogue:
+   out = f(x) W^T + bias + addend. One launch for "conv + eval-mode BatchNorm folded into (W, bias) + shortcut"
+   (reference: x = self.fc2(x) ... + shortcut, torch_vertex.py:183-195, graph_encoder.py:82-89, in eval mode). */
+int nsid_linear_fwd_res(const void* x, int ldx, const void* w, int w_dtype, const float* bias, const void* addend, int ldadd,
+                        void* out, int ldo, int M, int Nout, int K, int groups, const float* in_scale,
+                        const float* in_shift, int act_in, int act_dtype, void* stream);
 /* backward-data: din[m, g*K+k] = addend[m, g*K+k] + sum_n dout[m, g*Nout+n] * w[g*Nout+n, k]   (addend optional) */
 int nsid_linear_bwd_data(const void* dout, int ldd, const void* w, int w_dtype, const void* addend, int ldadd,
                          void* din, int ldi, int M, int Nout, int K, int groups,

@@ -15,6 +15,7 @@ LIB_PATH = os.environ.get("NSID_LIB") or os.path.join(_PKG, "libnsid_hip.so")   
 SIGNATURES = {
     "nsid_set_gemm_precision": "i",
     "nsid_linear_fwd": "pipippiiiiippiipiis",
+    "nsid_linear_fwd_res": "pipippipiiiiippiis",
     "nsid_linear_bwd_data": "pipipipiiiiiis",
     "nsid_linear_bwd_data_bn": "pipipipiiiiiipppppips",
     "nsid_linear_bwd_weight": "pipipiiiippiis",

@@ -551,7 +551,7 @@ void gemm_kernel(const GemmArgs p) {
     // Backward-data only: the residual-gradient addend and the BatchNorm input of every store pass are fetched NOW, all at
     // once. Loaded inside the pass they were two dependent HBM round trips per pass: 8 passes, one workgroup per CU and cold
     // caches made that epilogue 12.6 us behind a 19 us main loop (tools/gemm_trace.py --addend --bn 1 --cold).
-    constexpr bool CAN_ADD = A_RMAJOR && !B_RMAJOR;
+    constexpr bool CAN_ADD = A_RMAJOR;      // backward-data (residual gradient) and forward (residual stream, nsid_linear_fwd_res)
     constexpr int PPH = 32 / ROWS_PER_PASS, NPASS = (TM / 2) * PPH;
     f32x4 pre_a[CAN_ADD ? NPASS : 1], pre_r[CAN_BNRED ? NPASS : 1];
     if constexpr (CAN_ADD) {
@@ -764,9 +764,34 @@ extern "C" int nsid_set_gemm_precision(int mode) {
 extern "C" int nsid_get_gemm_precision(void) { return g_gemm_precision; }
 extern "C" int nsid_row_tiles(int M) { return (M + NSID_ROW_TILE - 1) / NSID_ROW_TILE; }
 
+static int linear_fwd_impl(const void* x, int ldx, const void* w, int w_dtype, const float* bias, void* out, int ldo,
+                           int M, int Nout, int K, int groups, const float* in_scale, const float* in_shift, int act_in,
+                           int act_out, float* stat, int ksplit, int act_dtype, const void* addend, int ldadd,
+                           void* stream);
+
 extern "C" int nsid_linear_fwd(const void* x, int ldx, const void* w, int w_dtype, const float* bias, void* out, int ldo,
                                int M, int Nout, int K, int groups, const float* in_scale, const float* in_shift,
                                int act_in, int act_out, float* stat, int ksplit, int act_dtype, void* stream) {
+  return linear_fwd_impl(x, ldx, w, w_dtype, bias, out, ldo, M, Nout, K, groups, in_scale, in_shift, act_in, act_out, stat,
+                         ksplit, act_dtype, nullptr, 0, stream);
+}
+
+// out = f(x) W^T + bias + addend: the residual stream added in the GEMM epilogue. With an eval-mode BatchNorm folded into
+// (W, bias) this is a whole "conv + BN + shortcut" in one launch (functional.py, eval path).
+extern "C" int nsid_linear_fwd_res(const void* x, int ldx, const void* w, int w_dtype, const float* bias,
+                                   const void* addend, int ldadd, void* out, int ldo, int M, int Nout, int K, int groups,
+                                   const float* in_scale, const float* in_shift, int act_in, int act_dtype,
+                                   void* stream) {
+  const int ch = act_dtype == NSID_BF16 ? 8 : 4;
+  NSID_REQUIRE(addend && ldadd % ch == 0 && ldadd >= groups * Nout && nsid_aligned16(addend));
+  return linear_fwd_impl(x, ldx, w, w_dtype, bias, out, ldo, M, Nout, K, groups, in_scale, in_shift, act_in,
+                         NSID_ACT_NONE, nullptr, 1, act_dtype, addend, ldadd, stream);
+}
+
+static int linear_fwd_impl(const void* x, int ldx, const void* w, int w_dtype, const float* bias, void* out, int ldo,
+                           int M, int Nout, int K, int groups, const float* in_scale, const float* in_shift, int act_in,
+                           int act_out, float* stat, int ksplit, int act_dtype, const void* addend, int ldadd,
+                           void* stream) {
   NSID_REQUIRE(x && w && out && M > 0 && Nout > 0 && K > 0 && groups > 0 && ksplit >= 1 && NSID_DTYPE_OK(act_dtype));
   NSID_REQUIRE(NSID_DTYPE_OK(w_dtype) && (w_dtype == NSID_F32 || (act_dtype == NSID_BF16 && K % 8 == 0)));
   const int ch = act_dtype == NSID_BF16 ? 8 : 4;     // elements per 16-byte chunk of the activation tensors
@@ -785,6 +810,7 @@ extern "C" int nsid_linear_fwd(const void* x, int ldx, const void* w, int w_dtyp
   p.I = M; p.J = Nout; p.R = K;
   p.a_scale = in_scale; p.a_shift = in_shift; p.a_slope = act_slope(act_in); p.a_aff_goff = K;
   p.bias = bias; p.bias_goff = Nout;
+  p.addend = addend; p.ldadd = ldadd;
   p.stat = stat; p.stat_ld = (long)groups * Nout; p.stat_plane = (long)nsid_row_tiles(M) * groups * Nout;
   p.rsplit = ksplit;
   p.rchunk = (K + ksplit - 1) / ksplit;

@@ -221,9 +221,12 @@ def _weight(w: torch.Tensor, dt: int, K: int):
 
 # ------------------------------------------------------------------------------------------------ linear
 def linear_fwd(x, w, bias, M, Nout, K, groups=1, in_scale=None, in_shift=None, act_in=ACT_NONE, act_out=ACT_NONE,
-               want_stat=False, ksplit=1, out=None) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+               want_stat=False, ksplit=1, out=None, addend=None) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+    """out = f(x) w^T + bias (+ addend, same layout and storage as out: the residual stream, nsid_linear_fwd_res)"""
     _chk(w, bias, in_scale, in_shift)
-    dt = _act(x, out)
+    dt = _act(x, out, addend)
+    if addend is not None and (want_stat or ksplit != 1 or act_out != ACT_NONE):
+        raise ValueError("the residual addend rides with a plain epilogue (no statistics, no split-K, no output activation)")
     ldx = x.shape[-1]
     if out is None:
         out = (torch.zeros if ksplit > 1 else torch.empty)((M, groups * Nout), device=x.device, dtype=x.dtype)
@@ -235,6 +238,12 @@ def linear_fwd(x, w, bias, M, Nout, K, groups=1, in_scale=None, in_shift=None, a
     name = "gemm_kernel<128,%d,true,true>" % (64 if narrow else 128)
     esz = x.element_size()
     wop, wdt = _weight(w, dt, K)
+    if addend is not None:
+        _timed(name, 2.0 * M * Nout * K * groups,
+               groups * (esz * M * K + float(wop.element_size()) * Nout * K + 2 * esz * M * Nout), lambda: call(
+            "nsid_linear_fwd_res", _p(x), ldx, _p(wop), wdt, _p(bias), _p(addend), addend.shape[-1], _p(out),
+            out.shape[-1], M, Nout, K, groups, _p(in_scale), _p(in_shift), act_in, dt, _stream()), (M, Nout, K, groups))
+        return out, None
     _timed(name, 2.0 * M * Nout * K * groups,
            groups * (esz * M * K + float(wop.element_size()) * Nout * K + esz * M * Nout), lambda: call(
         "nsid_linear_fwd", _p(x), ldx, _p(wop), wdt, _p(bias), _p(out), out.shape[-1], M, Nout, K, groups, _p(in_scale),
@@ -306,11 +315,59 @@ def colsum_acc(x, out) -> None:
 
 # ------------------------------------------------------------------------------------------------ batch norm
 class BNAffine:
-    """What a consumer needs to apply a producer's BatchNorm on load, plus what backward needs."""
-    __slots__ = ("scale", "shift", "mean", "invstd")
+    """What a consumer needs to apply a producer's BatchNorm on load, plus what backward needs.
+    identity: scale == 1, shift == 0 (an eval-mode BatchNorm folded into its conv): consumers that only normalise skip it,
+    consumers that also apply an activation on load use the ones/zeros vectors."""
+    __slots__ = ("scale", "shift", "mean", "invstd", "identity")
 
-    def __init__(self, scale, shift, mean=None, invstd=None):
-        self.scale, self.shift, self.mean, self.invstd = scale, shift, mean, invstd
+    def __init__(self, scale, shift, mean=None, invstd=None, identity=False):
+        self.scale, self.shift, self.mean, self.invstd, self.identity = scale, shift, mean, invstd, identity
+
+
+_IDENTITY_AFFINE = {}
+
+
+def identity_affine(C: int, device) -> BNAffine:
+    key = (C, str(device))
+    a = _IDENTITY_AFFINE.get(key)
+    if a is None:
+        a = _IDENTITY_AFFINE[key] = BNAffine(torch.ones(C, device=device), torch.zeros(C, device=device), identity=True)
+    return a
+
+
+# eval-mode BatchNorm folded into the preceding conv: BN(W x + b) = (s W) x + (s b + beta - mean s), s = gamma/sqrt(var+eps).
+# Constants of the checkpoint: computed once per layer (torch ops, off the hot path), bf16 shadow included, and kept until a
+# version counter of one of the six tensors moves.
+_FOLDED = {}      # id(gamma) -> (weakref(gamma), versions, w_fold, b_fold)
+
+
+def folded_conv_bn(w2d, bias, gamma, beta, running_mean, running_var, eps=BN_EPS, source=None):
+    """w2d: (Nout_total, K) weight matrix, or a callable that builds it from `source` (the downsample's packed weight);
+    `source` is the tensor whose version counter stands for the weight (default: w2d itself)."""
+    import weakref
+    src = w2d if source is None else source
+    versions = (src.data_ptr(), src._version, None if bias is None else (bias.data_ptr(), bias._version), gamma._version,
+                beta._version, running_mean._version, running_var._version, eps)
+    cacheable = not torch.cuda.is_current_stream_capturing()
+    e = _FOLDED.get(id(gamma)) if cacheable else None
+    if e is not None and e[0]() is gamma and e[1] == versions:
+        return e[2], e[3]
+    with torch.no_grad():
+        if callable(w2d):
+            w2d = w2d()
+        s = gamma.detach() / torch.sqrt(running_var + eps)
+        w_fold = (w2d.detach() * s[:, None]).contiguous()
+        b_fold = (beta.detach() - running_mean * s) if bias is None else (bias.detach() * s + beta.detach() - running_mean * s)
+        b_fold = b_fold.contiguous()
+        if w_fold.numel() % 8 == 0:
+            SHADOWS.register(w_fold, f32_to_bf16(w_fold), owner=w_fold, fresh=True)
+    if cacheable:
+        torch.cuda.current_stream().synchronize()       # once per layer: the constants are then valid on every stream
+        if len(_FOLDED) > 4096:
+            for k in [k for k, v in _FOLDED.items() if v[0]() is None]:
+                del _FOLDED[k]
+        _FOLDED[id(gamma)] = (weakref.ref(gamma), versions, w_fold, b_fold)
+    return w_fold, b_fold
 
 
 def bn_finalize(stat, M, gamma, beta, running_mean, running_var, num_batches_tracked,
@@ -384,6 +441,8 @@ def bn_backward(dout, r, aff: BNAffine, act, dgamma, dbeta, inplace=False, parti
 def knn_graph(r, B, N, C, k, dilation=1, aff: Optional[BNAffine] = None) -> torch.Tensor:
     """(B*N, C) features (optionally with a pending BatchNorm affine) -> int32 (B, N, k) clip-local neighbour ids"""
     dt = _act(r)
+    if aff is not None and aff.identity:
+        aff = None
     idx = torch.empty((B, N, k), device=r.device, dtype=torch.int32)
     kd = k * dilation
     name = "knn2_kernel" if kd <= 8 else ("knn_rank_kernel" if N <= 128 else ("knn_sel_kernel" if kd <= 64 else "knn_kernel"))
@@ -396,6 +455,8 @@ def knn_graph(r, B, N, C, k, dilation=1, aff: Optional[BNAffine] = None) -> torc
 
 def mr_aggregate_fwd(r, idx, B, N, C, aff: Optional[BNAffine] = None, want_argmax=True):
     dt = _act(r)
+    if aff is not None and aff.identity:
+        aff = None
     k = idx.shape[-1]
     u = torch.empty((B * N, 2 * C), device=r.device, dtype=r.dtype)
     amax = torch.empty((B * N, C), device=r.device, dtype=torch.uint8) if want_argmax else None

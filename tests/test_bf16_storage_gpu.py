@@ -235,3 +235,52 @@ def test_bwd_data_emits_bn_backward_sums(ops, M, Nout, K, groups, act, add):
     assert relerr(dg1, dg0) < 2e-5 and relerr(db1, db0) < 2e-5          # same inputs, different summation order
     assert relerr(got.float(), ref.float()) < 1e-5
 
+
+
+@pytest.mark.parametrize("M,Nout,K,groups,affine", [(512, 256, 512, 1, True), (200, 64, 64, 1, False), (384, 128, 128, 4, True)])
+def test_linear_fwd_with_residual_addend(ops, M, Nout, K, groups, affine):
+    """nsid_linear_fwd_res: out = f(x) W^T + bias + addend in one launch (eval path: conv + folded BatchNorm + shortcut)"""
+    x = synth_randn(f"rx{M}{K}", M, groups * K).to(BF)
+    w = synth_randn(f"rw{Nout}{K}", groups * Nout, K) * K ** -0.5
+    bias = synth_randn(f"rb{Nout}", groups * Nout)
+    add = synth_randn(f"ra{M}{Nout}", M, groups * Nout).to(BF)
+    sc = 1 + 0.2 * synth_randn("rsc", groups * K) if affine else None
+    sh = 0.3 * synth_randn("rsh", groups * K) if affine else None
+    xin = act_ref(x.float() * sc + sh, 1) if affine else x.float()
+    d = lambda t: None if t is None else t.to(DEV)
+    ref = torch.cat([bfr(xin[:, g * K:(g + 1) * K]) @ bfr(w[g * Nout:(g + 1) * Nout]).t() for g in range(groups)], 1)
+    ref = ref + bias.double() + add.double()
+    out, stat = ops.linear_fwd(d(x), d(w), d(bias), M, Nout, K, groups, d(sc), d(sh), 1 if affine else 0, 0, addend=d(add))
+    assert stat is None and out.dtype == BF and relerr(out, ref) < 2.5e-3
+    with pytest.raises(ValueError):
+        ops.linear_fwd(d(x), d(w), d(bias), M, Nout, K, groups, addend=d(add), want_stat=True)
+
+
+def test_eval_batchnorm_folding_matches_the_unfolded_path(ops, golden):
+    """fingerprint extraction with every eval-mode BatchNorm folded into its conv (and the shortcut in the GEMM epilogue)
+    = the conv / BatchNorm / shortcut passes kept apart, up to bf16 rounding of the folded weights"""
+    from neuralsampleid_amd import functional as F_
+    F_.set_activation_dtype("bf16")
+    g = golden("e2e_b8_k3")
+    model = build()
+    model.load_state_dict(synth_state(model.state_dict()))
+    model.to(DEV).eval()
+    x_i, x_j = g.t("x_i").to(DEV), g.t("x_j").to(DEV)
+    n = len([k for k in g if k.startswith("knn.eval.")])
+    gold_idx = [g.t(f"knn.eval.{c}") for c in range(n)]       # same neighbour sets on both sides (kNN near-ties)
+    outs = {}
+    try:
+        for fold in (False, True):
+            F_.FOLD_EVAL_BN = fold
+            F_.TAPE = F_.KnnTape(replay=gold_idx)
+            with torch.no_grad():
+                outs[fold] = model(x_i, x_j)
+    finally:
+        F_.TAPE = None
+        F_.FOLD_EVAL_BN = True
+    for a, b in zip(outs[True], outs[False]):
+        assert relerr(a, b) < 2e-2, relerr(a, b)
+    cos = torch.nn.functional.cosine_similarity(outs[True][2], outs[False][2], dim=1)
+    assert float(cos.min()) > 0.9995, float(cos.min())
+    # and the folded path meets the reference goldens like the unfolded one does
+    assert relerr(outs[True][0], g.t("h_i_eval")) < 4e-2
