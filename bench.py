@@ -70,7 +70,7 @@ def infer_bench(args, model, rank, world, dev, dist):
     """config 5: forward-only, eval-mode BN, contiguous shard per rank, no collective on the data path"""
     from neuralsampleid_amd import fingerprint
     lo, hi = fingerprint.shard_bounds(args.clips, rank, world)
-    mb = 1024
+    mb = args.micro_batch
     n_mb = (hi - lo + mb - 1) // mb
     out = torch.empty((mb, CFG["d"]), device=dev)
     front, waves = None, None
@@ -173,6 +173,7 @@ def main():
     ap.add_argument("--deep", action="store_true",
                     help="BASELINE config 4: blocks [4,4,12,4], k=18, intended dilation schedule (capped by N)")
     ap.add_argument("--no-overlap", action="store_true", help="run the two views on one stream instead of two")
+    ap.add_argument("--micro-batch", type=int, default=1024, help="--mode infer: clips per forward call (config 5: >= 1024)")
     ap.add_argument("--no-graph", action="store_true", help="do not capture the step in a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
