@@ -828,8 +828,16 @@ static int linear_fwd_impl(const void* x, int ldx, const void* w, int w_dtype, c
   if (half && t128 < 128) narrow = true;        // few row tiles (the projector head, M = batch): more, narrower workgroups
   if (force_narrow >= 0 && Nout > 64) narrow = force_narrow != 0;
   const bool wb = w_dtype == NSID_BF16;
-  const int rc = narrow ? launch<128, 64, true, true>(p, groups, s, act_dtype, wb)
-                        : launch<128, 128, true, true>(p, groups, s, act_dtype, wb);
+  // Forward-only work (no BatchNorm statistics: eval mode) with more 128x128 tiles than four rounds of the chip: 256x128
+  // tiles move a quarter fewer operand bytes L2 -> LDS, which is what bounds the main loop. The
+  // training step never takes it (it needs the statistics epilogue; 256x128 measured neutral there), fingerprinting at micro-batch
+  // 1 024 has 1 024 - 4 096 tiles per GEMM: +4 % clips/s.
+  static const int tall_min = getenv("NSID_TALL_MIN") ? atoi(getenv("NSID_TALL_MIN")) : 1024;
+  const bool tall = stat == nullptr && act_dtype == NSID_BF16 && wb && !narrow && t128 >= tall_min && M % 256 == 0 &&
+                    Nout % 128 == 0 && K % 64 == 0 && ksplit == 1;
+  const int rc = tall ? launch<256, 128, true, true>(p, groups, s, act_dtype, wb)
+                      : narrow ? launch<128, 64, true, true>(p, groups, s, act_dtype, wb)
+                               : launch<128, 128, true, true>(p, groups, s, act_dtype, wb);
   if (rc != NSID_OK || act_out != NSID_ACT_ELU) return rc;
   const long n = (long)M * groups * Nout;
   NSID_LAUNCH(elu_inplace_kernel, dim3((int)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256)), dim3(256), 0, s,

@@ -284,3 +284,27 @@ def test_eval_batchnorm_folding_matches_the_unfolded_path(ops, golden):
     assert float(cos.min()) > 0.9995, float(cos.min())
     # and the folded path meets the reference goldens like the unfolded one does
     assert relerr(outs[True][0], g.t("h_i_eval")) < 4e-2
+
+
+@pytest.mark.parametrize("M,Nout,K,affine,res", [(16384, 1024, 256, False, False), (8192, 2048, 512, True, True)])
+def test_tall_tile_forward_without_statistics(ops, M, Nout, K, affine, res):
+    """eval-mode forward GEMMs with >= 1024 tiles of 128x128 and bf16 weight shadows take the 256x128-tile kernel
+    (csrc/gemm.hip nsid_linear_fwd): same results as the reference product, with and without the residual addend"""
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(M, K, generator=g).to(BF).to(DEV)
+    w = (torch.randn(Nout, K, generator=g) * K ** -0.5).to(DEV)
+    ops.SHADOWS.register(w, ops.f32_to_bf16(w), owner=w)
+    bias = torch.randn(Nout, generator=g).to(DEV)
+    sc = (1 + 0.2 * torch.randn(K, generator=g)).to(DEV) if affine else None
+    sh = (0.3 * torch.randn(K, generator=g)).to(DEV) if affine else None
+    add = torch.randn(M, Nout, generator=g).to(BF).to(DEV) if res else None
+    xin = act_ref(x.float() * sc + sh, 1) if affine else x.float()
+    ref = xin.to(BF).double() @ w.to(BF).double().t() + bias.double()
+    if res:
+        ref = ref + add.double()
+    out, stat = ops.linear_fwd(x, w, bias, M, Nout, K, 1, sc, sh, 1 if affine else 0, 0, want_stat=False, addend=add)
+    assert stat is None and relerr(out, ref) < 2.5e-3
+    # the statistics epilogue keeps the 128-row tiles (training path): per-tile sums still match
+    out2, stat2 = ops.linear_fwd(x, w, bias, M, Nout, K, 1, sc, sh, 1 if affine else 0, 0, want_stat=True)
+    tiles = (ref - (add.double() if res else 0)).reshape(M // 128, 128, Nout)
+    assert relerr(stat2[0], tiles.sum(1)) < 1e-4 and relerr(out2, tiles.reshape(M, Nout)) < 2.5e-3
