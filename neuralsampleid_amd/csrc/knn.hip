@@ -445,7 +445,8 @@ __global__ __launch_bounds__(KNN2_THREADS) void knn2_kernel(const T* __restrict_
 // into LDS (4 MFMA accumulator chains), then every lane takes (row, j) pairs and counts the entries of that row that
 // precede D[row][j] in (distance, index) order — N compares on LDS broadcasts, no dependent reductions, no rounds. The
 // element of rank p*dilation is neighbour p. The strip kernel's k*d rounds of wave-wide arg-min took 330 us per call here.
-template <typename T>
+// NT = column tiles per MFMA pass (4, or 2 for N = 32): a template parameter for the same reason as in knn2_kernel.
+template <typename T, int NT>
 __global__ __launch_bounds__(KNN2_THREADS) void knn_rank_kernel(const T* __restrict__ r, long ldr,
                                                                 const float* __restrict__ scale,
                                                                 const float* __restrict__ shift, int N, int C, int k,
@@ -515,38 +516,41 @@ __global__ __launch_bounds__(KNN2_THREADS) void knn_rank_kernel(const T* __restr
 
   const int lr = lane & 15, rq = lane >> 4;
   const int NS = N >> 4;
-  const int NT = NS >= 4 ? 4 : NS;                  // column tiles per MFMA pass (2 for N = 32)
   const int kd = k * dilation;
   float* strip = strips + wave * 16 * SLD;
   for (int s = wave; s < NS; s += KNN2_WAVES) {      // no workgroup barrier below: a wave owns its strip buffer
     const float* arow = yn + (16 * s + lr) * LD + 4 * rq;
     for (int tn = 0; tn < NS; tn += NT) {
-      f32x4 acc[4];
+      f32x4 acc[NT];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int u = 0; u < NT; ++u) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
       const float* brow = yn + (16 * tn + lr) * LD + 4 * rq;
-      for (int ch = 0; ch < C; ch += 16) {
-        const f32x4 fa = *reinterpret_cast<const f32x4*>(arow + ch);
-        f32x4 fb[4];
+      // the fragments of the next 16 channels are read while the MFMAs of the current ones run
+      f32x4 fa = *reinterpret_cast<const f32x4*>(arow), fb[NT];
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
-          if (u < NT) fb[u] = *reinterpret_cast<const f32x4*>(brow + u * 16 * LD + ch);
+      for (int u = 0; u < NT; ++u) fb[u] = *reinterpret_cast<const f32x4*>(brow + u * 16 * LD);
+      for (int ch = 0; ch < C; ch += 16) {
+        const int chn = ch + 16 < C ? ch + 16 : ch;
+        const f32x4 na = *reinterpret_cast<const f32x4*>(arow + chn);
+        f32x4 nb[NT];
+#pragma unroll
+        for (int u = 0; u < NT; ++u) nb[u] = *reinterpret_cast<const f32x4*>(brow + u * 16 * LD + chn);
 #pragma unroll
         for (int e = 0; e < 4; ++e)
 #pragma unroll
-          for (int u = 0; u < 4; ++u)
-            if (u < NT) acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[e], fb[u][e], acc[u], 0, 0, 0);
+          for (int u = 0; u < NT; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[e], fb[u][e], acc[u], 0, 0, 0);
+        fa = na;
+#pragma unroll
+        for (int u = 0; u < NT; ++u) fb[u] = nb[u];
       }
       // C/D layout: column (node j) = lane&15, row (node i) = 4*(lane>>4) + reg
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        if (u < NT) {
-          const float sj = sq[16 * (tn + u) + lr];
+      for (int u = 0; u < NT; ++u) {
+        const float sj = sq[16 * (tn + u) + lr];
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const float si = sq[16 * s + 4 * rq + e];
-            strip[(4 * rq + e) * SLD + 16 * (tn + u) + lr] = (si + (-2.f * acc[u][e])) + sj;
-          }
+        for (int e = 0; e < 4; ++e) {
+          const float si = sq[16 * s + 4 * rq + e];
+          strip[(4 * rq + e) * SLD + 16 * (tn + u) + lr] = (si + (-2.f * acc[u][e])) + sj;
         }
       }
     }
@@ -765,20 +769,26 @@ int launch_knn_sel(const void* r, int ldr, const float* scale, const float* shif
   return nsid_launch_status();
 }
 
-template <typename T>
-int launch_knn_rank(const void* r, int ldr, const float* scale, const float* shift, int B, int N, int C, int k,
-                    int dilation, int32_t* idx, hipStream_t s) {
+template <typename T, int NT>
+int launch_knn_rank_nt(const void* r, int ldr, const float* scale, const float* shift, int B, int N, int C, int k,
+                       int dilation, int32_t* idx, hipStream_t s) {
   const size_t bytes = ((size_t)N * (C + 4) + N + (size_t)KNN2_WAVES * 16 * (N + 4)) * sizeof(float);
   static bool configured = false;
   if (!configured) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(knn_rank_kernel<T>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(knn_rank_kernel<T, NT>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
       return NSID_ELAUNCH;
     configured = true;
   }
-  NSID_LAUNCH((knn_rank_kernel<T>), dim3(B), dim3(KNN2_THREADS), bytes, s, static_cast<const T*>(r), (long)ldr, scale,
+  NSID_LAUNCH((knn_rank_kernel<T, NT>), dim3(B), dim3(KNN2_THREADS), bytes, s, static_cast<const T*>(r), (long)ldr, scale,
               shift, N, C, k, dilation, idx);
   return nsid_launch_status();
+}
+template <typename T>
+int launch_knn_rank(const void* r, int ldr, const float* scale, const float* shift, int B, int N, int C, int k,
+                    int dilation, int32_t* idx, hipStream_t s) {
+  return (N >> 4) >= 4 ? launch_knn_rank_nt<T, 4>(r, ldr, scale, shift, B, N, C, k, dilation, idx, s)
+                       : launch_knn_rank_nt<T, 2>(r, ldr, scale, shift, B, N, C, k, dilation, idx, s);
 }
 
 template <typename T, int KD, int NT>
