@@ -928,6 +928,20 @@ extern "C" int nsid_linear_bwd_weight(const void* dout, int ldd, const void* x, 
                                       static_cast<hipStream_t>(stream));
     if (rc != 1) return rc;                  // 1 = shape outside the fast form's preconditions
   }
+  // 128x64 tiles (a quarter fewer operand bytes per flop than 64x64) where they still give >= 256 workgroups of >= 1024
+  // rows, i.e. without more splits = atomic bytes than the square tiles need
+  // (a launch alone is ~8 % slower with them, the two-branch step 1 % faster: half the workgroups and LDS per CU leave the
+  // other view's kernels more room — judged by one-box A/B of the whole step)
+  static const int rect = getenv("NSID_WGRAD_RECT") ? atoi(getenv("NSID_WGRAD_RECT")) : 1;
+  if (rect && act_dtype == NSID_BF16 && Nout % 128 == 0 && K % 64 == 0 && M % 1024 == 0) {
+    const long tiles_r = (long)(Nout / 128) * (K / 64) * groups;
+    const long S = std::min<long>(M / 1024, std::max<long>(1, 512 / tiles_r));
+    if (tiles_r * S >= 256) {
+      p.rsplit = (int)S;
+      p.rchunk = (int)(M / S);
+      return launch<128, 64, false, false>(p, groups, static_cast<hipStream_t>(stream), act_dtype);
+    }
+  }
   // fp32 arithmetic (16x lower matrix rate) stays MFMA-bound: there the larger tile wins whenever it fills the chip.
   const bool half = g_gemm_precision == NSID_GEMM_BF16 || act_dtype == NSID_BF16;
   const long t128 = (long)((Nout + 127) / 128) * ((K + 127) / 128) * groups;

@@ -1,6 +1,7 @@
 """Tensor-level wrappers over the C ABI (include/nsid.h): torch supplies device memory and the stream, nothing else.
 
 Every function enqueues HIP kernels from libnsid_hip.so on torch's current stream; none falls back to ATen."""
+import os
 from typing import Optional, Tuple
 
 import torch
@@ -300,6 +301,10 @@ def linear_bwd_weight(dout, x, dw, M, Nout, K, groups=1, in_scale=None, in_shift
     half = dt == BF16 or lib.nsid_get_gemm_precision() == GEMM_BF16
     small = half or Nout <= 64 or K <= 64 or t128 * ((M + 511) // 512) < 256
     name = "gemm_kernel<%s,false,false>" % ("64,64" if small else "128,128")
+    if dt == BF16 and Nout % 128 == 0 and K % 64 == 0 and M % 1024 == 0:          # csrc/gemm.hip: 128x64 tiles
+        tiles_r = (Nout // 128) * (K // 64) * groups
+        if tiles_r * min(M // 1024, max(1, 512 // tiles_r)) >= 256 and os.environ.get("NSID_WGRAD_RECT", "1") != "0":
+            name = "gemm_kernel<128,64,false,false>"
     if dt == BF16 and Nout % 128 == 0 and K % 128 == 0 and M % 128 == 0 and (Nout // 128) * (K // 128) * groups >= 64:
         name = "wgrad3_kernel"              # csrc/wgrad.hip: 128x128 tiles, 8 waves
     esz = x.element_size()

@@ -89,3 +89,9 @@ print(f"  per CU: workgroups {min(cnt)}..{max(cnt)} (mean {np.mean(cnt):.2f}); m
 # rounds: start-time histogram
 h, edges = np.histogram(us(t0), bins=12)
 print("  start histogram (us):", " ".join(f"{edges[i]:.1f}:{h[i]}" for i in range(len(h))))
+# duration by XCD and by position in the grid (stragglers set the kernel time)
+dur = (te - t0) / 100.0
+print("  duration by XCD (median us):", " ".join(f"{x}:{np.median(dur[xcc == x]):.1f}" for x in sorted(set(xcc))))
+q = np.array_split(np.arange(n), 8)
+print("  duration by launch-order octile (median us):", " ".join(f"{np.median(dur[i]):.1f}" for i in q))
+print("  end-time percentiles (us): p50 %.1f p90 %.1f p99 %.1f max %.1f" % tuple(np.percentile(us(te), [50, 90, 99, 100])))
