@@ -104,6 +104,15 @@ int nsid_colsum_acc(const void* x, int ldx, int M, int C, float* out, int dtype,
 int nsid_bn_finalize(const float* stat, int tiles, int C, int M, const float* gamma, const float* beta,
                      float* running_mean, float* running_var, int64_t* num_batches_tracked, float momentum,
                      float eps, float* scale, float* shift, float* mean, float* invstd, void* stream);
+/* Training-mode finalize WITHOUT the running-statistics update, plus the unbiased variance (uvar) that update needs; and
+   the deferred update itself for n layers in one launch per 16 layers: running = (1-m)*running + m*stat for view a, then
+   (when mean_b / uvar_b are given) for view b — the order the reference applies them (simclr/simclr.py:36,42). The pointer
+   arrays live in host memory. */
+int nsid_bn_finalize_deferred(const float* stat, int tiles, int C, int M, const float* gamma, const float* beta, float eps,
+                              float* scale, float* shift, float* mean, float* invstd, float* uvar, void* stream);
+int nsid_bn_running_update(int n, const int* C, float* const* running_mean, float* const* running_var,
+                           int64_t* const* num_batches_tracked, const float* const* mean_a, const float* const* uvar_a,
+                           const float* const* mean_b, const float* const* uvar_b, float momentum, void* stream);
 /* eval mode: scale/shift from the running statistics */
 int nsid_bn_eval_affine(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
                         float eps, int C, float* scale, float* shift, void* stream);

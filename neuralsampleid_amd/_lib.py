@@ -21,6 +21,8 @@ SIGNATURES = {
     "nsid_linear_bwd_weight": "pipipiiiippiis",
     "nsid_colsum_acc": "piiipis",
     "nsid_bn_finalize": "piiipppppffpppps",
+    "nsid_bn_finalize_deferred": "piiippfppppps",
+    "nsid_bn_running_update": "ippppppppfs",
     "nsid_bn_eval_affine": "ppppfipps",
     "nsid_bn_apply": "pppippiiis",
     "nsid_bn_bwd_reduce": "ppiippppipis",

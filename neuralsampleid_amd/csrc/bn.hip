@@ -49,7 +49,7 @@ __device__ __forceinline__ void tile_sums(const float* __restrict__ p0, const fl
 __global__ __launch_bounds__(FIN_CH * FIN_TG) void bn_finalize_kernel(
     const float* __restrict__ stat, int tiles, int C, int M, const float* gamma, const float* beta,
     float* running_mean, float* running_var, int64_t* nbt, float momentum, float eps, float* scale, float* shift,
-    float* mean_out, float* invstd_out) {
+    float* mean_out, float* invstd_out, float* uvar_out) {
   __shared__ double red0[FIN_CH * FIN_TG], red1[FIN_CH * FIN_TG];
   const int c = blockIdx.x * FIN_CH + (threadIdx.x & (FIN_CH - 1)), tg = threadIdx.x / FIN_CH;
   if (blockIdx.x == 0 && threadIdx.x == 0 && nbt != nullptr) *nbt += 1;
@@ -65,8 +65,9 @@ __global__ __launch_bounds__(FIN_CH * FIN_TG) void bn_finalize_kernel(
   shift[c] = beta[c] - (float)mean * sc;
   mean_out[c] = (float)mean;
   invstd_out[c] = invstd;
+  const double unbiased = var * ((double)M / (double)(M > 1 ? M - 1 : 1));
+  if (uvar_out != nullptr) uvar_out[c] = (float)unbiased;      // for a deferred running-statistics update
   if (running_mean != nullptr) {
-    const double unbiased = var * ((double)M / (double)(M > 1 ? M - 1 : 1));
     running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
     running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
   }
@@ -295,8 +296,78 @@ extern "C" int nsid_bn_finalize(const float* stat, int tiles, int C, int M, cons
   NSID_REQUIRE((running_mean == nullptr) == (running_var == nullptr));
   NSID_LAUNCH(bn_finalize_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_TG), 0,
               static_cast<hipStream_t>(stream), stat, tiles, C, M, gamma, beta, running_mean, running_var, nbt,
-              momentum, eps, scale, shift, mean, invstd);
+              momentum, eps, scale, shift, mean, invstd, static_cast<float*>(nullptr));
   return nsid_launch_status();
+}
+
+// The same finalize without touching the running statistics; it also returns the unbiased variance so that
+// nsid_bn_running_update can apply the update later. Used when the two views of a step run on two streams: the reference
+// updates the running statistics view i first, then view j (simclr.py:36,42) — ordering every layer's two finalize
+// kernels across the streams costs one cross-branch graph edge per layer (0.2 ms per step); deferring the updates to ONE
+// launch after both forwards gives the same numbers (same float expressions, same order) with no edge at all.
+extern "C" int nsid_bn_finalize_deferred(const float* stat, int tiles, int C, int M, const float* gamma,
+                                         const float* beta, float eps, float* scale, float* shift, float* mean,
+                                         float* invstd, float* uvar, void* stream) {
+  NSID_REQUIRE(stat && gamma && beta && scale && shift && mean && invstd && uvar && C > 0 && M > 0);
+  NSID_REQUIRE(tiles == nsid_row_tiles(M));
+  NSID_LAUNCH(bn_finalize_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_TG), 0,
+              static_cast<hipStream_t>(stream), stat, tiles, C, M, gamma, beta, static_cast<float*>(nullptr),
+              static_cast<float*>(nullptr), static_cast<int64_t*>(nullptr), 0.f, eps, scale, shift, mean, invstd, uvar);
+  return nsid_launch_status();
+}
+
+namespace {
+constexpr int RU_LAYERS = 16;       // layers per launch: the pointer table travels in the kernel arguments (16 x 7 x 8 B)
+struct RunUpdArgs {
+  float* rm[RU_LAYERS]; float* rv[RU_LAYERS]; int64_t* nbt[RU_LAYERS];
+  const float* mean_a[RU_LAYERS]; const float* uvar_a[RU_LAYERS];
+  const float* mean_b[RU_LAYERS]; const float* uvar_b[RU_LAYERS];      // null: one update only
+  int C[RU_LAYERS];
+  float momentum;
+};
+__global__ __launch_bounds__(256) void bn_running_update_kernel(const RunUpdArgs a) {
+  const int l = blockIdx.x;
+  const float m = a.momentum;
+  const bool two = a.mean_b[l] != nullptr;
+  if (threadIdx.x == 0 && a.nbt[l] != nullptr) *a.nbt[l] += two ? 2 : 1;
+  for (int c = threadIdx.x; c < a.C[l]; c += blockDim.x) {
+    // exactly the two successive updates bn_finalize_kernel would have made (view a, then view b)
+    float rm = (1.f - m) * a.rm[l][c] + m * a.mean_a[l][c];
+    float rv = (1.f - m) * a.rv[l][c] + m * a.uvar_a[l][c];
+    if (two) {
+      rm = (1.f - m) * rm + m * a.mean_b[l][c];
+      rv = (1.f - m) * rv + m * a.uvar_b[l][c];
+    }
+    a.rm[l][c] = rm;
+    a.rv[l][c] = rv;
+  }
+}
+}  // namespace
+
+// host arrays of n pointers each (mean_b / uvar_b may be null arrays or hold null entries: a single update)
+extern "C" int nsid_bn_running_update(int n, const int* C, float* const* running_mean, float* const* running_var,
+                                      int64_t* const* num_batches_tracked, const float* const* mean_a,
+                                      const float* const* uvar_a, const float* const* mean_b,
+                                      const float* const* uvar_b, float momentum, void* stream) {
+  NSID_REQUIRE(n > 0 && C && running_mean && running_var && mean_a && uvar_a);
+  for (int base = 0; base < n; base += RU_LAYERS) {
+    RunUpdArgs a{};
+    const int cnt = n - base < RU_LAYERS ? n - base : RU_LAYERS;
+    for (int i = 0; i < cnt; ++i) {
+      NSID_REQUIRE(C[base + i] > 0 && running_mean[base + i] && running_var[base + i] && mean_a[base + i] && uvar_a[base + i]);
+      a.rm[i] = running_mean[base + i]; a.rv[i] = running_var[base + i];
+      a.nbt[i] = num_batches_tracked ? num_batches_tracked[base + i] : nullptr;
+      a.mean_a[i] = mean_a[base + i]; a.uvar_a[i] = uvar_a[base + i];
+      a.mean_b[i] = mean_b ? mean_b[base + i] : nullptr; a.uvar_b[i] = uvar_b ? uvar_b[base + i] : nullptr;
+      NSID_REQUIRE((a.mean_b[i] == nullptr) == (a.uvar_b[i] == nullptr));
+      a.C[i] = C[base + i];
+    }
+    a.momentum = momentum;
+    NSID_LAUNCH(bn_running_update_kernel, dim3(cnt), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    const int rc = nsid_launch_status();
+    if (rc != NSID_OK) return rc;
+  }
+  return NSID_OK;
 }
 
 extern "C" int nsid_bn_eval_affine(const float* gamma, const float* beta, const float* running_mean,

@@ -384,6 +384,40 @@ def bn_finalize(stat, M, gamma, beta, running_mean, running_var, num_batches_tra
     return BNAffine(buf[0], buf[1], buf[2], buf[3])
 
 
+def bn_finalize_deferred(stat, M, gamma, beta, eps=BN_EPS):
+    """training-mode statistics -> (BNAffine, unbiased variance) WITHOUT updating the running statistics (bn_running_update)"""
+    C = gamma.numel()
+    buf = torch.empty((5, C), device=gamma.device, dtype=torch.float32)
+    call("nsid_bn_finalize_deferred", _p(stat), row_tiles(M), C, M, _p(gamma), _p(beta), eps, _p(buf[0]), _p(buf[1]),
+         _p(buf[2]), _p(buf[3]), _p(buf[4]), _stream())
+    return BNAffine(buf[0], buf[1], buf[2], buf[3]), buf[4]
+
+
+def bn_running_update(layers_a, layers_b=None, momentum=BN_MOMENTUM) -> None:
+    """Deferred running-statistics updates of many BatchNorm layers in one launch per 16 layers.
+    layers_a: [(running_mean, running_var, num_batches_tracked or None, mean, uvar)] of the first view, in layer order;
+    layers_b: the same layers for the second view (its mean / uvar are applied after the first view's), or None."""
+    import ctypes
+    n = len(layers_a)
+    if n == 0:
+        return
+    if layers_b is not None and len(layers_b) != n:
+        raise ValueError("both views must have run the same BatchNorm layers")
+    arr = lambda vals: (ctypes.c_void_p * n)(*[None if v is None else v.data_ptr() for v in vals])
+    Cs = (ctypes.c_int * n)(*[la[0].numel() for la in layers_a])
+    for la in layers_a:
+        _chk(la[0], la[1], la[3], la[4])
+    if layers_b is not None:
+        for la, lb in zip(layers_a, layers_b):
+            if la[0].data_ptr() != lb[0].data_ptr():
+                raise ValueError("the two views disagree on the layer order")
+            _chk(lb[3], lb[4])
+    call("nsid_bn_running_update", n, Cs, arr([la[0] for la in layers_a]), arr([la[1] for la in layers_a]),
+         arr([la[2] for la in layers_a]), arr([la[3] for la in layers_a]), arr([la[4] for la in layers_a]),
+         None if layers_b is None else arr([lb[3] for lb in layers_b]),
+         None if layers_b is None else arr([lb[4] for lb in layers_b]), momentum, _stream())
+
+
 # eval-mode BatchNorm affines are constants of the checkpoint: computed once per layer and kept until one of the four tensors
 # changes (torch version counters) — fingerprinting spent 6 % of its GPU time recomputing 64 of them per micro-batch.
 _EVAL_AFFINE = {}     # id(gamma) -> (weakref(gamma), versions, eps, BNAffine, stream handle, event)

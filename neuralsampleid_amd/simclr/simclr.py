@@ -3,6 +3,7 @@ import torch
 import torch.nn as nn
 
 from .. import functional as F_
+from .. import ops
 from ..encoder.gcn_lib.torch_vertex import _split
 from ..encoder.graph_encoder import GraphEncoder
 from ..peak_extractor import GPUPeakExtractorv2
@@ -50,15 +51,18 @@ class SimCLR(nn.Module):
         side = self._side_stream
         side.wait_stream(main)                       # inputs/weights written on the main stream are visible
         vo = F_.VIEW_ORDER
-        vo.mode, vo.events, vo.pos = "record", [], 0
+        vo.mode, vo.pending = "a", {"a": [], "b": []}
         try:
             h_i, z_i = self._embed(x_i)
-            vo.mode = "wait"
+            vo.mode = "b"
             with torch.cuda.stream(side):
                 h_j, z_j = self._embed(x_j)
         finally:
             vo.mode = None
         main.wait_stream(side)
+        # running statistics: view i's update, then view j's, for every BatchNorm layer at once (see functional.ViewOrder)
+        ops.bn_running_update(vo.pending["a"], vo.pending["b"])
+        vo.pending = {"a": [], "b": []}
         for t in (h_j, z_j):                         # produced on the side stream, consumed on the main one
             t.record_stream(main)
         return h_i, h_j, z_i, z_j

@@ -371,11 +371,15 @@ def test_two_stream_views_equal_sequential(golden):
         loss.backward()
         opt.step()                                   # joins the side stream before reading the gradients
         res[overlap] = (float(loss), opt.flat_g.clone(), {k: v.clone() for k, v in model.state_dict().items()
-                                                          if k.endswith(("running_mean", "running_var"))})
+                                                          if k.endswith(("running_mean", "running_var",
+                                                                         "num_batches_tracked"))})
     assert abs(res[True][0] - res[False][0]) < 1e-5
     assert relerr(res[True][1], res[False][1]) < 1e-3                      # atomics order + kNN near-ties only
-    for k, v in res[False][2].items():
-        assert maxerr(res[True][2][k], v) < 1e-5, k
+    for k, v in res[False][2].items():              # two streams: the updates are deferred to one launch after both views
+        if k.endswith("num_batches_tracked"):
+            assert int(res[True][2][k]) == int(v) == 2, k
+        else:
+            assert maxerr(res[True][2][k], v) < 1e-6, k
 
 
 def test_fingerprint_db_files(tmp_path):
