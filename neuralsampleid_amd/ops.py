@@ -252,7 +252,7 @@ def linear_fwd(x, w, bias, M, Nout, K, groups=1, in_scale=None, in_shift=None, a
     return out, stat
 
 
-FUSE_BN_BWD_REDUCE = True     # backward-data GEMMs emit the next BatchNorm-backward's column sums (bf16 storage only)
+FUSE_BN_BWD_REDUCE = os.environ.get("NSID_FUSE_BN_BWD_REDUCE", "1") == "1"     # backward-data GEMMs emit the next BatchNorm-backward's column sums (bf16 storage only)
 
 
 def linear_bwd_data(dout, w, M, Nout, K, groups=1, addend=None, out=None, bn=None):
