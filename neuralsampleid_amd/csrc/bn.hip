@@ -46,6 +46,15 @@ __device__ __forceinline__ void tile_sums(const float* __restrict__ p0, const fl
     }
 }
 
+// running = (1 - m) * running + m * stat with every operation rounded on its own (no fused multiply-add): the two kernels
+// that apply it (ordered finalize, deferred update) then agree bit for bit, and with torch's elementwise expression
+__device__ __forceinline__ float running_blend(float old, float stat, float m) {
+#pragma clang fp contract(off)      // (HIP's __fmul_rn / __fadd_rn are plain operators: they contract like any other)
+  const float a = (1.f - m) * old;
+  const float b = m * stat;
+  return a + b;
+}
+
 __global__ __launch_bounds__(FIN_CH * FIN_TG) void bn_finalize_kernel(
     const float* __restrict__ stat, int tiles, int C, int M, const float* gamma, const float* beta,
     float* running_mean, float* running_var, int64_t* nbt, float momentum, float eps, float* scale, float* shift,
@@ -68,8 +77,8 @@ __global__ __launch_bounds__(FIN_CH * FIN_TG) void bn_finalize_kernel(
   const double unbiased = var * ((double)M / (double)(M > 1 ? M - 1 : 1));
   if (uvar_out != nullptr) uvar_out[c] = (float)unbiased;      // for a deferred running-statistics update
   if (running_mean != nullptr) {
-    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
-    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+    running_mean[c] = running_blend(running_mean[c], (float)mean, momentum);
+    running_var[c] = running_blend(running_var[c], (float)unbiased, momentum);
   }
 }
 
@@ -332,11 +341,11 @@ __global__ __launch_bounds__(256) void bn_running_update_kernel(const RunUpdArgs
   if (threadIdx.x == 0 && a.nbt[l] != nullptr) *a.nbt[l] += two ? 2 : 1;
   for (int c = threadIdx.x; c < a.C[l]; c += blockDim.x) {
     // exactly the two successive updates bn_finalize_kernel would have made (view a, then view b)
-    float rm = (1.f - m) * a.rm[l][c] + m * a.mean_a[l][c];
-    float rv = (1.f - m) * a.rv[l][c] + m * a.uvar_a[l][c];
+    float rm = running_blend(a.rm[l][c], a.mean_a[l][c], m);
+    float rv = running_blend(a.rv[l][c], a.uvar_a[l][c], m);
     if (two) {
-      rm = (1.f - m) * rm + m * a.mean_b[l][c];
-      rv = (1.f - m) * rv + m * a.uvar_b[l][c];
+      rm = running_blend(rm, a.mean_b[l][c], m);
+      rv = running_blend(rv, a.uvar_b[l][c], m);
     }
     a.rm[l][c] = rm;
     a.rv[l][c] = rv;

@@ -158,6 +158,41 @@ def knn_mismatch(idx, gold_idx, gap, tol=1e-4):
     return int((bad & (np.asarray(gap) >= tol)).sum()), int(bad.sum())
 
 
+def test_deferred_running_statistics_equal_two_ordered_finalizes(ops):
+    """nsid_bn_finalize_deferred x2 + ONE nsid_bn_running_update = nsid_bn_finalize for view i, then for view j: same
+    affine per view, same running statistics bit for bit, num_batches_tracked += 2 (reference order: simclr.py:36,42)"""
+    M, C = 640, 96
+    xs = [(rnd(f"dv{v}", M, C) * (1.0 + v) + 0.3 * v).to(DEV) for v in range(2)]
+    w = (rnd("dw", C, C) * C ** -0.5).to(DEV)
+    gamma, beta = (1 + 0.1 * rnd("dg", C)).to(DEV), (0.1 * rnd("db", C)).to(DEV)
+    stats = [ops.linear_fwd(x, w, None, M, C, C, want_stat=True)[1] for x in xs]
+    rm0, rv0 = rnd("drm", C).to(DEV), (0.5 + rnd("drv", C).abs()).to(DEV)
+    # ordered: two finalize launches that each update the running statistics
+    rm_a, rv_a, nbt_a = rm0.clone(), rv0.clone(), torch.zeros((), dtype=torch.int64, device=DEV)
+    affs = [ops.bn_finalize(st, M, gamma, beta, rm_a, rv_a, nbt_a) for st in stats]
+    # deferred: statistics only, then one update launch for both views
+    rm_b, rv_b, nbt_b = rm0.clone(), rv0.clone(), torch.zeros((), dtype=torch.int64, device=DEV)
+    pend = []
+    for st, ref in zip(stats, affs):
+        aff, uvar = ops.bn_finalize_deferred(st, M, gamma, beta)
+        for name in ("scale", "shift", "mean", "invstd"):
+            assert torch.equal(getattr(aff, name), getattr(ref, name)), name
+        pend.append((rm_b, rv_b, nbt_b, aff.mean, uvar))
+    ops.bn_running_update([pend[0]], [pend[1]])
+    assert torch.equal(rm_b, rm_a) and torch.equal(rv_b, rv_a) and int(nbt_b) == int(nbt_a) == 2
+    # one view only
+    rm_c, rv_c, nbt_c = rm0.clone(), rv0.clone(), torch.zeros((), dtype=torch.int64, device=DEV)
+    rm_d, rv_d, nbt_d = rm0.clone(), rv0.clone(), torch.zeros((), dtype=torch.int64, device=DEV)
+    ops.bn_finalize(stats[0], M, gamma, beta, rm_c, rv_c, nbt_c)
+    aff, uvar = ops.bn_finalize_deferred(stats[0], M, gamma, beta)
+    ops.bn_running_update([(rm_d, rv_d, nbt_d, aff.mean, uvar)] * 1)
+    assert torch.equal(rm_d, rm_c) and torch.equal(rv_d, rv_c) and int(nbt_d) == 1
+    # more layers than one launch carries (16)
+    many = [(rm0.clone(), rv0.clone(), None, aff.mean, uvar) for _ in range(19)]
+    ops.bn_running_update(many)
+    assert all(torch.equal(m[0], rm_c) and torch.equal(m[1], rv_c) for m in many)
+
+
 def test_batchnorm_eval_affine_is_cached_until_a_tensor_changes(ops):
     """eval-mode scale/shift are computed once per layer and follow in-place updates of any of the four tensors"""
     C = 96
