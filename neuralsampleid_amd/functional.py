@@ -150,9 +150,11 @@ def _bias_grad_before_bn(dr, g):
         ops.colsum_acc(dr, g)
 
 
-def _bn(P, S_unused, pre):
+def _bn(P, S, pre):
+    """the BatchNorm layer's tensors, and whether the block runs without a backward (S is None): only then may an eval-mode
+    BatchNorm be folded into its conv"""
     return P[pre + "weight"], P[pre + "bias"], P[pre + "running_mean"], P[pre + "running_var"], \
-        P.get(pre + "num_batches_tracked")
+        P.get(pre + "num_batches_tracked"), S is None
 
 
 # Eval mode with bf16 storage (fingerprint extraction): every BatchNorm is folded into the conv in front of it
@@ -162,16 +164,18 @@ def _bn(P, S_unused, pre):
 FOLD_EVAL_BN = _os.environ.get("NSID_FOLD_EVAL_BN", "1") == "1"
 
 
-def fold_eval(training: bool) -> bool:
-    return (not training) and FOLD_EVAL_BN and ACT_DTYPE == torch.bfloat16
+def fold_eval(training: bool, S) -> bool:
+    """S: the block's saved-tensor dict (None = no gradient is needed). Eval mode WITH gradients keeps the unfolded path."""
+    return (not training) and S is None and FOLD_EVAL_BN and ACT_DTYPE == torch.bfloat16
 
 
 def conv_bn(x: Tensor, M: int, K: int, Nout: int, w: Tensor, bias: Optional[Tensor], bn, training: bool,
             groups: int = 1, in_aff: Optional[BNAffine] = None, act_in: int = ACT_NONE, residual: Optional[Tensor] = None):
     """r = f(x) W^T (+b) on MFMA, plus the affine of the BatchNorm that follows (batch stats when training).
-    residual: only with fold_eval(training) — the result is then BN(r) + residual, with the identity affine."""
-    gamma, beta, rm, rv, nbt = bn
-    if fold_eval(training):
+    residual: only when the BatchNorm is folded (eval mode, no backward) — the result is then BN(r) + residual, with the
+    identity affine."""
+    gamma, beta, rm, rv, nbt, nograd = bn
+    if nograd and fold_eval(training, None):
         wf, bf = ops.folded_conv_bn(ops.w2d(w), bias, gamma, beta, rm, rv)
         r, _ = ops.linear_fwd(x, wf, bf, M, Nout, K, groups, in_aff.scale if in_aff else None,
                               in_aff.shift if in_aff else None, act_in, ACT_NONE, addend=residual)
@@ -228,7 +232,7 @@ def grapher_forward(x0: Tensor, P, S: Optional[dict], B: int, N: int, k: int, di
     pre = "graph_conv.gconv.nn."
     r2, a2 = conv_bn(u, M, C // 2, C // 2, P[pre + "0.weight"], P[pre + "0.bias"], _bn(P, S, pre + "1."), training,
                      groups=4)
-    if fold_eval(training):      # conv + BatchNorm + shortcut in one launch
+    if fold_eval(training, S):   # conv + BatchNorm + shortcut in one launch
         return conv_bn(r2, M, 2 * C, C, P["fc2.0.weight"], P["fc2.0.bias"], _bn(P, S, "fc2.1."), training,
                        in_aff=a2, act_in=ACT_RELU, residual=x0)[0]
     r3, a3 = conv_bn(r2, M, 2 * C, C, P["fc2.0.weight"], P["fc2.0.bias"], _bn(P, S, "fc2.1."), training,
@@ -275,7 +279,7 @@ def ffn_forward(x1: Tensor, P, S: Optional[dict], training: bool) -> Tensor:
     M, C = x1.shape
     H = P["fc1.0.weight"].shape[0]
     r4, a4 = conv_bn(x1, M, C, H, P["fc1.0.weight"], None, _bn(P, S, "fc1.1."), training)
-    if fold_eval(training):
+    if fold_eval(training, S):
         return conv_bn(r4, M, H, C, P["fc2.0.weight"], None, _bn(P, S, "fc2.1."), training, in_aff=a4, act_in=ACT_RELU,
                        residual=x1)[0]
     r5, a5 = conv_bn(r4, M, H, C, P["fc2.0.weight"], None, _bn(P, S, "fc2.1."), training, in_aff=a4, act_in=ACT_RELU)
@@ -308,8 +312,8 @@ def downsample_forward(x: Tensor, P, S: Optional[dict], B: int, N: int, training
     Co = P["conv.0.weight"].shape[0]
     No = ops.ds_out_nodes(N)
     col = ops.im2col3_fwd(x, B, N, C)
-    if fold_eval(training):      # packed weight with the eval-mode BatchNorm folded in: built once per checkpoint
-        gamma, beta, rm, rv, _ = _bn(P, S, "conv.1.")
+    if fold_eval(training, S):   # packed weight with the eval-mode BatchNorm folded in: built once per checkpoint
+        gamma, beta, rm, rv, _, _ = _bn(P, S, "conv.1.")
         wf, bf = ops.folded_conv_bn(lambda: ops.pack_ds_weight(P["conv.0.weight"]), P["conv.0.bias"], gamma, beta, rm, rv,
                                     source=P["conv.0.weight"])
         return ops.linear_fwd(col, wf, bf, B * No, Co, 3 * C)[0]
@@ -405,10 +409,12 @@ class _BlockFn(torch.autograd.Function):
     """Generic wrapper: forward(fwd, bwd, names, buffers, meta, x, *params) with P assembled from names."""
 
     @staticmethod
-    def forward(ctx, fwd, bwd, names, buffers, meta, x, *params):
+    def forward(ctx, fwd, bwd, names, buffers, meta, grad_on, x, *params):
         P = dict(zip(names, params))
         P.update(buffers)
-        need = any(ctx.needs_input_grad)       # grad mode is always off inside Function.forward
+        # grad_on: torch.is_grad_enabled() at the call site (inside Function.forward grad mode is always off, and
+        # needs_input_grad stays True for parameters under torch.no_grad(): without it inference kept a saved-tensor dict)
+        need = grad_on and any(ctx.needs_input_grad)
         S = {} if need else None
         out = fwd(x.contiguous(), P, S, *meta)
         ctx.S, ctx.P, ctx.bwd, ctx.names = S, P, bwd, names
@@ -424,13 +430,13 @@ class _BlockFn(torch.autograd.Function):
         ctx.S = None
         if direct and GRAD_READY_HOOK is not None:
             GRAD_READY_HOOK([P[n] for n in names])
-        head = (None, None, None, None, None, dx if ctx.x_needs else None)
+        head = (None, None, None, None, None, None, dx if ctx.x_needs else None)
         return head + tuple(None if direct else G[n] for n in names)
 
 
 def run_block(fwd, bwd, module_params: Dict[str, Tensor], module_buffers: Dict[str, Tensor], x: Tensor, *meta):
     names = tuple(module_params.keys())
-    return _BlockFn.apply(fwd, bwd, names, module_buffers, meta, x, *module_params.values())
+    return _BlockFn.apply(fwd, bwd, names, module_buffers, meta, torch.is_grad_enabled(), x, *module_params.values())
 
 
 class _ToRows(torch.autograd.Function):
@@ -466,8 +472,8 @@ def from_rows(rows: Tensor, B: int, N: int) -> Tensor:
 
 class _NtxentFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, z_i, z_j, tau):
-        need = any(ctx.needs_input_grad)
+    def forward(ctx, z_i, z_j, tau, grad_on=True):
+        need = grad_on and any(ctx.needs_input_grad)
         loss, dzi, dzj = ops.ntxent_fwd_bwd(z_i.contiguous(), z_j.contiguous(), tau, want_grad=need)
         ctx.save_for_backward(dzi, dzj) if need else None
         return loss.reshape(())
@@ -475,8 +481,8 @@ class _NtxentFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         dzi, dzj = ctx.saved_tensors
-        return dzi * g, dzj * g, None
+        return dzi * g, dzj * g, None, None
 
 
 def ntxent(z_i: Tensor, z_j: Tensor, tau: float) -> Tensor:
-    return _NtxentFn.apply(z_i, z_j, tau)
+    return _NtxentFn.apply(z_i, z_j, tau, torch.is_grad_enabled())

@@ -11,9 +11,9 @@ from . import functional as F_
 
 class _PatchifyFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, spec, weight, bias, pb, pf):
+    def forward(ctx, spec, weight, bias, pb, pf, grad_on=True):
         P = {"convs.0.weight": weight, "convs.0.bias": bias}
-        need = any(ctx.needs_input_grad)
+        need = grad_on and any(ctx.needs_input_grad)      # see functional._BlockFn.forward
         S = {} if need else None
         out = F_.patchify_forward(spec.contiguous(), P, S, pb, pf)
         ctx.S, ctx.P = S, P
@@ -28,8 +28,8 @@ class _PatchifyFn(torch.autograd.Function):
         if direct:
             if F_.GRAD_READY_HOOK is not None:
                 F_.GRAD_READY_HOOK(list(ctx.P.values()))
-            return None, None, None, None, None
-        return None, G["convs.0.weight"], G["convs.0.bias"], None, None
+            return None, None, None, None, None, None
+        return None, G["convs.0.weight"], G["convs.0.bias"], None, None, None
 
 
 class GPUPeakExtractorv2(nn.Module):
@@ -54,7 +54,8 @@ class GPUPeakExtractorv2(nn.Module):
     def forward_rows(self, spec_tensor):
         """(B, n_mels, n_frames) -> node-major (B*N, F)"""
         conv = self.convs[0]
-        return _PatchifyFn.apply(spec_tensor, conv.weight, conv.bias, self.patch_bins, self.patch_frames)
+        return _PatchifyFn.apply(spec_tensor, conv.weight, conv.bias, self.patch_bins, self.patch_frames,
+                                 torch.is_grad_enabled())
 
     def forward(self, spec_tensor):
         B, H, W = spec_tensor.shape

@@ -269,12 +269,14 @@ def test_eval_batchnorm_folding_matches_the_unfolded_path(ops, golden):
     n = len([k for k in g if k.startswith("knn.eval.")])
     gold_idx = [g.t(f"knn.eval.{c}") for c in range(n)]       # same neighbour sets on both sides (kNN near-ties)
     outs = {}
+    ops._FOLDED.clear()
     try:
         for fold in (False, True):
             F_.FOLD_EVAL_BN = fold
             F_.TAPE = F_.KnnTape(replay=gold_idx)
             with torch.no_grad():
                 outs[fold] = model(x_i, x_j)
+            assert (len(ops._FOLDED) > 50) == fold         # the folded path really ran (64 BatchNorm layers), only then
     finally:
         F_.TAPE = None
         F_.FOLD_EVAL_BN = True
