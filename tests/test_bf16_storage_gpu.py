@@ -304,7 +304,15 @@ def test_tall_tile_forward_without_statistics(ops, M, Nout, K, affine, res):
     ref = xin.to(BF).double() @ w.to(BF).double().t() + bias.double()
     if res:
         ref = ref + add.double()
-    out, stat = ops.linear_fwd(x, w, bias, M, Nout, K, 1, sc, sh, 1 if affine else 0, 0, want_stat=False, addend=add)
+    from neuralsampleid_amd._lib import lib
+    trace = torch.zeros(4 * 4096, dtype=torch.int64, device=DEV)          # one record per workgroup (nsid_debug_gemm_trace)
+    assert lib.nsid_debug_gemm_trace(trace.data_ptr()) == 0
+    try:
+        out, stat = ops.linear_fwd(x, w, bias, M, Nout, K, 1, sc, sh, 1 if affine else 0, 0, want_stat=False, addend=add)
+        torch.cuda.synchronize()
+    finally:
+        lib.nsid_debug_gemm_trace(None)
+    assert int((trace.view(-1, 4)[:, 0] != 0).sum()) == (M // 256) * (Nout // 128)      # 256x128 tiles really ran
     assert stat is None and relerr(out, ref) < 2.5e-3
     # the statistics epilogue keeps the 128-row tiles (training path): per-tile sums still match
     out2, stat2 = ops.linear_fwd(x, w, bias, M, Nout, K, 1, sc, sh, 1 if affine else 0, 0, want_stat=True)
