@@ -39,7 +39,8 @@ def bfr(x):
 
 CASES = [(512, 64, 64, 1, False, 0), (200, 256, 64, 1, True, 1), (384, 32, 32, 4, False, 0), (256, 128, 128, 4, True, 2),
          (640, 64, 8, 1, False, 0), (2048, 1024, 256, 1, True, 1), (136, 192, 384, 1, False, 0),
-         (512, 2048, 512, 1, True, 1), (256, 1024, 1024, 1, False, 0)]   # >= 64 tiles of 128x128: the 8-wave wgrad form
+         (512, 2048, 512, 1, True, 1), (256, 1024, 1024, 1, False, 0),   # >= 64 tiles of 128x128: the 8-wave wgrad form
+         (16384, 256, 512, 1, True, 1), (16384, 1024, 256, 1, False, 0)]  # 128x64 weight-gradient tiles (>= 256 workgroups of 1024 rows)
 
 
 @pytest.mark.parametrize("M,Nout,K,groups,affine,act", CASES)
