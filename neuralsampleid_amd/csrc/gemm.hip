@@ -145,7 +145,17 @@ __device__ __forceinline__ void colaffine_load(f32x4* sc, f32x4* sh, int row0, i
   }
 }
 
-template <int ROWS, bool RMAJOR, bool H, bool SRC16>
+// ReLU on eight bf16 values in their storage format: as signed 16-bit integers every negative float (sign bit set) is a
+// negative integer and every non-negative float a non-negative one, so max(x, 0) on int16 lanes IS ReLU (v_pk_max_i16: one
+// instruction per two elements; -0 -> +0; a NaN with the sign bit set becomes 0, one without passes)
+__device__ __forceinline__ f32x4 relu_bf16x8(f32x4 raw) {
+  typedef short s16x8 __attribute__((ext_vector_type(8)));
+  s16x8 h = __builtin_bit_cast(s16x8, raw);
+  h = __builtin_elementwise_max(h, s16x8{0, 0, 0, 0, 0, 0, 0, 0});
+  return __builtin_bit_cast(f32x4, h);
+}
+
+template <int ROWS, bool RMAJOR, bool H, bool SRC16, bool RELU16 = false>
 __device__ __forceinline__ void stage_store(char* lds, const StageRegs<ROWS, RMAJOR, H, SRC16>& s, bool affine,
                                             float slope, const f32x4* csc, const f32x4* csh) {
   using G = TileGeom<ROWS, RMAJOR, H, SRC16>;
@@ -159,6 +169,7 @@ __device__ __forceinline__ void stage_store(char* lds, const StageRegs<ROWS, RMA
     if (SRC16 && !affine) {           // wave-uniform: bf16 in HBM == bf16 in LDS
       f32x4 raw = s.v[q];
       if (!s.ok[q]) raw = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (RELU16) raw = relu_bf16x8(raw);
       *reinterpret_cast<f32x4*>(lds + lo) = raw;
       continue;
     }
@@ -256,7 +267,10 @@ __device__ __forceinline__ void chunk_to_float(const f32x4& raw, float* v) {
 // One scalar load and a uniform branch per workgroup when no buffer is installed.
 __device__ unsigned long long* g_gemm_trace = nullptr;
 
-template <int BM, int BN, bool A_RMAJOR, bool B_RMAJOR, bool H, bool ST, bool AAFF, bool WB = false, bool FULL = false>
+// ARELU: the left operand is a bf16 activation that only needs ReLU on load (an eval-mode BatchNorm folded into the producer's
+// weights leaves no affine): applied on the packed bf16 values, no conversion, no per-channel vectors.
+template <int BM, int BN, bool A_RMAJOR, bool B_RMAJOR, bool H, bool ST, bool AAFF, bool WB = false, bool FULL = false,
+          bool ARELU = false>
 __global__ __launch_bounds__(256, (FULL && WB && BM == 128 && BN == 128 && !AAFF) ? 3 : 2)   // 3 waves/SIMD: <= 168 registers
 void gemm_kernel(const GemmArgs p) {
   unsigned long long* const trace = g_gemm_trace;
@@ -264,6 +278,7 @@ void gemm_kernel(const GemmArgs p) {
   if (trace) t_start = __builtin_amdgcn_s_memrealtime();
   constexpr bool SA = ST, SB = (ST && !A_RMAJOR && !B_RMAJOR) || WB, SC = ST && A_RMAJOR;
   static_assert(!WB || (ST && A_RMAJOR), "bf16 weights ride with bf16 activations in the forward/backward-data GEMMs");
+  static_assert(!ARELU || (ST && A_RMAJOR && B_RMAJOR && !AAFF && FULL), "ReLU-on-load is a forward, full-tile, bf16 variant");
   using GA = TileGeom<BM, A_RMAJOR, H, SA>;
   using GB = TileGeom<BN, B_RMAJOR, H, SB>;
   constexpr int BK = Prec<H>::BK;
@@ -375,7 +390,7 @@ void gemm_kernel(const GemmArgs p) {
   };
   auto commit = [&](const auto& sa, const auto& sb, int st) {
     char* dst = lds_raw + (st & 1) * STAGE;
-    stage_store<BM, A_RMAJOR, H, SA>(dst, sa, a_aff, p.a_slope, acs, ach);
+    stage_store<BM, A_RMAJOR, H, SA, ARELU>(dst, sa, a_aff, p.a_slope, acs, ach);
     stage_store<BN, B_RMAJOR, H, SB>(dst + GA::BYTES, sb, b_aff, p.b_slope, bcs, bch);
   };
   auto compute = [&](int st) {
@@ -727,7 +742,13 @@ int launch(GemmArgs p, int groups, hipStream_t s, int act_dtype, bool w_bf16 = f
   const bool full = st16 && p.I % BM == 0 && p.J % BN == 0 && p.rchunk % (2 * bk) == 0 && p.R % p.rchunk == 0;
   if constexpr (AR) {
     if (st16 && w_bf16) {
-      if (full) {
+      const bool act_only = CAN_AFF && p.a_scale == nullptr && p.a_slope != 1.f;     // activation on load, no affine
+      if (act_only) {
+        if constexpr (CAN_AFF) {
+          if (!full || p.a_slope != 0.f) return NSID_EINVAL;          // only ReLU on full tiles (the caller checks: ops.py)
+          NSID_LAUNCH((gemm_kernel<BM, BN, AR, BR, true, true, false, true, true, true>), grid, dim3(256), 0, s, p);
+        }
+      } else if (full) {
         if (aff) NSID_LAUNCH((gemm_kernel<BM, BN, AR, BR, true, true, CAN_AFF, true, true>), grid, dim3(256), 0, s, p);
         else NSID_LAUNCH((gemm_kernel<BM, BN, AR, BR, true, true, false, true, true>), grid, dim3(256), 0, s, p);
       } else {
@@ -803,6 +824,9 @@ static int linear_fwd_impl(const void* x, int ldx, const void* w, int w_dtype, c
   NSID_REQUIRE((in_scale == nullptr) == (in_shift == nullptr));
   NSID_REQUIRE(ksplit == 1 || (stat == nullptr && act_out == NSID_ACT_NONE));
   NSID_REQUIRE(act_in != NSID_ACT_ELU && (act_out == NSID_ACT_NONE || act_out == NSID_ACT_ELU));
+  // an activation on load WITHOUT an affine exists as ReLU on bf16 operands with bf16 weights (full tiles; eval path)
+  NSID_REQUIRE(in_scale != nullptr || act_in == NSID_ACT_NONE ||
+               (act_in == NSID_ACT_RELU && act_dtype == NSID_BF16 && w_dtype == NSID_BF16));
   GemmArgs p{};
   p.A = x; p.lda = ldx; p.a_goff = K;
   p.B = w; p.ldb = K; p.b_goff = (long)Nout * K;

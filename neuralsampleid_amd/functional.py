@@ -177,8 +177,11 @@ def conv_bn(x: Tensor, M: int, K: int, Nout: int, w: Tensor, bias: Optional[Tens
     gamma, beta, rm, rv, nbt, nograd = bn
     if nograd and fold_eval(training, None):
         wf, bf = ops.folded_conv_bn(ops.w2d(w), bias, gamma, beta, rm, rv)
-        r, _ = ops.linear_fwd(x, wf, bf, M, Nout, K, groups, in_aff.scale if in_aff else None,
-                              in_aff.shift if in_aff else None, act_in, ACT_NONE, addend=residual)
+        sc, sh = (in_aff.scale, in_aff.shift) if in_aff else (None, None)
+        if in_aff is not None and in_aff.identity and act_in == ACT_RELU and M % 256 == 0 and Nout % 128 == 0 and \
+                K % 64 == 0 and wf.numel() % 8 == 0:
+            sc = sh = None       # the producer's BatchNorm is folded too: ReLU alone, on the packed bf16 values
+        r, _ = ops.linear_fwd(x, wf, bf, M, Nout, K, groups, sc, sh, act_in, ACT_NONE, addend=residual)
         return r, ops.identity_affine(groups * Nout, x.device)
     assert residual is None
     r, stat = ops.linear_fwd(x, ops.w2d(w), bias, M, Nout, K, groups,

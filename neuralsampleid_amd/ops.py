@@ -239,6 +239,14 @@ def linear_fwd(x, w, bias, M, Nout, K, groups=1, in_scale=None, in_shift=None, a
     name = "gemm_kernel<128,%d,true,true>" % (64 if narrow else 128)
     esz = x.element_size()
     wop, wdt = _weight(w, dt, K)
+    if in_scale is None and act_in != ACT_NONE:
+        # activation on load without an affine: only ReLU on bf16 operands, bf16 weights and whole tiles (csrc/gemm.hip ARELU)
+        bn_ = 64 if narrow else 128
+        bm_ = 256 if (not want_stat and not narrow and row_tiles(M) * ((Nout + 127) // 128) * groups >= 1024
+                      and M % 256 == 0 and Nout % 128 == 0) else 128
+        if not (act_in == ACT_RELU and dt == BF16 and wdt == BF16 and M % bm_ == 0 and Nout % bn_ == 0 and K % 64 == 0
+                and ksplit == 1):
+            raise ValueError("activation-on-load without an affine needs ReLU, bf16 storage, bf16 weights and whole tiles")
     if addend is not None:
         _timed(name, 2.0 * M * Nout * K * groups,
                groups * (esz * M * K + float(wop.element_size()) * Nout * K + 2 * esz * M * Nout), lambda: call(

@@ -319,3 +319,23 @@ def test_tall_tile_forward_without_statistics(ops, M, Nout, K, affine, res):
     out2, stat2 = ops.linear_fwd(x, w, bias, M, Nout, K, 1, sc, sh, 1 if affine else 0, 0, want_stat=True)
     tiles = (ref - (add.double() if res else 0)).reshape(M // 128, 128, Nout)
     assert relerr(stat2[0], tiles.sum(1)) < 1e-4 and relerr(out2, tiles.reshape(M, Nout)) < 2.5e-3
+
+
+@pytest.mark.parametrize("M,Nout,K,res", [(512, 256, 512, True), (16384, 1024, 256, False), (256, 128, 64, False)])
+def test_linear_fwd_relu_on_load_without_affine(ops, M, Nout, K, res):
+    """activation-on-load with no affine (eval path: the producer's BatchNorm is folded into its weights): ReLU applied on the
+    packed bf16 operand values == relu(x) W^T"""
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(M, K, generator=g).to(BF).to(DEV)
+    x[0, :8] = torch.tensor([-0.0, 0.0, -1.5, 2.0, -3e-39, 1e-38, -65504.0, 7.0]).to(BF)      # signed zeros, tiny values
+    w = (torch.randn(Nout, K, generator=g) * K ** -0.5).to(DEV)
+    ops.SHADOWS.register(w, ops.f32_to_bf16(w), owner=w)
+    bias = torch.randn(Nout, generator=g).to(DEV)
+    add = torch.randn(M, Nout, generator=g).to(BF).to(DEV) if res else None
+    ref = torch.relu(x.double()) @ w.to(BF).double().t() + bias.double()
+    if res:
+        ref = ref + add.double()
+    out, _ = ops.linear_fwd(x, w, bias, M, Nout, K, 1, None, None, 1, 0, addend=add)
+    assert relerr(out, ref) < 2.5e-3
+    with pytest.raises(ValueError):                       # LeakyReLU / ragged shapes have no such kernel: loud, not silent
+        ops.linear_fwd(x, w, bias, M, Nout, K, 1, None, None, 2, 0)
