@@ -187,9 +187,15 @@ def main():
 
     # data-path collectives: direct RCCL communicator (neuralsampleid_amd/rccl.py) on its own HIP stream; the
     # torch.distributed group (gloo) only carries the ncclUniqueId, the host barriers and the max-over-ranks of the time
-    rank, local, world = parallel.init_from_env("rccl")
+    # NSID_BENCH_REHEARSAL=gloo: rehearse the multi-rank orchestration on a box with fewer GPUs than ranks (RCCL refuses two
+    # ranks on one device): torch.distributed/gloo carries the data-path collectives, ranks share devices, no hipGraph
+    rehearsal = os.environ.get("NSID_BENCH_REHEARSAL", "") == "gloo"
+    rank, local, world = parallel.init_from_env("gloo" if rehearsal else "rccl")
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if rehearsal:
+        local %= torch.cuda.device_count()
+        args.no_graph = True
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
@@ -377,7 +383,9 @@ def main():
                                    f"(fwd x2 views + NT-Xent + bwd + clip + Adam), batch={args.batch} synthetic "
                                    f"(64,128) log-mel clip pairs per GPU, random-init weights",
                        "global_batch": args.batch * world, "k": args.k, "parallelism": f"dp{world}",
-                       "collectives": ("direct RCCL on a dedicated HIP stream: z all-gather + bucketed SUM all-reduce "
+                       "collectives": ("REHEARSAL over torch.distributed/gloo, ranks sharing devices — not a measurement"
+                                       if rehearsal else
+                                       "direct RCCL on a dedicated HIP stream: z all-gather + bucketed SUM all-reduce "
                                        "of gradients overlapped with backward" + (", captured in the hipGraph"
                                                                                    if graph is not None else "")
                                        if parallel._distributed() else "none (single process)"),

@@ -265,10 +265,14 @@ def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
         backend = "rccl" if torch.cuda.is_available() else "gloo"
     if backend in ("rccl", "nccl"):
         torch.cuda.set_device(local)
-    if world > 1 and not dist.is_initialized():
-        dist.init_process_group(backend="gloo" if backend == "rccl" else backend, rank=rank, world_size=world)
+    from .rccl import _stdout_to_stderr         # gloo announces "[Gloo] Rank r is connected to ..." on stdout: a program that
+    if world > 1 and not dist.is_initialized():  # prints one machine-readable line there (bench.py) must not carry it
+        with _stdout_to_stderr():
+            dist.init_process_group(backend="gloo" if backend == "rccl" else backend, rank=rank, world_size=world)
+            dist.barrier()                      # (connections are made here at the latest)
     elif force and backend != "rccl" and not dist.is_initialized():
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        with _stdout_to_stderr():
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
     if backend == "rccl" and (world > 1 or force) and COMM is None:
         from . import rccl
         set_default_comm(rccl.init_comm(rank, world, torch.device("cuda", local)))
