@@ -41,8 +41,7 @@ def synth_clips(batch, seed, device):
     return x_i.to(device), x_j.to(device)
 
 
-def cpu_baseline(k, batch=32, steps=3):
-    """The oracle (CPU restatement of the reference path, pinned to the reference's goldens) timed on this host."""
+def _oracle_setup(k, deep):
     from oracle import ref_torch as R
     try:
         cores = len(os.sched_getaffinity(0))
@@ -52,9 +51,18 @@ def cpu_baseline(k, batch=32, steps=3):
     from neuralsampleid_amd.encoder.graph_encoder import GraphEncoder
     from neuralsampleid_amd.simclr.simclr import SimCLR
     torch.manual_seed(42)
-    sd = SimCLR(CFG, GraphEncoder(CFG, in_channels=CFG["n_filters"], k=k, size="t")).state_dict()   # weights only
-    P = {n: v.clone() for n, v in sd.items()}
-    plan = R.encoder_plan("t", k)
+    kw = dict(blocks=[4, 4, 12, 4], use_dilation=True) if deep else {}
+    sd = SimCLR(CFG, GraphEncoder(CFG, in_channels=CFG["n_filters"], k=k, size="t", **kw)).state_dict()   # weights only
+    P = {n: v.clone() for n, v in sd.items() if "relative_pos" not in n}
+    plan = R.encoder_plan("t", k, blocks=[4, 4, 12, 4] if deep else None, use_dilation=deep)
+    return R, P, plan
+
+
+def cpu_baseline(k, batch=32, steps=3, deep=False):
+    """The oracle (CPU restatement of the reference path, pinned to the reference's goldens) timed on this host."""
+    R, P, plan = _oracle_setup(k, deep)
+    if deep:
+        batch, steps = 16, 2                           # 24 blocks at k = 18: keeps the sample within ~20 s
     opt = R.AdamState({n: P[n] for n in R.trainable_keys(P)}, lr=CFG["lr"])
     x_i, x_j = synth_clips(batch, 0, "cpu")
     R.train_step(P, x_i, x_j, CFG, plan, opt)          # warm-up
@@ -63,7 +71,65 @@ def cpu_baseline(k, batch=32, steps=3):
         R.train_step(P, x_i, x_j, CFG, plan, opt)
     dt = (time.perf_counter() - t0) / steps
     return {"value": round(batch / dt, 2), "unit": "clips/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{steps} full contrastive steps at batch {batch} (fp32, oracle/ref_torch.py), {dt:.2f} s/step"}
+            "sample": f"{steps} full contrastive steps at batch {batch} (fp32, oracle/ref_torch.py"
+                      f"{', deep plan' if deep else ''}), {dt:.2f} s/step"}
+
+
+def cpu_baseline_infer(k, batch=128, reps=3, deep=False):
+    """forward-only, eval-mode BatchNorm, one view: the oracle's restatement of generate.py:31-49 on this host"""
+    R, P, plan = _oracle_setup(k, deep)
+    x, _ = synth_clips(batch, 0, "cpu")
+    with torch.no_grad():
+        fwd = lambda: R.projector(R.graph_encoder(R.peak_patchify(x, P, "peak_extractor.", CFG), P, "encoder.", plan,
+                                                  False, None), P, "projector.")
+        fwd()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fwd()
+    dt = (time.perf_counter() - t0) / reps
+    return {"value": round(batch / dt, 2), "unit": "clips/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{reps} eval-mode forward passes of {batch} clips (fp32, oracle/ref_torch.py), {dt:.2f} s each"}
+
+
+def kernel_table(prof, elapsed_ms, precision):
+    """per-kernel summary of an ops.KernelProfile + the dominant GEMM-family kernel's roofline entry"""
+    mfma_peak = BF16_MFMA_PEAK_TFLOPS if precision == "bf16" else FP32_MFMA_PEAK_TFLOPS
+    kernels = {}
+    for n, d in prof.items():
+        tf = d["flops"] / (d["ms"] * 1e-3) / 1e12
+        gbs = d["bytes"] / (d["ms"] * 1e-3) / 1e9
+        # GEMM family: MFMA utilisation against the dense peak of the operand type; kNN: fp32 matrix pipe (exact
+        # distances); gather kernels: algorithmic HBM bytes only
+        peak = FP32_MFMA_PEAK_TFLOPS if n.startswith("knn") else mfma_peak
+        kernels[n] = {"launches": d["launches"], "avg_us": round(1e3 * d["ms"] / d["launches"], 2),
+                      "tflops": round(tf, 2), "mfma_frac": round(tf / peak, 4) if d["flops"] > 0 else None,
+                      "alg_GBps": round(gbs, 1), "hbm_frac": round(gbs / HBM_PEAK_GBPS, 4),
+                      "share_of_step": round(d["ms"] / elapsed_ms, 3)}
+    return kernels
+
+
+def roofline_entry(prof, precision, bracket_us, tag=""):
+    gemms = {n: d for n, d in prof.items() if n.startswith(("gemm_kernel", "wgrad3", "ffn_fused"))}
+    dom = max(gemms or prof, key=lambda n: prof[n]["ms"])
+    d = prof[dom]
+    tr = measured_traffic(dom, precision, tag)
+    common = {"kernel": dom, "traffic": tr[0] if tr else None,
+              "traffic_source": (tr[1] + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, bytes per launch)") if tr else None,
+              "launches_per_step": d["launches"],
+              "avg_launch_us": round(1e3 * d["ms"] / d["launches"], 2),
+              "flops_per_launch": round(d["flops"] / d["launches"]),
+              "alg_bytes_per_launch": round(d["bytes"] / d["launches"]),
+              "event_bracket_us": round(bracket_us, 2),
+              "method": "HIP events around every launch in one instrumented eager step after the timed region, "
+                        "minus the median duration of an empty event bracket (event_bracket_us)"}
+    if precision == "fp32":      # fp32 MFMA runs at 1/16 of the bf16 rate: the GEMMs are matrix-pipe bound
+        ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
+        return {"bound": "mfma", "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), **common}
+    # bf16 operands: every layer's intensity (<= 195 flop/B) is under the 312 flop/B ridge -> HBM is the roof
+    ach = d["bytes"] / (d["ms"] * 1e-3) / 1e9
+    return {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "frac": round(ach / HBM_PEAK_GBPS, 4), **common}
 
 
 def infer_bench(args, model, rank, world, dev, dist):
@@ -111,8 +177,25 @@ def infer_bench(args, model, rank, world, dev, dist):
         t = torch.tensor([elapsed], dtype=torch.float64)          # host-side group (gloo): max over ranks
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t)
+    roofline = kernels = cpu = None
+    if rank == 0 and not args.no_roofline:
+        from neuralsampleid_amd import ops
+        ops.PROFILE = ops.KernelProfile()
+        bracket_us = 1e3 * ops.PROFILE.bracket_ms
+        fingerprint.extract_fingerprints(model, pool[:mb], mb, out)
+        prof = ops.PROFILE.summary()
+        ops.PROFILE = None
+        kernels = kernel_table(prof, 1e3 * elapsed / n_mb, args.precision)
+        roofline = roofline_entry(prof, args.precision, bracket_us, "_infer")
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        log("timing the CPU baseline (oracle, eval forward) ...")
+        cpu = cpu_baseline_infer(args.k, deep=args.deep)
     if rank == 0:
+        # 9.8 MB per view-clip forward at 2 B/element with every conv output materialised once
+        fwd_bytes = 9.8e6 * (1.0 if args.precision == "bf16" else 2.0) * args.clips
         print(json.dumps({
+            "roofline": roofline, "kernels": kernels, "cpu_baseline": cpu,
+            "step_hbm_frac_algorithmic": round(fwd_bytes / elapsed / 1e9 / HBM_PEAK_GBPS, 4),
             "metric": "audio clips/sec (forward-only fingerprint extraction, grafp encoder)",
             "value": round(args.clips / elapsed, 1), "unit": "clips/s", "n_gpus": world, "steps": n_mb,
             "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / n_mb, 3), "higher_is_better": True,
@@ -129,26 +212,69 @@ def infer_bench(args, model, rank, world, dev, dist):
     parallel.shutdown()
 
 
-def measured_traffic(kernel, precision):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/*/hbm_traffic.json: separate
-    --pmc FETCH_SIZE / WRITE_SIZE runs of this same bench, gfx950 FETCH_SIZE x2 correction applied), or None."""
+def measured_traffic(kernel, precision, tag=""):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/*/hbm_traffic*.json: separate
+    --pmc FETCH_SIZE / WRITE_SIZE runs of this same bench, gfx950 FETCH_SIZE x2 correction applied), or None.
+    Keys there come from tools/hbm_traffic.py: `gemm_kernel<BM, BN, AR, BR, bf16>` for the GEMM template (its first five
+    arguments), the plain kernel name for everything else (wgrad3_kernel, knn2_kernel, ...)."""
     import glob
-    key = kernel.replace(" ", "")[:-1] + "," + ("true" if precision == "bf16" else "false") + ">"
+    import re
+    norm = lambda n: re.sub(r"\s+", "", n)
+    want = norm(kernel)
+    if want.startswith("gemm_kernel<"):
+        want = want[:-1] + "," + ("true" if precision == "bf16" else "false") + ">"
     best = None
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "hbm_traffic.json"))):
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", f"hbm_traffic{tag}.json"))):
         try:
             with open(path) as f:
                 ks = json.load(f)["kernels"]
         except (OSError, ValueError, KeyError):
             continue
         for name, v in ks.items():
-            if name.replace(" ", "") == key:
+            n = norm(name)
+            if n == want or (not want.startswith("gemm_kernel<") and n.split("<")[0] == want.split("<")[0]):
                 best = (int(v["hbm_bytes_per_launch"]), os.path.relpath(path, ROOT))
+    if best is None:
+        log(f"no committed PMC traffic entry matches kernel '{kernel}' (roofline.traffic = null)")
     return best
 
 
 def log(msg):
     print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
+def spawn_ranks(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher: start the N ranks as FRESH child processes through
+    torch.distributed.run — this process has made no GPU call (a process that has initialised the GPU must never exec or be
+    replaced) — relay rank 0's single JSON line, and exit non-zero if any rank fails or the job overruns its deadline."""
+    import signal
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    log(f"no launcher in the environment: spawning {n} ranks: {' '.join(cmd[1:8])} ...")
+    deadline = float(os.environ.get("NSID_BENCH_TIMEOUT_S", "1500"))
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, start_new_session=True)
+    try:
+        out, _ = proc.communicate(timeout=deadline)
+    except subprocess.TimeoutExpired:
+        log(f"the {n}-rank job did not finish within {deadline:.0f} s: terminating its process group")
+        os.killpg(proc.pid, signal.SIGTERM)
+        try:
+            proc.wait(timeout=20)
+        except subprocess.TimeoutExpired:
+            os.killpg(proc.pid, signal.SIGKILL)
+        return 124
+    lines = [ln for ln in out.splitlines() if ln.startswith("{")]
+    if proc.returncode != 0 or len(lines) != 1:
+        sys.stderr.write(out)
+        log(f"launcher exit code {proc.returncode}, {len(lines)} JSON lines")
+        return proc.returncode or 1
+    print(lines[0], flush=True)
+    return 0
 
 
 def main():
@@ -178,6 +304,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))
 
     import torch.distributed as dist
     from neuralsampleid_amd import ops, parallel
@@ -217,6 +345,7 @@ def main():
     opt = FusedClipAdam(model.parameters(), lr=CFG["lr"], max_norm=1.0)
     x_i, x_j = synth_clips(args.batch, 1000 + 2 * rank, dev)   # each rank owns different clips
     loss_buf = torch.zeros((), device=dev)
+    one = torch.ones((), device=dev)          # static grad_output of loss.backward(): autograd then launches no fill kernel
     reducer = parallel.GradReducer(opt.params, opt.flat_g, opt.offsets, bucket_bytes=16 << 20).install()
     parallel.ASYNC_LOSS_REDUCE = True        # reducer.finish() joins the communicator's stream before the loss is read
 
@@ -227,16 +356,17 @@ def main():
             reducer.streams = [torch.cuda.current_stream(), model._side_stream]
         _, _, z_i, z_j = model(x_i, x_j)
         loss = parallel.dist_ntxent_loss(z_i, z_j, CFG)      # z all-gather; NT-Xent over the global batch
-        loss.backward()                                      # bucketed all-reduce fires as buckets complete
+        loss.backward(one)                                   # bucketed all-reduce fires as buckets complete
         reducer.finish()
         opt.step()
-        loss_buf.copy_(loss.detach())
+        ops.scale_f32(loss.detach().reshape(1), None, loss_buf.reshape(1))      # own copy kernel: no ATen kernel in the step
 
     def barrier():
-        torch.cuda.synchronize()
+        # a rank that died leaves the others inside ncclAllReduce / a graph replay: bounded wait, then abort + exit(1)
+        parallel.sync_with_deadline(what="the bench step")
         if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+            dist.barrier()                         # gloo, created with an explicit timeout (parallel.init_from_env)
+        parallel.sync_with_deadline(what="the bench step")
 
     # ---- warm-up (eager), then capture the whole step in a hipGraph (launch-bound inner loop: ~1.2k kernels/step)
     n_eager = max(1, min(args.warmup, 3))
@@ -245,10 +375,9 @@ def main():
         torch.cuda.synchronize()
         if rank == 0:
             log(f"eager warm-up step {i} done, loss {float(loss_buf):.4f}")
-    graph = None
-    if world > 1 and os.environ.get("NSID_DP_GRAPH", "1") == "0":      # escape hatch: eager collectives, no capture
-        args.no_graph = True
-    if not args.no_graph:
+    def capture(tag):
+        """the whole step as ONE hipGraph (all ranks capture, or none does); None -> run eagerly"""
+        g = None
         try:
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
@@ -256,23 +385,30 @@ def main():
                 step()
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
-            graph = torch.cuda.CUDAGraph()
+            g = torch.cuda.CUDAGraph()
             # world > 1: RCCL's helper threads may touch the HIP runtime while we capture; only calls made by the
             # capturing thread may invalidate the capture ("thread_local"), not theirs
             mode = os.environ.get("NSID_CAPTURE_MODE", "thread_local" if world > 1 else "global")
-            with torch.cuda.graph(graph, capture_error_mode=mode):
+            with torch.cuda.graph(g, capture_error_mode=mode):
                 step()
             if rank == 0:
-                log("step captured in a hipGraph")
+                log(f"{tag} step captured in a hipGraph")
         except Exception as e:        # capture is an optimisation, never a requirement
             print(f"[bench] hipGraph capture unavailable ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
-            graph = None
+            g = None
             torch.cuda.synchronize()
         if world > 1:                 # replayed collectives must match on every rank: all capture, or none
-            ok = torch.tensor([1 if graph is not None else 0])
+            ok = torch.tensor([1 if g is not None else 0])
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)
             if int(ok) == 0:
-                graph = None
+                g = None
+        return g
+
+    graph = None
+    if world > 1 and os.environ.get("NSID_DP_GRAPH", "1") == "0":      # escape hatch: eager collectives, no capture
+        args.no_graph = True
+    if not args.no_graph:
+        graph = capture(args.precision)
     run = graph.replay if graph is not None else step
     for _ in range(max(0, args.warmup - n_eager)):
         run()
@@ -290,6 +426,12 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t)
     final_loss = float(loss_buf)
+    per_step_calls = None
+    if parallel.COMM is not None:          # collectives one step enqueues (all-gather of z, loss, gradient buckets)
+        c0 = parallel.COMM.calls
+        step()
+        parallel.sync_with_deadline(what="the collective-count step")
+        per_step_calls = parallel.COMM.calls - c0
 
     roofline, kernels = None, None
     if not args.no_roofline:
@@ -309,39 +451,8 @@ def main():
             with open(os.environ["NSID_BENCH_SHAPES"], "w") as f:
                 json.dump(ops.PROFILE.by_shape(), f, indent=0)
         ops.PROFILE = None
-        mfma_peak = BF16_MFMA_PEAK_TFLOPS if args.precision == "bf16" else FP32_MFMA_PEAK_TFLOPS
-        kernels = {}
-        for n, d in prof.items():
-            tf = d["flops"] / (d["ms"] * 1e-3) / 1e12
-            gbs = d["bytes"] / (d["ms"] * 1e-3) / 1e9
-            # GEMM family: MFMA utilisation against the dense peak of the operand type; kNN: fp32 matrix pipe (exact
-            # distances); gather kernels: algorithmic HBM bytes only
-            peak = FP32_MFMA_PEAK_TFLOPS if n.startswith("knn") else mfma_peak
-            kernels[n] = {"launches": d["launches"], "avg_us": round(1e3 * d["ms"] / d["launches"], 2),
-                          "tflops": round(tf, 2), "mfma_frac": round(tf / peak, 4) if d["flops"] > 0 else None,
-                          "alg_GBps": round(gbs, 1), "hbm_frac": round(gbs / HBM_PEAK_GBPS, 4),
-                          "share_of_step": round(d["ms"] / (1e3 * elapsed / args.steps), 3)}
-        gemms = {n: d for n, d in prof.items() if n.startswith(("gemm_kernel", "wgrad3"))}
-        dom = max(gemms or prof, key=lambda n: prof[n]["ms"])
-        d = prof[dom]
-        tr = measured_traffic(dom, args.precision)
-        common = {"kernel": dom, "traffic": tr[0] if tr else None,
-                  "traffic_source": (tr[1] + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, bytes per launch)") if tr else None,
-                  "launches_per_step": d["launches"],
-                  "avg_launch_us": round(1e3 * d["ms"] / d["launches"], 2),
-                  "flops_per_launch": round(d["flops"] / d["launches"]),
-                  "alg_bytes_per_launch": round(d["bytes"] / d["launches"]),
-                  "event_bracket_us": round(bracket_us, 2),
-                  "method": "HIP events around every launch in one instrumented eager step after the timed region, "
-                            "minus the median duration of an empty event bracket (event_bracket_us)"}
-        if args.precision == "fp32":      # fp32 MFMA runs at 1/16 of the bf16 rate: the GEMMs are matrix-pipe bound
-            ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
-            roofline = {"bound": "mfma", "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                        "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), **common}
-        else:   # bf16 MFMA with fp32 storage: every layer's intensity (<= 195 flop/B) is under the 312 flop/B ridge
-            ach = d["bytes"] / (d["ms"] * 1e-3) / 1e9
-            roofline = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                        "frac": round(ach / HBM_PEAK_GBPS, 4), **common}
+        kernels = kernel_table(prof, 1e3 * elapsed / args.steps, args.precision)
+        roofline = roofline_entry(prof, args.precision, bracket_us, "_deep" if args.deep else "")
 
     other = None
     if world == 1 and not args.no_roofline:
@@ -352,14 +463,21 @@ def main():
         for _ in range(2):
             step()
         torch.cuda.synchronize()
+        alt_graph = None if args.no_graph else capture(alt)     # same treatment as the headline: an eager loop of ~1 000
+        alt_run = alt_graph.replay if alt_graph is not None else step   # launches times the host, not the GPU
+        for _ in range(2):
+            alt_run()
+        torch.cuda.synchronize()
         t1 = time.perf_counter()
         n_alt = max(3, min(args.steps, 10))
         for _ in range(n_alt):
-            step()
+            alt_run()
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t1) / n_alt
         other = {"precision": alt, "ms_per_step": round(1e3 * dt, 3), "value": round(args.batch / dt, 1),
-                 "unit": "clips/s", "note": "eager launches, same model continued; fp32 = strict-parity arithmetic"}
+                 "unit": "clips/s", "hipgraph": alt_graph is not None,
+                 "note": "same model continued; fp32 = strict-parity arithmetic (exact fp32 MFMA, fp32 storage)"}
+        del alt_graph
         ops.set_gemm_precision(args.precision)
         F_.set_activation_dtype(args.storage)
         log(f"{alt}: {1e3 * dt:.2f} ms/step")
@@ -367,19 +485,20 @@ def main():
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         log("timing the CPU baseline (oracle) ...")
-        cpu = cpu_baseline(args.k)
+        cpu = cpu_baseline(args.k, deep=args.deep)
         log(f"cpu baseline {cpu['value']} clips/s on {cpu['cores']} threads")
 
     if rank == 0:
         clips = args.batch * world * args.steps
         ms = 1e3 * elapsed / args.steps
-        step_bytes = 57e6 * (1.0 if args.storage == "bf16" else 2.0) * args.batch   # 57 MB/pair at 2 B/elem
+        # 57 MB per clip pair and step at 2 B/element (115 MB for the deep configuration 4)
+        step_bytes = (115e6 if args.deep else 57e6) * (1.0 if args.storage == "bf16" else 2.0) * args.batch
         out = {
             "metric": "audio clips/sec (contrastive step, grafp encoder)", "value": round(clips / elapsed, 1),
             "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32" if args.precision == "fp32" else "bf16", "data": "synthetic",
-            "config": {"workload": f"grafp.yaml GraphEncoder('t', k={args.k}) full contrastive step "
+            "config": {"workload": f"grafp.yaml GraphEncoder('t', k={args.k}{', blocks [4,4,12,4], dilated kNN' if args.deep else ''}) full contrastive step "
                                    f"(fwd x2 views + NT-Xent + bwd + clip + Adam), batch={args.batch} synthetic "
                                    f"(64,128) log-mel clip pairs per GPU, random-init weights",
                        "global_batch": args.batch * world, "k": args.k, "parallelism": f"dp{world}",
@@ -393,7 +512,11 @@ def main():
                                            else "fp32 operands, fp32 accumulate"),
                        "activation_storage": args.storage,
                        "views": "two HIP streams (parallel graph branches)" if not args.no_overlap else "sequential",
-                       "hipgraph": graph is not None, "final_loss": round(final_loss, 5)},
+                       "hipgraph": graph is not None, "final_loss": round(final_loss, 5),
+                       "rccl": ({"ncclCommCount": parallel.COMM.count(), "collectives_per_step": per_step_calls,
+                                 "gradient_buckets": len(reducer.bounds), "bucket_bytes": 16 << 20,
+                                 "captured_on_every_rank": graph is not None}
+                                if parallel.COMM is not None else None)},
             "roofline": roofline,
             "step_hbm_frac_algorithmic": round(step_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
             "kernels": kernels,

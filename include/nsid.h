@@ -136,7 +136,8 @@ int nsid_bn_bwd_apply(const void* dout, const void* r, int M, int C, const float
  * L2-normalised over channels, D = |a|^2 - 2ab + |b|^2 is formed per clip in LDS (never written to HBM),
  * the k*dilation nearest are selected in ascending distance (ties: lower index first) and every dilation-th is
  * kept.  idx[(b*N+n)*k + j] is clip-local (0..N-1), int32; the reference's edge_index[1] (centre) is implicit.
- * Limits: N % 16 == 0, N <= 256, C % 4 == 0, k*dilation <= N. */
+ * Limits (checked, NSID_EINVAL otherwise): N % 32 == 0, N <= 256, C % 16 == 0, ldr >= C, k*dilation <= N, r 16-byte
+ * aligned; ldr % 4 == 0 (fp32) / % 8 == 0 (bf16). */
 int nsid_knn_graph(const void* r, int ldr, const float* scale, const float* shift, int B, int N, int C, int k,
                    int dilation, int32_t* idx, int dtype, void* stream);
 
@@ -149,6 +150,15 @@ int nsid_mr_aggregate_fwd(const void* r, int ldr, const float* scale, const floa
                           int N, int C, int k, void* u, uint8_t* argmax, int dtype, void* stream);
 int nsid_mr_aggregate_bwd(const void* du, const int32_t* idx, const uint8_t* argmax, int B, int N, int C, int k,
                           void* dy, int dtype, void* stream);
+
+/* batched_index_select(x, idx) of the reference (encoder/gcn_lib/torch_nn.py:79-98) in the reference's own layouts:
+ * x (B, C, N) fp32, idx (B, Nq, k) int32 clip-local -> out (B, C, Nq, k), out[b,c,n,j] = x[b,c,idx[b,n,j]].
+ * The hot path never materialises this tensor (nsid_mr_aggregate_fwd gathers while it aggregates); the entry serves
+ * drop-in callers of the Python symbol. bwd: dx[b,c,idx[b,n,j]] += dout[b,c,n,j] (zero dx first). */
+int nsid_batched_index_select_fwd(const float* x, const int32_t* idx, int B, int C, int N, int Nq, int k, float* out,
+                                  void* stream);
+int nsid_batched_index_select_bwd(const float* dout, const int32_t* idx, int B, int C, int N, int Nq, int k,
+                                  float* dx /* += */, void* stream);
 
 /* ---- Downsample: Conv2d 3x3 stride 2 pad 1 on a width-1 map (encoder/graph_encoder.py:44) ---------------
  * Only kernel column 1 meets data, so it is a 3-tap stride-2 conv along N = one GEMM over gathered rows:
@@ -209,6 +219,11 @@ int nsid_sumsq_blocks(long n);
 int nsid_sumsq_partial(const float* g, long n, float* partial, void* stream);
 int nsid_adam_step(float* p, const float* g, float* m, float* v, long n, const float* hyper, int64_t* step,
                    const float* partial, int nblocks, float* gnorm_out, void* stream);
+
+/* ---- step plumbing (train.py:54 zero_grad, loss hand-over, autograd's grad_output scaling): the captured step runs no
+ * ATen kernel. fill_zero: p 16-byte aligned; scale: out[i] = x[i] * (scale ? scale[0] : 1), out may alias x. */
+int nsid_fill_zero(void* p, size_t bytes, void* stream);
+int nsid_scale_f32(const float* x, const float* scale, long n, float* out, void* stream);
 
 /* ---- layout plumbing at the module boundary: (B, C, N) <-> node-major rows ------------------------------*/
 int nsid_bcn_to_rows(const float* x, int B, int C, int N, void* rows, int ld, int rows_dtype, void* stream);

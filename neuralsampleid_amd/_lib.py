@@ -11,7 +11,7 @@ import torch  # noqa: F401  -- must come first: torch bundles its own libamdhip6
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NSID_LIB") or os.path.join(_PKG, "libnsid_hip.so")     # NSID_LIB: an alternative build (kernel A/B experiments)
 
-# signature letters: p = device pointer, i = int, l = long, f = float, s = stream (void*)
+# signature letters: p = device pointer, i = int, l = long, z = size_t, f = float, s = stream (void*)
 SIGNATURES = {
     "nsid_set_gemm_precision": "i",
     "nsid_linear_fwd": "pipippiiiiippiipiis",
@@ -51,9 +51,14 @@ SIGNATURES = {
     "nsid_unfold_segments": "piiiiips",
     "nsid_bcn_to_rows": "piiipiis",
     "nsid_rows_to_bcn": "piiiipis",
+    "nsid_batched_index_select_fwd": "ppiiiiips",
+    "nsid_batched_index_select_bwd": "ppiiiiips",
+    "nsid_fill_zero": "pzs",
+    "nsid_scale_f32": "pplps",
 }
 
-_CT = {"p": ctypes.c_void_p, "i": ctypes.c_int, "l": ctypes.c_long, "f": ctypes.c_float, "s": ctypes.c_void_p}
+_CT = {"p": ctypes.c_void_p, "i": ctypes.c_int, "l": ctypes.c_long, "f": ctypes.c_float, "s": ctypes.c_void_p,
+       "z": ctypes.c_size_t}
 
 
 def _load():

@@ -1,0 +1,39 @@
+"""Reference-format checkpoints (util.py:149-164 save_ckp / load_ckp; consumers generate.py:88-97, test_fp.py:372-383).
+
+The reference stores {'epoch', 'loss', 'hit_rate_log', 'state_dict', 'optimizer', 'scheduler'} and, when it trained under
+nn.DataParallel (train.py:117-120), every state_dict key carries a `module.` prefix that its consumers strip by hand
+(generate.py:94-95, test_fp.py:381-382). The module shells here have the reference's key set, so loading is strict."""
+from typing import Dict, Mapping
+
+import torch
+
+DATA_PARALLEL_PREFIX = "module."
+
+
+def strip_data_parallel_prefix(state_dict: Mapping[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+    """`module.encoder.stem.0.weight` -> `encoder.stem.0.weight` when (as generate.py:94 tests it) the keys are prefixed"""
+    keys = list(state_dict.keys())
+    if keys and all(k.startswith(DATA_PARALLEL_PREFIX) for k in keys):
+        return {k[len(DATA_PARALLEL_PREFIX):]: v for k, v in state_dict.items()}
+    if any(k.startswith(DATA_PARALLEL_PREFIX) for k in keys):
+        raise KeyError("checkpoint mixes DataParallel-prefixed and plain keys")
+    return dict(state_dict)
+
+
+def load_reference_checkpoint(model: torch.nn.Module, path_or_dict, strict: bool = True, map_location="cpu") -> dict:
+    """Load a checkpoint written by the reference's save_ckp (or a bare state_dict) into `model`; returns the checkpoint
+    dict (epoch / loss / optimizer / scheduler entries untouched) so a caller can resume as train.py:131-137 does."""
+    ckpt = path_or_dict
+    if not isinstance(ckpt, Mapping):
+        ckpt = torch.load(path_or_dict, map_location=map_location)
+    sd = ckpt["state_dict"] if "state_dict" in ckpt and isinstance(ckpt["state_dict"], Mapping) else ckpt
+    model.load_state_dict(strip_data_parallel_prefix(sd), strict=strict)
+    return ckpt if sd is not ckpt else {"state_dict": sd}
+
+
+def save_reference_checkpoint(path, model: torch.nn.Module, epoch: int = 0, loss=None, optimizer=None, scheduler=None,
+                              hit_rate_log=None) -> None:
+    """the dict layout of train.py:150-158"""
+    torch.save({"epoch": epoch, "loss": loss, "hit_rate_log": hit_rate_log, "state_dict": model.state_dict(),
+                "optimizer": None if optimizer is None else optimizer.state_dict(),
+                "scheduler": None if scheduler is None else scheduler.state_dict()}, path)

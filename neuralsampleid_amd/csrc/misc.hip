@@ -658,3 +658,39 @@ extern "C" int nsid_rows_to_bcn(const void* rows, int ld, int B, int C, int N, f
   });
   return nsid_launch_status();
 }
+
+// ------------------------------------------------------------------ step plumbing that used to be ATen kernels inside the
+// captured step (zero_grad's fill, the loss hand-over copy, autograd's "grad_output *" scaling of the NT-Xent gradients)
+__global__ __launch_bounds__(256) void fill_zero_kernel(f32x4* __restrict__ p, long n16) {
+  const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (long)gridDim.x * blockDim.x) p[i] = z;
+}
+__global__ void fill_zero_tail_kernel(unsigned char* __restrict__ p, long n) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) p[i] = 0;
+}
+// out[i] = x[i] * (s ? s[0] : 1)   (out may alias x)
+__global__ void scale_f32_kernel(const float* __restrict__ x, const float* __restrict__ s, long n, float* __restrict__ out) {
+  const float f = s != nullptr ? s[0] : 1.f;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) out[i] = x[i] * f;
+}
+
+extern "C" int nsid_fill_zero(void* p, size_t bytes, void* stream) {
+  NSID_REQUIRE(p && bytes > 0 && nsid_aligned16(p));
+  const long n16 = (long)(bytes / 16);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (n16 > 0) {
+    NSID_LAUNCH(fill_zero_kernel, dim3(grid_for(n16, 2048)), dim3(256), 0, s, static_cast<f32x4*>(p), n16);
+    if (nsid_launch_status() != NSID_OK) return NSID_ELAUNCH;
+  }
+  if (bytes % 16) {
+    NSID_LAUNCH(fill_zero_tail_kernel, dim3(1), dim3(64), 0, s, static_cast<unsigned char*>(p) + 16 * n16,
+                (long)(bytes % 16));
+    return nsid_launch_status();
+  }
+  return NSID_OK;
+}
+extern "C" int nsid_scale_f32(const float* x, const float* scale, long n, float* out, void* stream) {
+  NSID_REQUIRE(x && out && n > 0);
+  NSID_LAUNCH(scale_f32_kernel, dim3(grid_for(n, 1024)), dim3(256), 0, static_cast<hipStream_t>(stream), x, scale, n, out);
+  return nsid_launch_status();
+}

@@ -1,7 +1,10 @@
 // Max-relative neighbour aggregation (MRConv2d without its grouped conv) — HBM-bound gather kernels.
 // forward : one thread per (row, channel quad); the k neighbour rows of a clip are re-read from L2 (a clip is 64 KB),
 //           so HBM sees x once in, u once out (2*N*C*4 + N*k*4 bytes per clip).
-// backward: one workgroup per clip accumulates dy in LDS (ds_add_f32), so the scatter never touches HBM atomics.
+// backward: a GATHER over the reversed graph, one workgroup per clip: du_odd and the arg-max bytes are staged in LDS,
+//           the neighbour lists are reversed into a CSR with integer LDS atomics, every thread sums its incoming edges.
+#include <algorithm>
+
 #include "nsid_common.h"
 
 namespace {
@@ -159,7 +162,47 @@ __global__ __launch_bounds__(MRB_THREADS) void mr_bwd_kernel(const T* __restrict
   }
 }
 
+// batched_index_select of the reference (torch_nn.py:79-98), in the reference's own layouts: x (B, C, N) fp32,
+// idx (B, N, k) clip-local -> out (B, C, N, k) contiguous, out[b,c,n,j] = x[b,c,idx[b,n,j]]. The hot path never
+// materialises this tensor (mr_fwd_kernel gathers while it aggregates); the symbol exists for drop-in callers.
+__global__ __launch_bounds__(256) void bis_fwd_kernel(const float* __restrict__ x, const int32_t* __restrict__ idx, int C,
+                                                      int N, int Nq, int k, long total, float* __restrict__ out) {
+  const long nk = (long)Nq * k;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long e = i % nk, bc = i / nk;
+    const long b = bc / C;
+    out[i] = x[bc * N + min(max(idx[b * nk + e], 0), N - 1)];
+  }
+}
+// backward: dx[b,c,idx[b,n,j]] += dout[b,c,n,j]  (dx zeroed by the caller)
+__global__ __launch_bounds__(256) void bis_bwd_kernel(const float* __restrict__ dout, const int32_t* __restrict__ idx,
+                                                      int C, int N, int Nq, int k, long total, float* __restrict__ dx) {
+  const long nk = (long)Nq * k;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long e = i % nk, bc = i / nk;
+    const long b = bc / C;
+    atomicAdd(dx + bc * N + min(max(idx[b * nk + e], 0), N - 1), dout[i]);
+  }
+}
+
 }  // namespace
+
+extern "C" int nsid_batched_index_select_fwd(const float* x, const int32_t* idx, int B, int C, int N, int Nq, int k,
+                                             float* out, void* stream) {
+  NSID_REQUIRE(x && idx && out && B > 0 && C > 0 && N > 0 && Nq > 0 && k > 0);
+  const long total = (long)B * C * Nq * k;
+  NSID_LAUNCH(bis_fwd_kernel, dim3((int)std::min<long>((total + 255) / 256, 4096)), dim3(256), 0,
+              static_cast<hipStream_t>(stream), x, idx, C, N, Nq, k, total, out);
+  return nsid_launch_status();
+}
+extern "C" int nsid_batched_index_select_bwd(const float* dout, const int32_t* idx, int B, int C, int N, int Nq, int k,
+                                             float* dx, void* stream) {
+  NSID_REQUIRE(dout && idx && dx && B > 0 && C > 0 && N > 0 && Nq > 0 && k > 0);
+  const long total = (long)B * C * Nq * k;
+  NSID_LAUNCH(bis_bwd_kernel, dim3((int)std::min<long>((total + 255) / 256, 4096)), dim3(256), 0,
+              static_cast<hipStream_t>(stream), dout, idx, C, N, Nq, k, total, dx);
+  return nsid_launch_status();
+}
 
 extern "C" int nsid_mr_aggregate_fwd(const void* r, int ldr, const float* scale, const float* shift,
                                      const int32_t* idx, int B, int N, int C, int k, void* u, uint8_t* argmax,

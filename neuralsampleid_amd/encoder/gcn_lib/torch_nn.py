@@ -3,6 +3,7 @@
 The torch layers built here are PARAMETER CONTAINERS — same classes, construction order and initialisers as the
 reference, so `state_dict` keys/shapes and seeded default initialisation are identical — their `forward` is never
 used on the hot path: the owning block runs the HIP kernels on their tensors (functional.py)."""
+import torch
 from torch import nn
 from torch.nn import Conv2d, Sequential as Seq
 
@@ -43,3 +44,27 @@ class BasicConv(Seq):
             elif isinstance(m, nn.BatchNorm2d):
                 m.weight.data.fill_(1)
                 m.bias.data.zero_()
+
+
+class _BatchedIndexSelect(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x3, idx):
+        from ... import ops
+        ctx.save_for_backward(idx)
+        ctx.n = x3.shape[2]
+        return ops.batched_index_select_fwd(x3, idx)
+
+    @staticmethod
+    def backward(ctx, dout):
+        from ... import ops
+        (idx,) = ctx.saved_tensors
+        return ops.batched_index_select_bwd(dout.contiguous(), idx, ctx.n), None
+
+
+def batched_index_select(x, idx):
+    """x (B, C, N, 1), idx (B, Nq, k) -> (B, C, Nq, k): features of the neighbours (reference :79-98).
+    Provided for drop-in callers; MRConv2d itself never materialises this tensor (csrc/mr.hip gathers while it aggregates)."""
+    if x.dim() != 4 or x.shape[3] != 1 or idx.dim() != 3 or idx.shape[0] != x.shape[0]:
+        raise RuntimeError("batched_index_select expects x (B, C, N, 1) and idx (B, N, k)")
+    x3 = x.reshape(x.shape[0], x.shape[1], x.shape[2]).contiguous().float()
+    return _BatchedIndexSelect.apply(x3, idx.to(torch.int32).contiguous())

@@ -28,10 +28,13 @@ class KnnTape:
     kNN is discontinuous, so end-to-end parity is stated as: indices equal outside near-ties, outputs equal when the
     indices are forced (tests/test_e2e_gpu.py)."""
 
-    def __init__(self, replay: Optional[List[Tensor]] = None):
+    def __init__(self, replay: Optional[List[Tensor]] = None, cyclic: bool = False):
+        """cyclic: the replay list describes ONE step and is re-used by every following step (warm-up steps and the
+        capture of a hipGraph: the captured kernels then read the replayed index tensors on every replay)"""
         self.replay = list(replay) if replay is not None else None
         self.recorded: List[Tensor] = []
         self.pos = 0
+        self.cyclic = cyclic
 
 
 TAPE: Optional[KnnTape] = None
@@ -230,7 +233,7 @@ def grapher_forward(x0: Tensor, P, S: Optional[dict], B: int, N: int, k: int, di
         TAPE.recorded.append(idx)
         if TAPE.replay is not None:
             idx = TAPE.replay[TAPE.pos].to(device=idx.device, dtype=torch.int32).contiguous()
-            TAPE.pos += 1
+            TAPE.pos = (TAPE.pos + 1) % len(TAPE.replay) if TAPE.cyclic else TAPE.pos + 1
     u, amax = ops.mr_aggregate_fwd(r1, idx, B, N, C, a1, want_argmax=S is not None)
     pre = "graph_conv.gconv.nn."
     r2, a2 = conv_bn(u, M, C // 2, C // 2, P[pre + "0.weight"], P[pre + "0.bias"], _bn(P, S, pre + "1."), training,
@@ -339,7 +342,7 @@ def downsample_backward(dout: Tensor, P, S, G) -> Tensor:
     Mo, Co = r.shape
     dr = ops.bn_backward(dout, r, aff, ACT_NONE, G["conv.1.weight"], G["conv.1.bias"], partial=_link_partial(S))
     _bias_grad_before_bn(dr, G["conv.0.bias"])
-    dwp = torch.zeros_like(wp)
+    dwp = ops.zeros(wp.shape, wp.device)
     ops.linear_bwd_weight(dr, col, dwp, Mo, Co, 3 * C)
     ops.unpack_ds_wgrad(dwp, G["conv.0.weight"])
     dcol = ops.linear_bwd_data(dr, wp, Mo, Co, 3 * C)
@@ -428,7 +431,7 @@ class _BlockFn(torch.autograd.Function):
     def backward(ctx, dout):
         P, S, names = ctx.P, ctx.S, ctx.names
         direct = DIRECT_GRADS and all(P[n].grad is not None and P[n].grad.is_contiguous() for n in names)
-        G = {n: (P[n].grad if direct else torch.zeros_like(P[n])) for n in names}
+        G = {n: (P[n].grad if direct else ops.zeros(P[n].shape, P[n].device)) for n in names}
         dx = ctx.bwd(dout.contiguous(), P, S, G)
         ctx.S = None
         if direct and GRAD_READY_HOOK is not None:
@@ -484,7 +487,7 @@ class _NtxentFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         dzi, dzj = ctx.saved_tensors
-        return dzi * g, dzj * g, None, None
+        return ops.scale_f32(dzi, g), ops.scale_f32(dzj, g), None, None
 
 
 def ntxent(z_i: Tensor, z_j: Tensor, tau: float) -> Tensor:

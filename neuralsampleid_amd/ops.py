@@ -143,16 +143,38 @@ def w2d(w: torch.Tensor) -> torch.Tensor:
     return w.reshape(w.shape[0], -1)
 
 
+# ------------------------------------------------------------------------------------------------ state epoch
+# Our kernels write parameters (nsid_adam_step) and BatchNorm running statistics (nsid_bn_finalize, nsid_bn_running_update)
+# through raw pointers, and a hipGraph replay runs no Python at all: torch's `_version` counters do not see those writes.
+# Every host-side entry that enqueues such a write bumps an epoch counter: WEIGHT_EPOCH for parameters
+# (FusedClipAdam.step, GraphedTrainStep.__call__), STATS_EPOCH for running statistics (bn_finalize, bn_running_update,
+# GraphedTrainStep.__call__). The caches below carry them in their keys — bf16 weight shadows: WEIGHT_EPOCH; eval-mode
+# BatchNorm affines and folded conv+BN weights: both — so an eval after training steps never reuses constants of older
+# weights or statistics.
+WEIGHT_EPOCH = 0
+STATS_EPOCH = 0
+
+
+def bump_state_epoch(weights: bool = True, stats: bool = True) -> None:
+    global WEIGHT_EPOCH, STATS_EPOCH
+    if weights:
+        WEIGHT_EPOCH += 1
+    if stats:
+        STATS_EPOCH += 1
+
+
 # ------------------------------------------------------------------------------------------------ bf16 weight shadows
 class WeightShadows:
     """bf16 copies of weight matrices for the bf16-storage GEMMs (forward / backward-data right operand): half the
     L2->LDS operand bytes and no convert pass in the kernel. Values are the RNE rounding the kernel applies to fp32
     weights anyway, so results are identical.
 
-    Entries are keyed by the fp32 tensor's data pointer: [shadow, version]. `FusedClipAdam` registers views of ONE flat
-    shadow buffer and refreshes all of it at the start of every step (its update kernel does not bump torch's version
-    counters); torch-side in-place changes (load_state_dict, torch.optim) are caught by the version check. Weights that
-    are not registered are converted on the fly (one small launch per GEMM)."""
+    Entries are keyed by the fp32 tensor's data pointer: [shadow, (version, WEIGHT_EPOCH)]. `FusedClipAdam` registers views
+    of ONE flat shadow buffer, refreshes all of it at the start of every step and marks its entries fresh (`mark_fresh`);
+    its update kernel bumps WEIGHT_EPOCH instead of torch's version counters, so a forward that runs after the last
+    `step()` (eval, fingerprint extraction) re-converts the weights it reads. Torch-side in-place changes
+    (load_state_dict, torch.optim) are caught by the version half of the key. Weights that are not registered are
+    converted on the fly (one small launch per GEMM)."""
 
     def __init__(self):
         self.entries = {}
@@ -162,7 +184,13 @@ class WeightShadows:
         reused by another tensor; once it is gone the entry is dropped on its next lookup. fresh: `shadow` already holds
         the conversion of the current contents of w"""
         import weakref
-        self.entries[w.data_ptr()] = [shadow, w._version if fresh else -1, w.numel(), weakref.ref(owner)]
+        self.entries[w.data_ptr()] = [shadow, (w._version, WEIGHT_EPOCH) if fresh else None, w.numel(), weakref.ref(owner)]
+
+    def mark_fresh(self, w: torch.Tensor) -> None:
+        """the registered shadow of `w` has just been refreshed by its owner (FusedClipAdam.sync_shadow)"""
+        e = self.entries.get(w.data_ptr())
+        if e is not None:
+            e[1] = (w._version, WEIGHT_EPOCH)
 
     def clear(self) -> None:
         self.entries.clear()
@@ -181,9 +209,10 @@ class WeightShadows:
             e = None
         if e is None or e[2] != w.numel():
             return f32_to_bf16(w)
-        if e[1] != w._version:
+        key = (w._version, WEIGHT_EPOCH)
+        if e[1] != key:
             f32_to_bf16(w, e[0])
-            e[1] = w._version
+            e[1] = key
         return e[0]
 
 
@@ -230,7 +259,9 @@ def linear_fwd(x, w, bias, M, Nout, K, groups=1, in_scale=None, in_shift=None, a
         raise ValueError("the residual addend rides with a plain epilogue (no statistics, no split-K, no output activation)")
     ldx = x.shape[-1]
     if out is None:
-        out = (torch.zeros if ksplit > 1 else torch.empty)((M, groups * Nout), device=x.device, dtype=x.dtype)
+        out = torch.empty((M, groups * Nout), device=x.device, dtype=x.dtype)
+        if ksplit > 1:
+            fill_zero(out)
     stat = torch.empty((2, row_tiles(M), groups * Nout), device=x.device, dtype=torch.float32) if want_stat else None
     half = dt == BF16 or lib.nsid_get_gemm_precision() == GEMM_BF16
     narrow = (Nout <= 64 or (Nout <= 128 and K <= 256 and in_scale is None)) if half else Nout <= 64
@@ -360,7 +391,7 @@ def folded_conv_bn(w2d, bias, gamma, beta, running_mean, running_var, eps=BN_EPS
     import weakref
     src = w2d if source is None else source
     versions = (src.data_ptr(), src._version, None if bias is None else (bias.data_ptr(), bias._version), gamma._version,
-                beta._version, running_mean._version, running_var._version, eps)
+                beta._version, running_mean._version, running_var._version, eps, WEIGHT_EPOCH, STATS_EPOCH)
     cacheable = not torch.cuda.is_current_stream_capturing()
     e = _FOLDED.get(id(gamma)) if cacheable else None
     if e is not None and e[0]() is gamma and e[1] == versions:
@@ -387,6 +418,8 @@ def bn_finalize(stat, M, gamma, beta, running_mean, running_var, num_batches_tra
                 momentum=BN_MOMENTUM, eps=BN_EPS) -> BNAffine:
     C = gamma.numel()
     buf = torch.empty((4, C), device=gamma.device, dtype=torch.float32)
+    if running_mean is not None:
+        bump_state_epoch(weights=False)
     call("nsid_bn_finalize", _p(stat), row_tiles(M), C, M, _p(gamma), _p(beta), _p(running_mean), _p(running_var),
          _p(num_batches_tracked), momentum, eps, _p(buf[0]), _p(buf[1]), _p(buf[2]), _p(buf[3]), _stream())
     return BNAffine(buf[0], buf[1], buf[2], buf[3])
@@ -411,6 +444,7 @@ def bn_running_update(layers_a, layers_b=None, momentum=BN_MOMENTUM) -> None:
         return
     if layers_b is not None and len(layers_b) != n:
         raise ValueError("both views must have run the same BatchNorm layers")
+    bump_state_epoch(weights=False)
     arr = lambda vals: (ctypes.c_void_p * n)(*[None if v is None else v.data_ptr() for v in vals])
     Cs = (ctypes.c_int * n)(*[la[0].numel() for la in layers_a])
     for la in layers_a:
@@ -434,7 +468,7 @@ _EVAL_AFFINE = {}     # id(gamma) -> (weakref(gamma), versions, eps, BNAffine, s
 def bn_eval_affine(gamma, beta, running_mean, running_var, eps=BN_EPS) -> BNAffine:
     import weakref
     versions = (gamma._version, beta._version, running_mean._version, running_var._version,
-                beta.data_ptr(), running_mean.data_ptr(), running_var.data_ptr())
+                beta.data_ptr(), running_mean.data_ptr(), running_var.data_ptr(), WEIGHT_EPOCH, STATS_EPOCH)
     cacheable = not torch.cuda.is_current_stream_capturing()
     e = _EVAL_AFFINE.get(id(gamma)) if cacheable else None
     if e is not None and e[0]() is gamma and e[1] == versions and e[2] == eps:
@@ -628,6 +662,49 @@ def ntxent_fwd_bwd(z_i, z_j, tau, p0=0, npairs=None, want_grad=True):
     call("nsid_ntxent_fwd_bwd", _p(z_i), _p(z_j), Bg, d, float(tau), p0, npairs, _p(ws), _p(loss), _p(dzi), _p(dzj),
          _stream())
     return loss, dzi, dzj
+
+
+# ------------------------------------------------------------------------------------------------ step plumbing
+def fill_zero(t: torch.Tensor) -> torch.Tensor:
+    """t[...] = 0 with our own streaming kernel (zero_grad: the captured step holds no ATen kernel)"""
+    if not (t.is_cuda and t.is_contiguous()):
+        raise RuntimeError("fill_zero needs a contiguous device tensor")
+    call("nsid_fill_zero", _p(t), t.numel() * t.element_size(), _stream())
+    return t
+
+
+def zeros(shape, device, dtype=torch.float32) -> torch.Tensor:
+    return fill_zero(torch.empty(shape, device=device, dtype=dtype))
+
+
+def scale_f32(x: torch.Tensor, scale: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out = x * scale[0] (scale: a device scalar such as autograd's grad_output; None: plain copy)"""
+    _chk(x, out)
+    if scale is not None:
+        scale = scale.reshape(-1)
+        _chk(scale)
+    if out is None:
+        out = torch.empty_like(x)
+    call("nsid_scale_f32", _p(x), _p(scale), x.numel(), _p(out), _stream())
+    return out
+
+
+def batched_index_select_fwd(x: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
+    """x (B, C, N) fp32, idx (B, Nq, k) int32 -> (B, C, Nq, k) — the reference's batched_index_select (torch_nn.py:79-98)"""
+    _chk(x)
+    B, C, N = x.shape
+    _, Nq, k = idx.shape
+    out = torch.empty((B, C, Nq, k), device=x.device, dtype=torch.float32)
+    call("nsid_batched_index_select_fwd", _p(x), _p(idx), B, C, N, Nq, k, _p(out), _stream())
+    return out
+
+
+def batched_index_select_bwd(dout: torch.Tensor, idx: torch.Tensor, N: int) -> torch.Tensor:
+    _chk(dout)
+    B, C, Nq, k = dout.shape
+    dx = zeros((B, C, N), dout.device)
+    call("nsid_batched_index_select_bwd", _p(dout), _p(idx), B, C, N, Nq, k, _p(dx), _stream())
+    return dx
 
 
 # ------------------------------------------------------------------------------------------------ optimiser

@@ -50,7 +50,7 @@ class FusedClipAdam:
     def zero_grad(self, set_to_none: bool = False):
         from . import functional
         functional.join_side_streams()
-        self.flat_g.zero_()
+        ops.fill_zero(self.flat_g)
         if functional.ACT_DTYPE == torch.bfloat16:
             self.sync_shadow()
 
@@ -58,6 +58,8 @@ class FusedClipAdam:
         """refresh the bf16 weight shadows from the fp32 master parameters"""
         n8 = self.numel                      # a multiple of 8 by construction
         ops.f32_to_bf16(self.flat_p[:n8], self.flat_p16)
+        for p in self.params:                # every registered view now holds the conversion of the current weights
+            ops.SHADOWS.mark_fresh(p.data)
 
     def set_lr(self, lr: float):
         self.hyper[0:1].fill_(lr)
@@ -70,5 +72,6 @@ class FusedClipAdam:
         from . import functional
         functional.join_side_streams()               # a view's backward may still be running on its side stream
         partial = ops.sumsq_partial(self.flat_g)
+        ops.bump_state_epoch(stats=False)            # the update kernel writes the weights behind torch's version counters
         ops.adam_step(self.flat_p, self.flat_g, self.exp_avg, self.exp_avg_sq, self.hyper, self.step_count, partial,
                       self.grad_norm)

@@ -100,7 +100,8 @@ class _DistNtxent(torch.autograd.Function):
         zi_all, zj_all = gather_pair(z_i.detach(), z_j.detach(), group)
         p0, n = shard_range(zi_all.shape[0], rank, world)
         part, dzi, dzj = rows_fn(zi_all, zj_all, tau, p0, n)        # part = sum of owned rows / (2*B_global)
-        loss = part.reshape(()).clone()
+        from . import ops
+        loss = (ops.scale_f32(part) if part.is_cuda else part.clone()).reshape(())
         if _distributed(group):                                        # every rank reports the global loss
             c = _comm_for(group)
             if c is not None and ASYNC_LOSS_REDUCE:
@@ -115,6 +116,9 @@ class _DistNtxent(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         dzi, dzj = ctx.saved_tensors
+        if dzi.is_cuda:
+            from . import ops
+            return ops.scale_f32(dzi, g), ops.scale_f32(dzj, g), None, None, None
         return dzi * g, dzj * g, None, None, None
 
 
@@ -251,6 +255,62 @@ class GradReducer:
         return self
 
 
+# Host-side deadlines. The direct RCCL path has no ProcessGroupNCCL watchdog (by design, rccl.py), so the host waits are
+# bounded instead: the bootstrap group gets an explicit timeout, and `sync_with_deadline` replaces a bare
+# torch.cuda.synchronize() wherever a peer's death would otherwise block this rank inside ncclAllReduce / a graph replay
+# for ever. On expiry (or an asynchronous RCCL error) the communicator is aborted and the process exits non-zero; the
+# launcher (torch.distributed.run, or bench.py's own spawner) then ends the remaining ranks. Never re-exec here.
+HOST_TIMEOUT_S = float(__import__("os").environ.get("NSID_HOST_TIMEOUT_S", "300"))
+
+
+class CollectiveTimeout(RuntimeError):
+    pass
+
+
+def sync_with_deadline(seconds: Optional[float] = None, what: str = "device work", fatal: bool = True) -> None:
+    """torch.cuda.synchronize() with a host deadline: an event recorded on every known stream is polled (1 ms sleeps),
+    the communicator's asynchronous error state is checked meanwhile. fatal: abort the communicator and os._exit(1)."""
+    import os
+    import sys
+    import time
+    seconds = HOST_TIMEOUT_S if seconds is None else seconds
+    from . import functional
+    streams = [torch.cuda.current_stream()] + [s for s in functional.SIDE_STREAMS]
+    if COMM is not None:
+        streams.append(COMM.stream)
+    evs = []
+    for st in streams:
+        e = torch.cuda.Event()
+        e.record(st)
+        evs.append(e)
+    t0 = time.monotonic()
+    err = None
+    while True:
+        if all(e.query() for e in evs):
+            return
+        if COMM is not None and COMM._h is not None:
+            try:
+                code = COMM.async_error()
+            except RuntimeError as ex:          # the query itself failed
+                code, err = -1, str(ex)
+            if code != 0:
+                err = err or f"RCCL asynchronous error {code}"
+                break
+        if time.monotonic() - t0 > seconds:
+            err = f"{what} did not finish within {seconds:.0f} s"
+            break
+        time.sleep(0.001)
+    if not fatal:
+        raise CollectiveTimeout(err)
+    print(f"[nsid] rank {_rank_world()[0]}: {err}; aborting the communicator and exiting", file=sys.stderr, flush=True)
+    if COMM is not None:
+        try:
+            COMM.abort()
+        except Exception:
+            pass
+    os._exit(1)
+
+
 def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
     """torchrun contract: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT. Returns (rank, local, world).
 
@@ -267,12 +327,17 @@ def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
         torch.cuda.set_device(local)
     from .rccl import _stdout_to_stderr         # gloo announces "[Gloo] Rank r is connected to ..." on stdout: a program that
     if world > 1 and not dist.is_initialized():  # prints one machine-readable line there (bench.py) must not carry it
+        import datetime
+        to = datetime.timedelta(seconds=HOST_TIMEOUT_S)     # a rank that never arrives fails the others, it does not hang them
         with _stdout_to_stderr():
-            dist.init_process_group(backend="gloo" if backend == "rccl" else backend, rank=rank, world_size=world)
+            dist.init_process_group(backend="gloo" if backend == "rccl" else backend, rank=rank, world_size=world,
+                                    timeout=to)
             dist.barrier()                      # (connections are made here at the latest)
     elif force and backend != "rccl" and not dist.is_initialized():
+        import datetime
         with _stdout_to_stderr():
-            dist.init_process_group(backend=backend, rank=rank, world_size=world)
+            dist.init_process_group(backend=backend, rank=rank, world_size=world,
+                                    timeout=datetime.timedelta(seconds=HOST_TIMEOUT_S))
     if backend == "rccl" and (world > 1 or force) and COMM is None:
         from . import rccl
         set_default_comm(rccl.init_comm(rank, world, torch.device("cuda", local)))

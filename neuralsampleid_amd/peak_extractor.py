@@ -22,7 +22,7 @@ class _PatchifyFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         direct = F_.DIRECT_GRADS and all(v.grad is not None for v in ctx.P.values())
-        G = {k: (v.grad if direct else torch.zeros_like(v)) for k, v in ctx.P.items()}
+        G = {k: (v.grad if direct else F_.ops.zeros(v.shape, v.device)) for k, v in ctx.P.items()}
         F_.patchify_backward(dout.contiguous(), ctx.P, ctx.S, G)
         ctx.S = None
         if direct:

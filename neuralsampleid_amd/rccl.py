@@ -190,6 +190,19 @@ class RcclComm:
         _check(lib().ncclCommGetAsyncError(self._h, ctypes.byref(e)), "ncclCommGetAsyncError")
         return e.value
 
+    def count(self) -> int:
+        """ncclCommCount: the number of ranks RCCL itself believes are in this communicator"""
+        n = ctypes.c_int(0)
+        _check(lib().ncclCommCount(self._h, ctypes.byref(n)), "ncclCommCount")
+        return n.value
+
+    def abort(self) -> None:
+        """ncclCommAbort: tear the communicator down WITHOUT waiting for outstanding collectives (a peer died or hung);
+        the only safe next step for the process is to exit"""
+        if self._h is not None:
+            lib().ncclCommAbort(self._h)
+            self._h = None
+
     def destroy(self) -> None:
         if self._h is not None:
             self.stream.synchronize()

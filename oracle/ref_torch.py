@@ -34,6 +34,21 @@ Tensor = torch.Tensor
 BN_MOMENTUM = 0.1
 BN_EPS = 1e-5
 
+# STORAGE = None: the reference's arithmetic (fp32 everywhere) — what the goldens pin.
+# STORAGE = "bf16": the SAME graph with a round-to-nearest-even bf16 rounding at every point where the MI355X path of
+# BASELINE config 2 stores an activation tensor in bf16 or stages a GEMM operand as bf16 (raw conv
+# outputs, materialised residual-stream tensors, the interleaved aggregation output, the patchify output; both operands
+# of every GEMM; BatchNorm statistics from the UNROUNDED accumulators). Rounding is a straight-through identity for
+# autograd. It is the checker of tests/test_timed_arithmetic_gpu.py: the HIP bf16 training step must agree with this
+# emulation far more tightly than bf16 agrees with fp32 (train-mode BatchNorm at small batch amplifies rounding 20-40x).
+STORAGE: Optional[str] = None
+
+
+def _q(x: Tensor) -> Tensor:
+    if STORAGE != "bf16":
+        return x
+    return x + (x.to(torch.bfloat16).to(torch.float32) - x).detach()
+
 SIZES = {  # encoder/graph_encoder.py:118-129
     "t": ([2, 2, 6, 2], [64, 128, 256, 512]),
     "s": ([2, 2, 6, 2], [80, 160, 400, 640]),
@@ -69,14 +84,14 @@ def batchnorm_rows(x: Tensor, P: Dict[str, Tensor], pre: str, training: bool, st
                 st.updates[key_n] = nb + 1
     else:
         mean, var = P[pre + "running_mean"], P[pre + "running_var"]
-    return (x - mean) * torch.rsqrt(var + BN_EPS) * w + b
+    return (_q(x) - mean) * torch.rsqrt(var + BN_EPS) * w + b      # x = a raw conv output: stored rounded under STORAGE
 
 
 def linear_rows(x: Tensor, P: Dict[str, Tensor], pre: str) -> Tensor:
     """1x1 Conv2d / Linear as a row GEMM; weight (Cout, Cin[,1,1])."""
     w = P[pre + "weight"]
     w = w.reshape(w.shape[0], -1)
-    y = x @ w.t()
+    y = _q(x) @ _q(w).t()
     if pre + "bias" in P:
         y = y + P[pre + "bias"]
     return y
@@ -95,7 +110,7 @@ def peak_patchify(spec: Tensor, P: Dict[str, Tensor], pre: str, cfg: dict) -> Te
     patches = img.unfold(2, pb, pb).unfold(3, pf, pf)                                  # (B,3,H/pb,W/pf,pb,pf)
     patches = patches.permute(0, 2, 3, 1, 4, 5).reshape(B, (H // pb) * (W // pf), 3 * pb * pf)
     w = P[pre + "convs.0.weight"].reshape(-1, 3 * pb * pf)
-    return torch.relu(patches @ w.t() + P[pre + "convs.0.bias"])
+    return _q(torch.relu(patches @ w.t() + P[pre + "convs.0.bias"]))
 
 
 class KnnTape:
@@ -140,7 +155,7 @@ def mr_aggregate(y: Tensor, idx: Tensor) -> Tensor:
     k = idx.shape[-1]
     nbr = torch.gather(y.unsqueeze(1).expand(B, N, N, C), 2, idx.unsqueeze(-1).expand(B, N, k, C))
     m = (nbr - y.unsqueeze(2)).max(dim=2).values
-    return torch.stack((y, m), dim=-1).reshape(B, N, 2 * C)
+    return _q(torch.stack((y, m), dim=-1).reshape(B, N, 2 * C))
 
 
 def grouped_linear(u: Tensor, P: Dict[str, Tensor], pre: str, groups: int = 4) -> Tensor:
@@ -148,8 +163,8 @@ def grouped_linear(u: Tensor, P: Dict[str, Tensor], pre: str, groups: int = 4) -
     w = P[pre + "weight"]
     cout, cin_g = w.shape[0], w.shape[1]
     wg = w.reshape(groups, cout // groups, cin_g)
-    ug = u.reshape(*u.shape[:-1], groups, cin_g)
-    out = torch.einsum("...gi,goi->...go", ug, wg).reshape(*u.shape[:-1], cout)
+    ug = _q(u).reshape(*u.shape[:-1], groups, cin_g)
+    out = torch.einsum("...gi,goi->...go", ug, _q(wg)).reshape(*u.shape[:-1], cout)
     if pre + "bias" in P:
         out = out + P[pre + "bias"]
     return out
@@ -164,7 +179,7 @@ def grapher(x: Tensor, P, pre: str, k: int, dilation: int, training: bool, st) -
     v = torch.relu(batchnorm_rows(grouped_linear(u, P, pre + "graph_conv.gconv.nn.0."),
                                   P, pre + "graph_conv.gconv.nn.1.", training, st))
     w = batchnorm_rows(linear_rows(v, P, pre + "fc2.0."), P, pre + "fc2.1.", training, st)
-    return (w + rows).reshape(B, N, C)
+    return _q(w + rows).reshape(B, N, C)
 
 
 def ffn(x: Tensor, P, pre: str, training: bool, st) -> Tensor:
@@ -172,7 +187,7 @@ def ffn(x: Tensor, P, pre: str, training: bool, st) -> Tensor:
     rows = x.reshape(B * N, C)
     hdn = torch.relu(batchnorm_rows(linear_rows(rows, P, pre + "fc1.0."), P, pre + "fc1.1.", training, st))
     out = batchnorm_rows(linear_rows(hdn, P, pre + "fc2.0."), P, pre + "fc2.1.", training, st)
-    return (out + rows).reshape(B, N, C)
+    return _q(out + rows).reshape(B, N, C)
 
 
 def downsample(x: Tensor, P, pre: str, training: bool, st) -> Tensor:
@@ -182,9 +197,9 @@ def downsample(x: Tensor, P, pre: str, training: bool, st) -> Tensor:
     xp = F.pad(x, (0, 0, 1, 1))                                   # zero node either side
     n_out = (N + 2 - 3) // 2 + 1
     taps = [xp[:, t: t + 2 * n_out: 2, :] for t in range(3)]      # node 2n'-1+t
-    out = sum(taps[t] @ w[:, :, t].t() for t in range(3)) + P[pre + "conv.0.bias"]
+    out = sum(_q(taps[t]) @ _q(w[:, :, t]).t() for t in range(3)) + P[pre + "conv.0.bias"]
     cp = out.shape[-1]
-    return batchnorm_rows(out.reshape(B * n_out, cp), P, pre + "conv.1.", training, st).reshape(B, n_out, cp)
+    return _q(batchnorm_rows(out.reshape(B * n_out, cp), P, pre + "conv.1.", training, st)).reshape(B, n_out, cp)
 
 
 def encoder_plan(size: str = "t", k: int = 3, blocks: Optional[List[int]] = None,
@@ -215,7 +230,7 @@ def graph_encoder(x: Tensor, P, pre: str, plan: List[tuple], training: bool, st)
     """x (B, N, Cin) node-major -> (B, emb_dims)."""
     B, N, Cin = x.shape
     rows = linear_rows(x.reshape(B * N, Cin), P, pre + "stem.0.")
-    rows = F.leaky_relu(batchnorm_rows(rows, P, pre + "stem.1.", training, st), 0.2)
+    rows = _q(F.leaky_relu(batchnorm_rows(rows, P, pre + "stem.1.", training, st), 0.2))
     x = rows.reshape(B, N, -1)
     for i, entry in enumerate(plan):
         bp = f"{pre}backbone.{i}."
@@ -226,6 +241,8 @@ def graph_encoder(x: Tensor, P, pre: str, plan: List[tuple], training: bool, st)
             x = grapher(x, P, bp + "0.", k, d, training, st)
             x = ffn(x, P, bp + "1.", training, st)
     B, N, C = x.shape
+    if STORAGE == "bf16":     # the MI355X path pools first (mean and the 1x1 projection commute): the GEMM operand is bf16(mean)
+        return linear_rows(x.mean(dim=1), P, pre + "proj.")
     out = linear_rows(x.reshape(B * N, C), P, pre + "proj.").reshape(B, N, -1)
     return out.mean(dim=1)
 

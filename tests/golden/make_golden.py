@@ -93,9 +93,12 @@ def bn_stats(module):
 # ---------------------------------------------------------------- kNN graph
 def gold_knn():
     print("knn")
-    cases = [("c64n256", 2, 64, 256, [(3, 1), (5, 1), (4, 2), (18, 3)]),
+    # the last entries of each list are BASELINE config 4's shapes (k = 18, dilation 1 / 2 / 3 / 1 by stage)
+    cases = [("c64n256", 2, 64, 256, [(3, 1), (5, 1), (4, 2), (18, 3), (18, 1)]),
              ("c128n128", 2, 128, 128, [(3, 1), (18, 2)]),
-             ("c512n32", 3, 512, 32, [(3, 1), (5, 2), (18, 1)])]
+             ("c256n64", 3, 256, 64, [(3, 1), (18, 3), (9, 2)]),
+             ("c512n32", 3, 512, 32, [(3, 1), (5, 2), (18, 1)]),
+             ("c80n256", 2, 80, 256, [(3, 1), (9, 2)])]          # size 's' channel count: the general (strip) kernel
     for tag, B, C, N, kds in cases:
         x = synth_randn("knn_" + tag, B, C, N, 1)
         out = {"x": x}
@@ -151,7 +154,7 @@ def gold_block():
     print("block")
     cases = [("c64n256_k3d1", 2, 64, 256, 3, 1), ("c64n256_k4d2", 2, 64, 256, 4, 2),
              ("c128n128_k5d1", 2, 128, 128, 5, 1), ("c512n32_k3d1", 4, 512, 32, 3, 1),
-             ("c64n256_k18d3", 2, 64, 256, 18, 3)]
+             ("c64n256_k18d3", 2, 64, 256, 18, 3), ("c256n64_k18d3", 4, 256, 64, 18, 3)]
     for tag, B, C, N, k, d in cases:
         blk = nn.Sequential(
             Grapher(C, k, d, "mr", "relu", "batch", True, False, 0.2, 1, n=N, drop_path=0.0, relative_pos=True),
@@ -305,6 +308,133 @@ def gold_e2e():
         print("   losses", losses, "gnorm", gnorms)
 
 
+def deep_reference_encoder(k=18, blocks=(4, 4, 12, 4)):
+    """BASELINE config 4 built from the REFERENCE's own classes. The reference's GraphEncoder never advances its block
+    counter (graph_encoder.py:161-173: every Grapher gets dilation 1) and has no [4,4,12,4] size, so the backbone is
+    assembled here from the reference's Grapher / FFN / Downsample with the schedule its constructor spells out
+    (`min(idx // 4 + 1, max_dilation)`), capped so that k * dilation fits the stage's node count — the plan
+    oracle.ref_torch.encoder_plan(use_dilation=True) and neuralsampleid_amd GraphEncoder(use_dilation=True) follow."""
+    enc = GraphEncoder(CFG, in_channels=CFG["n_filters"], k=k, size="t")
+    channels = [64, 128, 256, 512]
+    n_pos = n_real = CFG["n_mels"] * CFG["n_frames"] // (CFG["patch_bins"] * CFG["patch_frames"])
+    max_d = max(128 // k, 1)
+    layers, idx, plan = [], 0, []
+    for i, nb in enumerate(blocks):
+        if i > 0:
+            layers.append(Downsample(channels[i - 1], channels[i]))
+            n_pos //= 4
+            n_real = (n_real - 1) // 2 + 1
+        for _ in range(nb):
+            d = max(1, min(idx // 4 + 1, max_d, n_real // k))
+            plan.append((channels[i], n_real, k, d))
+            layers.append(nn.Sequential(
+                Grapher(channels[i], k, d, "mr", "relu", "batch", True, False, 0.2, 1, n=n_pos, drop_path=0.0,
+                        relative_pos=True),
+                FFN(in_features=channels[i], hidden_features=channels[i] * 4, out_features=channels[i], act="relu",
+                    drop_path=0.0)))
+            idx += 1
+    enc.backbone = nn.Sequential(*layers)
+    return enc, plan
+
+
+def gold_deep():
+    """config 4 (24 blocks, k = 18, dilated): eval forward and step 0 of training at B = 4"""
+    print("deep")
+    B = 4
+    x_i, x_j = synth_clips(B)
+    enc, plan = deep_reference_encoder()
+    model = SimCLR(CFG, enc)
+    load_synth(model)
+    tape = KnnTape(model)
+    model.eval()
+    with torch.no_grad():
+        h_i, h_j, z_i, z_j = model(x_i, x_j)
+        loss_eval = ntxent_loss(z_i, z_j, CFG)
+    out = dict(x_i=x_i, x_j=x_j, h_i_eval=h_i, h_j_eval=h_j, z_i_eval=z_i, z_j_eval=z_j, loss_eval=loss_eval.reshape(1),
+               plan=np.array(plan, np.int32))
+    out.update(tape.take("eval"))
+    model.train()
+    model.zero_grad()
+    h_i, h_j, z_i, z_j = model(x_i, x_j)
+    loss = ntxent_loss(z_i, z_j, CFG)
+    loss.backward()
+    out.update(tape.take("s0"))
+    out.update(h_i_train=h_i, h_j_train=h_j, z_i_train=z_i, z_j_train=z_j, loss_train=loss.detach().reshape(1))
+    sums = _checksums((n, p.grad) for n, p in model.named_parameters() if p.grad is not None)
+    out.update({"grad." + n: p.grad.clone() for n, p in model.named_parameters() if n in (
+        "encoder.stem.0.weight", "encoder.backbone.0.0.fc1.0.weight", "encoder.backbone.12.0.graph_conv.gconv.nn.0.weight",
+        "encoder.backbone.26.1.fc2.1.weight", "encoder.proj.bias", "projector.2.bias")})
+    gn = torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=1.0)
+    out["gnorm"] = np.array([float(gn)])
+    stats1 = _checksums((n, t.float()) for n, t in model.state_dict().items() if n.endswith(("running_mean", "running_var")))
+    save("deep_b4_k18", **out)
+    with open(os.path.join(HERE, "deep_b4_k18_checksums.json"), "w") as f:
+        json.dump({"grad": sums, "bn_after_step1": stats1, "keys": list(model.state_dict().keys())}, f, indent=0)
+    print("   plan", sorted(set(plan)), "loss eval", float(loss_eval), "train", float(loss), "gnorm", float(gn))
+
+
+def _reference_function(path, name):
+    """compile ONE function of a reference script that cannot be imported whole (faiss / torchaudio / dgl at module level)"""
+    import ast
+    with open(os.path.join(REF, path)) as f:
+        tree = ast.parse(f.read())
+    fn = next(n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == name)
+    return fn
+
+
+def gold_fpdb():
+    """Fingerprint-DB files written and read by the REFERENCE's own code. eval.py and test_fp.py import
+    faiss / torchaudio / dgl at module level, so the two pieces are compiled from their syntax trees here, in the build
+    container: `load_memmap_data` (eval.py:154-196) whole, and the writer statements of `create_ref_db`
+    (test_fp.py:120-133: np.concatenate ... json.dump) as the body of a function of the variables they read.
+    Only the resulting BYTES (data files) are committed."""
+    import ast
+    import shutil
+    print("fpdb")
+    ns = {"os": os, "np": np, "json": json}
+    reader = _reference_function("eval.py", "load_memmap_data")
+    exec(compile(ast.Module(body=[reader], type_ignores=[]), "eval.py", "exec"), ns)
+    create = _reference_function("test_fp.py", "create_ref_db")
+    first = next(i for i, st in enumerate(create.body) if not isinstance(st, ast.For) and "np.concatenate" in ast.unparse(st))
+    tail = create.body[first:]                 # everything after the extraction loop: the statements of test_fp.py:120-133
+    assert "np.memmap" in ast.unparse(tail[2]) and "json.dump" in ast.unparse(tail[-1]), [ast.unparse(t) for t in tail]
+    writer = ast.FunctionDef(name="reference_writer",
+                             args=ast.arguments(posonlyargs=[], args=[ast.arg(a) for a in
+                                                                       ("fp", "z_i", "output_root_dir", "fname", "lookup_table")],
+                                                kwonlyargs=[], kw_defaults=[], defaults=[]),
+                             body=tail, decorator_list=[])
+    mod = ast.fix_missing_locations(ast.Module(body=[writer], type_ignores=[]))
+    exec(compile(mod, "test_fp.py", "exec"), ns)
+    out_dir = os.path.join(HERE, "fpdb")
+    shutil.rmtree(out_dir, ignore_errors=True)
+    os.makedirs(out_dir)
+    rng = np.random.default_rng(7)
+    chunks = [rng.standard_normal((n, 128)).astype(np.float32) for n in (5, 1, 7)]       # per-song fingerprint blocks
+    chunks = [c / np.linalg.norm(c, axis=1, keepdims=True) for c in chunks]
+    chunks[2][3, 17] = np.nan                                                           # the reader zeroes NaNs in place
+    names = ["songA"] * 5 + ["songB"] + ["songC"] * 7
+    qnames = ["songA_0"] * 5 + ["songB_1"] + ["songC_2"] * 7
+    for fname, lk in (("ref_db", names), ("query_db", qnames)):
+        ns["reference_writer"](list(chunks), chunks[-1], out_dir, fname, lk)
+    np.save(os.path.join(out_dir, "input_chunks.npy"), np.concatenate(chunks))
+    np.save(os.path.join(out_dir, "input_chunk_sizes.npy"), np.array([5, 1, 7]))
+    # what the reference's reader returns for these files (on a copy: it rewrites NaNs in the file it maps)
+    tmp = os.path.join(out_dir, "_tmp")
+    os.makedirs(tmp)
+    for suffix in (".mm", "_shape.npy"):
+        shutil.copy(os.path.join(out_dir, "ref_db" + suffix), os.path.join(tmp, "ref_db" + suffix))
+    data, shape = ns["load_memmap_data"](tmp, "ref_db", display=False)
+    np.save(os.path.join(out_dir, "reader_data.npy"), np.asarray(data))
+    np.save(os.path.join(out_dir, "reader_shape.npy"), np.asarray(shape))
+    data2, shape2 = ns["load_memmap_data"](tmp, "ref_db", append_extra_length=3, display=False)
+    np.save(os.path.join(out_dir, "reader_extra3_shape.npy"), np.asarray(data2.shape))
+    only_shape = ns["load_memmap_data"](tmp, "ref_db", shape_only=True)
+    assert tuple(only_shape) == (13, 128)
+    del data, data2
+    shutil.rmtree(tmp)
+    print("   files:", sorted(os.listdir(out_dir)))
+
+
 def gold_shapes():
     """state_dict key names + shapes of SimCLR(GraphEncoder 't'): data for the state_dict-compat tests."""
     print("shapes")
@@ -335,6 +465,7 @@ def gold_relpos():
 
 if __name__ == "__main__":
     torch.manual_seed(0)
-    only = sys.argv[1:] or ["shapes", "init", "relpos", "knn", "mrconv", "block", "downsample", "peak", "ntxent", "e2e"]
+    only = sys.argv[1:] or ["shapes", "init", "relpos", "knn", "mrconv", "block", "downsample", "peak", "ntxent", "e2e",
+                            "deep", "fpdb"]
     for name in only:
         globals()["gold_" + name]()

@@ -100,7 +100,8 @@ def test_downsample_module(golden):
 
 
 BLOCKS = [("c64n256_k3d1", 64, 256, 3, 1), ("c64n256_k4d2", 64, 256, 4, 2), ("c128n128_k5d1", 128, 128, 5, 1),
-          ("c512n32_k3d1", 512, 32, 3, 1), ("c64n256_k18d3", 64, 256, 18, 3)]
+          ("c512n32_k3d1", 512, 32, 3, 1), ("c64n256_k18d3", 64, 256, 18, 3),
+          ("c256n64_k18d3", 256, 64, 18, 3)]          # the stage that holds 12 of config 4's 24 blocks
 
 
 @pytest.mark.parametrize("tag,C,N,k,d", BLOCKS)
@@ -239,8 +240,73 @@ def test_simclr_e2e(golden, k):
                 assert abs(float(sd[name].double().norm()) - nrm) <= 1e-4 * max(nrm, 1.0), name
         gn = torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=1.0)
         opt.step()
+        print(f"e2e k={k} step {step}: |dloss| {abs(float(loss.detach()) - g['losses'][step]):.3e} "
+              f"gnorm rel {abs(float(gn) - g['gnorms'][step]) / g['gnorms'][step]:.3e}")
         assert abs(float(loss) - g["losses"][step]) < (5e-5 if step == 0 else 2e-2), (step, float(loss))
         assert abs(float(gn) - g["gnorms"][step]) / g["gnorms"][step] < (1e-2 if step == 0 else 0.2), (step, float(gn))
+
+
+def test_deep_config4_e2e(golden):
+    """BASELINE config 4 — GraphEncoder(blocks=[4,4,12,4], k=18, use_dilation=True): dilation 1/2/3/1 by stage, i.e. kNN
+    through knn_sel_kernel (N = 256, k*d = 18) and knn_rank_kernel (k*d = 36 / 54 / 18) — against the reference's own
+    classes assembled with that schedule (make_golden.py::deep_reference_encoder): eval forward, then step 0 of training."""
+    from neuralsampleid_amd import functional as F_
+    from neuralsampleid_amd.encoder.graph_encoder import GraphEncoder
+    from neuralsampleid_amd.simclr.ntxent import ntxent_loss
+    from neuralsampleid_amd.simclr.simclr import SimCLR
+    g = golden("deep_b4_k18")
+    with open(os.path.join(GOLDEN, "deep_b4_k18_checksums.json")) as f:
+        chk = json.load(f)
+    model = SimCLR(GRAFP_CFG, GraphEncoder(GRAFP_CFG, in_channels=GRAFP_CFG["n_filters"], k=18, size="t",
+                                           blocks=[4, 4, 12, 4], use_dilation=True))
+    assert list(model.state_dict().keys()) == chk["keys"]                 # same module tree as the reference-built encoder
+    ds = [(m.graph_conv.k, m.graph_conv.d) for m in model.modules() if type(m).__name__ == "Grapher"]
+    assert ds == [(18, 1)] * 4 + [(18, 2)] * 4 + [(18, 3)] * 12 + [(18, 1)] * 4
+    load_synth(model)
+    x_i, x_j = g.t("x_i").to(DEV), g.t("x_j").to(DEV)
+    gold_idx, gaps = tape_of(g, "eval")
+    model.eval()
+    F_.TAPE = F_.KnnTape(replay=gold_idx)
+    with torch.no_grad():
+        h_i, h_j, z_i, z_j = model(x_i, x_j)
+        loss = ntxent_loss(z_i, z_j, GRAFP_CFG)
+    rec = F_.TAPE.recorded
+    F_.TAPE = None
+    assert len(rec) == 48
+    hard, soft, rows = check_tape(rec, gold_idx, gaps)
+    assert hard == 0 and soft <= rows * 5e-3, (hard, soft, rows)
+    assert maxerr(h_i, g.t("h_i_eval")) < 1e-4 * max(1.0, float(g.t("h_i_eval").abs().max()))
+    assert maxerr(z_i, g.t("z_i_eval")) < 2e-5 and maxerr(z_j, g.t("z_j_eval")) < 2e-5
+    assert abs(float(loss) - float(g["loss_eval"][0])) < 1e-5
+    model.train()
+    gold_idx, gaps = tape_of(g, "s0")
+    F_.TAPE = F_.KnnTape(replay=gold_idx)
+    model.zero_grad()
+    h_i, h_j, z_i, z_j = model(x_i, x_j)
+    loss = ntxent_loss(z_i, z_j, GRAFP_CFG)
+    loss.backward()
+    rec = F_.TAPE.recorded
+    F_.TAPE = None
+    hard, soft, rows = check_tape(rec, gold_idx, gaps)
+    assert hard == 0 and soft <= rows * 5e-3, (hard, soft, rows)
+    assert maxerr(h_i, g.t("h_i_train")) < 5e-4 and maxerr(z_i, g.t("z_i_train")) < 5e-5
+    # B = 4 through 24 train-mode blocks: the fp32 summation-order noise of 120 BatchNorm layers reaches the loss at 8.9e-5
+    # (measured on MI355X; the CPU oracle, same BLAS as the reference, sits at < 5e-5)
+    assert abs(float(loss.detach()) - float(g["loss_train"][0])) < 3e-4
+    grads = {n: p.grad for n, p in model.named_parameters() if p.grad is not None}
+    for name in [n for n in g if n.startswith("grad.")]:
+        ref = g.t(name)
+        if float(ref.norm()) < 1e-5:
+            assert float(grads[name[5:]].norm()) < 1e-5, name
+            continue
+        late = name.startswith(("grad.encoder.backbone.26", "grad.encoder.proj", "grad.projector"))
+        print("deep grad", name, relerr(grads[name[5:]], ref))
+        assert relerr(grads[name[5:]], ref) < (1e-3 if late else 8e-2), (name, relerr(grads[name[5:]], ref))
+    gn = torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=1.0)
+    assert abs(float(gn) - float(g["gnorm"][0])) / float(g["gnorm"][0]) < 2e-2
+    sd = model.state_dict()
+    for name, (s_, nrm) in chk["bn_after_step1"].items():
+        assert abs(float(sd[name].double().norm()) - nrm) <= 1e-4 * max(nrm, 1.0), name
 
 
 def test_fused_optimizer_matches_torch_adam(golden):
@@ -435,7 +501,8 @@ def test_graphed_train_step_equals_eager():
                 losses.append(float(loss))
         res[graphed] = (losses, opt.flat_p.clone())
     assert int(opt.step_count) == 3
-    print("losses", res[True][0], res[False][0])
+    print("graphed-vs-eager losses", res[True][0], res[False][0], "mean |dp|/lr",
+          float((res[True][1] - res[False][1]).abs().mean()) / 8e-5)
     assert abs(res[True][0][0] - res[False][0][0]) < 1e-5                           # same state, same inputs
     # after an update the two runs differ by fp32 atomics order and kNN near-tie flips (chaotic at B = 16): trajectories
     # stay close, weights moved by the same 3 Adam steps

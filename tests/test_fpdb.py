@@ -57,3 +57,43 @@ def test_node_matrix_dump(tmp_path):
     for k, v in mats.items():
         got = np.load(tmp_path / "nm" / f"{k}.npy")
         assert got.dtype == np.float32 and np.array_equal(got, v)
+
+
+FIX = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fpdb")
+
+
+@pytest.mark.parametrize("impl", ["product", "oracle"])
+def test_db_files_match_bytes_written_by_the_reference(tmp_path, impl):
+    """tests/golden/fpdb/* were written and read back by the REFERENCE's own statements (test_fp.py:120-133 and
+    eval.py:154-196, compiled from their syntax trees by tests/golden/make_golden.py::gold_fpdb): neuralsampleid_amd/fpdb.py
+    and the restatement oracle/ref_fpdb.py must both produce those bytes and read them the same way."""
+    import shutil
+    from neuralsampleid_amd import fpdb
+    fp = np.load(os.path.join(FIX, "input_chunks.npy"))
+    sizes = np.load(os.path.join(FIX, "input_chunk_sizes.npy"))
+    chunks = np.split(fp, np.cumsum(sizes)[:-1])
+    for fname in ("ref_db", "query_db"):
+        with open(os.path.join(FIX, f"{fname}_lookup.json")) as f:
+            names = json.load(f)
+        if impl == "product":
+            assert fpdb.write_fp_db(str(tmp_path), fname, fp, names) == (13, 128)
+        else:
+            ref_fpdb.write_db(str(tmp_path), fname, list(chunks), names)
+        for suffix in (".mm", "_shape.npy", "_lookup.json"):
+            assert filecmp.cmp(tmp_path / f"{fname}{suffix}", os.path.join(FIX, f"{fname}{suffix}"), shallow=False), \
+                (fname, suffix)
+    # reading: on a copy of the REFERENCE-written files (the reader zeroes NaNs in the file it maps)
+    rd = tmp_path / "read"
+    rd.mkdir()
+    for suffix in (".mm", "_shape.npy"):
+        shutil.copy(os.path.join(FIX, "ref_db" + suffix), rd / ("ref_db" + suffix))
+    load = fpdb.load_memmap_data if impl == "product" else ref_fpdb.load_memmap_data
+    assert tuple(load(str(rd), "ref_db", shape_only=True)) == (13, 128)
+    data, shape = load(str(rd), "ref_db")
+    assert np.array_equal(np.asarray(shape), np.load(os.path.join(FIX, "reader_shape.npy")))
+    want = np.load(os.path.join(FIX, "reader_data.npy"))
+    assert np.isnan(fp).sum() == 1 and not np.isnan(want).any()          # the fixture holds a NaN; the reader zeroed it
+    assert np.array_equal(np.asarray(data), want)
+    del data
+    data3, shape3 = load(str(rd), "ref_db", append_extra_length=3)
+    assert tuple(data3.shape) == tuple(np.load(os.path.join(FIX, "reader_extra3_shape.npy"))) == (16, 128)

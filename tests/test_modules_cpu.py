@@ -61,3 +61,46 @@ def test_relative_pos_matches_reference(golden):
         got = sd["encoder." + key]
         assert got.shape == ref.shape and not got.requires_grad
         assert float((got - ref).abs().max()) <= 2.4e-7 * max(1.0, float(ref.abs().max())), key
+
+
+def test_load_reference_checkpoint_strips_the_dataparallel_prefix(tmp_path):
+    """generate.py:94-95 / test_fp.py:381-382: checkpoints of a DataParallel run carry `module.` on every key; the
+    reference's checkpoint dict is util.py:160-164's {'epoch', 'loss', ..., 'state_dict', 'optimizer', 'scheduler'}"""
+    import pytest
+    from neuralsampleid_amd.checkpoint import (load_reference_checkpoint, save_reference_checkpoint,
+                                               strip_data_parallel_prefix)
+    torch.manual_seed(3)
+    src = build()
+    for b in src.buffers():                                     # make the BN buffers distinguishable from a fresh model
+        if b.dtype.is_floating_point:
+            b.add_(torch.rand_like(b))
+    sd = src.state_dict()
+    ck = {"epoch": 7, "loss": 1.5, "hit_rate_log": [], "optimizer": {}, "scheduler": {},
+          "state_dict": {"module." + k: v for k, v in sd.items()}}           # what nn.DataParallel(model).state_dict() is
+    path = tmp_path / "model_tc_35_best.pth"
+    torch.save(ck, path)
+    torch.manual_seed(4)
+    dst = build()
+    out = load_reference_checkpoint(dst, str(path))                           # strict=True: all 443 keys must match
+    assert out["epoch"] == 7
+    got = dst.state_dict()
+    assert list(got.keys()) == list(sd.keys()) and all(torch.equal(got[k], sd[k]) for k in sd)
+    # un-prefixed checkpoint and a bare state_dict load the same way
+    torch.manual_seed(5)
+    dst2 = build()
+    load_reference_checkpoint(dst2, {"state_dict": sd})
+    load_reference_checkpoint(dst2, sd)
+    assert all(torch.equal(dst2.state_dict()[k], sd[k]) for k in sd)
+    with pytest.raises(KeyError):
+        strip_data_parallel_prefix({"module.a": torch.zeros(1), "b": torch.zeros(1)})
+    with pytest.raises(RuntimeError):                                          # strict: a missing key is an error
+        load_reference_checkpoint(dst2, {k: v for k, v in sd.items() if k != "encoder.proj.bias"})
+    save_reference_checkpoint(str(tmp_path / "out.pth"), src, epoch=3, loss=0.5)
+    back = torch.load(tmp_path / "out.pth")
+    assert sorted(back) == ["epoch", "hit_rate_log", "loss", "optimizer", "scheduler", "state_dict"]
+
+
+def test_batched_index_select_symbol_exists_with_the_reference_signature():
+    import inspect
+    from neuralsampleid_amd.encoder.gcn_lib.torch_nn import batched_index_select
+    assert list(inspect.signature(batched_index_select).parameters) == ["x", "idx"]      # torch_nn.py:79

@@ -209,9 +209,13 @@ def test_batchnorm_eval_affine_is_cached_until_a_tensor_changes(ops):
     assert torch.allclose(a3.scale, ref()[0], rtol=1e-6, atol=1e-7) and torch.allclose(a3.shift, ref()[1], rtol=1e-6, atol=1e-6)
 
 
-@pytest.mark.parametrize("tag,kds", [("c64n256", [(3, 1), (5, 1), (4, 2), (18, 3)]),
+# k = 18 entries: BASELINE config 4's four shapes — (C64,N256,d1) -> knn_sel_kernel, (C128,N128,d2) / (C256,N64,d3) / (C512,N32,d1)
+# -> knn_rank_kernel; c80n256 (size 's' channel count, not a power of two) -> the general strip kernel knn_kernel
+@pytest.mark.parametrize("tag,kds", [("c64n256", [(3, 1), (5, 1), (4, 2), (18, 3), (18, 1)]),
                                      ("c128n128", [(3, 1), (18, 2)]),
-                                     ("c512n32", [(3, 1), (5, 2), (18, 1)])])
+                                     ("c256n64", [(3, 1), (18, 3), (9, 2)]),
+                                     ("c512n32", [(3, 1), (5, 2), (18, 1)]),
+                                     ("c80n256", [(3, 1), (9, 2)])])
 def test_knn_graph_golden(ops, golden, tag, kds):
     g = golden("knn_" + tag)
     y = to_rows(g.t("x"))
@@ -358,6 +362,62 @@ def test_ntxent_sharded(ops, golden):
     assert abs(float(loss) - float(lref)) < 2e-6
     close(dzi, zi2.grad, tol=2e-6, what="ragged dz_i")
     close(dzj, zj2.grad, tol=2e-6, what="ragged dz_j")
+
+
+def test_ntxent_global_batch_2048_row_slices(ops):
+    """BASELINE config 3 on one GPU: the rank-local NT-Xent of each of the 8 ranks of a global batch of 2048 pairs (every
+    rank owns 256 pairs = 512 rows of the interleaved 4096 x 4096 problem, all columns) against the oracle's row-sliced
+    closed form + autograd; the 8 losses sum to the global mean loss and the concatenated dz equal its gradient
+    (reference: ntxent.py:5-30 on the DataParallel-gathered batch, train.py:63)."""
+    Bg, d, tau, world = 2048, 128, 0.05, 8
+    zi = torch.nn.functional.normalize(rnd("g2048_i", Bg, d), dim=1)
+    zj = torch.nn.functional.normalize(zi + 0.5 * rnd("g2048_j", Bg, d), dim=1)
+    zi_r, zj_r = zi.clone().requires_grad_(True), zj.clone().requires_grad_(True)
+    full = R.ntxent(zi_r, zj_r, tau)
+    full.backward()
+    zi_d, zj_d = zi.to(DEV), zj.to(DEV)
+    z_all = torch.stack((zi, zj), 1).reshape(2 * Bg, d)
+    losses, dzi, dzj = [], [], []
+    per = Bg // world
+    for r in range(world):
+        loss, gi, gj = ops.ntxent_fwd_bwd(zi_d, zj_d, tau, r * per, per)
+        want = float(R.ntxent_rows(z_all, 2 * r * per, 2 * per, tau)) / (2 * Bg)
+        assert abs(float(loss) - want) < 2e-6 * max(1.0, abs(want)), (r, float(loss), want)
+        losses.append(float(loss)); dzi.append(gi); dzj.append(gj)
+    assert abs(sum(losses) - float(full)) < 5e-6
+    close(torch.cat(dzi), zi_r.grad, tol=2e-6, what="dz_i of the 8 slices")
+    close(torch.cat(dzj), zj_r.grad, tol=2e-6, what="dz_j of the 8 slices")
+    # one launch over the whole global batch (what a single-GPU step at B = 2048 would run) agrees as well
+    loss, gi, gj = ops.ntxent_fwd_bwd(zi_d, zj_d, tau)
+    assert abs(float(loss) - float(full)) < 5e-6
+    close(gi, zi_r.grad, tol=2e-6, what="dz_i global")
+
+
+def test_batched_index_select_symbol(ops):
+    """encoder/gcn_lib/torch_nn.py:79-98 restated with torch ops: flat gather of (B, C, N, 1) by (B, N, k) -> (B, C, N, k)"""
+    from neuralsampleid_amd.encoder.gcn_lib.torch_nn import batched_index_select
+    B, C, N, k = 3, 20, 48, 5
+    x = rnd("bisx", B, C, N, 1)
+    idx = torch.stack([torch.randperm(N, generator=torch.Generator().manual_seed(b))[:k].repeat(N, 1) for b in range(B)])
+    idx = (idx + torch.arange(N).view(1, N, 1)) % N
+    xr = x.clone().requires_grad_(True)
+    idx_base = torch.arange(B).view(-1, 1, 1) * N
+    flat = xr.transpose(2, 1).reshape(B * N, C)[(idx + idx_base).view(-1)]
+    ref = flat.view(B, N, k, C).permute(0, 3, 1, 2).contiguous()
+    gout = rnd("bisg", B, C, N, k)
+    ref.backward(gout)
+    xd = x.to(DEV).requires_grad_(True)
+    got = batched_index_select(xd, idx.to(DEV))
+    got.backward(gout.to(DEV))
+    assert got.shape == (B, C, N, k) and torch.equal(got.detach().cpu(), ref.detach())
+    close(xd.grad.reshape(B, C, N, 1), xr.grad, tol=1e-6, what="batched_index_select dx")
+    z = ops.zeros((5, 7), DEV)
+    assert torch.equal(z.cpu(), torch.zeros(5, 7))
+    buf = torch.full((1031,), 3.0, device=DEV)
+    ops.fill_zero(buf[:1030])                        # 257 16-byte granules + an 8-byte tail; the bytes beyond stay
+    assert float(buf[:1030].abs().sum()) == 0 and float(buf[1030:].sum()) == 3.0
+    s2 = torch.tensor([0.5], device=DEV)
+    assert torch.equal(ops.scale_f32(torch.arange(9.0, device=DEV), s2).cpu(), torch.arange(9.0) * 0.5)
 
 
 def test_clip_adam(ops):

@@ -40,9 +40,14 @@ def knn_set_mismatch(idx, gold_idx, gap, tol=1e-4):
     return int((bad & (np.asarray(gap) >= tol)).sum()), int(bad.sum())
 
 
-@pytest.mark.parametrize("tag,kds", [("c64n256", [(3, 1), (5, 1), (4, 2), (18, 3)]),
-                                     ("c128n128", [(3, 1), (18, 2)]),
-                                     ("c512n32", [(3, 1), (5, 2), (18, 1)])])
+KNN_CASES = [("c64n256", [(3, 1), (5, 1), (4, 2), (18, 3), (18, 1)]),       # k = 18: BASELINE config 4's four shapes
+             ("c128n128", [(3, 1), (18, 2)]),
+             ("c256n64", [(3, 1), (18, 3), (9, 2)]),
+             ("c512n32", [(3, 1), (5, 2), (18, 1)]),
+             ("c80n256", [(3, 1), (9, 2)])]
+
+
+@pytest.mark.parametrize("tag,kds", KNN_CASES)
 def test_knn(golden, tag, kds):
     g = golden("knn_" + tag)
     y = to_rows(g.t("x"))
@@ -88,7 +93,7 @@ def test_mrconv(golden):
 
 
 BLOCKS = [("c64n256_k3d1", 64, 3, 1), ("c64n256_k4d2", 64, 4, 2), ("c128n128_k5d1", 128, 5, 1),
-          ("c512n32_k3d1", 512, 3, 1), ("c64n256_k18d3", 64, 18, 3)]
+          ("c512n32_k3d1", 512, 3, 1), ("c64n256_k18d3", 64, 18, 3), ("c256n64_k18d3", 256, 18, 3)]
 
 
 @pytest.mark.parametrize("tag,C,k,d", BLOCKS)
@@ -260,3 +265,86 @@ def test_e2e(golden, k):
         print("step", step, "loss", l, g["losses"][step], "gnorm", gn, g["gnorms"][step])
         assert abs(l - g["losses"][step]) < (5e-5 if step == 0 else 2e-2), (step, l, g["losses"][step])
         assert abs(gn - g["gnorms"][step]) / g["gnorms"][step] < (1e-2 if step == 0 else 0.2), (step, gn)
+
+
+def deep_state_shapes():
+    """state_dict of SimCLR(GraphEncoder(blocks=[4,4,12,4])) from the reference's key list + the per-block shape rule"""
+    with open(os.path.join(GOLDEN, "deep_b4_k18_checksums.json")) as f:
+        keys = json.load(f)["keys"]
+    base = full_state_shapes(3)
+    shapes = {}
+    chan = {}
+    plan = R.encoder_plan("t", 18, blocks=[4, 4, 12, 4], use_dilation=True)
+    for i, e in enumerate(plan):
+        chan[i] = e[1] if e[0] == "block" else (e[1], e[2])
+    for k_ in keys:
+        if not k_.startswith("encoder.backbone."):
+            shapes[k_] = base[k_]
+            continue
+        i = int(k_.split(".")[2])
+        rest = k_.split(".", 3)[3]
+        if isinstance(chan[i], tuple):
+            ci, co = chan[i]
+            shapes[k_] = {"conv.0.weight": (co, ci, 3, 3), "conv.1.num_batches_tracked": ()}.get(rest, (co,))
+        else:
+            C = chan[i]
+            sh = block_shapes(C)
+            shapes[k_] = sh[rest] if rest in sh else None
+    return shapes, plan
+
+
+def test_deep_config4(golden):
+    """BASELINE config 4 (blocks [4,4,12,4], k = 18, dilation 1/2/3/1 by stage) against the reference's own classes
+    assembled with that schedule (tests/golden/make_golden.py::deep_reference_encoder): eval forward and step 0"""
+    g = golden("deep_b4_k18")
+    with open(os.path.join(GOLDEN, "deep_b4_k18_checksums.json")) as f:
+        chk = json.load(f)
+    shapes, plan = deep_state_shapes()
+    assert [tuple(r) for r in g["plan"]] == [(e[1], n, e[2], e[3]) for e, n in zip(
+        [e for e in plan if e[0] == "block"], [256] * 4 + [128] * 4 + [64] * 12 + [32] * 4)]
+    P = {}
+    for k_, s_ in shapes.items():
+        if s_ is None:                 # relative_pos: dead in the reference (torch_vertex.py:189), never read by the oracle
+            continue
+        P[k_] = synth_tensor(k_, torch.empty(s_))
+    x_i, x_j = g.t("x_i"), g.t("x_j")
+    gold_idx, gaps = tape_of(g, "eval")
+    R.TAPE = R.KnnTape(replay=gold_idx)
+    try:
+        with torch.no_grad():
+            h_i, h_j, z_i, z_j = R.simclr_forward(x_i, x_j, P, GRAFP_CFG, plan, False)
+            loss = R.ntxent(z_i, z_j, GRAFP_CFG["tau"])
+        rec = R.TAPE.recorded
+    finally:
+        R.TAPE = None
+    assert len(rec) == 48
+    hard, soft, rows = check_tape(rec, gold_idx, gaps)
+    assert hard == 0 and soft <= rows * 5e-3, (hard, soft, rows)
+    assert (h_i - g.t("h_i_eval")).abs().max() < 1e-4 * max(1.0, float(g.t("h_i_eval").abs().max()))
+    assert (z_j - g.t("z_j_eval")).abs().max() < 2e-5
+    assert abs(float(loss) - float(g["loss_eval"][0])) < 1e-5
+    keys = R.trainable_keys(P)
+    for k_ in keys:
+        P[k_].requires_grad_(True)
+    gold_idx, gaps = tape_of(g, "s0")
+    R.TAPE = R.KnnTape(replay=gold_idx)
+    try:
+        st = R.BNState()
+        h_i, h_j, z_i, z_j = R.simclr_forward(x_i, x_j, P, GRAFP_CFG, plan, True, st)
+        loss = R.ntxent(z_i, z_j, GRAFP_CFG["tau"])
+        loss.backward()
+    finally:
+        R.TAPE = None
+    assert (h_i - g.t("h_i_train")).abs().max() < 5e-4 and (z_i - g.t("z_i_train")).abs().max() < 5e-5
+    assert abs(float(loss) - float(g["loss_train"][0])) < 5e-5
+    for name in [n for n in g if n.startswith("grad.")]:
+        ref, got = g.t(name), P[name[5:]].grad
+        if float(ref.norm()) < 1e-5:
+            assert float(got.norm()) < 1e-5, name
+            continue
+        late = name.startswith(("grad.encoder.backbone.26", "grad.encoder.proj", "grad.projector"))
+        rel = float((got - ref).norm() / ref.norm())
+        print(name, rel)
+        assert rel < (1e-3 if late else 8e-2), (name, rel)         # B = 4, 24 blocks: twice the depth of test_e2e's floor
+    for name, (s_, nrm) in chk["bn_after_step1"].items():
+        assert abs(float(st.updates[name].double().norm()) - nrm) <= 1e-4 * max(nrm, 1.0), name
