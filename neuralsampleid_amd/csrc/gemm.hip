@@ -49,11 +49,16 @@ struct GemmArgs {
 //                      HBM and fp32 accumulation, v_mfma_f32_16x16x32_bf16 (16x the fp32 matrix rate), BK = 32.
 template <bool H> struct Prec { static constexpr int BK = H ? 32 : 16; static constexpr int ESZ = H ? 2 : 4; };
 
-template <int ROWS, bool RMAJOR, bool H, bool SRC16 = false>
+// KS: 32-deep MFMA sub-steps per stage of the bf16 path (BK = 32*KS). KS = 2 doubles the bytes a workgroup keeps in flight
+// and halves the barriers per reduction element: the GEMMs with <= 2 workgroups per CU (the C = 256 / 512 stages: 256-512
+// tiles) were fetching at 16 GB/s per CU against the 60-70 GB/s the L2 -> LDS path delivers (round-2 shape table).
+template <int ROWS, bool RMAJOR, bool H, bool SRC16 = false, int KS = 1>
 struct TileGeom {
-  static constexpr int BK = Prec<H>::BK, ESZ = Prec<H>::ESZ;
+  static_assert(KS == 1 || H, "deeper stages exist on the bf16 path only");
+  static constexpr int BK = Prec<H>::BK * KS, ESZ = Prec<H>::ESZ;
   // Bank-conflict-free LDS images (MI355X_MICROARCH.md, LDS: banking is per instruction, over fixed lane groups):
-  //  RMAJOR: lds[row][BK elements + 32 B pad] (row = i or j, R contiguous): 96-byte rows in both precisions. A fragment
+  //  RMAJOR: lds[row][BK elements + 32 B pad] (row = i or j, R contiguous): 96-byte rows in both precisions (160-byte rows
+  //          with KS = 2: 16-byte block (10*lr + rq) mod 16 is a bijection for the same lane split). A fragment
   //          read is one ds_read_b128 per lane at (row lr, 16-byte chunk rq); the hardware serves lanes {0-3,12-15,20-27}
   //          etc. together, i.e. all 16 rows with chunk rq on half of them and rq+1 on the other half: 16-byte block
   //          (6*lr + rq) mod 16 is a bijection for that split (80-byte rows, 5*lr + rq, collide 3 ways per group: half of
@@ -78,19 +83,19 @@ struct TileGeom {
 // (issue early / write late): stage_load only ISSUES the 16-byte loads; stage_store, which runs after the MFMAs,
 // applies affine + activation, zero-fills out-of-range chunks, rounds to bf16 in the H path, and writes LDS.
 // A bf16-stored operand without affine is copied chunk-for-chunk (its HBM image IS the LDS image).
-template <int ROWS, bool RMAJOR, bool H, bool SRC16>
+template <int ROWS, bool RMAJOR, bool H, bool SRC16, int KS = 1>
 struct StageRegs {
-  static constexpr int VEC = TileGeom<ROWS, RMAJOR, H, SRC16>::VEC;
+  static constexpr int VEC = TileGeom<ROWS, RMAJOR, H, SRC16, KS>::VEC;
   f32x4 v[VEC];      // raw 16-byte chunks (4 fp32 or 8 bf16)
   bool ok[VEC];
 };
 
 // FULL: the tile and every stage lie inside the operand (host-checked), so there is no predication at all — the bounds
 // logic (compare, select, zero-fill per chunk) is a third of the instructions of a K = 256 tile otherwise.
-template <int ROWS, bool RMAJOR, bool H, bool SRC16, bool FULL>
-__device__ __forceinline__ void stage_load(StageRegs<ROWS, RMAJOR, H, SRC16>& s, const char* __restrict__ base, long ld,
+template <int ROWS, bool RMAJOR, bool H, bool SRC16, bool FULL, int KS = 1>
+__device__ __forceinline__ void stage_load(StageRegs<ROWS, RMAJOR, H, SRC16, KS>& s, const char* __restrict__ base, long ld,
                                            int row0, int nrows, int r0, int rend) {
-  using G = TileGeom<ROWS, RMAJOR, H, SRC16>;
+  using G = TileGeom<ROWS, RMAJOR, H, SRC16, KS>;
   const int t = threadIdx.x;
 #pragma unroll
   for (int q = 0; q < G::VEC; ++q) {
@@ -112,10 +117,10 @@ __device__ __forceinline__ void stage_load(StageRegs<ROWS, RMAJOR, H, SRC16>& s,
 // reduction-indexed affine (producer BatchNorm) of an R-major operand for the stage that starts at r0. VMEM completes in
 // order, so these small loads must be issued BEFORE the operand loads of a later stage: issued after them, the first
 // use would wait for the whole prefetch (vmcnt is positional) and collapse the pipeline.
-template <int ROWS, bool H, bool SRC16>
+template <int ROWS, bool H, bool SRC16, int KS = 1>
 __device__ __forceinline__ void affine_prefetch(f32x4* sc, f32x4* sh, int r0, int rend, const float* scale,
                                                 const float* shift) {
-  using G = TileGeom<ROWS, true, H, SRC16>;
+  using G = TileGeom<ROWS, true, H, SRC16, KS>;
 #pragma unroll
   for (int q = 0; q < G::VEC; ++q) {
     const int gr = r0 + ((threadIdx.x + 256 * q) % G::CPR) * G::EPC;
@@ -129,10 +134,10 @@ __device__ __forceinline__ void affine_prefetch(f32x4* sc, f32x4* sh, int r0, in
 }
 
 // column-indexed affine of an i/j-major operand is the same for every stage: fetched once per kernel
-template <int ROWS, bool H, bool SRC16>
+template <int ROWS, bool H, bool SRC16, int KS = 1>
 __device__ __forceinline__ void colaffine_load(f32x4* sc, f32x4* sh, int row0, int nrows, const float* scale,
                                                const float* shift) {
-  using G = TileGeom<ROWS, false, H, SRC16>;
+  using G = TileGeom<ROWS, false, H, SRC16, KS>;
 #pragma unroll
   for (int q = 0; q < G::VEC; ++q) {
     const int cv = ((threadIdx.x + 256 * q) % G::CPC) * G::EPC;
@@ -155,10 +160,10 @@ __device__ __forceinline__ f32x4 relu_bf16x8(f32x4 raw) {
   return __builtin_bit_cast(f32x4, h);
 }
 
-template <int ROWS, bool RMAJOR, bool H, bool SRC16, bool RELU16 = false>
-__device__ __forceinline__ void stage_store(char* lds, const StageRegs<ROWS, RMAJOR, H, SRC16>& s, bool affine,
+template <int ROWS, bool RMAJOR, bool H, bool SRC16, bool RELU16 = false, int KS = 1>
+__device__ __forceinline__ void stage_store(char* lds, const StageRegs<ROWS, RMAJOR, H, SRC16, KS>& s, bool affine,
                                             float slope, const f32x4* csc, const f32x4* csh) {
-  using G = TileGeom<ROWS, RMAJOR, H, SRC16>;
+  using G = TileGeom<ROWS, RMAJOR, H, SRC16, KS>;
   const int t = threadIdx.x;
 #pragma unroll
   for (int q = 0; q < G::VEC; ++q) {
@@ -228,14 +233,15 @@ __device__ __forceinline__ f32x4 frag_read_f32(const char* lds, int row, int rq)
 // tile row lr.  R-major tiles: one ds_read_b128.  i/j-major tiles: two ds_read_b64_tr_b16 — per 16-lane group the
 // hardware gathers a 4 (reduction) x 16 (i/j) block and hands every lane its column, i.e. a free transpose; lane
 // 4q+p of the group supplies the address of block row q, columns 4p..4p+3 (EXEC is all ones here: no divergence).
-template <int ROWS, bool RMAJOR>
-__device__ __forceinline__ bf16x8 frag_read_bf16(const char* lds, int tile_row0, int lr, int rq) {
-  using G = TileGeom<ROWS, RMAJOR, true>;
+template <int ROWS, bool RMAJOR, int KS = 1>
+__device__ __forceinline__ bf16x8 frag_read_bf16(const char* lds, int tile_row0, int lr, int rq, int ks = 0) {
+  using G = TileGeom<ROWS, RMAJOR, true, false, KS>;
   if (RMAJOR) {
-    return *reinterpret_cast<const bf16x8*>(lds + (tile_row0 + lr) * G::STRIDE + 16 * rq);
+    return *reinterpret_cast<const bf16x8*>(lds + (tile_row0 + lr) * G::STRIDE + 16 * rq + 64 * ks);
   } else {
     typedef bf16x4 __attribute__((address_space(3))) * lds_bf16x4_ptr;
-    const char* base = lds + (8 * rq + (lr >> 2)) * G::STRIDE + rq * G::SHIFT8 + (tile_row0 + 4 * (lr & 3)) * 2;
+    const char* base = lds + (32 * ks + 8 * rq + (lr >> 2)) * G::STRIDE + (4 * ks + rq) * G::SHIFT8 +
+                       (tile_row0 + 4 * (lr & 3)) * 2;
     const bf16x4 t0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(base));
     const bf16x4 t1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(base + 4 * G::STRIDE));
     return __builtin_shufflevector(t0, t1, 0, 1, 2, 3, 4, 5, 6, 7);
@@ -269,9 +275,12 @@ __device__ unsigned long long* g_gemm_trace = nullptr;
 
 // ARELU: the left operand is a bf16 activation that only needs ReLU on load (an eval-mode BatchNorm folded into the producer's
 // weights leaves no affine): applied on the packed bf16 values, no conversion, no per-channel vectors.
+// KS / PD: 32-deep sub-steps per stage and register sets (= stages in flight) of the pipelined loop; PD = 0 keeps the round-1
+// rule (2 sets, 1 for the full-tile forward kernel). The deep forms (KS = 2 and/or PD = 4) are FULL-tile bf16 variants for the
+// shapes that put <= 2 workgroups on a CU, where only bytes in flight per workgroup hide the memory latency.
 template <int BM, int BN, bool A_RMAJOR, bool B_RMAJOR, bool H, bool ST, bool AAFF, bool WB = false, bool FULL = false,
-          bool ARELU = false>
-__global__ __launch_bounds__(256, (FULL && WB && BM == 128 && BN == 128 && !AAFF) ? 3 : 2)   // 3 waves/SIMD: <= 168 registers
+          bool ARELU = false, int KS = 1, int PD = 0, bool EC = false>
+__global__ __launch_bounds__(256, (KS > 1 || PD > 2) ? 1 : ((FULL && WB && BM == 128 && BN == 128 && !AAFF) ? 3 : 2))   // 3 waves/SIMD: <= 168 registers
 void gemm_kernel(const GemmArgs p) {
   unsigned long long* const trace = g_gemm_trace;
   unsigned long long t_start = 0, t_loop = 0;
@@ -279,14 +288,21 @@ void gemm_kernel(const GemmArgs p) {
   constexpr bool SA = ST, SB = (ST && !A_RMAJOR && !B_RMAJOR) || WB, SC = ST && A_RMAJOR;
   static_assert(!WB || (ST && A_RMAJOR), "bf16 weights ride with bf16 activations in the forward/backward-data GEMMs");
   static_assert(!ARELU || (ST && A_RMAJOR && B_RMAJOR && !AAFF && FULL), "ReLU-on-load is a forward, full-tile, bf16 variant");
-  using GA = TileGeom<BM, A_RMAJOR, H, SA>;
-  using GB = TileGeom<BN, B_RMAJOR, H, SB>;
-  constexpr int BK = Prec<H>::BK;
+  static_assert((KS == 1 && PD == 0) || (FULL && H && ST), "the deep pipelines are full-tile bf16-storage variants");
+  static_assert(!EC || PD >= 2, "early commit rides with the deep pipelines");
+  using GA = TileGeom<BM, A_RMAJOR, H, SA, KS>;
+  using GB = TileGeom<BN, B_RMAJOR, H, SB, KS>;
+  constexpr int BK = Prec<H>::BK * KS;
   constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 16, TN = WN / 16;
   constexpr int STAGE = GA::BYTES + GB::BYTES;
   constexpr int OUT_STAGE = 4 * 32 * (WN + 4) * 4      // epilogue transpose buffers (4 waves x 32 rows), bytes
                             + 16 * BN * 4;             // + parked BatchNorm sums [2][2 wave-rows][4 row groups][BN]
-  constexpr int LDS_BYTES = 2 * STAGE > OUT_STAGE ? 2 * STAGE : OUT_STAGE;
+  // EC (early commit): THREE stage buffers, so that stage s+1 can be written to LDS while stage s is still being read: the
+  // loop then issues the fragment reads of stage s, commits stage s+1 (its waits and ds_writes run under the read latency)
+  // and only then starts the MFMAs — in the two-buffer order (MFMA, then commit, then barrier) a wave's LDS-read latency,
+  // its ds_write completion and the barrier were all exposed: ~800 cycles per 32-deep slab against 256 cycles of MFMA.
+  constexpr int NBUF = EC ? 3 : 2;
+  constexpr int LDS_BYTES = NBUF * STAGE > OUT_STAGE ? NBUF * STAGE : OUT_STAGE;
   __shared__ __attribute__((aligned(16))) char lds_raw[LDS_BYTES];
   float* lds = reinterpret_cast<float*>(lds_raw);
 
@@ -331,7 +347,7 @@ void gemm_kernel(const GemmArgs p) {
   constexpr bool a_aff = AAFF;
   const bool b_aff = !B_RMAJOR && b_sc != nullptr;
   f32x4 bcs[GB::VEC * GB::EPC / 4], bch[GB::VEC * GB::EPC / 4];
-  if (b_aff) colaffine_load<BN, H, SB>(bcs, bch, j0, p.J, b_sc, b_sh);
+  if (b_aff) colaffine_load<BN, H, SB, KS>(bcs, bch, j0, p.J, b_sc, b_sh);
   const int nstage = (rend - rbeg + BK - 1) / BK;
 
   // Register prefetch depth: fp32 MFMA blocks (64 x 32 cycles) cover one memory round trip, so one stage in flight
@@ -340,9 +356,10 @@ void gemm_kernel(const GemmArgs p) {
   // Exception: the full-tile forward kernel with bf16 weights and no operand affine keeps ONE stage in flight: measured
   // 7-10 % faster than the deeper prefetch when introduced and equal to it now (tools/gemm_trace.py: 3 workgroups per CU
   // are resident either way, the loop is bound by the L2 -> LDS rate, ~53 GB/s per CU, not by load latency).
-  constexpr int DEPTH = (H && !(FULL && WB && !AAFF && BN == 128 && A_RMAJOR && B_RMAJOR)) ? 2 : 1;
-  StageRegs<BM, A_RMAJOR, H, SA> ra[DEPTH];
-  StageRegs<BN, B_RMAJOR, H, SB> rb[DEPTH];
+  constexpr int DEPTH = PD > 0 ? PD : ((H && !(FULL && WB && !AAFF && BN == 128 && A_RMAJOR && B_RMAJOR)) ? 2 : 1);
+  static_assert(DEPTH == 1 || DEPTH == 2 || DEPTH == 4, "the unrolled loop body needs an even number of register sets");
+  StageRegs<BM, A_RMAJOR, H, SA, KS> ra[DEPTH];
+  StageRegs<BN, B_RMAJOR, H, SB, KS> rb[DEPTH];
 
   f32x4 acs[GA::VEC * GA::EPC / 4], ach[GA::VEC * GA::EPC / 4];   // reduction-indexed affine of the stage being committed
   // FULL tiles address a stage as (uniform 64-bit base in SGPRs) + (32-bit lane offset fixed for the whole kernel): the
@@ -381,32 +398,71 @@ void gemm_kernel(const GemmArgs p) {
         sb.ok[q] = true;
       }
     } else {
-      stage_load<BM, A_RMAJOR, H, SA, FULL>(sa, A, p.lda, i0, p.I, r0, rend);
-      stage_load<BN, B_RMAJOR, H, SB, FULL>(sb, B, p.ldb, j0, p.J, r0, rend);
+      stage_load<BM, A_RMAJOR, H, SA, FULL, KS>(sa, A, p.lda, i0, p.I, r0, rend);
+      stage_load<BN, B_RMAJOR, H, SB, FULL, KS>(sb, B, p.ldb, j0, p.J, r0, rend);
     }
   };
   auto aff_fetch = [&](int st) {
-    if constexpr (AAFF) affine_prefetch<BM, H, SA>(acs, ach, rbeg + st * BK, rend, a_sc, a_sh);
+    if constexpr (AAFF) affine_prefetch<BM, H, SA, KS>(acs, ach, rbeg + st * BK, rend, a_sc, a_sh);
   };
   auto commit = [&](const auto& sa, const auto& sb, int st) {
-    char* dst = lds_raw + (st & 1) * STAGE;
-    stage_store<BM, A_RMAJOR, H, SA, ARELU>(dst, sa, a_aff, p.a_slope, acs, ach);
-    stage_store<BN, B_RMAJOR, H, SB>(dst + GA::BYTES, sb, b_aff, p.b_slope, bcs, bch);
+    char* dst = lds_raw + (EC ? st % 3 : (st & 1)) * STAGE;
+    stage_store<BM, A_RMAJOR, H, SA, ARELU, KS>(dst, sa, a_aff, p.a_slope, acs, ach);
+    stage_store<BN, B_RMAJOR, H, SB, false, KS>(dst + GA::BYTES, sb, b_aff, p.b_slope, bcs, bch);
+  };
+  // early-commit form of one stage: the fragment reads of stage st, the global loads of stage st+DEPTH (`loads()`), the commit
+  // of stage st+1 (`between()`) and the MFMAs of stage st are ONE scheduling region, and the sched_group_barrier sequence
+  // asks for: all fragment reads first, then {2 MFMAs, 1 global load, 1 ds_write} repeated — a wave that issues its 16
+  // global loads back to back sits in the memory pipeline's issue queue for hundreds of cycles (a 1 KB wave-load takes the
+  // CU's vector memory path >= 16 cycles) and, alone on its SIMD, issues no MFMA meanwhile.
+  auto compute_ec = [&](int st, auto&& loads, auto&& between) {
+    const char* la = lds_raw + (st % 3) * STAGE;
+    const char* lb = la + GA::BYTES;
+    bf16x8 fa[KS][TM], fb[KS][TN];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+      for (int a = 0; a < TM; ++a) fa[ks][a] = frag_read_bf16<BM, A_RMAJOR, KS>(la, wm0 + 16 * a, lr, rq, ks);
+#pragma unroll
+      for (int b = 0; b < TN; ++b) fb[ks][b] = frag_read_bf16<BN, B_RMAJOR, KS>(lb, wn0 + 16 * b, lr, rq, ks);
+    }
+    loads();
+    between();
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+          acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[ks][a], fb[ks][b], acc[a][b], 0, 0, 0);
+    constexpr int NMFMA = KS * TM * TN, NLOAD = GA::VEC + GB::VEC;
+    constexpr int NDSR = KS * (TM * (A_RMAJOR ? 1 : 2) + TN * (B_RMAJOR ? 1 : 2));
+    __builtin_amdgcn_sched_group_barrier(0x100, NDSR, 0);
+    constexpr int PER = NMFMA / NLOAD > 0 ? NMFMA / NLOAD : 1;
+#pragma unroll
+    for (int i = 0; i < NLOAD; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, PER, 0);
+      __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+    }
   };
   auto compute = [&](int st) {
     const char* la = lds_raw + (st & 1) * STAGE;
     const char* lb = la + GA::BYTES;
     if (H) {
-      bf16x8 fa[TM], fb[TN];
 #pragma unroll
-      for (int a = 0; a < TM; ++a) fa[a] = frag_read_bf16<BM, A_RMAJOR>(la, wm0 + 16 * a, lr, rq);
+      for (int ks = 0; ks < KS; ++ks) {
+        bf16x8 fa[TM], fb[TN];
 #pragma unroll
-      for (int b = 0; b < TN; ++b) fb[b] = frag_read_bf16<BN, B_RMAJOR>(lb, wn0 + 16 * b, lr, rq);
+        for (int a = 0; a < TM; ++a) fa[a] = frag_read_bf16<BM, A_RMAJOR, KS>(la, wm0 + 16 * a, lr, rq, ks);
 #pragma unroll
-      for (int a = 0; a < TM; ++a)
+        for (int b = 0; b < TN; ++b) fb[b] = frag_read_bf16<BN, B_RMAJOR, KS>(lb, wn0 + 16 * b, lr, rq, ks);
 #pragma unroll
-        for (int b = 0; b < TN; ++b)
-          acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[a], fb[b], acc[a][b], 0, 0, 0);
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+          for (int b = 0; b < TN; ++b)
+            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[a], fb[b], acc[a][b], 0, 0, 0);
+      }
     } else {
       f32x4 fa[TM], fb[TN];
 #pragma unroll
@@ -448,26 +504,31 @@ void gemm_kernel(const GemmArgs p) {
     // Invariant at the top of an iteration: LDS[st&1] holds stage st, register set 1 holds stage st+1 (in flight),
     // register set 0 is free. Plain loads stay in flight across __syncthreads(); the scheduling barriers pin the
     // phase order issue -> MFMA -> commit.
+    // DEPTH register sets: at the top of sub-step u of an iteration, LDS[s&1] holds stage s = st+u, set u is free (it held
+    // stage s) and the other DEPTH-1 sets hold stages s+1 .. s+DEPTH-1 in flight.
     aff_fetch(0);
     issue(ra[0], rb[0], 0);
     commit(ra[0], rb[0], 0);
-    issue(ra[DEPTH - 1], rb[DEPTH - 1], 1);
+#pragma unroll
+    for (int d = 1; d < DEPTH; ++d) issue(ra[d], rb[d], d);
     __syncthreads();
-    for (int st = 0; st < nstage; st += 2) {
-      aff_fetch(st + 1);
-      issue(ra[0], rb[0], st + 2);
-      __builtin_amdgcn_sched_barrier(0);
-      compute(st);
-      __builtin_amdgcn_sched_barrier(0);
-      commit(ra[DEPTH - 1], rb[DEPTH - 1], st + 1);
-      __syncthreads();
-      aff_fetch(st + 2);
-      issue(ra[DEPTH - 1], rb[DEPTH - 1], st + 3);
-      __builtin_amdgcn_sched_barrier(0);
-      compute(st + 1);
-      __builtin_amdgcn_sched_barrier(0);
-      commit(ra[0], rb[0], st + 2);
-      __syncthreads();
+    for (int st = 0; st < nstage; st += DEPTH) {
+#pragma unroll
+      for (int u = 0; u < DEPTH; ++u) {
+        if constexpr (EC) {
+          aff_fetch(st + u + 1);
+          compute_ec(st + u, [&] { issue(ra[u], rb[u], st + u + DEPTH); },
+                     [&] { commit(ra[(u + 1) % DEPTH], rb[(u + 1) % DEPTH], st + u + 1); });
+        } else {
+          aff_fetch(st + u + 1);
+          issue(ra[u], rb[u], st + u + DEPTH);
+          __builtin_amdgcn_sched_barrier(0);
+          compute(st + u);
+          __builtin_amdgcn_sched_barrier(0);
+          commit(ra[(u + 1) % DEPTH], rb[(u + 1) % DEPTH], st + u + 1);
+        }
+        __syncthreads();
+      }
     }
   }
 
@@ -740,17 +801,71 @@ int launch(GemmArgs p, int groups, hipStream_t s, int act_dtype, bool w_bf16 = f
   } while (0)
   // FULL: whole tiles and an even number of whole stages per split -> the predication-free instantiation
   const bool full = st16 && p.I % BM == 0 && p.J % BN == 0 && p.rchunk % (2 * bk) == 0 && p.R % p.rchunk == 0;
+  // Deep pipeline (KS = 2: 64-deep stages; PD = 4: four stages in flight) for launches that put at most ~2 workgroups on a
+  // CU: there the round-1 loop kept 16-32 KB per workgroup in flight and fetched at ~16 GB/s per CU (shape table of round 2:
+  // the 256-tile GEMMs of the C = 256 stage ran 32 us against a 7 us HBM/MFMA bound). NSID_GEMM_DEEP="ks,pd[,maxwg]".
+  // Measured on MI355X with cold operands (tools/gemm_bench.py --cold, round 2), 256-512 workgroups per launch:
+  //   forward        : KS = 2, two register sets, early commit with the interleaved schedule: 26.4 -> 18.2 us (16384x256x1024),
+  //                    44.5 -> 27.0 us (8192x512x2048), 15.7 -> 11.9 us (16384x256x512);
+  //   weight gradient: KS = 2 without early commit: 16.4 -> 12.9 us (16384x256x256), 20.8 -> 18.7 us; early commit loses 30 %;
+  //   backward-data  : no deep form wins (the epilogue with addend / BatchNorm sums dominates): round-1 loop kept.
+  // In the TWO-STREAM training step the isolated gains mostly vanish: a workgroup that owns a CU's LDS (120 KB with three
+  // stage buffers) keeps the other view's kernels off that CU, and what the step rewards is little resource-time per
+  // tile, not latency. One-box A/B of the whole step (two repetitions each): round-1 loops 8.52 / 8.52 ms, KS = 2 for
+  // forward + weight gradient 8.41 / 8.43 ms, the same with early commit 8.55 / 8.57 ms -> KS = 2 without early commit is the
+  // default; early commit (NSID_GEMM_DEEP=2,2,512,1) remains for single-stream use (inference, microbenchmarks).
+  static int deep_ks = -1, deep_pd = 0, deep_maxwg = 512, deep_ec = 0;
+  if (deep_ks < 0) {
+    deep_ks = 2; deep_pd = 2;
+    if (const char* e = getenv("NSID_GEMM_DEEP")) {
+      int a = 1, b = 0, c = 512, d = 0;
+      const int n = sscanf(e, "%d,%d,%d,%d", &a, &b, &c, &d);
+      if (n >= 1) deep_ks = a;
+      if (n >= 2) deep_pd = b;
+      if (n >= 3) deep_maxwg = c;
+      if (n >= 4) deep_ec = d;
+    }
+  }
+  // which GEMM kinds take the deep form: bit 0 forward, bit 1 backward-data, bit 2 weight gradient
+  static const int deep_kinds = getenv("NSID_GEMM_DEEP_KINDS") ? atoi(getenv("NSID_GEMM_DEEP_KINDS")) : 5;
+  constexpr int kind_bit = AR ? (BR ? 1 : 2) : 4;
+  const long wgs = (long)tiles * p.rsplit * groups;
+  int ks = 1, pd = 0;
+  if (full && wgs <= deep_maxwg && (deep_ks > 1 || deep_pd > 2) && (deep_kinds & kind_bit)) {
+    ks = deep_ks == 2 ? 2 : 1;
+    pd = deep_pd == 4 ? 4 : (ks == 2 ? 2 : 0);
+    const int need = 32 * ks * (pd ? pd : 2);                     // whole register-set rounds of whole stages
+    if (p.rchunk % need != 0) {                                   // fall back one notch at a time
+      if (pd == 4 && p.rchunk % (32 * ks * 2) == 0) pd = ks == 2 ? 2 : 0;
+      else if (ks == 2 && p.rchunk % (32 * (pd ? pd : 2)) == 0) ks = 1;
+      else { ks = 1; pd = 0; }
+      if (ks == 1 && pd == 2) pd = 0;
+    }
+  }
+  const bool ec = deep_ec != 0 && BM * BN <= 128 * 128 && (AR && BR);   // forward only; three buffers of a 256x128 tile do not fit LDS
+#define NSID_GEMM_DEEP_GO(AFF_, WB_, RELU_)                                                                       \
+  do {                                                                                                            \
+    if constexpr (BM * BN <= 128 * 128) {                                                                         \
+      if (ec && ks == 2 && pd == 4) { NSID_LAUNCH((gemm_kernel<BM, BN, AR, BR, true, true, AFF_, WB_, true, RELU_, 2, 4, true>), grid, dim3(256), 0, s, p); break; } \
+      if (ec && ks == 2) { NSID_LAUNCH((gemm_kernel<BM, BN, AR, BR, true, true, AFF_, WB_, true, RELU_, 2, 2, true>), grid, dim3(256), 0, s, p); break; }            \
+      if (ec && pd == 4) { NSID_LAUNCH((gemm_kernel<BM, BN, AR, BR, true, true, AFF_, WB_, true, RELU_, 1, 4, true>), grid, dim3(256), 0, s, p); break; }            \
+    }                                                                                                             \
+    if (ks == 2 && pd == 4) NSID_LAUNCH((gemm_kernel<BM, BN, AR, BR, true, true, AFF_, WB_, true, RELU_, 2, 4>), grid, dim3(256), 0, s, p); \
+    else if (ks == 2) NSID_LAUNCH((gemm_kernel<BM, BN, AR, BR, true, true, AFF_, WB_, true, RELU_, 2, 2>), grid, dim3(256), 0, s, p);       \
+    else if (pd == 4) NSID_LAUNCH((gemm_kernel<BM, BN, AR, BR, true, true, AFF_, WB_, true, RELU_, 1, 4>), grid, dim3(256), 0, s, p);       \
+    else NSID_LAUNCH((gemm_kernel<BM, BN, AR, BR, true, true, AFF_, WB_, true, RELU_>), grid, dim3(256), 0, s, p);                           \
+  } while (0)
   if constexpr (AR) {
     if (st16 && w_bf16) {
       const bool act_only = CAN_AFF && p.a_scale == nullptr && p.a_slope != 1.f;     // activation on load, no affine
       if (act_only) {
         if constexpr (CAN_AFF) {
           if (!full || p.a_slope != 0.f) return NSID_EINVAL;          // only ReLU on full tiles (the caller checks: ops.py)
-          NSID_LAUNCH((gemm_kernel<BM, BN, AR, BR, true, true, false, true, true, true>), grid, dim3(256), 0, s, p);
+          NSID_GEMM_DEEP_GO(false, true, true);
         }
       } else if (full) {
-        if (aff) NSID_LAUNCH((gemm_kernel<BM, BN, AR, BR, true, true, CAN_AFF, true, true>), grid, dim3(256), 0, s, p);
-        else NSID_LAUNCH((gemm_kernel<BM, BN, AR, BR, true, true, false, true, true>), grid, dim3(256), 0, s, p);
+        if (aff) NSID_GEMM_DEEP_GO(CAN_AFF, true, false);
+        else NSID_GEMM_DEEP_GO(false, true, false);
       } else {
         if (aff) NSID_LAUNCH((gemm_kernel<BM, BN, AR, BR, true, true, CAN_AFF, true>), grid, dim3(256), 0, s, p);
         else NSID_LAUNCH((gemm_kernel<BM, BN, AR, BR, true, true, false, true>), grid, dim3(256), 0, s, p);
@@ -759,10 +874,11 @@ int launch(GemmArgs p, int groups, hipStream_t s, int act_dtype, bool w_bf16 = f
     }
   } else {
     if (st16 && full) {            // weight gradient, bf16 operands
-      NSID_LAUNCH((gemm_kernel<BM, BN, AR, BR, true, true, false, false, true>), grid, dim3(256), 0, s, p);
+      NSID_GEMM_DEEP_GO(false, false, false);
       return nsid_launch_status();
     }
   }
+#undef NSID_GEMM_DEEP_GO
   if (w_bf16) return NSID_EINVAL;
   if (st16) NSID_GEMM_GO(true, true);
   else if (half) NSID_GEMM_GO(true, false);

@@ -22,6 +22,51 @@ SHAPES = [  # (M, Nout, K, groups, affine)
 ]
 
 
+def run_cold(args, M, N, K, G, aff, adt, dev):
+    esz = 2 if adt == torch.bfloat16 else 4
+    per_set = esz * M * G * (2 * K + 2 * N)
+    nb = max(2, int(600e6 // per_set) + 1)
+    xs = [torch.randn(M, G * K, device=dev).to(adt) for _ in range(nb)]
+    douts = [torch.randn(M, G * N, device=dev).to(adt) for _ in range(nb)]
+    outs = [torch.empty(M, G * N, device=dev, dtype=adt) for _ in range(nb)]
+    dins = [torch.empty(M, G * K, device=dev, dtype=adt) for _ in range(nb)]
+    w = torch.randn(G * N, K, device=dev) * K ** -0.5
+    if args.storage == "bf16" and not args.fp32_weights:
+        ops.SHADOWS.register(w, ops.f32_to_bf16(w), owner=w)
+    sc = (1 + 0.1 * torch.randn(G * K, device=dev)) if aff else None
+    sh = (0.1 * torch.randn(G * K, device=dev)) if aff else None
+    dw = torch.zeros(G * N, K, device=dev)
+    act = ops.ACT_RELU if aff else 0
+    runs = {
+        "fwd": lambda i: ops.linear_fwd(xs[i], w, None, M, N, K, G, sc, sh, act, 0, want_stat=not args.no_stat, out=outs[i]),
+        "bwd_data": lambda i: ops.linear_bwd_data(douts[i], w, M, N, K, G, out=dins[i]),
+        "bwd_weight": lambda i: ops.linear_bwd_weight(douts[i], xs[i], dw, M, N, K, G, sc, sh, act),
+    }
+    nbytes = {"fwd": G * (esz * M * K + 2.0 * N * K + esz * M * N), "bwd_data": G * (esz * M * N + 2.0 * N * K + esz * M * K),
+              "bwd_weight": G * (esz * M * N + esz * M * K + 4.0 * N * K)}
+    flops = 2.0 * M * N * K * G
+    line = f"M={M:6d} N={N:5d} K={K:5d} G={G} aff={int(aff)} cold x{nb}"
+    reps = max(args.reps, nb) // nb * nb
+    for name in args.only.split(","):
+        fn = runs[name]
+        for i in range(nb):
+            fn(i)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for r in range(reps):
+                fn(r % nb)
+        g.replay()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        g.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        us = 1e3 * e0.elapsed_time(e1) / reps
+        line += f" | {name} {us:6.1f}us {flops / us / 1e6:5.0f}TF {nbytes[name] / us / 1e3:5.0f}GB/s"
+    print(line, flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reps", type=int, default=20)
@@ -31,6 +76,9 @@ def main():
     ap.add_argument("--no-stat", action="store_true", help="forward GEMM without the BatchNorm statistics epilogue")
     ap.add_argument("--fp32-weights", action="store_true", help="do not use bf16 weight shadows")
     ap.add_argument("--storage", default="bf16", help="activation storage: bf16 (needs --precision bf16) or fp32")
+    ap.add_argument("--cold", action="store_true",
+                    help="rotate over enough copies of the activation operands/outputs (> 600 MB) that no repetition finds "
+                         "its operands in the 256 MB Infinity Cache: inside the training step every operand is cold")
     args = ap.parse_args()
     dev = "cuda"
     ops.set_gemm_precision(args.precision)
@@ -39,6 +87,9 @@ def main():
     if args.shapes:
         shapes = [tuple(int(v) for v in s.split("x")) + (False,) for s in args.shapes.split(",")]
     for M, N, K, G, aff in shapes:
+        if args.cold:
+            run_cold(args, M, N, K, G, aff, adt, dev)
+            continue
         x = torch.randn(M, G * K, device=dev).to(adt)
         w = torch.randn(G * N, K, device=dev) * K ** -0.5
         if args.storage == "bf16" and not args.fp32_weights:
