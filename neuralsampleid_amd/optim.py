@@ -59,7 +59,7 @@ class FusedClipAdam:
         n8 = self.numel                      # a multiple of 8 by construction
         ops.f32_to_bf16(self.flat_p[:n8], self.flat_p16)
         for p in self.params:                # every registered view now holds the conversion of the current weights
-            ops.SHADOWS.mark_fresh(p.data)
+            ops.SHADOWS.mark_fresh(p)        # (the Parameter, not p.data: a .data alias carries its own version counter)
 
     def set_lr(self, lr: float):
         self.hyper[0:1].fill_(lr)

@@ -388,3 +388,31 @@ def test_eval_after_fused_and_graphed_training_sees_current_state(golden, mode):
     finally:
         ops.set_gemm_precision("fp32")
         F_.set_activation_dtype("fp32")
+
+
+def test_weight_shadows_are_not_reconverted_every_step(bf16_mode):
+    """FusedClipAdam refreshes all bf16 weight shadows with ONE launch per step; the per-weight lookups of the GEMM wrappers
+    must then find them fresh (a per-weight conversion launch per GEMM cost 0.3 ms per step when a version-counter mix-up
+    made every lookup miss: 68 conversions per step instead of 7 in the rocprofv3 trace)."""
+    from neuralsampleid_amd import ops
+    from neuralsampleid_amd.optim import FusedClipAdam
+    from neuralsampleid_amd.simclr.ntxent import ntxent_loss
+    model = build(3)
+    model.load_state_dict(synth_state(model.state_dict()))
+    model.to(DEV).train()
+    opt = FusedClipAdam(model.parameters(), lr=1e-4)
+    x = torch.randn(4, 64, 128, device=DEV)
+    calls = []
+    real = ops.f32_to_bf16
+    ops.f32_to_bf16 = lambda src, dst=None: (calls.append(src.numel()), real(src, dst))[1]
+    try:
+        for _ in range(3):
+            calls.clear()
+            opt.zero_grad()
+            _, _, z_i, z_j = model(x, x + 0.1)
+            ntxent_loss(z_i, z_j, GRAFP_CFG).backward()
+            opt.step()
+    finally:
+        ops.f32_to_bf16 = real
+    # one flat refresh + the three downsample layers' packed weights (forward shadow registered per block) x 2 views
+    assert len(calls) <= 8 and max(calls) == opt.numel, calls

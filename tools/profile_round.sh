@@ -1,25 +1,34 @@
 #!/bin/bash
 # The measurement set behind profiles/<name>/ (run on the MI355X box from the repo root):
-#   tools/profile_round.sh r01d_valu_diet
-# PMC passes first (separate runs, no other trace domains), so that the bench line can cite the measured traffic; then the
-# kernel statistics, the per-step trace summary and the default bench run itself. Results land in gpurun_out/<name>/.
+#   tools/profile_round.sh r02a_baseline [train|infer|deep ...]
+# PMC passes first (separate runs, --kernel-trace only beside --pmc), so that the bench line can cite the measured traffic;
+# then the kernel statistics (rocprofv3 --kernel-trace --stats), the per-step trace summary and the un-profiled bench run.
+# Everything lands in gpurun_out/<name>/ (the only directory gpurun brings back); copy the summaries to profiles/<name>/:
+#   mkdir -p profiles/<name> && cp gpurun_out/<name>/{*.json,*.csv,*.txt} profiles/<name>/
 set -e
-name=$1
+name=$1; shift
+modes=${@:-train infer deep}
 out=gpurun_out/$name
-mkdir -p $out profiles/$name
+mkdir -p $out
 export TMPDIR=/tmp
 common="--no-cpu-baseline --no-roofline"
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -- python3 bench.py --steps 2 --warmup 1 $common --no-graph --no-overlap > $out/pmc_fetch.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -- python3 bench.py --steps 2 --warmup 1 $common --no-graph --no-overlap > $out/pmc_write.log 2>&1
-python3 tools/hbm_traffic.py $out/pmc_fetch $out/pmc_write profiles/$name/hbm_traffic.json
-cp profiles/$name/hbm_traffic.json $out/
-rm -rf $out/pmc_fetch $out/pmc_write
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 bench.py --steps 10 --warmup 4 --no-cpu-baseline > $out/bench_under_rocprof.json 2> $out/stats.log
-cp $(find $out/stats -name "*kernel_stats.csv" | head -1) $out/kernel_stats.csv
-rm -rf $out/stats
-# per-step kernel budget of the bf16 step alone (the run above also times the fp32 arithmetic at its end)
-rocprofv3 --kernel-trace --output-format csv -d $out/trace -- python3 bench.py --steps 10 --warmup 4 $common > $out/trace.log 2>&1
-python3 tools/trace_summary.py $out/trace 8 > $out/trace_summary.txt
-rm -rf $out/trace
-python3 bench.py > $out/bench.json 2> $out/bench.log
-tail -c 600 $out/bench.json
+for mode in $modes; do
+  case $mode in
+    train) flags=""; tag="" ;;
+    infer) flags="--mode infer --clips 20480"; tag="_infer" ;;
+    deep)  flags="--deep"; tag="_deep" ;;
+  esac
+  eager="--no-graph --no-overlap"; [ $mode = infer ] && eager=""
+  rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch$tag -- python3 bench.py --steps 2 --warmup 1 $common $eager $flags > $out/pmc_fetch$tag.log 2>&1
+  rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/pmc_write$tag -- python3 bench.py --steps 2 --warmup 1 $common $eager $flags > $out/pmc_write$tag.log 2>&1
+  python3 tools/hbm_traffic.py $out/pmc_fetch$tag $out/pmc_write$tag $out/hbm_traffic$tag.json
+  rm -rf $out/pmc_fetch$tag $out/pmc_write$tag
+  rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats$tag -- python3 bench.py --steps 10 --warmup 4 $common $flags > $out/bench_under_rocprof$tag.json 2> $out/stats$tag.log
+  cp $(find $out/stats$tag -name "*kernel_stats.csv" | head -1) $out/kernel_stats$tag.csv
+  if [ $mode != infer ]; then
+    python3 tools/trace_summary.py $out/stats$tag 8 > $out/trace_summary$tag.txt || true
+  fi
+  rm -rf $out/stats$tag
+  python3 bench.py $flags > $out/bench$tag.json 2> $out/bench$tag.log
+  tail -c 400 $out/bench$tag.json; echo
+done
