@@ -41,6 +41,64 @@ def extract_fingerprints(model, specs: torch.Tensor, batch: int = 1024, out: tor
         model.train(was_training)
 
 
+class GraphedFingerprinter:
+    """Forward-only extraction of FULL micro-batches as one hipGraph replay each: a micro-batch is ~130 kernel launches of
+    10-90 us, so on a slow host the eager Python loop (not the GPU) sets the rate (round 2, MI355X boxes: 4.1 ms per
+    micro-batch of 512 AND of 1024 clips eagerly; 3.5 ms per 1024 clips once the host is out of the way).
+
+        fp = GraphedFingerprinter(model, micro_batch=1024)     # eval mode, captures once (weights are read in place)
+        z = fp(specs)                                          # (S, n_mels, n_frames) -> (S, d); a ragged tail runs eagerly
+
+    The captured kernels read the weights and the folded conv+BatchNorm constants in place: after a change of the weights
+    (training steps, load_state_dict) build a new GraphedFingerprinter."""
+
+    def __init__(self, model, micro_batch: int = 1024, example: torch.Tensor = None):
+        from . import functional, ops
+        self.model, self.mb = model, int(micro_batch)
+        dev = next(model.parameters()).device
+        cfg = model.cfg
+        shape = (self.mb, cfg["n_mels"], cfg["n_frames"]) if example is None else (self.mb,) + tuple(example.shape[1:])
+        self.x = torch.zeros(shape, device=dev)
+        self.d = model.projector[-1].out_features
+        self.epochs = (ops.WEIGHT_EPOCH, ops.STATS_EPOCH)
+        was_training = model.training
+        model.eval()
+        try:
+            with torch.no_grad():
+                if functional.ACT_DTYPE == torch.bfloat16:
+                    ops.register_weight_shadows(model)
+                side = torch.cuda.Stream(device=dev)
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    for _ in range(2):            # builds every cached constant (folded weights, shadows) outside the capture
+                        model._embed(self.x)
+                torch.cuda.current_stream().wait_stream(side)
+                torch.cuda.synchronize()
+                self.graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.graph):
+                    _, self.z = model._embed(self.x)
+        finally:
+            model.train(was_training)
+
+    @torch.no_grad()
+    def __call__(self, specs: torch.Tensor, out: torch.Tensor = None) -> torch.Tensor:
+        from . import ops
+        if (ops.WEIGHT_EPOCH, ops.STATS_EPOCH) != self.epochs:
+            raise RuntimeError("the model's weights or running statistics changed since this graph was captured: "
+                               "build a new GraphedFingerprinter")
+        S = specs.shape[0]
+        if out is None:
+            out = torch.empty((S, self.d), device=specs.device, dtype=torch.float32)
+        full = S // self.mb * self.mb
+        for lo in range(0, full, self.mb):
+            self.x.copy_(specs[lo:lo + self.mb], non_blocking=True)
+            self.graph.replay()
+            out[lo:lo + self.mb].copy_(self.z, non_blocking=True)
+        if full < S:
+            extract_fingerprints(self.model, specs[full:], self.mb, out[full:])
+        return out
+
+
 @torch.no_grad()
 def fingerprints_from_waveform(model, front, wave: torch.Tensor, batch: int = 1024) -> torch.Tensor:
     """mono fp32 waveform on the GPU -> (S, d) fingerprints: log-mel front end (frontend.LogMelFrontEnd, the reference's

@@ -267,9 +267,12 @@ def linear_fwd(x, w, bias, M, Nout, K, groups=1, in_scale=None, in_shift=None, a
     narrow = (Nout <= 64 or (Nout <= 128 and K <= 256 and in_scale is None)) if half else Nout <= 64
     if half and row_tiles(M) * ((Nout + 127) // 128) * groups < 128:
         narrow = True
-    name = "gemm_kernel<128,%d,true,true>" % (64 if narrow else 128)
     esz = x.element_size()
     wop, wdt = _weight(w, dt, K)
+    # csrc/gemm.hip linear_fwd_impl: forward-only work with >= NSID_TALL_MIN (1024) tiles of 128x128 takes 256x128 tiles
+    tall = (not want_stat and dt == BF16 and wdt == BF16 and not narrow and ksplit == 1 and M % 256 == 0 and Nout % 128 == 0
+            and K % 64 == 0 and row_tiles(M) * ((Nout + 127) // 128) * groups >= int(os.environ.get("NSID_TALL_MIN", "1024")))
+    name = "gemm_kernel<%d,%d,true,true>" % (256 if tall else 128, 64 if narrow else 128)
     if in_scale is None and act_in != ACT_NONE:
         # activation on load without an affine: only ReLU on bf16 operands, bf16 weights and whole tiles (csrc/gemm.hip ARELU)
         bn_ = 64 if narrow else 128
@@ -392,8 +395,10 @@ def folded_conv_bn(w2d, bias, gamma, beta, running_mean, running_var, eps=BN_EPS
     src = w2d if source is None else source
     versions = (src.data_ptr(), src._version, None if bias is None else (bias.data_ptr(), bias._version), gamma._version,
                 beta._version, running_mean._version, running_var._version, eps, WEIGHT_EPOCH, STATS_EPOCH)
+    # under stream capture nothing is INSERTED (the constants would be produced by captured work), but an entry made
+    # before the capture is used: the replayed kernels then read the cached constants in place (GraphedFingerprinter)
     cacheable = not torch.cuda.is_current_stream_capturing()
-    e = _FOLDED.get(id(gamma)) if cacheable else None
+    e = _FOLDED.get(id(gamma))
     if e is not None and e[0]() is gamma and e[1] == versions:
         return e[2], e[3]
     with torch.no_grad():
@@ -470,11 +475,11 @@ def bn_eval_affine(gamma, beta, running_mean, running_var, eps=BN_EPS) -> BNAffi
     versions = (gamma._version, beta._version, running_mean._version, running_var._version,
                 beta.data_ptr(), running_mean.data_ptr(), running_var.data_ptr(), WEIGHT_EPOCH, STATS_EPOCH)
     cacheable = not torch.cuda.is_current_stream_capturing()
-    e = _EVAL_AFFINE.get(id(gamma)) if cacheable else None
+    e = _EVAL_AFFINE.get(id(gamma))
     if e is not None and e[0]() is gamma and e[1] == versions and e[2] == eps:
-        if e[4] != _stream():
-            torch.cuda.current_stream().wait_event(e[5])      # produced on another stream
-        return e[3]
+        if e[4] != _stream() and cacheable:
+            torch.cuda.current_stream().wait_event(e[5])      # produced on another stream (a capture starts after a full
+        return e[3]                                           # device synchronisation: nothing to wait for there)
     C = gamma.numel()
     buf = torch.empty((2, C), device=gamma.device, dtype=torch.float32)
     call("nsid_bn_eval_affine", _p(gamma), _p(beta), _p(running_mean), _p(running_var), eps, C, _p(buf[0]),

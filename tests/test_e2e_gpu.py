@@ -530,3 +530,27 @@ def test_graphed_train_step_equals_eager():
 
 
 GRAPH_TOL = {"loss": 1.0, "dp": 10.0, "bn": 1.0}      # PROVISIONAL until measured
+
+
+def test_graphed_fingerprinter_equals_eager_extraction(golden):
+    """fingerprint.GraphedFingerprinter: full micro-batches as hipGraph replays + an eager ragged tail == extract_fingerprints;
+    a weight change after the capture is refused instead of silently fingerprinting with the old weights"""
+    from neuralsampleid_amd.fingerprint import GraphedFingerprinter, extract_fingerprints
+    from neuralsampleid_amd.optim import FusedClipAdam
+    from neuralsampleid_amd.simclr.ntxent import ntxent_loss
+    g = golden("e2e_b8_k3")
+    model = build_model(3).train()
+    x = torch.cat([g.t("x_i"), g.t("x_j"), g.t("x_i")[:3]]).to(DEV)          # 19 clips: 4 full micro-batches of 4 + a tail of 3
+    ref = extract_fingerprints(model, x, batch=4)
+    fp = GraphedFingerprinter(model, micro_batch=4)
+    z = fp(x)
+    assert model.training and z.shape == (19, 128)
+    assert maxerr(z, ref) < 2e-6                                             # same kernels; split-K atomics in the projector
+    assert maxerr(z[:8], g.t("z_i_eval")) < 1e-2                             # and the reference's eval goldens (own kNN)
+    opt = FusedClipAdam(model.parameters(), lr=1e-3)
+    opt.zero_grad()
+    _, _, z_i, z_j = model(x[:8], x[8:16])
+    ntxent_loss(z_i, z_j, GRAFP_CFG).backward()
+    opt.step()
+    with pytest.raises(RuntimeError):
+        fp(x)

@@ -111,6 +111,90 @@ def test_two_rank_step_matches_single_process():
     assert torch.allclose(gz, z_i.detach(), atol=1e-6)                  # rank-major gather == global pair order
 
 
+def _model_state():
+    """state of SimCLR(GraphEncoder 't', k=3) from the reference's key/shape list + the synthetic per-key rule"""
+    import json
+    from synth import synth_tensor
+    with open(os.path.join(ROOT, "tests", "golden", "state_shapes.json")) as f:
+        shapes = {k: tuple(v) for k, v in json.load(f).items()}
+    return {k: synth_tensor(k, torch.empty(s)) for k, s in shapes.items() if "relative_pos" not in k}
+
+
+def _replica_forward(P, x_i, x_j):
+    """one replica's forward on its shard: per-replica BatchNorm statistics (nn.DataParallel, train.py:117-120; no SyncBN)"""
+    plan = R.encoder_plan("t", 3)
+    _, _, z_i, z_j = R.simclr_forward(x_i, x_j, P, GRAFP_CFG, plan, True, R.BNState())
+    return z_i, z_j
+
+
+def _model_worker(rank, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(WORLD),
+                      LOCAL_RANK=str(rank))
+    torch.set_num_threads(2)
+    from neuralsampleid_amd import parallel
+    from synth import synth_clips
+    parallel.init_from_env("gloo")
+    Bg = 4
+    p0, n = parallel.shard_range(Bg, rank, WORLD)
+    x_i, x_j = synth_clips(Bg)
+    P = _model_state()
+    keys = R.trainable_keys(P)
+    for k in keys:
+        P[k].requires_grad_(True)
+    z_i, z_j = _replica_forward(P, x_i[p0:p0 + n], x_j[p0:p0 + n])
+    loss = parallel.dist_ntxent_loss(z_i, z_j, GRAFP_CFG, rows_fn=oracle_rows)      # z all-gather, global-batch negatives
+    loss.backward()
+    flat = torch.cat([P[k].grad.reshape(-1) for k in keys if P[k].grad is not None])
+    parallel.allreduce_gradients(flat, bucket_bytes=16 << 20)                        # SUM over ranks, 16 MB buckets
+    if rank == 0:
+        chk = [float(flat.double().norm()), float(flat.double().sum()), float(flat[::100003].double().abs().sum())]
+        out.put((float(loss.detach()), chk, flat[::4099].tolist()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_step_on_the_real_model_graph():
+    """BASELINE config 3 on CPU: the GraFP model itself (the oracle's graph: 12 Grapher + FFN blocks, train-mode BatchNorm
+    per replica) stepped by two gloo ranks through neuralsampleid_amd/parallel.py — embedding all-gather, rank-local NT-Xent
+    rows over the global batch, bucketed SUM all-reduce of all 18.4 M gradients — equals the single-process evaluation
+    of what nn.DataParallel computes (train.py:117-120: every replica normalises with its own batch statistics, the loss
+    sees the gathered global batch, gradients are summed)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    port = _free_port()
+    procs = [ctx.Process(target=_model_worker, args=(r, port, q)) for r in range(WORLD)]
+    for p in procs:
+        p.start()
+    # single-process reference while the ranks run
+    torch.set_num_threads(4)
+    from synth import synth_clips
+    Bg = 4
+    x_i, x_j = synth_clips(Bg)
+    P = _model_state()
+    keys = R.trainable_keys(P)
+    for k in keys:
+        P[k].requires_grad_(True)
+    zs = [_replica_forward(P, x_i[r * 2:(r + 1) * 2], x_j[r * 2:(r + 1) * 2]) for r in range(WORLD)]
+    loss1 = R.ntxent(torch.cat([z[0] for z in zs]), torch.cat([z[1] for z in zs]), GRAFP_CFG["tau"])
+    loss1.backward()
+    flat1 = torch.cat([P[k].grad.reshape(-1) for k in keys if P[k].grad is not None])
+    deadline = time.time() + 300
+    while q.empty():
+        assert time.time() < deadline and all(p.exitcode in (None, 0) for p in procs), \
+            f"ranks died or hung: {[p.exitcode for p in procs]}"
+        time.sleep(0.2)
+    loss2, chk, sample = q.get()
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert flat1.numel() == 18366856
+    assert abs(loss2 - float(loss1)) < 2e-5
+    n1 = float(flat1.double().norm())
+    assert abs(chk[0] - n1) / n1 < 2e-3, (chk[0], n1)                   # fp32 summation order only (two threads vs four)
+    s1 = flat1[::4099]
+    assert float((torch.tensor(sample) - s1).norm() / s1.norm()) < 2e-2      # early-layer gradients: the fp32 floor of DESIGN.md section 4
+
+
 def _reducer_worker(rank, port, out):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(WORLD),
                       LOCAL_RANK=str(rank))
