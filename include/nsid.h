@@ -163,6 +163,20 @@ int nsid_batched_index_select_bwd(const float* dout, const int32_t* idx, int B, 
 /* ---- Downsample: Conv2d 3x3 stride 2 pad 1 on a width-1 map (encoder/graph_encoder.py:44) ---------------
  * Only kernel column 1 meets data, so it is a 3-tap stride-2 conv along N = one GEMM over gathered rows:
  * col[b*No+n', t*C+c] = x[b*N + 2n'-1+t, c] (0 outside), wp[o, t*C+c] = w[o, c, t, 1]. */
+/* Without im2col (N even): the im2col matrix is a zero-padded strided VIEW of x (row stride 2C, K = 3C, base x - C; the
+ * first C columns of the first output node of every clip are the left padding), read in place by the GEMM's operand loads.
+ *   fwd        : out[B*No][Cout] = col . wp^T + bias (+ BatchNorm partial statistics `stat`, may be NULL); wp as below
+ *   bwd_weight : dwp[Cout][3C] += dout^T . col   (then nsid_unpack_ds_wgrad)
+ *   bwd_data   : dx[2n'] = dout[n'] . W_1,  dx[2n'+1] = dout[n'] . W_2 + dout[n'+1] . W_0  (two GEMMs, no col2im);
+ *                w_odd = [W_2 ; W_0] as (2*Cout, C) from nsid_pack_ds_weight_bwd; wp / w_odd share w_dtype. */
+int nsid_downsample3_fwd(const void* x, int B, int N, int C, const void* wp, int w_dtype, const float* bias, void* out,
+                         int Cout, float* stat, int act_dtype, void* stream);
+int nsid_downsample3_bwd_weight(const void* dout, const void* x, float* dwp /* += */, int B, int N, int C, int Cout,
+                                int act_dtype, void* stream);
+int nsid_downsample3_bwd_data(const void* dout, const void* wp, const void* w_odd, int w_dtype, void* dx, int B, int N,
+                              int C, int Cout, int act_dtype, void* stream);
+int nsid_pack_ds_weight_bwd(const float* w, int Cout, int Cin, float* w_odd, void* stream);
+/* The materialising form (any N): */
 int nsid_im2col3_fwd(const void* x, int B, int N, int C, void* col, int dtype, void* stream);
 int nsid_im2col3_bwd(const void* dcol, int B, int N, int C, void* dx, int dtype, void* stream);
 int nsid_pack_ds_weight(const float* w, int Cout, int Cin, float* wp, void* stream);

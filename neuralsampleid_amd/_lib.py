@@ -34,6 +34,10 @@ SIGNATURES = {
     "nsid_im2col3_fwd": "piiipis",
     "nsid_im2col3_bwd": "piiipis",
     "nsid_pack_ds_weight": "piips",
+    "nsid_pack_ds_weight_bwd": "piips",
+    "nsid_downsample3_fwd": "piiipippipis",
+    "nsid_downsample3_bwd_weight": "pppiiiiis",
+    "nsid_downsample3_bwd_data": "pppipiiiiis",
     "nsid_unpack_ds_wgrad": "piips",
     "nsid_peak_patchify_fwd": "pppiiiiiipipis",
     "nsid_peak_patchify_bwd": "ppppiiiiiiippis",

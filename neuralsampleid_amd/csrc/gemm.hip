@@ -42,6 +42,11 @@ struct GemmArgs {
   const void* bn_r; long bn_ldr;
   const float* bn_scale; const float* bn_shift; const float* bn_mean; const float* bn_invstd; float bn_slope;
   float* bn_partial; long bn_plane; long bn_ld;
+  // Zero-padded strided views (Downsample as a 3-tap stride-2 GEMM over x itself, no im2col): elements of the padded
+  // operand whose row index r satisfies r % pad_period == pad_phase and whose column lies in [pad_c0, pad_c1) read as 0
+  // and are never fetched (they lie in the neighbouring clip or outside the tensor). "row" = i (R-major A) or the
+  // reduction index (i/j-major B); pad_safe = an element offset that is always inside the operand.
+  int pad_period, pad_phase, pad_c0, pad_c1; long pad_safe;
 };
 
 // Precision H = false: fp32 operands, v_mfma_f32_16x16x4_f32, BK = 16 (exact fp32 — the parity path).
@@ -92,10 +97,11 @@ struct StageRegs {
 
 // FULL: the tile and every stage lie inside the operand (host-checked), so there is no predication at all — the bounds
 // logic (compare, select, zero-fill per chunk) is a third of the instructions of a K = 256 tile otherwise.
-template <int ROWS, bool RMAJOR, bool H, bool SRC16, bool FULL, int KS = 1>
+template <int ROWS, bool RMAJOR, bool H, bool SRC16, bool FULL, int KS = 1, bool PAD = false>
 __device__ __forceinline__ void stage_load(StageRegs<ROWS, RMAJOR, H, SRC16, KS>& s, const char* __restrict__ base, long ld,
-                                           int row0, int nrows, int r0, int rend) {
+                                           int row0, int nrows, int r0, int rend, const GemmArgs* pad = nullptr) {
   using G = TileGeom<ROWS, RMAJOR, H, SRC16, KS>;
+  static_assert(!PAD || !FULL, "padded views take the predicated path");
   const int t = threadIdx.x;
 #pragma unroll
   for (int q = 0; q < G::VEC; ++q) {
@@ -104,11 +110,13 @@ __device__ __forceinline__ void stage_load(StageRegs<ROWS, RMAJOR, H, SRC16, KS>
     if (RMAJOR) {
       const int gi = row0 + idx / G::CPR, gr = r0 + (idx % G::CPR) * G::EPC;
       s.ok[q] = FULL || (gi < nrows && gr < rend);    // extents are multiples of the chunk: all-in or all-out
-      off = s.ok[q] ? (long)gi * ld + gr : 0;         // out-of-range chunks read element 0 and are zeroed later
+      if (PAD) s.ok[q] = s.ok[q] && !(gi % pad->pad_period == pad->pad_phase && gr >= pad->pad_c0 && gr < pad->pad_c1);
+      off = s.ok[q] ? (long)gi * ld + gr : (PAD ? pad->pad_safe : 0);   // skipped chunks read a safe element, zeroed later
     } else {
       const int gr = r0 + idx / G::CPC, gc = row0 + (idx % G::CPC) * G::EPC;
       s.ok[q] = FULL || (gr < rend && gc < nrows);
-      off = s.ok[q] ? (long)gr * ld + gc : 0;
+      if (PAD) s.ok[q] = s.ok[q] && !(gr % pad->pad_period == pad->pad_phase && gc >= pad->pad_c0 && gc < pad->pad_c1);
+      off = s.ok[q] ? (long)gr * ld + gc : (PAD ? pad->pad_safe : 0);
     }
     s.v[q] = *reinterpret_cast<const f32x4*>(base + off * G::SSZ);
   }
@@ -279,7 +287,7 @@ __device__ unsigned long long* g_gemm_trace = nullptr;
 // rule (2 sets, 1 for the full-tile forward kernel). The deep forms (KS = 2 and/or PD = 4) are FULL-tile bf16 variants for the
 // shapes that put <= 2 workgroups on a CU, where only bytes in flight per workgroup hide the memory latency.
 template <int BM, int BN, bool A_RMAJOR, bool B_RMAJOR, bool H, bool ST, bool AAFF, bool WB = false, bool FULL = false,
-          bool ARELU = false, int KS = 1, int PD = 0, bool EC = false>
+          bool ARELU = false, int KS = 1, int PD = 0, bool EC = false, int PADX = 0>
 __global__ __launch_bounds__(256, (KS > 1 || PD > 2) ? 1 : ((FULL && WB && BM == 128 && BN == 128 && !AAFF) ? 3 : 2))   // 3 waves/SIMD: <= 168 registers
 void gemm_kernel(const GemmArgs p) {
   unsigned long long* const trace = g_gemm_trace;
@@ -398,8 +406,8 @@ void gemm_kernel(const GemmArgs p) {
         sb.ok[q] = true;
       }
     } else {
-      stage_load<BM, A_RMAJOR, H, SA, FULL, KS>(sa, A, p.lda, i0, p.I, r0, rend);
-      stage_load<BN, B_RMAJOR, H, SB, FULL, KS>(sb, B, p.ldb, j0, p.J, r0, rend);
+      stage_load<BM, A_RMAJOR, H, SA, FULL, KS, PADX == 1>(sa, A, p.lda, i0, p.I, r0, rend, &p);
+      stage_load<BN, B_RMAJOR, H, SB, FULL, KS, PADX == 2>(sb, B, p.ldb, j0, p.J, r0, rend, &p);
     }
   };
   auto aff_fetch = [&](int st) {
@@ -887,9 +895,125 @@ int launch(GemmArgs p, int groups, hipStream_t s, int act_dtype, bool w_bf16 = f
   return nsid_launch_status();
 }
 
+// padded strided views (PADX = 1: left operand, 2: right operand): predicated instantiations only, every arithmetic mode
+template <int BM, int BN, bool AR, bool BR, int PADX>
+int launch_pad(GemmArgs p, int groups, hipStream_t s, int act_dtype, bool w_bf16) {
+  const int tiles = ((p.I + BM - 1) / BM) * ((p.J + BN - 1) / BN);
+  const bool st16 = act_dtype == NSID_BF16;
+  const bool half = g_gemm_precision == NSID_GEMM_BF16 || st16;
+  const int bk = half ? 32 : 16;
+  p.rchunk = (p.rchunk + bk - 1) / bk * bk;
+  p.rsplit = (p.R + p.rchunk - 1) / p.rchunk;
+  p.split_major = p.rsplit > 1 && (p.rsplit % 8) == 0;
+  dim3 grid(p.split_major ? p.rsplit : tiles, p.split_major ? tiles : p.rsplit, groups);
+  if (w_bf16 && !(st16 && AR)) return NSID_EINVAL;
+  if (st16 && w_bf16) {
+    if constexpr (AR)
+      NSID_LAUNCH((gemm_kernel<BM, BN, AR, BR, true, true, false, true, false, false, 1, 0, false, PADX>), grid, dim3(256), 0, s, p);
+  } else if (st16) {
+    NSID_LAUNCH((gemm_kernel<BM, BN, AR, BR, true, true, false, false, false, false, 1, 0, false, PADX>), grid, dim3(256), 0, s, p);
+  } else if (half) {
+    NSID_LAUNCH((gemm_kernel<BM, BN, AR, BR, true, false, false, false, false, false, 1, 0, false, PADX>), grid, dim3(256), 0, s, p);
+  } else {
+    NSID_LAUNCH((gemm_kernel<BM, BN, AR, BR, false, false, false, false, false, false, 1, 0, false, PADX>), grid, dim3(256), 0, s, p);
+  }
+  return nsid_launch_status();
+}
+
 }  // namespace
 
-extern "C" int nsid_version(void) { return 2; }
+extern "C" int nsid_version(void) { return 3; }
+
+// ---- Downsample (Conv2d 3x3 stride 2 pad 1 on a width-1 map, encoder/graph_encoder.py:44) WITHOUT im2col -------------------
+// Only kernel column 1 meets data: out[b*No + n'] = sum_t x[b*N + 2n'-1+t] . W_t (t = 0,1,2; row -1 of a clip is padding).
+// With N even, x row-major and wp[o][t*C + c] = w[o][c][t][1], the im2col matrix is a VIEW of x:
+//   col[m][kk] = xflat[(2m - 1)*C + kk],  kk in [0, 3C): row stride 2C, overlapping rows, base x - C,
+// except that the first C columns of the rows m with m % No == 0 are the left padding (zero; they would alias the previous
+// clip's last row). The three GEMMs below read that view through the padded-operand loads of gemm_kernel.
+extern "C" int nsid_downsample3_fwd(const void* x, int B, int N, int C, const void* wp, int w_dtype, const float* bias,
+                                    void* out, int Cout, float* stat, int act_dtype, void* stream) {
+  NSID_REQUIRE(x && wp && out && B > 0 && N > 0 && N % 2 == 0 && C > 0 && Cout > 0 && NSID_DTYPE_OK(act_dtype));
+  const int ch = act_dtype == NSID_BF16 ? 8 : 4;
+  NSID_REQUIRE(C % ch == 0 && C % 4 == 0 && Cout % ch == 0 && Cout % 4 == 0 && nsid_aligned16(x) && nsid_aligned16(wp) &&
+               nsid_aligned16(out) && NSID_DTYPE_OK(w_dtype) && (w_dtype == NSID_F32 || act_dtype == NSID_BF16));
+  const int No = N / 2, M = B * No;
+  const long esz = act_dtype == NSID_BF16 ? 2 : 4;
+  GemmArgs p{};
+  p.A = static_cast<const char*>(x) - (long)C * esz; p.lda = 2L * C; p.a_goff = 3L * C;
+  p.B = wp; p.ldb = 3L * C; p.b_goff = (long)Cout * 3 * C;
+  p.C = out; p.ldc = Cout; p.c_goff = Cout;
+  p.I = M; p.J = Cout; p.R = 3 * C;
+  p.a_slope = 1.f;
+  p.bias = bias; p.bias_goff = Cout;
+  p.stat = stat; p.stat_ld = Cout; p.stat_plane = (long)nsid_row_tiles(M) * Cout;
+  p.rsplit = 1; p.rchunk = 3 * C;
+  p.pad_period = No; p.pad_phase = 0; p.pad_c0 = 0; p.pad_c1 = C; p.pad_safe = C;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const bool wb = w_dtype == NSID_BF16;
+  if (Cout <= 64) return launch_pad<128, 64, true, true, 1>(p, 1, s, act_dtype, wb);
+  return launch_pad<128, 128, true, true, 1>(p, 1, s, act_dtype, wb);
+}
+
+// dwp[o][kk] += sum_m dout[m][o] * col[m][kk]   (fp32 atomics over row splits, like every weight gradient)
+extern "C" int nsid_downsample3_bwd_weight(const void* dout, const void* x, float* dwp, int B, int N, int C, int Cout,
+                                           int act_dtype, void* stream) {
+  NSID_REQUIRE(dout && x && dwp && B > 0 && N > 0 && N % 2 == 0 && C > 0 && Cout > 0 && NSID_DTYPE_OK(act_dtype));
+  const int ch = act_dtype == NSID_BF16 ? 8 : 4;
+  NSID_REQUIRE(C % ch == 0 && Cout % ch == 0 && nsid_aligned16(dout) && nsid_aligned16(x));
+  const int No = N / 2, M = B * No;
+  const long esz = act_dtype == NSID_BF16 ? 2 : 4;
+  GemmArgs p{};
+  p.A = dout; p.lda = Cout; p.a_goff = Cout;                                   // A[R = m][i = o]
+  p.B = static_cast<const char*>(x) - (long)C * esz; p.ldb = 2L * C; p.b_goff = 3L * C;   // B[R = m][j = kk]: the view
+  p.C = dwp; p.ldc = 3L * C; p.c_goff = (long)Cout * 3 * C;
+  p.I = Cout; p.J = 3 * C; p.R = M;
+  p.b_slope = 1.f;
+  p.atomic_out = 1;
+  p.pad_period = No; p.pad_phase = 0; p.pad_c0 = 0; p.pad_c1 = C; p.pad_safe = C;
+  const long tiles = (long)((Cout + 63) / 64) * ((3 * C + 63) / 64);
+  long S = std::min<long>((M + 1023) / 1024, std::max<long>(1, 1024 / tiles));
+  S = std::max<long>(S, (256 + tiles - 1) / tiles);
+  S = std::min<long>(S, (M + 255) / 256);
+  p.rsplit = (int)std::max<long>(S, 1);
+  p.rchunk = (M + p.rsplit - 1) / p.rsplit;
+  return launch_pad<64, 64, false, false, 2>(p, 1, static_cast<hipStream_t>(stream), act_dtype, false);
+}
+
+// dx[2n'] = dout[n'] . W_1 ; dx[2n'+1] = dout[n'] . W_2 + dout[n'+1] . W_0 (n'+1 inside the clip).
+// w_even = wp + C (row stride 3C: the tap-1 columns), w_odd = [W_2 ; W_0] stacked as (2*Cout, C) (nsid_pack_ds_weight_bwd).
+// The odd rows are ONE GEMM over overlapping rows of dout: A[m][0:2Cout] = doutflat[m*Cout : m*Cout + 2Cout], with the
+// second half masked on the last node of every clip.
+extern "C" int nsid_downsample3_bwd_data(const void* dout, const void* wp, const void* w_odd, int w_dtype, void* dx, int B,
+                                         int N, int C, int Cout, int act_dtype, void* stream) {
+  NSID_REQUIRE(dout && wp && w_odd && dx && B > 0 && N > 0 && N % 2 == 0 && C > 0 && Cout > 0 && NSID_DTYPE_OK(act_dtype));
+  const int ch = act_dtype == NSID_BF16 ? 8 : 4;
+  NSID_REQUIRE(C % ch == 0 && Cout % ch == 0 && nsid_aligned16(dout) && nsid_aligned16(wp) && nsid_aligned16(w_odd) &&
+               nsid_aligned16(dx) && NSID_DTYPE_OK(w_dtype) && (w_dtype == NSID_F32 || act_dtype == NSID_BF16));
+  const int No = N / 2, M = B * No;
+  const long esz = act_dtype == NSID_BF16 ? 2 : 4, wsz = w_dtype == NSID_BF16 ? 2 : 4;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const bool wb = w_dtype == NSID_BF16;
+  GemmArgs p{};
+  p.A = dout; p.lda = Cout; p.a_goff = Cout;
+  p.B = static_cast<const char*>(wp) + (long)C * wsz; p.ldb = 3L * C; p.b_goff = 0;      // B[R = o][j = c] = wp[o][C + c]
+  p.C = dx; p.ldc = 2L * C; p.c_goff = C;
+  p.I = M; p.J = C; p.R = Cout;
+  p.rsplit = 1; p.rchunk = Cout;
+  p.bn_slope = 1.f;
+  int rc = C <= 64 ? launch<128, 64, true, false>(p, 1, s, act_dtype, wb) : launch<128, 128, true, false>(p, 1, s, act_dtype, wb);
+  if (rc != NSID_OK) return rc;
+  GemmArgs q{};
+  q.A = dout; q.lda = Cout; q.a_goff = 2L * Cout;
+  q.B = w_odd; q.ldb = C; q.b_goff = 0;
+  q.C = static_cast<char*>(dx) + (long)C * esz; q.ldc = 2L * C; q.c_goff = C;
+  q.I = M; q.J = C; q.R = 2 * Cout;
+  q.rsplit = 1; q.rchunk = 2 * Cout;
+  q.bn_slope = 1.f;
+  q.pad_period = No; q.pad_phase = No - 1; q.pad_c0 = Cout; q.pad_c1 = 2 * Cout; q.pad_safe = 0;
+  return C <= 64 ? launch_pad<128, 64, true, false, 1>(q, 1, s, act_dtype, wb)
+                 : launch_pad<128, 128, true, false, 1>(q, 1, s, act_dtype, wb);
+}
+
 extern "C" int nsid_debug_gemm_trace(void* buf) {
   return hipMemcpyToSymbol(HIP_SYMBOL(g_gemm_trace), &buf, sizeof(buf)) == hipSuccess ? NSID_OK : NSID_EINVAL;
 }

@@ -66,6 +66,17 @@ __global__ void pack_ds_weight_kernel(const float* __restrict__ w, int Cout, int
     wp[q] = w[((o * Cin + c) * 3 + t) * 3 + 1];     // w[o][c][t][1]
   }
 }
+// backward-data weights of the odd input rows: wb[r][c] = w[o][c][2][1] for r = o < Cout, w[o][c][0][1] for r = Cout + o
+__global__ void pack_ds_weight_bwd_kernel(const float* __restrict__ w, int Cout, int Cin, float* __restrict__ wb) {
+  const long total = 2L * Cout * Cin;
+  for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(q % Cin);
+    const long r = q / Cin;
+    const long o = r % Cout;
+    const int t = r < Cout ? 2 : 0;
+    wb[q] = w[((o * Cin + c) * 3 + t) * 3 + 1];
+  }
+}
 __global__ void unpack_ds_wgrad_kernel(const float* __restrict__ dwp, int Cout, int Cin, float* __restrict__ dw) {
   const long total = (long)Cout * 3 * Cin;
   for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += (long)gridDim.x * blockDim.x) {
@@ -459,6 +470,12 @@ extern "C" int nsid_pack_ds_weight(const float* w, int Cout, int Cin, float* wp,
   NSID_REQUIRE(w && wp && Cout > 0 && Cin > 0);
   NSID_LAUNCH(pack_ds_weight_kernel, dim3(grid_for((long)Cout * 3 * Cin)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), w, Cout, Cin, wp);
+  return nsid_launch_status();
+}
+extern "C" int nsid_pack_ds_weight_bwd(const float* w, int Cout, int Cin, float* wb, void* stream) {
+  NSID_REQUIRE(w && wb && Cout > 0 && Cin > 0);
+  NSID_LAUNCH(pack_ds_weight_bwd_kernel, dim3(grid_for(2L * Cout * Cin)), dim3(256), 0, static_cast<hipStream_t>(stream),
+              w, Cout, Cin, wb);
   return nsid_launch_status();
 }
 extern "C" int nsid_unpack_ds_wgrad(const float* dwp, int Cout, int Cin, float* dw, void* stream) {

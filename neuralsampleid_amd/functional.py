@@ -190,16 +190,20 @@ def conv_bn(x: Tensor, M: int, K: int, Nout: int, w: Tensor, bias: Optional[Tens
     r, stat = ops.linear_fwd(x, ops.w2d(w), bias, M, Nout, K, groups,
                              in_aff.scale if in_aff else None, in_aff.shift if in_aff else None, act_in,
                              ACT_NONE, want_stat=training)
+    return r, bn_affine_from(stat, M, gamma, beta, rm, rv, nbt, training)
+
+
+def bn_affine_from(stat, M, gamma, beta, rm, rv, nbt, training: bool) -> BNAffine:
+    """the affine of the BatchNorm that follows a conv: batch statistics (from the GEMM epilogue's partial sums) when
+    training, running statistics otherwise"""
     if training:
         vo = VIEW_ORDER
         if vo.mode is not None and rm is not None:
             aff, uvar = ops.bn_finalize_deferred(stat, M, gamma, beta)
             vo.pending[vo.mode].append((rm, rv, nbt, aff.mean, uvar))
-        else:
-            aff = ops.bn_finalize(stat, M, gamma, beta, rm, rv, nbt)
-    else:
-        aff = ops.bn_eval_affine(gamma, beta, rm, rv)
-    return r, aff
+            return aff
+        return ops.bn_finalize(stat, M, gamma, beta, rm, rv, nbt)
+    return ops.bn_eval_affine(gamma, beta, rm, rv)
 
 
 # ------------------------------------------------------------------------------------------------ stem
@@ -314,35 +318,50 @@ def ffn_backward(dx2: Tensor, P, S, G) -> Tensor:
 
 # ------------------------------------------------------------------------------------------------ Downsample
 def downsample_forward(x: Tensor, P, S: Optional[dict], B: int, N: int, training: bool) -> Tensor:
+    """Conv2d 3x3 s2 p1 on the (B, C, N, 1) map + BatchNorm (graph_encoder.py:44-50). N even (every GraFP stage): the conv is a
+    GEMM over a zero-padded strided VIEW of x (csrc/gemm.hip nsid_downsample3_*): no im2col matrix is written or read, in
+    either direction. Odd N keeps the materialising form."""
     M, C = x.shape
     Co = P["conv.0.weight"].shape[0]
     No = ops.ds_out_nodes(N)
-    col = ops.im2col3_fwd(x, B, N, C)
+    view = N % 2 == 0
+    col = None if view else ops.im2col3_fwd(x, B, N, C)
     if fold_eval(training, S):   # packed weight with the eval-mode BatchNorm folded in: built once per checkpoint
         gamma, beta, rm, rv, _, _ = _bn(P, S, "conv.1.")
         wf, bf = ops.folded_conv_bn(lambda: ops.pack_ds_weight(P["conv.0.weight"]), P["conv.0.bias"], gamma, beta, rm, rv,
                                     source=P["conv.0.weight"])
+        if view:
+            return ops.downsample3_fwd(x, B, N, C, wf, bf, Co)[0]
         return ops.linear_fwd(col, wf, bf, B * No, Co, 3 * C)[0]
     wp = ops.pack_ds_weight(P["conv.0.weight"])
     if ACT_DTYPE == torch.bfloat16 and S is not None:
         # the packed weight lives until this block's backward: one bf16 conversion serves the forward and the backward-data
         # GEMM (an unregistered weight is converted at every use)
         ops.SHADOWS.register(wp, ops.f32_to_bf16(wp), owner=wp, fresh=True)
-    r, aff = conv_bn(col, B * No, 3 * C, Co, wp, P["conv.0.bias"], _bn(P, S, "conv.1."), training)
+    if view:
+        gamma, beta, rm, rv, nbt, _ = _bn(P, S, "conv.1.")
+        r, stat = ops.downsample3_fwd(x, B, N, C, wp, P["conv.0.bias"], Co, want_stat=training)
+        aff = bn_affine_from(stat, B * No, gamma, beta, rm, rv, nbt, training)
+    else:
+        r, aff = conv_bn(col, B * No, 3 * C, Co, wp, P["conv.0.bias"], _bn(P, S, "conv.1."), training)
     out = ops.bn_apply(r, aff, ACT_NONE)
     if S is not None:
-        S.update(col=col, wp=wp, r=r, aff=aff, B=B, N=N, C=C)
+        S.update(col=col, x=x if view else None, wp=wp, r=r, aff=aff, B=B, N=N, C=C)
         if CHAIN is not None:
-            CHAIN.produce(S, r, aff, ACT_NONE)      # (its own input gradient comes from im2col3_bwd: nothing to fuse)
+            CHAIN.produce(S, r, aff, ACT_NONE)      # (its own input gradient is written by two GEMMs / col2im: nothing to fuse)
     return out
 
 
 def downsample_backward(dout: Tensor, P, S, G) -> Tensor:
-    col, wp, r, aff, B, N, C = (S[k_] for k_ in ("col", "wp", "r", "aff", "B", "N", "C"))
+    col, x, wp, r, aff, B, N, C = (S[k_] for k_ in ("col", "x", "wp", "r", "aff", "B", "N", "C"))
     Mo, Co = r.shape
     dr = ops.bn_backward(dout, r, aff, ACT_NONE, G["conv.1.weight"], G["conv.1.bias"], partial=_link_partial(S))
     _bias_grad_before_bn(dr, G["conv.0.bias"])
     dwp = ops.zeros(wp.shape, wp.device)
+    if col is None:                                  # strided-view form: x is the operand
+        ops.downsample3_bwd_weight(dr, x, dwp, B, N, C, Co)
+        ops.unpack_ds_wgrad(dwp, G["conv.0.weight"])
+        return ops.downsample3_bwd_data(dr, wp, ops.pack_ds_weight_bwd(P["conv.0.weight"]), B, N, C, Co)
     ops.linear_bwd_weight(dr, col, dwp, Mo, Co, 3 * C)
     ops.unpack_ds_wgrad(dwp, G["conv.0.weight"])
     dcol = ops.linear_bwd_data(dr, wp, Mo, Co, 3 * C)

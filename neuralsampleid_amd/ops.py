@@ -583,6 +583,62 @@ def im2col3_bwd(dcol, B, N, C) -> torch.Tensor:
     return dx
 
 
+def downsample3_fwd(x, B, N, C, wp, bias, Cout, want_stat=False):
+    """Conv2d 3x3 s2 p1 on a width-1 map as ONE GEMM over a zero-padded strided view of x (no im2col): (B*N, C) ->
+    (B*N/2, Cout) raw conv output (+ BatchNorm partial statistics). wp: packed weight (Cout, 3C) fp32 (pack_ds_weight)."""
+    _chk(wp, bias)
+    dt = _act(x)
+    No = N // 2
+    M = B * No
+    out = torch.empty((M, Cout), device=x.device, dtype=x.dtype)
+    stat = torch.empty((2, row_tiles(M), Cout), device=x.device, dtype=torch.float32) if want_stat else None
+    wop, wdt = _weight(wp, dt, 3 * C)
+    esz = x.element_size()
+    _timed("gemm_kernel<128,%d,true,true>" % (64 if Cout <= 64 else 128), 2.0 * M * Cout * 3 * C,
+           esz * B * N * C + float(wop.element_size()) * Cout * 3 * C + esz * M * Cout, lambda: call(
+        "nsid_downsample3_fwd", _p(x), B, N, C, _p(wop), wdt, _p(bias), _p(out), Cout, _p(stat), dt, _stream()),
+        (M, Cout, 3 * C, 1))
+    return out, stat
+
+
+def downsample3_bwd_weight(dout, x, dwp, B, N, C, Cout) -> None:
+    """dwp (Cout, 3C) += dout^T col(x), col read as a view of x"""
+    _chk(dwp)
+    dt = _act(dout, x)
+    M = B * (N // 2)
+    esz = x.element_size()
+    _timed("gemm_kernel<64,64,false,false>", 2.0 * M * Cout * 3 * C, esz * (M * Cout + B * N * C) + 4.0 * Cout * 3 * C,
+           lambda: call("nsid_downsample3_bwd_weight", _p(dout), _p(x), _p(dwp), B, N, C, Cout, dt, _stream()),
+           (M, Cout, 3 * C, 1))
+
+
+def downsample3_bwd_data(dout, wp, w_odd, B, N, C, Cout) -> torch.Tensor:
+    """dx (B*N, C) from dout (B*N/2, Cout): even rows one GEMM, odd rows one GEMM over overlapping rows of dout (no col2im)"""
+    _chk(wp, w_odd)
+    dt = _act(dout)
+    dx = torch.empty((B * N, C), device=dout.device, dtype=dout.dtype)
+    wop, wdt = _weight(wp, dt, 3 * C)
+    oop, odt = _weight(w_odd, dt, C)
+    if odt != wdt:                       # both from the same arithmetic mode
+        wop, wdt, oop, odt = wp, F32, w_odd, F32
+    M = B * (N // 2)
+    esz = dout.element_size()
+    _timed("gemm_kernel<128,%d,true,false>" % (64 if C <= 64 else 128), 2.0 * M * Cout * 3 * C,
+           esz * (M * Cout + B * N * C) + float(wop.element_size()) * Cout * 3 * C, lambda: call(
+        "nsid_downsample3_bwd_data", _p(dout), _p(wop), _p(oop), wdt, _p(dx), B, N, C, Cout, dt, _stream()),
+        (M, Cout, 3 * C, 1))
+    return dx
+
+
+def pack_ds_weight_bwd(w) -> torch.Tensor:
+    """(Cout, Cin, 3, 3) -> (2*Cout, Cin): [W_2 ; W_0] of kernel column 1, the right operand of the odd-row backward GEMM"""
+    _chk(w)
+    Cout, Cin = w.shape[0], w.shape[1]
+    wb = torch.empty((2 * Cout, Cin), device=w.device, dtype=torch.float32)
+    call("nsid_pack_ds_weight_bwd", _p(w), Cout, Cin, _p(wb), _stream())
+    return wb
+
+
 def pack_ds_weight(w) -> torch.Tensor:
     _chk(w)
     Cout, Cin = w.shape[0], w.shape[1]

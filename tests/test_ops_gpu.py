@@ -298,6 +298,56 @@ def test_downsample_pieces(ops):
     assert torch.equal(dw.cpu(), ref)
 
 
+@pytest.mark.parametrize("B,N,C,Co,dtype", [(3, 64, 64, 128, "fp32"), (2, 256, 64, 128, "fp32"), (5, 32, 256, 512, "fp32"),
+                                             (3, 64, 64, 128, "bf16"), (4, 128, 128, 256, "bf16"), (256, 64, 256, 512, "bf16")])
+def test_downsample3_strided_view_equals_reference_conv(ops, B, N, C, Co, dtype):
+    """nsid_downsample3_fwd / _bwd_weight / _bwd_data (GEMMs over a zero-padded strided view of x, no im2col) against
+    torch's Conv2d 3x3 stride 2 pad 1 on the (B, C, N, 1) map (encoder/graph_encoder.py:44) in fp64, forward and backward;
+    the clip boundaries (left padding of node 0, no right neighbour for the last output node) are where a view could leak"""
+    from neuralsampleid_amd import functional as F_
+    bf = dtype == "bf16"
+    ops.set_gemm_precision(dtype)
+    try:
+        adt = torch.bfloat16 if bf else torch.float32
+        x = rnd(f"d3x{B}{N}{C}", B * N, C).to(adt)
+        w = rnd(f"d3w{C}{Co}", Co, C, 3, 3) * (3 * C) ** -0.5
+        bias = rnd(f"d3b{Co}", Co)
+        dout = rnd(f"d3d{B}{N}{Co}", B * (N // 2), Co).to(adt)
+        q = (lambda t: t.to(torch.bfloat16).double()) if bf else (lambda t: t.double())
+        x4 = x.double().reshape(B, N, C).transpose(1, 2).unsqueeze(-1).clone().requires_grad_(True)     # (B, C, N, 1)
+        w64 = q(w).requires_grad_(True)
+        ref = torch.nn.functional.conv2d(x4, w64, bias.double(), stride=2, padding=1)                  # (B, Co, N/2, 1)
+        ref.backward(dout.double().reshape(B, N // 2, Co).transpose(1, 2).unsqueeze(-1))
+        ref_rows = ref.detach().squeeze(-1).transpose(1, 2).reshape(B * (N // 2), Co)
+        wp = ops.pack_ds_weight(w.to(DEV))
+        out, stat = ops.downsample3_fwd(x.to(DEV), B, N, C, wp, bias.to(DEV), Co, want_stat=True)
+        tol = 2.5e-3 if bf else 2e-4
+        assert out.dtype == adt
+        err = float((out.double().cpu() - ref_rows).norm() / ref_rows.norm())
+        assert err < tol, err
+        tiles = ops.row_tiles(B * (N // 2))
+        pad = torch.zeros(tiles * 128 - ref_rows.shape[0], Co, dtype=torch.float64)
+        close(stat[0], torch.cat([ref_rows, pad]).reshape(tiles, 128, Co).sum(1), tol=1e-3 if bf else 5e-4, what="stat")
+        # the im2col form computes the same thing
+        col = ops.im2col3_fwd(x.to(DEV), B, N, C)
+        out2, _ = ops.linear_fwd(col, wp, bias.to(DEV), B * (N // 2), Co, 3 * C)
+        assert float((out.double() - out2.double()).norm() / out2.double().norm()) < (4e-3 if bf else 1e-5)
+        # weight gradient (fp32 accumulation; only kernel column 1 receives any)
+        dwp = torch.zeros(Co, 3 * C, device=DEV)
+        ops.downsample3_bwd_weight(dout.to(DEV), x.to(DEV), dwp, B, N, C, Co)
+        gw = w64.grad[:, :, :, 1].permute(0, 2, 1).reshape(Co, 3 * C)
+        assert float((dwp.double().cpu() - gw).norm() / gw.norm()) < (1e-4 if bf else 3e-4)
+        assert float(w64.grad[:, :, :, 0].abs().max()) == 0.0 and float(w64.grad[:, :, :, 2].abs().max()) == 0.0
+        # input gradient
+        dx = ops.downsample3_bwd_data(dout.to(DEV), wp, ops.pack_ds_weight_bwd(w.to(DEV)), B, N, C, Co)
+        gx = x4.grad.squeeze(-1).transpose(1, 2).reshape(B * N, C)
+        assert dx.dtype == adt and float((dx.double().cpu() - gx).norm() / gx.norm()) < tol
+        first = torch.arange(B) * N                         # node 0 of every clip: only tap 1 of output node 0 reaches it
+        assert float((dx.double().cpu()[first] - gx[first]).abs().max()) < tol * float(gx.abs().max()) * 4
+    finally:
+        ops.set_gemm_precision("fp32")
+
+
 def test_peak_patchify_golden(ops, golden):
     g = golden("peak_b8")
     w = synth_tensor("peak_extractor.convs.0.weight", torch.empty(8, 3, 4, 8))

@@ -1,3 +1,5 @@
-for mb in 512 1024 2048 4096; do
-  python bench.py --mode infer --micro-batch $mb --no-cpu-baseline --no-roofline 2>/dev/null | python -c "import sys,json; d=json.load(sys.stdin); print('infer mb $mb', d['value'], d['ms_per_step'])"
+python -m pytest tests/test_ops_gpu.py -q -k "downsample" 2>&1 | tail -15
+python -m pytest tests -m gpu -q 2>&1 | tail -3
+for rep in 1 2; do
+  python bench.py --no-cpu-baseline --no-roofline 2>&1 >/dev/null | grep timed
 done
