@@ -51,6 +51,9 @@ int nsid_debug_knn_trace(void* device_buf);
 /* process-wide arithmetic of the nsid_linear_* GEMMs (BASELINE config 2 names bf16 compute); returns NSID_OK/EINVAL */
 int nsid_set_gemm_precision(int mode);
 int nsid_get_gemm_precision(void);
+/* tuning: smallest number of 128x128 output tiles for which nsid_linear_fwd (bf16 storage, bf16 weights, whole tiles) takes
+   the 8-wave 256x128-tile kernel; 0 = never (default; env NSID_W8_MIN sets the initial value) */
+int nsid_set_gemm_w8_min(int tiles);
 /* number of NSID_ROW_TILE row tiles of an M-row matrix: size of the partial-statistics buffers */
 int nsid_row_tiles(int M);
 

@@ -14,6 +14,7 @@ LIB_PATH = os.environ.get("NSID_LIB") or os.path.join(_PKG, "libnsid_hip.so")   
 # signature letters: p = device pointer, i = int, l = long, z = size_t, f = float, s = stream (void*)
 SIGNATURES = {
     "nsid_set_gemm_precision": "i",
+    "nsid_set_gemm_w8_min": "i",
     "nsid_linear_fwd": "pipippiiiiippiipiis",
     "nsid_linear_fwd_res": "pipippipiiiiippiis",
     "nsid_linear_bwd_data": "pipipipiiiiiis",

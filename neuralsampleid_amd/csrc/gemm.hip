@@ -57,7 +57,7 @@ template <bool H> struct Prec { static constexpr int BK = H ? 32 : 16; static co
 // KS: 32-deep MFMA sub-steps per stage of the bf16 path (BK = 32*KS). KS = 2 doubles the bytes a workgroup keeps in flight
 // and halves the barriers per reduction element: the GEMMs with <= 2 workgroups per CU (the C = 256 / 512 stages: 256-512
 // tiles) were fetching at 16 GB/s per CU against the 60-70 GB/s the L2 -> LDS path delivers (round-2 shape table).
-template <int ROWS, bool RMAJOR, bool H, bool SRC16 = false, int KS = 1>
+template <int ROWS, bool RMAJOR, bool H, bool SRC16 = false, int KS = 1, int NT = 256>
 struct TileGeom {
   static_assert(KS == 1 || H, "deeper stages exist on the bf16 path only");
   static constexpr int BK = Prec<H>::BK * KS, ESZ = Prec<H>::ESZ;
@@ -78,7 +78,8 @@ struct TileGeom {
   // SRC16: the operand is stored as bf16 in HBM -> one 16-byte load carries 8 elements instead of 4
   static constexpr int EPC = SRC16 ? 8 : 4;             // elements per 16-byte source chunk
   static constexpr int SSZ = SRC16 ? 2 : 4;             // source element size
-  static constexpr int VEC = ROWS * BK / EPC / 256;     // 16-byte chunks per thread per stage
+  static constexpr int VEC = ROWS * BK / EPC / NT;      // 16-byte chunks per thread per stage (NT threads per workgroup)
+  static_assert(ROWS * BK / EPC % NT == 0, "a stage is a whole number of chunks per thread");
   static constexpr int CPR = BK / EPC;                  // chunks per row of an R-major tile
   static constexpr int CPC = ROWS / EPC;                // chunks per (reduction) row of an i/j-major tile
   static_assert(!SRC16 || H, "bf16 storage implies the bf16 MFMA path");
@@ -88,24 +89,24 @@ struct TileGeom {
 // (issue early / write late): stage_load only ISSUES the 16-byte loads; stage_store, which runs after the MFMAs,
 // applies affine + activation, zero-fills out-of-range chunks, rounds to bf16 in the H path, and writes LDS.
 // A bf16-stored operand without affine is copied chunk-for-chunk (its HBM image IS the LDS image).
-template <int ROWS, bool RMAJOR, bool H, bool SRC16, int KS = 1>
+template <int ROWS, bool RMAJOR, bool H, bool SRC16, int KS = 1, int NT = 256>
 struct StageRegs {
-  static constexpr int VEC = TileGeom<ROWS, RMAJOR, H, SRC16, KS>::VEC;
+  static constexpr int VEC = TileGeom<ROWS, RMAJOR, H, SRC16, KS, NT>::VEC;
   f32x4 v[VEC];      // raw 16-byte chunks (4 fp32 or 8 bf16)
   bool ok[VEC];
 };
 
 // FULL: the tile and every stage lie inside the operand (host-checked), so there is no predication at all — the bounds
 // logic (compare, select, zero-fill per chunk) is a third of the instructions of a K = 256 tile otherwise.
-template <int ROWS, bool RMAJOR, bool H, bool SRC16, bool FULL, int KS = 1, bool PAD = false>
-__device__ __forceinline__ void stage_load(StageRegs<ROWS, RMAJOR, H, SRC16, KS>& s, const char* __restrict__ base, long ld,
+template <int ROWS, bool RMAJOR, bool H, bool SRC16, bool FULL, int KS = 1, bool PAD = false, int NT = 256>
+__device__ __forceinline__ void stage_load(StageRegs<ROWS, RMAJOR, H, SRC16, KS, NT>& s, const char* __restrict__ base, long ld,
                                            int row0, int nrows, int r0, int rend, const GemmArgs* pad = nullptr) {
-  using G = TileGeom<ROWS, RMAJOR, H, SRC16, KS>;
+  using G = TileGeom<ROWS, RMAJOR, H, SRC16, KS, NT>;
   static_assert(!PAD || !FULL, "padded views take the predicated path");
   const int t = threadIdx.x;
 #pragma unroll
   for (int q = 0; q < G::VEC; ++q) {
-    const int idx = t + 256 * q;
+    const int idx = t + NT * q;
     long off;
     if (RMAJOR) {
       const int gi = row0 + idx / G::CPR, gr = r0 + (idx % G::CPR) * G::EPC;
@@ -125,13 +126,13 @@ __device__ __forceinline__ void stage_load(StageRegs<ROWS, RMAJOR, H, SRC16, KS>
 // reduction-indexed affine (producer BatchNorm) of an R-major operand for the stage that starts at r0. VMEM completes in
 // order, so these small loads must be issued BEFORE the operand loads of a later stage: issued after them, the first
 // use would wait for the whole prefetch (vmcnt is positional) and collapse the pipeline.
-template <int ROWS, bool H, bool SRC16, int KS = 1>
+template <int ROWS, bool H, bool SRC16, int KS = 1, int NT = 256>
 __device__ __forceinline__ void affine_prefetch(f32x4* sc, f32x4* sh, int r0, int rend, const float* scale,
                                                 const float* shift) {
-  using G = TileGeom<ROWS, true, H, SRC16, KS>;
+  using G = TileGeom<ROWS, true, H, SRC16, KS, NT>;
 #pragma unroll
   for (int q = 0; q < G::VEC; ++q) {
-    const int gr = r0 + ((threadIdx.x + 256 * q) % G::CPR) * G::EPC;
+    const int gr = r0 + ((threadIdx.x + NT * q) % G::CPR) * G::EPC;
     const int ga = gr < rend ? gr : 0;
 #pragma unroll
     for (int e = 0; e < G::EPC; e += 4) {        // raw float4 registers: nothing consumes them before the commit
@@ -142,13 +143,13 @@ __device__ __forceinline__ void affine_prefetch(f32x4* sc, f32x4* sh, int r0, in
 }
 
 // column-indexed affine of an i/j-major operand is the same for every stage: fetched once per kernel
-template <int ROWS, bool H, bool SRC16, int KS = 1>
+template <int ROWS, bool H, bool SRC16, int KS = 1, int NT = 256>
 __device__ __forceinline__ void colaffine_load(f32x4* sc, f32x4* sh, int row0, int nrows, const float* scale,
                                                const float* shift) {
-  using G = TileGeom<ROWS, false, H, SRC16, KS>;
+  using G = TileGeom<ROWS, false, H, SRC16, KS, NT>;
 #pragma unroll
   for (int q = 0; q < G::VEC; ++q) {
-    const int cv = ((threadIdx.x + 256 * q) % G::CPC) * G::EPC;
+    const int cv = ((threadIdx.x + NT * q) % G::CPC) * G::EPC;
     const int gc = row0 + cv < nrows ? row0 + cv : 0;
 #pragma unroll
     for (int e = 0; e < G::EPC; e += 4) {
@@ -168,14 +169,14 @@ __device__ __forceinline__ f32x4 relu_bf16x8(f32x4 raw) {
   return __builtin_bit_cast(f32x4, h);
 }
 
-template <int ROWS, bool RMAJOR, bool H, bool SRC16, bool RELU16 = false, int KS = 1>
-__device__ __forceinline__ void stage_store(char* lds, const StageRegs<ROWS, RMAJOR, H, SRC16, KS>& s, bool affine,
+template <int ROWS, bool RMAJOR, bool H, bool SRC16, bool RELU16 = false, int KS = 1, int NT = 256>
+__device__ __forceinline__ void stage_store(char* lds, const StageRegs<ROWS, RMAJOR, H, SRC16, KS, NT>& s, bool affine,
                                             float slope, const f32x4* csc, const f32x4* csh) {
-  using G = TileGeom<ROWS, RMAJOR, H, SRC16, KS>;
+  using G = TileGeom<ROWS, RMAJOR, H, SRC16, KS, NT>;
   const int t = threadIdx.x;
 #pragma unroll
   for (int q = 0; q < G::VEC; ++q) {
-    const int idx = t + 256 * q;
+    const int idx = t + NT * q;
     const int lo = RMAJOR ? (idx / G::CPR) * G::STRIDE + (idx % G::CPR) * G::EPC * G::ESZ
                           : (idx / G::CPC) * G::STRIDE + ((idx / G::CPC) >> 3) * G::SHIFT8 +
                                 (idx % G::CPC) * G::EPC * G::ESZ;
@@ -286,9 +287,12 @@ __device__ unsigned long long* g_gemm_trace = nullptr;
 // KS / PD: 32-deep sub-steps per stage and register sets (= stages in flight) of the pipelined loop; PD = 0 keeps the round-1
 // rule (2 sets, 1 for the full-tile forward kernel). The deep forms (KS = 2 and/or PD = 4) are FULL-tile bf16 variants for the
 // shapes that put <= 2 workgroups on a CU, where only bytes in flight per workgroup hide the memory latency.
+// NW: waves per workgroup, laid out (NW/2) x 2 over the tile. NW = 8 on 256x128 tiles gives every wave the 64x64 sub-tile
+// of the 4-wave 128x128 kernel while a stage moves a quarter fewer operand bytes per flop, at two workgroups = 16 waves
+// per CU (the 4-wave 256x128 form needs 201 registers: 8 waves per CU).
 template <int BM, int BN, bool A_RMAJOR, bool B_RMAJOR, bool H, bool ST, bool AAFF, bool WB = false, bool FULL = false,
-          bool ARELU = false, int KS = 1, int PD = 0, bool EC = false, int PADX = 0>
-__global__ __launch_bounds__(256, (KS > 1 || PD > 2) ? 1 : ((FULL && WB && BM == 128 && BN == 128 && !AAFF) ? 3 : 2))   // 3 waves/SIMD: <= 168 registers
+          bool ARELU = false, int KS = 1, int PD = 0, bool EC = false, int PADX = 0, int NW = 4>
+__global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : ((KS > 1 || PD > 2) ? 1 : ((FULL && WB && BM == 128 && BN == 128 && !AAFF) ? 3 : 2)))   // waves per SIMD
 void gemm_kernel(const GemmArgs p) {
   unsigned long long* const trace = g_gemm_trace;
   unsigned long long t_start = 0, t_loop = 0;
@@ -298,13 +302,18 @@ void gemm_kernel(const GemmArgs p) {
   static_assert(!ARELU || (ST && A_RMAJOR && B_RMAJOR && !AAFF && FULL), "ReLU-on-load is a forward, full-tile, bf16 variant");
   static_assert((KS == 1 && PD == 0) || (FULL && H && ST), "the deep pipelines are full-tile bf16-storage variants");
   static_assert(!EC || PD >= 2, "early commit rides with the deep pipelines");
-  using GA = TileGeom<BM, A_RMAJOR, H, SA, KS>;
-  using GB = TileGeom<BN, B_RMAJOR, H, SB, KS>;
+  static_assert(NW == 4 || NW == 8, "4 waves as 2x2 or 8 waves as 4x2");
+  constexpr int NT = 64 * NW, WROWS = NW / 2;
+  using GA = TileGeom<BM, A_RMAJOR, H, SA, KS, NT>;
+  using GB = TileGeom<BN, B_RMAJOR, H, SB, KS, NT>;
   constexpr int BK = Prec<H>::BK * KS;
-  constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 16, TN = WN / 16;
+  constexpr int WM = BM / WROWS, WN = BN / 2, TM = WM / 16, TN = WN / 16;
+  // BatchNorm partial sums are per NSID_ROW_TILE = 128 rows: a tile of BM rows covers STILES of them, each made of WPT wave-rows
+  constexpr int STILES = BM >= 128 ? BM / 128 : 1, WPT = WROWS / STILES;
   constexpr int STAGE = GA::BYTES + GB::BYTES;
-  constexpr int OUT_STAGE = 4 * 32 * (WN + 4) * 4      // epilogue transpose buffers (4 waves x 32 rows), bytes
-                            + 16 * BN * 4;             // + parked BatchNorm sums [2][2 wave-rows][4 row groups][BN]
+  constexpr int RB = NW == 8 ? 16 : 32;                // rows a wave transposes through LDS at a time (epilogue)
+  constexpr int OUT_STAGE = NW * RB * (WN + 4) * 4     // epilogue transpose buffers (one per wave x RB rows), bytes
+                            + 2 * WROWS * 4 * BN * 4;  // + parked BatchNorm sums [2][wave-rows][4 row groups][BN]
   // EC (early commit): THREE stage buffers, so that stage s+1 can be written to LDS while stage s is still being read: the
   // loop then issues the fragment reads of stage s, commits stage s+1 (its waits and ds_writes run under the read latency)
   // and only then starts the MFMAs — in the two-buffer order (MFMA, then commit, then barrier) a wave's LDS-read latency,
@@ -355,7 +364,7 @@ void gemm_kernel(const GemmArgs p) {
   constexpr bool a_aff = AAFF;
   const bool b_aff = !B_RMAJOR && b_sc != nullptr;
   f32x4 bcs[GB::VEC * GB::EPC / 4], bch[GB::VEC * GB::EPC / 4];
-  if (b_aff) colaffine_load<BN, H, SB, KS>(bcs, bch, j0, p.J, b_sc, b_sh);
+  if (b_aff) colaffine_load<BN, H, SB, KS, NT>(bcs, bch, j0, p.J, b_sc, b_sh);
   const int nstage = (rend - rbeg + BK - 1) / BK;
 
   // Register prefetch depth: fp32 MFMA blocks (64 x 32 cycles) cover one memory round trip, so one stage in flight
@@ -366,8 +375,8 @@ void gemm_kernel(const GemmArgs p) {
   // are resident either way, the loop is bound by the L2 -> LDS rate, ~53 GB/s per CU, not by load latency).
   constexpr int DEPTH = PD > 0 ? PD : ((H && !(FULL && WB && !AAFF && BN == 128 && A_RMAJOR && B_RMAJOR)) ? 2 : 1);
   static_assert(DEPTH == 1 || DEPTH == 2 || DEPTH == 4, "the unrolled loop body needs an even number of register sets");
-  StageRegs<BM, A_RMAJOR, H, SA, KS> ra[DEPTH];
-  StageRegs<BN, B_RMAJOR, H, SB, KS> rb[DEPTH];
+  StageRegs<BM, A_RMAJOR, H, SA, KS, NT> ra[DEPTH];
+  StageRegs<BN, B_RMAJOR, H, SB, KS, NT> rb[DEPTH];
 
   f32x4 acs[GA::VEC * GA::EPC / 4], ach[GA::VEC * GA::EPC / 4];   // reduction-indexed affine of the stage being committed
   // FULL tiles address a stage as (uniform 64-bit base in SGPRs) + (32-bit lane offset fixed for the whole kernel): the
@@ -378,13 +387,13 @@ void gemm_kernel(const GemmArgs p) {
   if constexpr (FULL) {
 #pragma unroll
     for (int q = 0; q < GA::VEC; ++q) {
-      const int idx = threadIdx.x + 256 * q;
+      const int idx = threadIdx.x + NT * q;
       voa[q] = A_RMAJOR ? (unsigned)(((idx / GA::CPR) * (int)p.lda + (idx % GA::CPR) * GA::EPC) * GA::SSZ)
                         : (unsigned)(((idx / GA::CPC) * (int)p.lda + (idx % GA::CPC) * GA::EPC) * GA::SSZ);
     }
 #pragma unroll
     for (int q = 0; q < GB::VEC; ++q) {
-      const int idx = threadIdx.x + 256 * q;
+      const int idx = threadIdx.x + NT * q;
       vob[q] = B_RMAJOR ? (unsigned)(((idx / GB::CPR) * (int)p.ldb + (idx % GB::CPR) * GB::EPC) * GB::SSZ)
                         : (unsigned)(((idx / GB::CPC) * (int)p.ldb + (idx % GB::CPC) * GB::EPC) * GB::SSZ);
     }
@@ -406,17 +415,17 @@ void gemm_kernel(const GemmArgs p) {
         sb.ok[q] = true;
       }
     } else {
-      stage_load<BM, A_RMAJOR, H, SA, FULL, KS, PADX == 1>(sa, A, p.lda, i0, p.I, r0, rend, &p);
-      stage_load<BN, B_RMAJOR, H, SB, FULL, KS, PADX == 2>(sb, B, p.ldb, j0, p.J, r0, rend, &p);
+      stage_load<BM, A_RMAJOR, H, SA, FULL, KS, PADX == 1, NT>(sa, A, p.lda, i0, p.I, r0, rend, &p);
+      stage_load<BN, B_RMAJOR, H, SB, FULL, KS, PADX == 2, NT>(sb, B, p.ldb, j0, p.J, r0, rend, &p);
     }
   };
   auto aff_fetch = [&](int st) {
-    if constexpr (AAFF) affine_prefetch<BM, H, SA, KS>(acs, ach, rbeg + st * BK, rend, a_sc, a_sh);
+    if constexpr (AAFF) affine_prefetch<BM, H, SA, KS, NT>(acs, ach, rbeg + st * BK, rend, a_sc, a_sh);
   };
   auto commit = [&](const auto& sa, const auto& sb, int st) {
     char* dst = lds_raw + (EC ? st % 3 : (st & 1)) * STAGE;
-    stage_store<BM, A_RMAJOR, H, SA, ARELU, KS>(dst, sa, a_aff, p.a_slope, acs, ach);
-    stage_store<BN, B_RMAJOR, H, SB, false, KS>(dst + GA::BYTES, sb, b_aff, p.b_slope, bcs, bch);
+    stage_store<BM, A_RMAJOR, H, SA, ARELU, KS, NT>(dst, sa, a_aff, p.a_slope, acs, ach);
+    stage_store<BN, B_RMAJOR, H, SB, false, KS, NT>(dst + GA::BYTES, sb, b_aff, p.b_slope, bcs, bch);
   };
   // early-commit form of one stage: the fragment reads of stage st, the global loads of stage st+DEPTH (`loads()`), the commit
   // of stage st+1 (`between()`) and the MFMAs of stage st are ONE scheduling region, and the sched_group_barrier sequence
@@ -575,7 +584,7 @@ void gemm_kernel(const GemmArgs p) {
     // Stores go through LDS so that every lane writes 16 contiguous bytes of an output row (4-byte stores from the
     // accumulator layout are store-issue bound). Each wave transposes its own 64 x WN sub-tile, 32 rows at a time.
     constexpr int OLD = WN + 4;                  // staggers rq groups over the banks, keeps rows 16-B aligned
-    float* ost = lds + wave * (32 * OLD);        // 4 waves x 32 x (WN+4) floats <= one stage buffer
+    float* ost = lds + wave * (RB * OLD);        // one RB x (WN+4) float buffer per wave
     constexpr int OE = SC ? 8 : 4;               // output elements per lane per store (16 bytes either way)
     constexpr int OSZ = SC ? 2 : 4;
     constexpr int Q_PER_ROW = WN / OE, ROWS_PER_PASS = 64 / Q_PER_ROW;
@@ -587,7 +596,7 @@ void gemm_kernel(const GemmArgs p) {
     if (p.stat != nullptr) {
       // BatchNorm partial statistics of (acc + bias) from the accumulator registers, parked in LDS behind the transpose
       // buffers BEFORE the store loop: its barrier publishes them and the stores hide the LDS latency
-      float* red = lds + 4 * 32 * OLD;       // [2 sums][2 wave-rows][4 row groups][BN]
+      float* red = lds + NW * RB * OLD;      // [2 sums][wave-rows][4 row groups][BN]
 #pragma unroll
       for (int b = 0; b < TN; ++b) {
         const bool jok = FULL || j0 + wn0 + 16 * b + lr < p.J;
@@ -605,8 +614,8 @@ void gemm_kernel(const GemmArgs p) {
           q2 += lo * lo; q2 += hi * hi;
         }
         const int c = wn0 + 16 * b + lr;
-        red[((0 * 2 + (wave >> 1)) * 4 + rq) * BN + c] = s2[0] + s2[1];
-        red[((1 * 2 + (wave >> 1)) * 4 + rq) * BN + c] = q2[0] + q2[1];
+        red[((0 * WROWS + (wave >> 1)) * 4 + rq) * BN + c] = s2[0] + s2[1];
+        red[((1 * WROWS + (wave >> 1)) * 4 + rq) * BN + c] = q2[0] + q2[1];
       }
     }
     // fused BatchNorm-backward column sums (backward-data, bf16 output): g = dy * act'(scale*r+shift), xhat = (r-mean)*invstd
@@ -636,13 +645,14 @@ void gemm_kernel(const GemmArgs p) {
     // once. Loaded inside the pass they were two dependent HBM round trips per pass: 8 passes, one workgroup per CU and cold
     // caches made that epilogue 12.6 us behind a 19 us main loop (tools/gemm_trace.py --addend --bn 1 --cold).
     constexpr bool CAN_ADD = A_RMAJOR;      // backward-data (residual gradient) and forward (residual stream, nsid_linear_fwd_res)
-    constexpr int PPH = 32 / ROWS_PER_PASS, NPASS = (TM / 2) * PPH;
+    constexpr int PPH = RB / ROWS_PER_PASS, NPASS = (WM / RB) * PPH;
+    static_assert(RB % ROWS_PER_PASS == 0 && WM % RB == 0, "a transpose batch is whole store passes");
     f32x4 pre_a[CAN_ADD ? NPASS : 1], pre_r[CAN_BNRED ? NPASS : 1];
     if constexpr (CAN_ADD) {
       if (p.addend) {
 #pragma unroll
         for (int q = 0; q < NPASS; ++q) {
-          const int ib = i0 + wm0 + 32 * (q / PPH) + (q % PPH) * ROWS_PER_PASS;
+          const int ib = i0 + wm0 + RB * (q / PPH) + (q % PPH) * ROWS_PER_PASS;
           const bool ok = (FULL || ib + orow < p.I) && jqok;
           pre_a[q] = *reinterpret_cast<const f32x4*>(Ab + (ok ? ((long)ib * p.ldadd + (j0 + wn0)) * OSZ + lo_a : 0));
         }
@@ -652,7 +662,7 @@ void gemm_kernel(const GemmArgs p) {
       if (bnred) {
 #pragma unroll
         for (int q = 0; q < NPASS; ++q) {
-          const int ib = i0 + wm0 + 32 * (q / PPH) + (q % PPH) * ROWS_PER_PASS;
+          const int ib = i0 + wm0 + RB * (q / PPH) + (q % PPH) * ROWS_PER_PASS;
           const bool ok = (FULL || ib + orow < p.I) && jqok;
           pre_r[q] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(p.bn_r) +
                                                      (ok ? ((long)ib * p.bn_ldr + g * p.c_goff + (j0 + wn0)) * 2 + lo_r : 0));
@@ -660,19 +670,19 @@ void gemm_kernel(const GemmArgs p) {
       }
     }
 #pragma unroll
-    for (int h = 0; h < TM / 2; ++h) {
+    for (int h = 0; h < WM / RB; ++h) {
 #pragma unroll
-      for (int a2 = 0; a2 < 2; ++a2)
+      for (int a2 = 0; a2 < RB / 16; ++a2)
 #pragma unroll
         for (int b = 0; b < TN; ++b)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) ost[(16 * a2 + 4 * rq + r) * OLD + 16 * b + lr] = acc[2 * h + a2][b][r];
+          for (int r = 0; r < 4; ++r) ost[(16 * a2 + 4 * rq + r) * OLD + 16 * b + lr] = acc[(RB / 16) * h + a2][b][r];
       // no workgroup barrier: a wave reads back only its own transpose buffer, and the LDS operations of one wave execute in
       // issue order (four barriers per tile were pure skew)
 #pragma unroll
-      for (int pass = 0; pass < 32 / ROWS_PER_PASS; ++pass) {
+      for (int pass = 0; pass < RB / ROWS_PER_PASS; ++pass) {
         const int rr = pass * ROWS_PER_PASS + orow;
-        const int ib = i0 + wm0 + 32 * h + pass * ROWS_PER_PASS;          // uniform first row of the pass
+        const int ib = i0 + wm0 + RB * h + pass * ROWS_PER_PASS;          // uniform first row of the pass
         if ((FULL || ib + orow < p.I) && jqok) {
           float v[OE];
 #pragma unroll
@@ -719,47 +729,53 @@ void gemm_kernel(const GemmArgs p) {
     __syncthreads();                // every wave is done with its transpose buffer; publishes the parked statistics
     if (CAN_BNRED) {
       if (bnred) {                  // uniform; the stage / transpose buffers are free (barrier above)
-        float* red2 = lds;          // [2][4 waves][ROWS_PER_PASS][WN]
+        float* red2 = lds;          // [2][NW waves][ROWS_PER_PASS][WN]
 #pragma unroll
         for (int e = 0; e < OE; ++e) {
-          red2[((0 * 4 + wave) * ROWS_PER_PASS + orow) * WN + oq + e] = s0[e / 2][e & 1];
-          red2[((1 * 4 + wave) * ROWS_PER_PASS + orow) * WN + oq + e] = s1[e / 2][e & 1];
+          red2[((0 * NW + wave) * ROWS_PER_PASS + orow) * WN + oq + e] = s0[e / 2][e & 1];
+          red2[((1 * NW + wave) * ROWS_PER_PASS + orow) * WN + oq + e] = s1[e / 2][e & 1];
         }
         __syncthreads();
         if (threadIdx.x < BN) {
           const int c = threadIdx.x, half = c / WN, cw = c % WN;
           const int j = j0 + c;
           if (FULL || j < p.J) {
-            float a0 = 0.f, a1 = 0.f;
-#pragma unroll
-            for (int wr = 0; wr < 2; ++wr)
-#pragma unroll
-              for (int o = 0; o < ROWS_PER_PASS; ++o) {     // unrolled: the LDS reads pipeline instead of one round trip each
-                a0 += red2[((0 * 4 + (2 * wr + half)) * ROWS_PER_PASS + o) * WN + cw];
-                a1 += red2[((1 * 4 + (2 * wr + half)) * ROWS_PER_PASS + o) * WN + cw];
-              }
             const long col = g * p.c_goff + j;
-            p.bn_partial[(long)ti * p.bn_ld + col] = a0;
-            p.bn_partial[p.bn_plane + (long)ti * p.bn_ld + col] = a1;
+#pragma unroll
+            for (int t2 = 0; t2 < STILES; ++t2) {           // one row of partial sums per 128-row statistics tile
+              float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+              for (int wr = WPT * t2; wr < WPT * (t2 + 1); ++wr)
+#pragma unroll
+                for (int o = 0; o < ROWS_PER_PASS; ++o) {   // unrolled: the LDS reads pipeline instead of one round trip each
+                  a0 += red2[((0 * NW + (2 * wr + half)) * ROWS_PER_PASS + o) * WN + cw];
+                  a1 += red2[((1 * NW + (2 * wr + half)) * ROWS_PER_PASS + o) * WN + cw];
+                }
+              p.bn_partial[((long)ti * STILES + t2) * p.bn_ld + col] = a0;
+              p.bn_partial[p.bn_plane + ((long)ti * STILES + t2) * p.bn_ld + col] = a1;
+            }
           }
         }
       }
     }
   }
   if (p.stat != nullptr) {   // uniform branch: the column sums were parked in LDS before the store loop (see above)
-    const float* red = lds + 4 * 32 * ((BN / 2) + 4);
+    const float* red = lds + NW * RB * ((BN / 2) + 4);
     if (threadIdx.x < BN) {
       const int j = j0 + threadIdx.x;
       if (FULL || j < p.J) {
         const long col = g * p.c_goff + j;     // forward: c_goff == Nout per group == column offset
-        float s = 0.f, q = 0.f;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {          // 2 wave-rows x 4 row groups, fixed order
-          s += red[(0 * 8 + k) * BN + threadIdx.x];
-          q += red[(1 * 8 + k) * BN + threadIdx.x];
+        for (int t2 = 0; t2 < STILES; ++t2) {  // one row of partial sums per 128-row statistics tile
+          float s = 0.f, q = 0.f;
+#pragma unroll
+          for (int k = 4 * WPT * t2; k < 4 * WPT * (t2 + 1); ++k) {      // WPT wave-rows x 4 row groups, fixed order
+            s += red[(0 * WROWS * 4 + k) * BN + threadIdx.x];
+            q += red[(1 * WROWS * 4 + k) * BN + threadIdx.x];
+          }
+          p.stat[((long)ti * STILES + t2) * p.stat_ld + col] = s;
+          p.stat[p.stat_plane + ((long)ti * STILES + t2) * p.stat_ld + col] = q;
         }
-        p.stat[(long)ti * p.stat_ld + col] = s;
-        p.stat[p.stat_plane + (long)ti * p.stat_ld + col] = q;
       }
     }
   }
@@ -787,8 +803,12 @@ __global__ void elu_inplace_kernel(float* __restrict__ x, long rows, int cols, l
 }
 
 int g_gemm_precision = NSID_GEMM_FP32;     // process-wide (nsid_set_gemm_precision)
+// smallest number of 128x128 tiles for which the forward GEMM takes the 8-wave 256x128 form (0 = never; nsid_set_gemm_w8_min).
+// Cold-operand microbenchmark: -12 ... -20 % on every >= 1024-tile forward GEMM (24.6 -> 20.1 us at 16384x1024x256); whole
+// training step 8.31 / 8.33 ms without against 8.35 / 8.38 ms with it, inference 286 k against 282 k clips/s: off by default.
+int g_w8_min = -1;
 
-template <int BM, int BN, bool AR, bool BR>
+template <int BM, int BN, bool AR, bool BR, int NW = 4>
 int launch(GemmArgs p, int groups, hipStream_t s, int act_dtype, bool w_bf16 = false) {
   const int tiles = ((p.I + BM - 1) / BM) * ((p.J + BN - 1) / BN);
   const bool st16 = act_dtype == NSID_BF16;
@@ -839,7 +859,7 @@ int launch(GemmArgs p, int groups, hipStream_t s, int act_dtype, bool w_bf16 = f
   constexpr int kind_bit = AR ? (BR ? 1 : 2) : 4;
   const long wgs = (long)tiles * p.rsplit * groups;
   int ks = 1, pd = 0;
-  if (full && wgs <= deep_maxwg && (deep_ks > 1 || deep_pd > 2) && (deep_kinds & kind_bit)) {
+  if (NW == 4 && full && wgs <= deep_maxwg && (deep_ks > 1 || deep_pd > 2) && (deep_kinds & kind_bit)) {
     ks = deep_ks == 2 ? 2 : 1;
     pd = deep_pd == 4 ? 4 : (ks == 2 ? 2 : 0);
     const int need = 32 * ks * (pd ? pd : 2);                     // whole register-set rounds of whole stages
@@ -853,6 +873,10 @@ int launch(GemmArgs p, int groups, hipStream_t s, int act_dtype, bool w_bf16 = f
   const bool ec = deep_ec != 0 && BM * BN <= 128 * 128 && (AR && BR);   // forward only; three buffers of a 256x128 tile do not fit LDS
 #define NSID_GEMM_DEEP_GO(AFF_, WB_, RELU_)                                                                       \
   do {                                                                                                            \
+    if constexpr (NW == 8) {                                                                                      \
+      NSID_LAUNCH((gemm_kernel<BM, BN, AR, BR, true, true, AFF_, WB_, true, RELU_, 1, 0, false, 0, 8>), grid, dim3(512), 0, s, p); \
+      break;                                                                                                      \
+    }                                                                                                             \
     if constexpr (BM * BN <= 128 * 128) {                                                                         \
       if (ec && ks == 2 && pd == 4) { NSID_LAUNCH((gemm_kernel<BM, BN, AR, BR, true, true, AFF_, WB_, true, RELU_, 2, 4, true>), grid, dim3(256), 0, s, p); break; } \
       if (ec && ks == 2) { NSID_LAUNCH((gemm_kernel<BM, BN, AR, BR, true, true, AFF_, WB_, true, RELU_, 2, 2, true>), grid, dim3(256), 0, s, p); break; }            \
@@ -863,6 +887,9 @@ int launch(GemmArgs p, int groups, hipStream_t s, int act_dtype, bool w_bf16 = f
     else if (pd == 4) NSID_LAUNCH((gemm_kernel<BM, BN, AR, BR, true, true, AFF_, WB_, true, RELU_, 1, 4>), grid, dim3(256), 0, s, p);       \
     else NSID_LAUNCH((gemm_kernel<BM, BN, AR, BR, true, true, AFF_, WB_, true, RELU_>), grid, dim3(256), 0, s, p);                           \
   } while (0)
+  if constexpr (NW == 8) {
+    if (!(st16 && full && (w_bf16 || !AR))) return NSID_EINVAL;      // the 8-wave form exists for full bf16 tiles only
+  }
   if constexpr (AR) {
     if (st16 && w_bf16) {
       const bool act_only = CAN_AFF && p.a_scale == nullptr && p.a_slope != 1.f;     // activation on load, no affine
@@ -1023,6 +1050,11 @@ extern "C" int nsid_set_gemm_precision(int mode) {
   return NSID_OK;
 }
 extern "C" int nsid_get_gemm_precision(void) { return g_gemm_precision; }
+extern "C" int nsid_set_gemm_w8_min(int tiles) {
+  if (tiles < 0) return NSID_EINVAL;
+  g_w8_min = tiles;
+  return NSID_OK;
+}
 extern "C" int nsid_row_tiles(int M) { return (M + NSID_ROW_TILE - 1) / NSID_ROW_TILE; }
 
 static int linear_fwd_impl(const void* x, int ldx, const void* w, int w_dtype, const float* bias, void* out, int ldo,
@@ -1099,9 +1131,17 @@ static int linear_fwd_impl(const void* x, int ldx, const void* w, int w_dtype, c
   static const int tall_min = getenv("NSID_TALL_MIN") ? atoi(getenv("NSID_TALL_MIN")) : 1024;
   const bool tall = stat == nullptr && act_dtype == NSID_BF16 && wb && !narrow && t128 >= tall_min && M % 256 == 0 &&
                     Nout % 128 == 0 && K % 64 == 0 && ksplit == 1;
-  const int rc = tall ? launch<256, 128, true, true>(p, groups, s, act_dtype, wb)
-                      : narrow ? launch<128, 64, true, true>(p, groups, s, act_dtype, wb)
-                               : launch<128, 128, true, true>(p, groups, s, act_dtype, wb);
+  // 8 waves on 256x128 tiles (round 2): same per-wave work as the 128x128 kernel, a quarter fewer operand bytes per flop,
+  // statistics epilogue included (two 128-row statistics tiles per workgroup). NSID_W8_MIN = smallest number of 128x128
+  // tiles that takes it (0 = never).
+  if (g_w8_min < 0) g_w8_min = getenv("NSID_W8_MIN") ? atoi(getenv("NSID_W8_MIN")) : 0;
+  const int w8_min = g_w8_min;
+  const bool w8 = w8_min > 0 && act_dtype == NSID_BF16 && wb && !narrow && t128 >= w8_min && M % 256 == 0 && Nout % 128 == 0 &&
+                  K % 64 == 0 && ksplit == 1;
+  const int rc = w8 ? launch<256, 128, true, true, 8>(p, groups, s, act_dtype, wb)
+                    : tall ? launch<256, 128, true, true>(p, groups, s, act_dtype, wb)
+                           : narrow ? launch<128, 64, true, true>(p, groups, s, act_dtype, wb)
+                                    : launch<128, 128, true, true>(p, groups, s, act_dtype, wb);
   if (rc != NSID_OK || act_out != NSID_ACT_ELU) return rc;
   const long n = (long)M * groups * Nout;
   NSID_LAUNCH(elu_inplace_kernel, dim3((int)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256)), dim3(256), 0, s,
@@ -1163,6 +1203,11 @@ static int linear_bwd_data_impl(const void* dout, int ldd, const void* w, int w_
   bool narrow = half ? (K <= 64 || (K <= 128 && Nout <= 256)) : K <= 64;
   if (half && t128 < 128) narrow = true;        // few row tiles (the projector head, M = batch)
   if (force_narrow >= 0 && K > 64) narrow = force_narrow != 0;
+  // the 8-wave 256x128 form loses here (16384x256x1024: 21.8 -> 41.4 us cold): 169 registers = one workgroup per CU, and the
+  // transposed weight reads + addend / BatchNorm-sum epilogue do not shrink with the tile. Kept for experiments only.
+  static const int w8_min = getenv("NSID_W8_BWD_MIN") ? atoi(getenv("NSID_W8_BWD_MIN")) : 0;
+  if (w8_min > 0 && !narrow && act_dtype == NSID_BF16 && wb && t128 >= w8_min && M % 256 == 0 && K % 128 == 0 && Nout % 64 == 0)
+    return launch<256, 128, true, false, 8>(p, groups, s, act_dtype, wb);
   if (narrow) return launch<128, 64, true, false>(p, groups, s, act_dtype, wb);
   return launch<128, 128, true, false>(p, groups, s, act_dtype, wb);
 }

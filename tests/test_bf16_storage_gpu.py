@@ -40,7 +40,9 @@ def bfr(x):
 CASES = [(512, 64, 64, 1, False, 0), (200, 256, 64, 1, True, 1), (384, 32, 32, 4, False, 0), (256, 128, 128, 4, True, 2),
          (640, 64, 8, 1, False, 0), (2048, 1024, 256, 1, True, 1), (136, 192, 384, 1, False, 0),
          (512, 2048, 512, 1, True, 1), (256, 1024, 1024, 1, False, 0),   # >= 64 tiles of 128x128: the 8-wave wgrad form
-         (16384, 256, 512, 1, True, 1), (16384, 1024, 256, 1, False, 0)]  # 128x64 weight-gradient tiles (>= 256 workgroups of 1024 rows)
+         (16384, 256, 512, 1, True, 1), (16384, 1024, 256, 1, False, 0),  # 128x64 weight-gradient tiles (>= 256 workgroups of 1024 rows)
+         (16384, 1024, 256, 1, True, 1), (16384, 256, 1024, 1, True, 1),  # >= 1024 tiles of 128x128: 8-wave 256x128 forward (affine
+         (32768, 512, 128, 1, False, 0)]                                  # + statistics: two 128-row tiles per workgroup) / backward-data
 
 
 @pytest.mark.parametrize("M,Nout,K,groups,affine,act", CASES)
@@ -215,7 +217,9 @@ def test_training_curve_bf16_storage_tracks_fp32(ops):
 
 @pytest.mark.parametrize("M,Nout,K,groups,act,add", [(512, 256, 1024, 1, 1, False), (640, 64, 128, 1, 1, True),
                                                        (384, 128, 64, 1, 0, False), (200, 64, 256, 1, 2, True),
-                                                       (256, 32, 32, 4, 1, False)])
+                                                       (256, 32, 32, 4, 1, False),
+                                                       (16384, 256, 1024, 1, 1, True),      # 8-wave 256x128 tiles: two partial rows each
+                                                       (16384, 128, 1024, 1, 0, False)])
 def test_bwd_data_emits_bn_backward_sums(ops, M, Nout, K, groups, act, add):
     """linear_bwd_data(bn=...) = the plain GEMM plus the column sums nsid_bn_bwd_reduce computes from its stored output"""
     C = groups * K
@@ -287,6 +291,38 @@ def test_eval_batchnorm_folding_matches_the_unfolded_path(ops, golden):
     assert float(cos.min()) > 0.9995, float(cos.min())
     # and the folded path meets the reference goldens like the unfolded one does
     assert relerr(outs[True][0], g.t("h_i_eval")) < 4e-2
+
+
+@pytest.mark.parametrize("M,Nout,K,affine,stat,res", [(16384, 1024, 256, False, True, False), (16384, 1024, 256, True, True, False),
+                                                       (8192, 2048, 512, True, False, True), (32768, 512, 128, False, True, False)])
+def test_eight_wave_forward_tiles(ops, M, Nout, K, affine, stat, res):
+    """the 8-wave 256x128-tile forward kernel (nsid_set_gemm_w8_min; off by default): product, bias, operand-load affine +
+    ReLU, residual addend, and the BatchNorm statistics epilogue with TWO 128-row statistics tiles per workgroup"""
+    from neuralsampleid_amd._lib import call, lib
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(M, K, generator=g).to(BF).to(DEV)
+    w = (torch.randn(Nout, K, generator=g) * K ** -0.5).to(DEV)
+    ops.SHADOWS.register(w, ops.f32_to_bf16(w), owner=w)
+    bias = torch.randn(Nout, generator=g).to(DEV)
+    sc = (1 + 0.2 * torch.randn(K, generator=g)).to(DEV) if affine else None
+    sh = (0.3 * torch.randn(K, generator=g)).to(DEV) if affine else None
+    add = torch.randn(M, Nout, generator=g).to(BF).to(DEV) if res else None
+    xin = act_ref(x.float() * sc + sh, 1) if affine else x.float()
+    ref = xin.to(BF).double() @ w.to(BF).double().t() + bias.double()
+    trace = torch.zeros(4 * 8192, dtype=torch.int64, device=DEV)
+    call("nsid_set_gemm_w8_min", 1024)
+    assert lib.nsid_debug_gemm_trace(trace.data_ptr()) == 0
+    try:
+        out, st = ops.linear_fwd(x, w, bias, M, Nout, K, 1, sc, sh, 1 if affine else 0, 0, want_stat=stat, addend=add)
+        torch.cuda.synchronize()
+    finally:
+        lib.nsid_debug_gemm_trace(None)
+        call("nsid_set_gemm_w8_min", 0)
+    assert int((trace.view(-1, 4)[:, 0] != 0).sum()) == (M // 256) * (Nout // 128)      # 256x128 tiles really ran
+    assert relerr(out, ref + (add.double() if res else 0)) < 2.5e-3
+    if stat:
+        tiles = ref.reshape(M // 128, 128, Nout)
+        assert relerr(st[0], tiles.sum(1)) < 1e-4 and relerr(st[1], (tiles * tiles).sum(1)) < 1e-4
 
 
 @pytest.mark.parametrize("M,Nout,K,affine,res", [(16384, 1024, 256, False, False), (8192, 2048, 512, True, True)])
