@@ -323,3 +323,21 @@ def test_stacked_view_gather_keeps_rank_major_pair_order():
     gathered = torch.cat([torch.stack((a, b)) for a, b in zip(zi, zj)])            # what ncclAllGather returns
     gi, gj = parallel._split_views(gathered, world)
     assert torch.equal(gi, torch.cat(zi)) and torch.equal(gj, torch.cat(zj))
+
+
+def test_bench_spawns_its_own_ranks_and_fails_loudly_without_gpus():
+    """`python bench.py --gpus 2` with no launcher in the environment starts two ranks through torch.distributed.run (fresh
+    child processes, before this process makes any GPU call). In this container there is no GPU, so the ranks die: the
+    spawner must come back promptly with a non-zero exit code and no JSON line — never hang, never print a fake result."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["NSID_BENCH_TIMEOUT_S"] = "240"
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
+                        "--no-cpu-baseline"], capture_output=True, text=True, env=env, timeout=280)
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 2:
+        assert r.returncode == 0 and len([ln for ln in r.stdout.splitlines() if ln.startswith("{")]) == 1
+        return
+    assert r.returncode != 0
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert "spawning 2 ranks" in r.stderr and time.time() - t0 < 240
