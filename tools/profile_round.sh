@@ -23,6 +23,10 @@ for mode in $modes; do
   rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/pmc_write$tag -- python3 bench.py --steps 2 --warmup 1 $common $eager $flags > $out/pmc_write$tag.log 2>&1
   python3 tools/hbm_traffic.py $out/pmc_fetch$tag $out/pmc_write$tag $out/hbm_traffic$tag.json
   rm -rf $out/pmc_fetch$tag $out/pmc_write$tag
+  # matrix-core busy cycles and LDS bank conflicts per kernel (SQ counters: their own pass)
+  rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE --output-format csv -d $out/pmc_sq$tag -- python3 bench.py --steps 2 --warmup 1 $common $eager $flags > $out/pmc_sq$tag.log 2>&1
+  python3 tools/pmc_sq_summary.py $(find $out/pmc_sq$tag -name "*counter_collection.csv" | head -1) $(find $out/pmc_sq$tag -name "*kernel_trace.csv" | head -1) > $out/pmc_sq_summary$tag.txt || true
+  rm -rf $out/pmc_sq$tag
   rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats$tag -- python3 bench.py --steps 10 --warmup 4 $common $flags > $out/bench_under_rocprof$tag.json 2> $out/stats$tag.log
   cp $(find $out/stats$tag -name "*kernel_stats.csv" | head -1) $out/kernel_stats$tag.csv
   if [ $mode != infer ]; then
