@@ -98,7 +98,14 @@ _ERR = {-1: "NSID_EINVAL (unsupported shape, misaligned pointer or bad argument)
         -2: "NSID_ELAUNCH (HIP runtime refused the launch)"}
 
 
+# NSID_ABLATE=name1,name2: timing experiments ONLY — the listed entry points return immediately without launching, so that
+# `bench.py` shows what a kernel family costs in the two-stream step (results are then garbage; tools/ablate.sh)
+_ABLATE = frozenset(n for n in os.environ.get("NSID_ABLATE", "").split(",") if n)
+
+
 def call(name, *args):
+    if _ABLATE and name in _ABLATE:
+        return
     rc = getattr(lib, name)(*args)
     if rc != 0:
         raise RuntimeError(f"{name} failed: {_ERR.get(rc, rc)}")

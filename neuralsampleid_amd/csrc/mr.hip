@@ -77,11 +77,14 @@ __global__ __launch_bounds__(MRF_THREADS) void mr_fwd_lds_kernel(const T* __rest
                                                                  const float* __restrict__ scale,
                                                                  const float* __restrict__ shift,
                                                                  const int32_t* __restrict__ idx, int N, int C, int k,
-                                                                 T* __restrict__ u, uint8_t* __restrict__ argmax) {
+                                                                 T* __restrict__ u, uint8_t* __restrict__ argmax,
+                                                                 int split) {
   extern __shared__ __attribute__((aligned(16))) char mrf_smem[];
   constexpr int NV = Chunk<T>::N;
   T* clip = reinterpret_cast<T*>(mrf_smem);                       // [N][C] raw values (the affine is applied at use)
-  const int b = blockIdx.x, t = threadIdx.x;
+  // split > 1: `split` workgroups share a clip — each stages all of it (the second read is an L2 hit) and aggregates its
+  // own slice of the (node, chunk) pairs: at batch 256 one workgroup per clip is one per CU and purely latency-bound
+  const int b = blockIdx.x / split, part = blockIdx.x % split, t = threadIdx.x;
   const long row0 = (long)b * N;
   const int CV = C / NV, total = N * CV;
   for (int q = t; q < total; q += MRF_THREADS) {
@@ -89,7 +92,8 @@ __global__ __launch_bounds__(MRF_THREADS) void mr_fwd_lds_kernel(const T* __rest
     *reinterpret_cast<f32x4*>(clip + (long)n * C + c) = *reinterpret_cast<const f32x4*>(r + (row0 + n) * ldr + c);
   }
   __syncthreads();
-  for (int q = t; q < total; q += MRF_THREADS) {
+  const int per = total / split;
+  for (int q = part * per + t; q < (part + 1) * per; q += MRF_THREADS) {
     const int n = q / CV, c = (q % CV) * NV;
     float sc[NV], sh[NV], y[NV], best[NV];
     int arg[NV];
@@ -288,9 +292,14 @@ extern "C" int nsid_mr_aggregate_fwd(const void* r, int ldr, const float* scale,
         return NSID_ELAUNCH;
       configured = true;
     }
+    static const int force_split = getenv("NSID_MR_SPLIT") ? atoi(getenv("NSID_MR_SPLIT")) : 0;
+    // measured (batch 256, four stage shapes): 10.6-10.9 us with one workgroup per clip, 11-11.4 / 12.8 / 19.6 us with 2 / 4 / 8
+    // per clip: the redundant staging costs more than the extra residency hides; 1 is the default (NSID_MR_SPLIT overrides)
+    int split = force_split > 0 ? force_split : 1;
+    while (split > 1 && ((long)N * (C / nv)) % split != 0) split >>= 1;
     NSID_DISPATCH_DTYPE(dtype, T, {
-      NSID_LAUNCH((mr_fwd_lds_kernel<T>), dim3(B), dim3(MRF_THREADS), clip_bytes, static_cast<hipStream_t>(stream),
-                  static_cast<const T*>(r), (long)ldr, scale, shift, idx, N, C, k, static_cast<T*>(u), argmax);
+      NSID_LAUNCH((mr_fwd_lds_kernel<T>), dim3(B * split), dim3(MRF_THREADS), clip_bytes, static_cast<hipStream_t>(stream),
+                  static_cast<const T*>(r), (long)ldr, scale, shift, idx, N, C, k, static_cast<T*>(u), argmax, split);
     });
     return nsid_launch_status();
   }

@@ -1,0 +1,18 @@
+#!/bin/bash
+# Marginal cost of each kernel family INSIDE the two-stream hipGraph step: bench.py with the family's launches skipped
+# (NSID_ABLATE, _lib.py). The arithmetic is wrong in these runs (NaN-guard may skip the optimiser update); only the step time
+# is read. Usage (GPU box): tools/ablate.sh > gpurun_out/ablate.txt
+run() { NSID_ABLATE=$2 python bench.py --no-cpu-baseline --no-roofline 2>&1 >/dev/null | grep timed | sed "s/^/$1: /"; }
+run "baseline" ""
+run "no bn_finalize (fwd)" "nsid_bn_finalize,nsid_bn_finalize_deferred"
+run "no bn_bwd_finalize" "nsid_bn_bwd_finalize"
+run "no bn_bwd_apply" "nsid_bn_bwd_apply"
+run "no bn_apply" "nsid_bn_apply"
+run "no weight gradients" "nsid_linear_bwd_weight,nsid_downsample3_bwd_weight"
+run "no backward-data" "nsid_linear_bwd_data,nsid_linear_bwd_data_bn,nsid_downsample3_bwd_data"
+run "no forward GEMMs" "nsid_linear_fwd,nsid_linear_fwd_res,nsid_downsample3_fwd"
+run "no kNN" "nsid_knn_graph"
+run "no aggregation fwd+bwd" "nsid_mr_aggregate_fwd,nsid_mr_aggregate_bwd"
+run "no col_reduce (bn_bwd_reduce)" "nsid_bn_bwd_reduce"
+run "no optimiser" "nsid_adam_step,nsid_sumsq_partial,nsid_fill_zero,nsid_f32_to_bf16"
+run "baseline again" ""
