@@ -81,20 +81,20 @@ __global__ __launch_bounds__(MRF_THREADS) void mr_fwd_lds_kernel(const T* __rest
                                                                  int split) {
   extern __shared__ __attribute__((aligned(16))) char mrf_smem[];
   constexpr int NV = Chunk<T>::N;
-  T* clip = reinterpret_cast<T*>(mrf_smem);                       // [N][C] raw values (the affine is applied at use)
-  // split > 1: `split` workgroups share a clip — each stages all of it (the second read is an L2 hit) and aggregates its
-  // own slice of the (node, chunk) pairs: at batch 256 one workgroup per clip is one per CU and purely latency-bound
+  T* clip = reinterpret_cast<T*>(mrf_smem);                       // [N][Cp] raw values (the affine is applied at use)
+  // split > 1: `split` workgroups share a clip BY CHANNELS — channels are independent in the aggregation, so each workgroup
+  // stages and aggregates only its own C/split columns (no redundant bytes) and two or four workgroups per CU overlap
+  // their load / compute / store phases: at batch 256 one workgroup per clip is one per CU and latency-bound
   const int b = blockIdx.x / split, part = blockIdx.x % split, t = threadIdx.x;
   const long row0 = (long)b * N;
-  const int CV = C / NV, total = N * CV;
+  const int CV = C / NV, CVp = CV / split, Cp = CVp * NV, c_lo = part * Cp, total = N * CVp;
   for (int q = t; q < total; q += MRF_THREADS) {
-    const int n = q / CV, c = (q % CV) * NV;
-    *reinterpret_cast<f32x4*>(clip + (long)n * C + c) = *reinterpret_cast<const f32x4*>(r + (row0 + n) * ldr + c);
+    const int n = q / CVp, cl = (q % CVp) * NV;
+    *reinterpret_cast<f32x4*>(clip + (long)n * Cp + cl) = *reinterpret_cast<const f32x4*>(r + (row0 + n) * ldr + c_lo + cl);
   }
   __syncthreads();
-  const int per = total / split;
-  for (int q = part * per + t; q < (part + 1) * per; q += MRF_THREADS) {
-    const int n = q / CV, c = (q % CV) * NV;
+  for (int q = t; q < total; q += MRF_THREADS) {
+    const int n = q / CVp, cl = (q % CVp) * NV, c = c_lo + cl;
     float sc[NV], sh[NV], y[NV], best[NV];
     int arg[NV];
 #pragma unroll
@@ -103,14 +103,14 @@ __global__ __launch_bounds__(MRF_THREADS) void mr_fwd_lds_kernel(const T* __rest
       load_channels<NV>(scale, c, sc);
       load_channels<NV>(shift, c, sh);
     }
-    Chunk<T>::load(clip + (long)n * C + c, y);
+    Chunk<T>::load(clip + (long)n * Cp + cl, y);
 #pragma unroll
     for (int e = 0; e < NV; ++e) y[e] = sc[e] * y[e] + sh[e];
     const int32_t* nb = idx + (row0 + n) * k;
     for (int j = 0; j < k; ++j) {
       const int m = min(max(nb[j], 0), N - 1);                    // ids come from the caller: never read outside the clip
       float v[NV];
-      Chunk<T>::load(clip + (long)m * C + c, v);
+      Chunk<T>::load(clip + (long)m * Cp + cl, v);
 #pragma unroll
       for (int e = 0; e < NV; ++e) {
         const float d = (sc[e] * v[e] + sh[e]) - y[e];
@@ -293,12 +293,10 @@ extern "C" int nsid_mr_aggregate_fwd(const void* r, int ldr, const float* scale,
       configured = true;
     }
     static const int force_split = getenv("NSID_MR_SPLIT") ? atoi(getenv("NSID_MR_SPLIT")) : 0;
-    // measured (batch 256, four stage shapes): 10.6-10.9 us with one workgroup per clip, 11-11.4 / 12.8 / 19.6 us with 2 / 4 / 8
-    // per clip: the redundant staging costs more than the extra residency hides; 1 is the default (NSID_MR_SPLIT overrides)
-    int split = force_split > 0 ? force_split : 1;
-    while (split > 1 && ((long)N * (C / nv)) % split != 0) split >>= 1;
+    int split = force_split > 0 ? force_split : (B <= 256 ? 2 : 1);
+    while (split > 1 && (C / nv) % split != 0) split >>= 1;
     NSID_DISPATCH_DTYPE(dtype, T, {
-      NSID_LAUNCH((mr_fwd_lds_kernel<T>), dim3(B * split), dim3(MRF_THREADS), clip_bytes, static_cast<hipStream_t>(stream),
+      NSID_LAUNCH((mr_fwd_lds_kernel<T>), dim3(B * split), dim3(MRF_THREADS), clip_bytes / split, static_cast<hipStream_t>(stream),
                   static_cast<const T*>(r), (long)ldr, scale, shift, idx, N, C, k, static_cast<T*>(u), argmax, split);
     });
     return nsid_launch_status();
