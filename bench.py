@@ -120,8 +120,9 @@ def roofline_entry(prof, precision, bracket_us, tag=""):
               "flops_per_launch": round(d["flops"] / d["launches"]),
               "alg_bytes_per_launch": round(d["bytes"] / d["launches"]),
               "event_bracket_us": round(bracket_us, 2),
-              "method": "HIP events around every launch in one instrumented eager step after the timed region, "
-                        "minus the median duration of an empty event bracket (event_bracket_us)"}
+              "method": "HIP events around every launch in one instrumented eager single-stream step after the timed region, "
+                        "enqueued behind a spin kernel so that the launches run back to back (an idle GPU would add the host's "
+                        "launch gap to every pair), minus the median duration of an empty event bracket (event_bracket_us)"}
     if precision == "fp32":      # fp32 MFMA runs at 1/16 of the bf16 rate: the GEMMs are matrix-pipe bound
         ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
         return {"bound": "mfma", "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -193,6 +194,7 @@ def infer_bench(args, model, rank, world, dev, dist):
         from neuralsampleid_amd import ops
         ops.PROFILE = ops.KernelProfile()
         bracket_us = 1e3 * ops.PROFILE.bracket_ms
+        ops.KernelProfile.plug(20.0)
         fingerprint.extract_fingerprints(model, pool[:mb], mb, out)
         prof = ops.PROFILE.summary()
         ops.PROFILE = None
@@ -457,6 +459,7 @@ def main():
         ops.PROFILE = ops.KernelProfile()
         bracket_us = 1e3 * ops.PROFILE.bracket_ms
         model.overlap_views = False          # one stream: a launch's events then bracket that kernel alone
+        ops.KernelProfile.plug()             # the host runs ahead of the GPU: event pairs bracket kernels, not launch gaps
         step()
         model.overlap_views = not args.no_overlap
         prof = ops.PROFILE.summary()

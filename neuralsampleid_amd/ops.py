@@ -23,10 +23,20 @@ class KernelProfile:
         self.bracket_ms = self._empty_bracket_ms()
 
     @staticmethod
+    def plug(ms: float = 120.0) -> None:
+        """Keep the GPU busy for ~`ms` so that the host runs AHEAD of it: an eager step is host-bound (~7 us of Python / ctypes
+        per launch), and an event pair around a launch on an idle GPU also measures the wait for the launch packet
+        (a tiny kernel reads 12.4 us, a 19.4 us GEMM 27 us). Behind a plug the queue is full, kernels run back to back and an
+        event pair brackets the kernel alone (the same GEMM reads 21.2 us: rocprofv3 says 20.6 us). Measurement aid only:
+        never inside a timed region."""
+        torch.cuda._sleep(int(ms * 1e-3 * 2.0e9))
+
+    @staticmethod
     def _empty_bracket_ms(n: int = 64) -> float:
         """median elapsed time of an EMPTY event bracket on the current stream: two timed events cost a marker each, and
         that cost sits inside every per-launch measurement of an eager step; it is subtracted in summary()/by_shape()"""
         torch.cuda.synchronize()
+        KernelProfile.plug(2.0)
         evs = []
         for _ in range(n):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
