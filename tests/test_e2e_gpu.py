@@ -562,12 +562,13 @@ def test_graphed_train_step_equals_eager():
         worst_bn = max(worst_bn, max(maxerr(b.double(), v.double()) / max(1.0, float(v.double().abs().max()))
                                      for b, v in zip(model2.buffers(), want[1])))
     print(f"graphed vs eager, per state: |dloss| {worst_loss:.2e}, mean |dp|/lr {worst_dp:.3e}, BN buffers {worst_bn:.2e}")
-    # measured on MI355X (round 2): |dloss| <= GRAPH_TOL/3 etc. (same state in => same forward; the update differs where
-    # fp32 atomics order flips the sign of a near-zero gradient under Adam's normalisation)
+    # measured on MI355X (round 2, gpurun_out/r02_plug/graphed.log): |dloss| 1.2e-7, mean |dp|/lr 2.1e-6, BN buffers 0
+    # (same state in => same forward; the update differs only where the order of fp32 atomics in the split-K GEMMs flips
+    # the last bit of a near-zero gradient under Adam's normalisation). GRAPH_TOL is <= 3x those, 1e-7 floor for the buffers.
     assert worst_loss < GRAPH_TOL["loss"] and worst_dp < GRAPH_TOL["dp"] and worst_bn < GRAPH_TOL["bn"]
 
 
-GRAPH_TOL = {"loss": 1.0, "dp": 10.0, "bn": 1.0}      # PROVISIONAL until measured
+GRAPH_TOL = {"loss": 4e-7, "dp": 6e-6, "bn": 1e-7}
 
 
 def test_graphed_fingerprinter_equals_eager_extraction(golden):
