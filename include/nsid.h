@@ -54,6 +54,11 @@ int nsid_get_gemm_precision(void);
 /* tuning: smallest number of 128x128 output tiles for which nsid_linear_fwd (bf16 storage, bf16 weights, whole tiles) takes
    the 8-wave 256x128-tile kernel; 0 = never (default; env NSID_W8_MIN sets the initial value) */
 int nsid_set_gemm_w8_min(int tiles);
+/* tuning: smallest number of 256x256 output tiles for which nsid_linear_fwd / nsid_linear_fwd_res (bf16 storage, bf16 weights,
+   one group, M % 256 == 0, Nout % 256 == 0, K % 128 == 0, no operand-load affine) take the LDS-DMA 256x256-tile kernel
+   (csrc/gemm256.hip); 0 = never (env NSID_G256_MIN sets the initial value). nsid_gemm_g256_launches() = launches that took it. */
+int nsid_set_gemm_g256_min(int tiles);
+long nsid_gemm_g256_launches(void);
 /* number of NSID_ROW_TILE row tiles of an M-row matrix: size of the partial-statistics buffers */
 int nsid_row_tiles(int M);
 
@@ -71,7 +76,8 @@ int nsid_row_tiles(int M);
  *           stat (optional): [2][nsid_row_tiles(M)][groups*Nout] per-row-tile column sums / sums of squares of the
  *           pre-activation output, the input of nsid_bn_finalize (training-mode BatchNorm statistics).
  *           ksplit > 1 splits K over workgroups and accumulates atomically: `out` must be zeroed, stat == NULL,
- *           act_out == NSID_ACT_NONE. */
+ *           act_out == NSID_ACT_NONE.  act_out: NSID_ACT_NONE, NSID_ACT_ELU (fp32 storage only) or NSID_ACT_RELU (stat == NULL,
+ *           ksplit == 1: eval mode with the BatchNorm folded into (w, bias) writes relu(BN(conv)) and its consumer loads plain values). */
 int nsid_linear_fwd(const void* x, int ldx, const void* w, int w_dtype, const float* bias, void* out, int ldo, int M,
                     int Nout, int K, int groups, const float* in_scale, const float* in_shift, int act_in, int act_out,
                     float* stat, int ksplit, int act_dtype /* of x and out */, void* stream);

@@ -15,6 +15,7 @@ LIB_PATH = os.environ.get("NSID_LIB") or os.path.join(_PKG, "libnsid_hip.so")   
 SIGNATURES = {
     "nsid_set_gemm_precision": "i",
     "nsid_set_gemm_w8_min": "i",
+    "nsid_set_gemm_g256_min": "i",
     "nsid_linear_fwd": "pipippiiiiippiipiis",
     "nsid_linear_fwd_res": "pipippipiiiiippiis",
     "nsid_linear_bwd_data": "pipipipiiiiiis",
@@ -82,6 +83,8 @@ def _load():
     lib.nsid_debug_knn_trace.argtypes = [ctypes.c_void_p]
     lib.nsid_debug_knn_trace.restype = ctypes.c_int
     lib.nsid_get_gemm_precision.restype = ctypes.c_int
+    lib.nsid_gemm_g256_launches.argtypes = []
+    lib.nsid_gemm_g256_launches.restype = ctypes.c_long
     lib.nsid_row_tiles.argtypes = [ctypes.c_int]
     lib.nsid_row_tiles.restype = ctypes.c_int
     lib.nsid_sumsq_blocks.argtypes = [ctypes.c_long]
@@ -92,7 +95,7 @@ def _load():
 
 
 lib = _load()
-EXPORTS = list(SIGNATURES) + ["nsid_version", "nsid_debug_gemm_trace", "nsid_debug_knn_trace", "nsid_get_gemm_precision", "nsid_row_tiles", "nsid_sumsq_blocks", "nsid_ntxent_ws_floats"]
+EXPORTS = list(SIGNATURES) + ["nsid_version", "nsid_debug_gemm_trace", "nsid_debug_knn_trace", "nsid_get_gemm_precision", "nsid_gemm_g256_launches", "nsid_row_tiles", "nsid_sumsq_blocks", "nsid_ntxent_ws_floats"]
 
 _ERR = {-1: "NSID_EINVAL (unsupported shape, misaligned pointer or bad argument)",
         -2: "NSID_ELAUNCH (HIP runtime refused the launch)"}

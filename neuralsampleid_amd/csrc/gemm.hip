@@ -47,6 +47,7 @@ struct GemmArgs {
   // and are never fetched (they lie in the neighbouring clip or outside the tensor). "row" = i (R-major A) or the
   // reduction index (i/j-major B); pad_safe = an element offset that is always inside the operand.
   int pad_period, pad_phase, pad_c0, pad_c1; long pad_safe;
+  int relu_out;   // forward, non-atomic store path: out = max(acc + bias, 0) (eval mode: the consumer then needs no activation on load)
 };
 
 // Precision H = false: fp32 operands, v_mfma_f32_16x16x4_f32, BK = 16 (exact fp32 — the parity path).
@@ -691,6 +692,10 @@ void gemm_kernel(const GemmArgs p) {
 #pragma unroll
             for (int k4 = 0; k4 < 4; ++k4) v[e + k4] = t4[k4];
           }
+          if (p.relu_out) {              // uniform
+#pragma unroll
+            for (int e = 0; e < OE; ++e) v[e] = fmaxf(v[e], 0.f);
+          }
           if constexpr (CAN_ADD) {
             if (p.addend) {
               float ad[OE];
@@ -807,6 +812,9 @@ int g_gemm_precision = NSID_GEMM_FP32;     // process-wide (nsid_set_gemm_precis
 // Cold-operand microbenchmark: -12 ... -20 % on every >= 1024-tile forward GEMM (24.6 -> 20.1 us at 16384x1024x256); whole
 // training step 8.31 / 8.33 ms without against 8.35 / 8.38 ms with it, inference 286 k against 282 k clips/s: off by default.
 int g_w8_min = -1;
+// smallest number of 256x256 tiles for which the forward GEMM takes gemm256.hip (LDS-DMA staging); 0 = never
+int g_g256_min = -1;
+long g_g256_launches = 0;     // launches that took it (tests check that the kernel under test really ran)
 
 template <int BM, int BN, bool AR, bool BR, int NW = 4>
 int launch(GemmArgs p, int groups, hipStream_t s, int act_dtype, bool w_bf16 = false) {
@@ -1041,7 +1049,9 @@ extern "C" int nsid_downsample3_bwd_data(const void* dout, const void* wp, const
                  : launch_pad<128, 128, true, false, 1>(q, 1, s, act_dtype, wb);
 }
 
+void* g_gemm_trace_host = nullptr;     // the same buffer for kernels of other translation units (gemm256.hip takes it as an argument)
 extern "C" int nsid_debug_gemm_trace(void* buf) {
+  g_gemm_trace_host = buf;
   return hipMemcpyToSymbol(HIP_SYMBOL(g_gemm_trace), &buf, sizeof(buf)) == hipSuccess ? NSID_OK : NSID_EINVAL;
 }
 extern "C" int nsid_set_gemm_precision(int mode) {
@@ -1055,6 +1065,12 @@ extern "C" int nsid_set_gemm_w8_min(int tiles) {
   g_w8_min = tiles;
   return NSID_OK;
 }
+extern "C" int nsid_set_gemm_g256_min(int tiles) {
+  NSID_REQUIRE(tiles >= 0);
+  g_g256_min = tiles;
+  return NSID_OK;
+}
+extern "C" long nsid_gemm_g256_launches(void) { return g_g256_launches; }
 extern "C" int nsid_row_tiles(int M) { return (M + NSID_ROW_TILE - 1) / NSID_ROW_TILE; }
 
 static int linear_fwd_impl(const void* x, int ldx, const void* w, int w_dtype, const float* bias, void* out, int ldo,
@@ -1089,13 +1105,14 @@ static int linear_fwd_impl(const void* x, int ldx, const void* w, int w_dtype, c
   NSID_REQUIRE(NSID_DTYPE_OK(w_dtype) && (w_dtype == NSID_F32 || (act_dtype == NSID_BF16 && K % 8 == 0)));
   const int ch = act_dtype == NSID_BF16 ? 8 : 4;     // elements per 16-byte chunk of the activation tensors
   NSID_REQUIRE(K % ch == 0 && ldx % ch == 0 && nsid_aligned16(x) && nsid_aligned16(w) && K % 4 == 0);
-  NSID_REQUIRE(act_dtype == NSID_F32 || (ksplit == 1 && act_out == NSID_ACT_NONE && Nout % 8 == 0 && ldo % 8 == 0));
+  NSID_REQUIRE(act_dtype == NSID_F32 || (ksplit == 1 && (act_out == NSID_ACT_NONE || act_out == NSID_ACT_RELU) && Nout % 8 == 0 && ldo % 8 == 0));
+  NSID_REQUIRE(act_out != NSID_ACT_RELU || (ksplit == 1 && stat == nullptr && addend == nullptr));
   // ldx < K (overlapping rows of x, read-only) is allowed for one group: the STFT front end frames a waveform that way
   NSID_REQUIRE((ldx >= groups * K || (groups == 1 && ldx > 0)) && ldo >= groups * Nout);
   NSID_REQUIRE(Nout % 4 == 0 && ldo % 4 == 0 && nsid_aligned16(out) && (bias == nullptr || nsid_aligned16(bias)));
   NSID_REQUIRE((in_scale == nullptr) == (in_shift == nullptr));
   NSID_REQUIRE(ksplit == 1 || (stat == nullptr && act_out == NSID_ACT_NONE));
-  NSID_REQUIRE(act_in != NSID_ACT_ELU && (act_out == NSID_ACT_NONE || act_out == NSID_ACT_ELU));
+  NSID_REQUIRE(act_in != NSID_ACT_ELU && (act_out == NSID_ACT_NONE || act_out == NSID_ACT_ELU || act_out == NSID_ACT_RELU));
   // an activation on load WITHOUT an affine exists as ReLU on bf16 operands with bf16 weights (full tiles; eval path)
   NSID_REQUIRE(in_scale != nullptr || act_in == NSID_ACT_NONE ||
                (act_in == NSID_ACT_RELU && act_dtype == NSID_BF16 && w_dtype == NSID_BF16));
@@ -1111,6 +1128,7 @@ static int linear_fwd_impl(const void* x, int ldx, const void* w, int w_dtype, c
   p.rsplit = ksplit;
   p.rchunk = (K + ksplit - 1) / ksplit;
   p.atomic_out = ksplit > 1;
+  p.relu_out = act_out == NSID_ACT_RELU;
   hipStream_t s = static_cast<hipStream_t>(stream);
   // the statistics tile must be NSID_ROW_TILE rows, so BM = 128 always; narrow outputs take the 64-column tile
   // bf16 operands make the kernel latency/HBM-bound: when 128-wide tiles would give fewer than two workgroups per CU,
@@ -1138,6 +1156,16 @@ static int linear_fwd_impl(const void* x, int ldx, const void* w, int w_dtype, c
   const int w8_min = g_w8_min;
   const bool w8 = w8_min > 0 && act_dtype == NSID_BF16 && wb && !narrow && t128 >= w8_min && M % 256 == 0 && Nout % 128 == 0 &&
                   K % 64 == 0 && ksplit == 1;
+  // 256x256 tiles with LDS-DMA staging (gemm256.hip): NSID_G256_MIN = smallest number of 256x256 tiles that takes it (0 = never)
+  if (g_g256_min < 0) g_g256_min = getenv("NSID_G256_MIN") ? atoi(getenv("NSID_G256_MIN")) : 0;
+  const int g256_min = g_g256_min;
+  if (g256_min > 0 && act_dtype == NSID_BF16 && wb && groups == 1 && in_scale == nullptr && ksplit == 1 &&
+      (act_out == NSID_ACT_NONE || act_out == NSID_ACT_RELU) && act_in == NSID_ACT_NONE && ldx >= K &&
+      (long)(M / 256) * (Nout / 256) >= g256_min) {
+    const int rc256 = nsid_gemm256_fwd_launch(x, ldx, w, bias, addend, ldadd, out, ldo, M, Nout, K, act_out == NSID_ACT_RELU, stat,
+                                              p.stat_plane, p.stat_ld, s);
+    if (rc256 != 1) { ++g_g256_launches; return rc256; }
+  }
   const int rc = w8 ? launch<256, 128, true, true, 8>(p, groups, s, act_dtype, wb)
                     : tall ? launch<256, 128, true, true>(p, groups, s, act_dtype, wb)
                            : narrow ? launch<128, 64, true, true>(p, groups, s, act_dtype, wb)

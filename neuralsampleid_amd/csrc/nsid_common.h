@@ -130,3 +130,10 @@ static inline bool nsid_aligned16(const void* p) { return (reinterpret_cast<uint
 // wgrad.hip: 128x128-tile form of the bf16 weight-gradient GEMM; returns 1 when the shape is outside its preconditions
 int nsid_wgrad2_launch(const void* dout, int ldd, const void* x, int ldx, float* dw, int M, int Nout, int K, int groups,
                        const float* in_scale, const float* in_shift, float slope, hipStream_t stream);
+
+// gemm256.hip: forward GEMM on 256x256 tiles with LDS-DMA staging (bf16 activations and weights, one group); returns 1 when the
+// shape is outside its preconditions
+int nsid_gemm256_fwd_launch(const void* x, int ldx, const void* w, const float* bias, const void* addend, int ldadd, void* out,
+                            int ldo, int M, int Nout, int K, bool relu_out, float* stat, long stat_plane, long stat_ld,
+                            hipStream_t stream);
+extern void* g_gemm_trace_host;        // gemm.hip: the buffer installed by nsid_debug_gemm_trace (nullptr = none)

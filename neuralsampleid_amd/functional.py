@@ -173,10 +173,14 @@ def fold_eval(training: bool, S) -> bool:
 
 
 def conv_bn(x: Tensor, M: int, K: int, Nout: int, w: Tensor, bias: Optional[Tensor], bn, training: bool,
-            groups: int = 1, in_aff: Optional[BNAffine] = None, act_in: int = ACT_NONE, residual: Optional[Tensor] = None):
+            groups: int = 1, in_aff: Optional[BNAffine] = None, act_in: int = ACT_NONE, residual: Optional[Tensor] = None,
+            folded_act: int = ACT_NONE):
     """r = f(x) W^T (+b) on MFMA, plus the affine of the BatchNorm that follows (batch stats when training).
     residual: only when the BatchNorm is folded (eval mode, no backward) — the result is then BN(r) + residual, with the
-    identity affine."""
+    identity affine.
+    folded_act: the activation that FOLLOWS this layer's BatchNorm (BasicConv's / FFN's ReLU). Used only on the folded path, where
+    the GEMM writes act(BN(conv)) itself (ReLU commutes with the bf16 rounding of the store: same stored values as a ReLU on
+    load) and returns None as the affine: the consumer then loads plain values (in_aff = None, act_in = ACT_NONE)."""
     gamma, beta, rm, rv, nbt, nograd = bn
     if nograd and fold_eval(training, None):
         wf, bf = ops.folded_conv_bn(ops.w2d(w), bias, gamma, beta, rm, rv)
@@ -184,8 +188,10 @@ def conv_bn(x: Tensor, M: int, K: int, Nout: int, w: Tensor, bias: Optional[Tens
         if in_aff is not None and in_aff.identity and act_in == ACT_RELU and M % 256 == 0 and Nout % 128 == 0 and \
                 K % 64 == 0 and wf.numel() % 8 == 0:
             sc = sh = None       # the producer's BatchNorm is folded too: ReLU alone, on the packed bf16 values
-        r, _ = ops.linear_fwd(x, wf, bf, M, Nout, K, groups, sc, sh, act_in, ACT_NONE, addend=residual)
-        return r, ops.identity_affine(groups * Nout, x.device)
+        if in_aff is None:
+            act_in = ACT_NONE
+        r, _ = ops.linear_fwd(x, wf, bf, M, Nout, K, groups, sc, sh, act_in, folded_act, addend=residual)
+        return r, (None if folded_act != ACT_NONE else ops.identity_affine(groups * Nout, x.device))
     assert residual is None
     r, stat = ops.linear_fwd(x, ops.w2d(w), bias, M, Nout, K, groups,
                              in_aff.scale if in_aff else None, in_aff.shift if in_aff else None, act_in,
@@ -241,8 +247,8 @@ def grapher_forward(x0: Tensor, P, S: Optional[dict], B: int, N: int, k: int, di
     u, amax = ops.mr_aggregate_fwd(r1, idx, B, N, C, a1, want_argmax=S is not None)
     pre = "graph_conv.gconv.nn."
     r2, a2 = conv_bn(u, M, C // 2, C // 2, P[pre + "0.weight"], P[pre + "0.bias"], _bn(P, S, pre + "1."), training,
-                     groups=4)
-    if fold_eval(training, S):   # conv + BatchNorm + shortcut in one launch
+                     groups=4, folded_act=ACT_RELU)
+    if fold_eval(training, S):   # conv + BatchNorm + shortcut in one launch; r2 already is relu(BN(conv)) (a2 is None)
         return conv_bn(r2, M, 2 * C, C, P["fc2.0.weight"], P["fc2.0.bias"], _bn(P, S, "fc2.1."), training,
                        in_aff=a2, act_in=ACT_RELU, residual=x0)[0]
     r3, a3 = conv_bn(r2, M, 2 * C, C, P["fc2.0.weight"], P["fc2.0.bias"], _bn(P, S, "fc2.1."), training,
@@ -288,8 +294,8 @@ def grapher_backward(dx1: Tensor, P, S, G) -> Tensor:
 def ffn_forward(x1: Tensor, P, S: Optional[dict], training: bool) -> Tensor:
     M, C = x1.shape
     H = P["fc1.0.weight"].shape[0]
-    r4, a4 = conv_bn(x1, M, C, H, P["fc1.0.weight"], None, _bn(P, S, "fc1.1."), training)
-    if fold_eval(training, S):
+    r4, a4 = conv_bn(x1, M, C, H, P["fc1.0.weight"], None, _bn(P, S, "fc1.1."), training, folded_act=ACT_RELU)
+    if fold_eval(training, S):     # r4 already is relu(BN(conv)) (a4 is None)
         return conv_bn(r4, M, H, C, P["fc2.0.weight"], None, _bn(P, S, "fc2.1."), training, in_aff=a4, act_in=ACT_RELU,
                        residual=x1)[0]
     r5, a5 = conv_bn(r4, M, H, C, P["fc2.0.weight"], None, _bn(P, S, "fc2.1."), training, in_aff=a4, act_in=ACT_RELU)

@@ -325,6 +325,60 @@ def test_eight_wave_forward_tiles(ops, M, Nout, K, affine, stat, res):
         assert relerr(st[0], tiles.sum(1)) < 1e-4 and relerr(st[1], (tiles * tiles).sum(1)) < 1e-4
 
 
+@pytest.mark.parametrize("M,Nout,K,relu,stat,res,bias", [(16384, 1024, 256, False, True, False, False),
+                                                          (16384, 1024, 256, False, True, False, True),
+                                                          (8192, 2048, 512, False, True, False, False),
+                                                          (16384, 256, 1024, False, False, True, True),
+                                                          (16384, 256, 1024, True, False, False, True),
+                                                          (1024, 256, 128, False, False, True, True), (1024, 256, 128, False, True, False, True),
+                                                          (512, 512, 2048, True, False, False, False)])
+def test_lds_dma_256_tile_forward(ops, M, Nout, K, relu, stat, res, bias):
+    """csrc/gemm256.hip (nsid_set_gemm_g256_min): 256x256 tiles staged by LDS-DMA through a four-slot ring — product, bias,
+    ReLU in the epilogue, residual addend and the BatchNorm statistics epilogue against an fp64 product of the bf16 operands.
+    K = 128 is the shortest ring (prologue + tail only), K = 2048 runs 15 steady-state rounds."""
+    from neuralsampleid_amd._lib import call, lib
+    g = torch.Generator().manual_seed(31)
+    x = torch.randn(M, K, generator=g).to(BF).to(DEV)
+    w = (torch.randn(Nout, K, generator=g) * K ** -0.5).to(DEV)
+    ops.SHADOWS.register(w, ops.f32_to_bf16(w), owner=w)
+    b = torch.randn(Nout, generator=g).to(DEV) if bias else None
+    add = torch.randn(M, Nout, generator=g).to(BF).to(DEV) if res else None
+    ref = x.double() @ w.to(BF).double().t() + (b.double() if bias else 0)
+    if relu:
+        ref = ref.clamp_min(0)
+    n0 = lib.nsid_gemm_g256_launches()
+    call("nsid_set_gemm_g256_min", 1)
+    try:
+        out, st = ops.linear_fwd(x, w, b, M, Nout, K, 1, None, None, 0, 1 if relu else 0, want_stat=stat, addend=add)
+        torch.cuda.synchronize()
+    finally:
+        call("nsid_set_gemm_g256_min", 0)
+    assert lib.nsid_gemm_g256_launches() == n0 + 1                       # the kernel under test really ran
+    # the only rounding is the bf16 store of the fp32 result
+    full = ref + (add.double() if res else 0)
+    err = (out.double() - full).abs()
+    assert float((err / (full.abs() + 1.0)).max()) < 2 ** -8, float((err / (full.abs() + 1.0)).max())
+    assert relerr(out, full) < 2.5e-3
+    if stat:
+        tiles = ref.reshape(M // 128, 128, Nout)
+        assert relerr(st[0], tiles.sum(1)) < 1e-4 and relerr(st[1], (tiles * tiles).sum(1)) < 1e-4
+
+
+@pytest.mark.parametrize("M,Nout,K,groups", [(16384, 1024, 256, 1), (8192, 128, 128, 4), (640, 72, 40, 1), (131072, 256, 64, 1)])
+def test_forward_relu_epilogue(ops, M, Nout, K, groups):
+    """act_out = ReLU in the store path of every forward tile shape (128x128, grouped 128x64, ragged, tall 256x128): the values an
+    eval-mode consumer used to obtain by ReLU on load"""
+    g = torch.Generator().manual_seed(41)
+    x = torch.randn(M, groups * K, generator=g).to(BF).to(DEV)
+    w = (torch.randn(groups * Nout, K, generator=g) * K ** -0.5).to(DEV)
+    ops.SHADOWS.register(w, ops.f32_to_bf16(w), owner=w)
+    b = torch.randn(groups * Nout, generator=g).to(DEV)
+    out, _ = ops.linear_fwd(x, w, b, M, Nout, K, groups, None, None, 0, 1)
+    plain, _ = ops.linear_fwd(x, w, b, M, Nout, K, groups)
+    assert torch.equal(out, plain.clamp_min(0))              # ReLU commutes with the bf16 rounding of the store
+    assert float(out.float().min()) == 0.0
+
+
 @pytest.mark.parametrize("M,Nout,K,affine,res", [(16384, 1024, 256, False, False), (8192, 2048, 512, True, True)])
 def test_tall_tile_forward_without_statistics(ops, M, Nout, K, affine, res):
     """eval-mode forward GEMMs with >= 1024 tiles of 128x128 and bf16 weight shadows take the 256x128-tile kernel

@@ -1,11 +1,17 @@
 #!/bin/bash
 # Build an alternative kernel library with extra compiler flags for A/B experiments:
 #   tools/build_variant.sh alt -DNSID_RPAD=16     ->  neuralsampleid_amd/libnsid_hip_alt.so   (use with NSID_LIB=<path>)
+#   ONLY="gemm256" tools/build_variant.sh x -DFOO ->  recompiles only the named sources; the other objects come from the main build
 set -e
 name=$1; shift
 root=$(cd "$(dirname "$0")/.." && pwd)
 obj=/tmp/nsid_variant_$name; mkdir -p $obj
-for s in gemm wgrad bn knn mr ntxent misc; do
+all="gemm gemm256 wgrad bn knn mr ntxent misc"
+for s in $all; do
+  if [ -n "$ONLY" ] && ! echo " $ONLY " | grep -q " $s "; then
+    cp $root/neuralsampleid_amd/csrc/_obj/$s.o $obj/$s.o
+    continue
+  fi
   /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -fPIC -std=c++17 -fno-gpu-rdc -I $root/include "$@" -c $root/neuralsampleid_amd/csrc/$s.hip -o $obj/$s.o &
 done
 wait

@@ -36,16 +36,26 @@ def run_cold(args, M, N, K, G, aff, adt, dev):
     sc = (1 + 0.1 * torch.randn(G * K, device=dev)) if aff else None
     sh = (0.1 * torch.randn(G * K, device=dev)) if aff else None
     dw = torch.zeros(G * N, K, device=dev)
-    act = ops.ACT_RELU if aff else 0
+    act = ops.ACT_RELU if (aff or args.relu_in) else 0
+    adds = [torch.randn(M, G * N, device=dev).to(adt) for _ in range(nb)] if args.addend else None
     runs = {
-        "fwd": lambda i: ops.linear_fwd(xs[i], w, None, M, N, K, G, sc, sh, act, 0, want_stat=not args.no_stat, out=outs[i]),
+        "fwd": lambda i: ops.linear_fwd(xs[i], w, None, M, N, K, G, sc, sh, act, 0, want_stat=not (args.no_stat or args.addend),
+                                        out=outs[i], addend=adds[i] if adds else None),
         "bwd_data": lambda i: ops.linear_bwd_data(douts[i], w, M, N, K, G, out=dins[i]),
         "bwd_weight": lambda i: ops.linear_bwd_weight(douts[i], xs[i], dw, M, N, K, G, sc, sh, act),
     }
+    if args.blas:      # YARDSTICK ONLY (never on the product path): the vendor library's plain bf16 GEMM on the same cold operands
+        wb = w.to(adt)
+        dwb = torch.empty(G * N, K, device=dev, dtype=adt)
+        if G != 1:
+            return
+        runs = {"fwd": lambda i: torch.mm(xs[i], wb.t(), out=outs[i]),
+                "bwd_data": lambda i: torch.mm(douts[i], wb, out=dins[i]),
+                "bwd_weight": lambda i: torch.mm(douts[i].t(), xs[i], out=dwb)}
     nbytes = {"fwd": G * (esz * M * K + 2.0 * N * K + esz * M * N), "bwd_data": G * (esz * M * N + 2.0 * N * K + esz * M * K),
               "bwd_weight": G * (esz * M * N + esz * M * K + 4.0 * N * K)}
     flops = 2.0 * M * N * K * G
-    line = f"M={M:6d} N={N:5d} K={K:5d} G={G} aff={int(aff)} cold x{nb}"
+    line = f"M={M:6d} N={N:5d} K={K:5d} G={G} aff={int(aff)} cold x{nb}" + (" BLAS" if args.blas else "")
     reps = max(args.reps, nb) // nb * nb
     for name in args.only.split(","):
         fn = runs[name]
@@ -79,6 +89,11 @@ def main():
     ap.add_argument("--cold", action="store_true",
                     help="rotate over enough copies of the activation operands/outputs (> 600 MB) that no repetition finds "
                          "its operands in the 256 MB Infinity Cache: inside the training step every operand is cold")
+    ap.add_argument("--relu-in", action="store_true", help="--cold fwd: ReLU on the operand load without an affine (eval-mode fc2)")
+    ap.add_argument("--addend", action="store_true", help="--cold fwd: residual addend in the epilogue (implies no statistics)")
+    ap.add_argument("--blas", action="store_true",
+                    help="with --cold: time torch.mm (hipBLASLt / rocBLAS) on the same operands instead: a yardstick for the "
+                         "plain product without the fused load transform / epilogues")
     args = ap.parse_args()
     dev = "cuda"
     ops.set_gemm_precision(args.precision)

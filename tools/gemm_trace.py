@@ -60,6 +60,7 @@ t0, tl, te, hw = t[:, 0], t[:, 1], t[:, 2], t[:, 3]
 base = t0.min()
 us = lambda v: (v - base) / 100.0
 xcc = (hw >> 32) & 0xF
+pro = hw >> 40                      # gemm256.hip only: ticks from start to "first sub-tile landed"
 hwid = hw & 0xFFFFFFFF
 cu = (hwid >> 8) & 0xF
 sh = (hwid >> 12) & 0x1
@@ -69,6 +70,8 @@ print(f"{args.dir} {M}x{N}x{K}: {n} workgroups on {len(set(where))} CUs; span {u
 print(f"  start times: median {np.median(us(t0)):.2f}  p90 {np.percentile(us(t0), 90):.2f}  max {us(t0).max():.2f} us")
 print(f"  workgroup duration: median {np.median(te - t0) / 100:.2f}  p10 {np.percentile(te - t0, 10) / 100:.2f}  p90 {np.percentile(te - t0, 90) / 100:.2f} us;"
       f"  main loop median {np.median(tl - t0) / 100:.2f}, epilogue median {np.median(te - tl) / 100:.2f} us")
+if pro.max() > 0:
+    print(f"  prologue (start -> first sub-tile in LDS): median {np.median(pro) / 100:.2f}  p90 {np.percentile(pro, 90) / 100:.2f} us")
 per = collections.defaultdict(list)
 for i in range(n):
     per[where[i]].append((t0[i], te[i]))
