@@ -1157,7 +1157,10 @@ static int linear_fwd_impl(const void* x, int ldx, const void* w, int w_dtype, c
   const bool w8 = w8_min > 0 && act_dtype == NSID_BF16 && wb && !narrow && t128 >= w8_min && M % 256 == 0 && Nout % 128 == 0 &&
                   K % 64 == 0 && ksplit == 1;
   // 256x256 tiles with LDS-DMA staging (gemm256.hip): NSID_G256_MIN = smallest number of 256x256 tiles that takes it (0 = never)
-  if (g_g256_min < 0) g_g256_min = getenv("NSID_G256_MIN") ? atoi(getenv("NSID_G256_MIN")) : 0;
+  // default 512 (two tiles per CU and more: fingerprinting at micro-batch 2 048): 7.09 -> 6.56 ms per micro-batch. The training step
+  // (<= 256 such tiles per launch) is neutral to slightly worse with it (8.30 vs 8.34 ms: a workgroup that owns 150 KB of a CU's LDS
+  // keeps the other view's kernels off that CU), so it stays on gemm.hip.
+  if (g_g256_min < 0) g_g256_min = getenv("NSID_G256_MIN") ? atoi(getenv("NSID_G256_MIN")) : 512;
   const int g256_min = g_g256_min;
   if (g256_min > 0 && act_dtype == NSID_BF16 && wb && groups == 1 && in_scale == nullptr && ksplit == 1 &&
       (act_out == NSID_ACT_NONE || act_out == NSID_ACT_RELU) && act_in == NSID_ACT_NONE && ldx >= K &&
