@@ -109,7 +109,7 @@ def kernel_table(prof, elapsed_ms, precision):
 
 
 def roofline_entry(prof, precision, bracket_us, tag=""):
-    gemms = {n: d for n, d in prof.items() if n.startswith(("gemm_kernel", "wgrad3", "ffn_fused"))}
+    gemms = {n: d for n, d in prof.items() if n.startswith(("gemm_kernel", "gemm256", "wgrad3"))}
     dom = max(gemms or prof, key=lambda n: prof[n]["ms"])
     d = prof[dom]
     tr = measured_traffic(dom, precision, tag)

@@ -82,13 +82,14 @@ PROFILE: Optional[KernelProfile] = None
 
 
 def _timed(name, flops, nbytes, fn, shape=()):
+    """name: a string, or a callable evaluated AFTER the launch (a launcher that picks its kernel in C reports it then)"""
     if PROFILE is None:
         return fn()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     fn()
     e1.record()
-    PROFILE.records.append((name, flops, nbytes, e0, e1, shape))
+    PROFILE.records.append((name() if callable(name) else name, flops, nbytes, e0, e1, shape))
 
 
 def _p(t: Optional[torch.Tensor]):
@@ -282,7 +283,10 @@ def linear_fwd(x, w, bias, M, Nout, K, groups=1, in_scale=None, in_shift=None, a
     # csrc/gemm.hip linear_fwd_impl: forward-only work with >= NSID_TALL_MIN (1024) tiles of 128x128 takes 256x128 tiles
     tall = (not want_stat and dt == BF16 and wdt == BF16 and not narrow and ksplit == 1 and M % 256 == 0 and Nout % 128 == 0
             and K % 64 == 0 and row_tiles(M) * ((Nout + 127) // 128) * groups >= int(os.environ.get("NSID_TALL_MIN", "1024")))
-    name = "gemm_kernel<%d,%d,true,true>" % (256 if tall else 128, 64 if narrow else 128)
+    name_ = "gemm_kernel<%d,%d,true,true>" % (256 if tall else 128, 64 if narrow else 128)
+    n256 = lib.nsid_gemm_g256_launches() if PROFILE is not None else 0
+    # csrc/gemm.hip decides between the tile families; the launch counter of the 256x256-tile LDS-DMA kernel says which one ran
+    name = lambda: "gemm256_fwd_kernel" if lib.nsid_gemm_g256_launches() > n256 else name_
     if in_scale is None and act_in != ACT_NONE:
         # activation on load without an affine: only ReLU on bf16 operands, bf16 weights and whole tiles (csrc/gemm.hip ARELU)
         bn_ = 64 if narrow else 128
