@@ -3,6 +3,7 @@
 //   consumer GEMM applies scale/shift(+act) on load; the residual stream is materialised by bn_apply.
 // Backward: bn_bwd_reduce (two column reductions) -> bn_bwd_finalize -> bn_bwd_apply (dr, in place).
 // Activation tensors are fp32 or bf16 (template parameter T); statistics, coefficients and arithmetic are fp32/fp64.
+#include <cstdlib>
 #include "nsid_common.h"
 
 namespace {
@@ -438,7 +439,12 @@ extern "C" int nsid_bn_bwd_apply(const void* dout, const void* r, int M, int C, 
     int g0 = CV, d256 = 256;
     while (d256 % 2 == 0 && g0 % 2 == 0) { d256 /= 2; g0 /= 2; }          // g0 = CV / gcd(CV, 256)
     long want = (nchunks + 256L * U - 1) / (256L * U);
-    if (want > 2048) want = 2048;
+    // At most 384 workgroups (1.5 per CU): with 2 048 the pass takes every wave slot and saturates HBM for its 9 us while the
+    // OTHER view's branch of the step stalls (this pass was 88 % exposed in the two-stream step, tools/ablate.sh); fewer, longer
+    // workgroups stream a little slower alone and leave room beside them. One-box A/B of the whole step, three repetitions each:
+    // 2 048: 8.31 / 8.28 / 8.28 ms, 512: 8.21 / 8.23 / 8.23, 384: 8.22 / 8.18 / 8.17 (NSID_BNBA_MAXWG overrides).
+    static const long max_wg = getenv("NSID_BNBA_MAXWG") ? atol(getenv("NSID_BNBA_MAXWG")) : 384;
+    if (want > max_wg) want = max_wg;
     const long grid = (want + g0 - 1) / g0 * g0;
     NSID_LAUNCH((bn_bwd_apply_kernel<T, U>), dim3((int)grid), dim3(256), 0, static_cast<hipStream_t>(stream),
                 static_cast<const T*>(dout), static_cast<const T*>(r), (long)M, CV, scale, shift, mean,
