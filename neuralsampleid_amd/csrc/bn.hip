@@ -261,7 +261,8 @@ inline float bn_slope(int act) { return act == NSID_ACT_RELU ? 0.f : (act == NSI
 
 inline int stream_grid(long nchunks) {
   long b = (nchunks + 255) / 256;
-  return (int)(b > 2048 ? 2048 : (b < 1 ? 1 : b));   // cap and grid-stride (guide §6 G11)
+  static const long cap = getenv("NSID_STREAM_MAXWG") ? atol(getenv("NSID_STREAM_MAXWG")) : 2048;
+  return (int)(b > cap ? cap : (b < 1 ? 1 : b));   // cap and grid-stride (guide §6 G11)
 }
 
 template <typename T>

@@ -1273,10 +1273,15 @@ extern "C" int nsid_linear_bwd_weight(const void* dout, int ldd, const void* x, 
   // (a launch alone is ~8 % slower with them, the two-branch step 1 % faster: half the workgroups and LDS per CU leave the
   // other view's kernels more room — judged by one-box A/B of the whole step)
   static const int rect = getenv("NSID_WGRAD_RECT") ? atoi(getenv("NSID_WGRAD_RECT")) : 1;
+  static const long wg_rect = getenv("NSID_WGRAD_WGS_RECT") ? atol(getenv("NSID_WGRAD_WGS_RECT")) : 256;    // workgroup targets: rect 512 -> 256 is worth
+  // 0.12 ms of the two-stream step (8.23 -> 8.11 ms, one-box A/B x2; 192 / 128 fall back to square tiles and lose 0.2 ms): half the splits =
+  // half the atomic bytes, and a weight gradient is off the critical chain, so its own latency does not matter
+  static const long wg_sq = getenv("NSID_WGRAD_WGS_SQ") ? atol(getenv("NSID_WGRAD_WGS_SQ")) : 1024;
   if (rect && act_dtype == NSID_BF16 && Nout % 128 == 0 && K % 64 == 0 && M % 1024 == 0) {
     const long tiles_r = (long)(Nout / 128) * (K / 64) * groups;
-    const long S = std::min<long>(M / 1024, std::max<long>(1, 512 / tiles_r));
-    if (tiles_r * S >= 256) {
+    const long S = std::min<long>(M / 1024, std::max<long>(1, wg_rect / tiles_r));
+    static const long rect_min = getenv("NSID_WGRAD_RECT_MIN") ? atol(getenv("NSID_WGRAD_RECT_MIN")) : 256;
+    if (tiles_r * S >= rect_min) {
       p.rsplit = (int)S;
       p.rchunk = (int)(M / S);
       return launch<128, 64, false, false>(p, groups, static_cast<hipStream_t>(stream), act_dtype);
@@ -1290,7 +1295,7 @@ extern "C" int nsid_linear_bwd_weight(const void* dout, int ldd, const void* x, 
   const long tiles = (long)((Nout + bm - 1) / bm) * ((K + bm - 1) / bm) * groups;
   long S;
   if (half) {
-    S = std::min<long>((M + 1023) / 1024, std::max<long>(1, 1024 / tiles));
+    S = std::min<long>((M + 1023) / 1024, std::max<long>(1, wg_sq / tiles));
     S = std::max<long>(S, (256 + tiles - 1) / tiles);
     S = std::min<long>(S, (M + 255) / 256);
   } else {
