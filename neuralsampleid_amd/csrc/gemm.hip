@@ -1296,7 +1296,8 @@ extern "C" int nsid_linear_bwd_weight(const void* dout, int ldd, const void* x, 
   long S;
   if (half) {
     S = std::min<long>((M + 1023) / 1024, std::max<long>(1, wg_sq / tiles));
-    S = std::max<long>(S, (256 + tiles - 1) / tiles);
+    static const long sq_min = getenv("NSID_WGRAD_SQ_MIN") ? atol(getenv("NSID_WGRAD_SQ_MIN")) : 256;
+    S = std::max<long>(S, (sq_min + tiles - 1) / tiles);
     S = std::min<long>(S, (M + 255) / 256);
   } else {
     S = std::min<long>((512 + tiles - 1) / tiles, (M + 511) / 512);
