@@ -555,27 +555,99 @@ __global__ __launch_bounds__(KNN2_THREADS) void knn_rank_kernel(const T* __restr
       }
     }
     // rank counting over the strip (LDS operations of one wave are ordered: no barrier needed).
-    // rank(j) = #{m : D[m] < D[j]} + #{m < j : D[m] == D[j]}; the tie term needs a second pass only for lanes whose value
-    // occurs more than once in the row (duplicated nodes), which is rare: the common pass is one compare + add per entry.
-    for (int p = lane; p < 16 * N; p += 64) {
-      const int row = p / N, j = p % N;
-      const float* drow = strip + row * SLD;
-      const float dj = drow[j];
-      int rank = 0, same = 0;
-      for (int m = 0; m < N; m += 4) {
-        const f32x4 dm = *reinterpret_cast<const f32x4*>(drow + m);
+    // rank(j) = #{m : D[m] < D[j]} + #{m < j : D[m] == D[j]}. The tie term matters only for values that occur more than once in a
+    // row (duplicated nodes): rare, and counting `==` beside `<` was half of the loop's instructions. Without ties the N ranks of
+    // a row are a permutation of 0 .. N-1; tied entries all get the LOWER rank, so the row's rank sum falls short of N (N-1) / 2.
+    // A row is visited by min(64, N) lanes at once, each holding N / 64 (or 1) of its entries: the lanes add their ranks up, and
+    // only on a shortfall does the row run the equality pass.
+    if (N < 128) {
+      // small graphs: both counters in one pass (measured: the row-sum form below costs 4 % more here, its per-row reduction is not
+      // amortised over 64 entries)
+      for (int p = lane; p < 16 * N; p += 64) {
+        const int row = p / N, j = p % N;
+        const float* drow = strip + row * SLD;
+        const float dj = drow[j];
+        int rank = 0, same = 0;
+        for (int m = 0; m < N; m += 4) {
+          const f32x4 dm = *reinterpret_cast<const f32x4*>(drow + m);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { rank += dm[e] < dj ? 1 : 0; same += dm[e] == dj ? 1 : 0; }
+          for (int e = 0; e < 4; ++e) { rank += dm[e] < dj ? 1 : 0; same += dm[e] == dj ? 1 : 0; }
+        }
+        if (__any(same > 1)) {                           // wave-uniform
+          if (same > 1)
+            for (int m = 0; m < j; ++m) rank += drow[m] == dj ? 1 : 0;
+        }
+        int32_t* out = idx + ((long)b * N + 16 * s + row) * k;
+        if (dj != dj) {                                  // NaN distances: every entry ranks 0 — emit valid ids anyway
+          if (j < k) out[j] = j;
+        } else if (rank < kd && rank % dilation == 0) {
+          out[rank / dilation] = j;
+        }
       }
-      if (__any(same > 1)) {                           // wave-uniform
-        if (same > 1)
-          for (int m = 0; m < j; ++m) rank += drow[m] == dj ? 1 : 0;
-      }
-      int32_t* out = idx + ((long)b * N + 16 * s + row) * k;
-      if (dj != dj) {                                  // NaN distances: every entry ranks 0 — emit valid ids anyway
-        if (j < k) out[j] = j;
-      } else if (rank < kd && rank % dilation == 0) {
-        out[rank / dilation] = j;
+    } else
+    {
+      const int lprw = N < 64 ? N : 64;                  // lanes per row
+      const int parts = N > 64 ? N >> 6 : 1;             // entries per lane and row (1 or 2: N <= 128)
+      const int rpt = 64 / lprw;                         // rows per trip
+      const int jb = lane % lprw;
+      for (int row0 = 0; row0 < 16; row0 += rpt) {
+        const int row = row0 + lane / lprw;
+        const float* drow = strip + row * SLD;
+        float dj[2];
+        int rank[2] = {0, 0};
+#pragma unroll
+        for (int q = 0; q < 2; ++q) dj[q] = drow[q < parts ? jb + 64 * q : jb];
+        if (parts > 1) {                                 // uniform: one LDS broadcast feeds both of the lane's entries
+          for (int m = 0; m < N; m += 4) {
+            const f32x4 dm = *reinterpret_cast<const f32x4*>(drow + m);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              rank[0] += dm[e] < dj[0] ? 1 : 0;
+              rank[1] += dm[e] < dj[1] ? 1 : 0;
+            }
+          }
+        } else {
+          for (int m = 0; m < N; m += 4) {
+            const f32x4 dm = *reinterpret_cast<const f32x4*>(drow + m);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) rank[0] += dm[e] < dj[0] ? 1 : 0;
+          }
+        }
+        int sum = rank[0] + (parts > 1 ? rank[1] : 0);
+        if (lprw == 64) {
+          sum = (int)wave_sum((float)sum);               // DPP only, exact: the total is < 2^24
+        } else {
+          for (int o = 1; o < lprw; o <<= 1) sum += __shfl_xor(sum, o, 64);
+        }
+        const bool suspect = sum != N * (N - 1) / 2;     // also true for rows that hold NaN (harmless: NaN equals nothing)
+        if (__any(suspect)) {                            // wave-uniform
+          if (suspect) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+              if (q >= parts) continue;
+              const int j = jb + 64 * q;
+              int same = 0;
+              for (int m = 0; m < N; m += 4) {
+                const f32x4 dm = *reinterpret_cast<const f32x4*>(drow + m);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) same += dm[e] == dj[q] ? 1 : 0;
+              }
+              if (same > 1)
+                for (int m = 0; m < j; ++m) rank[q] += drow[m] == dj[q] ? 1 : 0;
+            }
+          }
+        }
+        int32_t* out = idx + ((long)b * N + 16 * s + row) * k;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          if (q >= parts) continue;
+          const int j = jb + 64 * q;
+          if (dj[q] != dj[q]) {                          // NaN distances: every entry ranks 0 — emit valid ids anyway
+            if (j < k) out[j] = j;
+          } else if (rank[q] < kd && rank[q] % dilation == 0) {
+            out[rank[q] / dilation] = j;
+          }
+        }
       }
     }
   }
@@ -665,9 +737,9 @@ __global__ __launch_bounds__(KNN2_THREADS) void knn_sel_kernel(const T* __restri
   const int kd = k * dilation;
   const int pair = wave >> 1, hw = wave & 1;         // two waves per strip: column halves in phase A, row halves in phase B
   float* strip = strips + pair * 16 * SLD;
-  float* lmins = scratch + wave * (64 + 2 * N);
-  float* cval = lmins + 64;
-  int* cidx = reinterpret_cast<int*>(cval + N);
+  float* lmins = scratch + wave * (64 + 2 * N + 8);
+  float* cval = lmins + 64;                          // [N + 4]: room for the float4 padding behind the last candidate
+  int* cidx = reinterpret_cast<int*>(cval + N + 4);  // [N + 4]
   const int NE = N >> 6;                             // entries per lane (2 or 4)
   for (int s0 = 0; s0 < NS; s0 += KSEL_STRIPS) {     // uniform trip count: workgroup barriers inside
     const int s = s0 + pair;
@@ -736,13 +808,20 @@ __global__ __launch_bounds__(KNN2_THREADS) void knn_sel_kernel(const T* __restri
       if (base < kd) {                                         // NaN-poisoned row: fewer finite entries than wanted
         if (lane < k) out[lane] = lane;
       }
+      if (lane < 4) cval[base + lane] = __builtin_inff();      // pad to whole float4 groups: +inf precedes nothing
       for (int c0 = lane; c0 < base; c0 += 64) {
         const float dv = cval[c0];
         const int di = cidx[c0];
         int rank = 0;
-        for (int m = 0; m < base; ++m) {
-          const float ov = cval[m];
-          rank += (ov < dv || (ov == dv && cidx[m] < di)) ? 1 : 0;
+        // four candidates per pair of 16-byte LDS broadcasts (one element per iteration was two dependent LDS round trips per
+        // candidate: ~9 000 cycles per row, most of the kernel's 7 us per row)
+        for (int m = 0; m < base; m += 4) {
+          const f32x4 ov = *reinterpret_cast<const f32x4*>(cval + m);
+          const int4 oi = *reinterpret_cast<const int4*>(cidx + m);
+          rank += (ov[0] < dv || (ov[0] == dv && oi.x < di)) ? 1 : 0;
+          rank += (ov[1] < dv || (ov[1] == dv && oi.y < di)) ? 1 : 0;
+          rank += (ov[2] < dv || (ov[2] == dv && oi.z < di)) ? 1 : 0;
+          rank += (ov[3] < dv || (ov[3] == dv && oi.w < di)) ? 1 : 0;
         }
         if (rank < kd && rank % dilation == 0) out[rank / dilation] = di;
       }
@@ -754,7 +833,7 @@ __global__ __launch_bounds__(KNN2_THREADS) void knn_sel_kernel(const T* __restri
 template <typename T>
 int launch_knn_sel(const void* r, int ldr, const float* scale, const float* shift, int B, int N, int C, int k,
                    int dilation, int32_t* idx, hipStream_t s) {
-  const size_t bytes = ((size_t)N * (C + 4) + N + (size_t)KSEL_STRIPS * 16 * (N + 4) + (size_t)KNN2_WAVES * (64 + 2 * N)) *
+  const size_t bytes = ((size_t)N * (C + 4) + N + (size_t)KSEL_STRIPS * 16 * (N + 4) + (size_t)KNN2_WAVES * (64 + 2 * N + 8)) *
                        sizeof(float);
   if (bytes > 160 * 1024) return 1;
   static bool configured = false;

@@ -233,6 +233,38 @@ def test_knn_graph_golden(ops, golden, tag, kds):
         assert exact.mean() > 0.98, (k, d, exact.mean())
 
 
+@pytest.mark.parametrize("N,C,k,d", [(128, 128, 18, 2), (64, 256, 18, 3), (256, 64, 18, 1), (256, 64, 3, 1), (32, 512, 18, 1)])
+def test_knn_graph_duplicated_nodes_take_the_lower_index(ops, N, C, k, d):
+    """exact ties (duplicated nodes: identical rows give bit-identical distances) in every selection kernel: rank counting with the
+    row-sum tie detection (N = 128), the one-pass form (N <= 64), threshold select (N = 256, k*d > 8) and the register lists
+    (k*d <= 8) order equal distances by node index, like a stable sort of the reference's distances"""
+    B = 3
+    x = rnd(f"dupknn{N}", B * N, C)
+    x = x.reshape(B, N, C).clone()
+    x[0, 5] = x[0, 3]                       # a pair
+    x[1, N - 1] = x[1, 2]
+    x[1, N // 2] = x[1, 2]                  # a triple
+    x[2, 1] = x[2, 0]
+    x[2, 7] = x[2, 6]                       # two pairs in one clip
+    idx = ops.knn_graph(x.reshape(B * N, C).contiguous().to(DEV), B, N, C, k, d).cpu()
+    xn = torch.nn.functional.normalize(x.double(), dim=-1)
+    dist = (xn * xn).sum(-1, keepdim=True) - 2 * xn @ xn.transpose(1, 2) + (xn * xn).sum(-1).unsqueeze(1)
+    for (b, i, twins) in [(0, 3, [3, 5]), (0, 5, [3, 5]), (1, 2, [2, N // 2, N - 1]), (1, N - 1, [2, N // 2, N - 1]), (2, 0, [0, 1]),
+                          (2, 6, [6, 7])]:
+        got = idx[b, i].tolist()
+        # the duplicates of node i are at distance 0 from it, bit-identical: they must lead the list in index order (dilation keeps
+        # every d-th of the sorted neighbours)
+        want = twins[::d][:k]
+        assert got[:len(want)] == want, (N, b, i, got[:4], want)
+    # everything else still matches a stable sort of fp64 distances wherever those are well separated
+    order = torch.argsort(dist, dim=-1, stable=True)[..., :k * d:d]
+    srt = torch.sort(dist, dim=-1).values
+    gap = (srt[..., 1:k * d + 1] - srt[..., :k * d]).clamp_min(0)
+    clear = (gap[..., 2:].min(-1).values > 1e-4)              # (the first gaps are the exact ties made above)
+    same = (idx.long() == order).all(-1) | ~clear
+    assert same.float().mean() > 0.97, float(same.float().mean())
+
+
 def test_knn_graph_affine(ops):
     B, N, C, k = 4, 64, 256, 5
     r = rnd("knnaff", B * N, C)
