@@ -293,6 +293,40 @@ def test_eval_batchnorm_folding_matches_the_unfolded_path(ops, golden):
     assert relerr(outs[True][0], g.t("h_i_eval")) < 4e-2
 
 
+def test_lds_dma_gemm_inside_the_eval_forward(ops, golden):
+    """the folded eval forward with EVERY eligible GEMM on csrc/gemm256.hip (threshold forced to one tile: the C >= 128 stages' fc1 / fc2 /
+    FFN layers take the plain, ReLU and residual epilogues) against the same forward on csrc/gemm.hip and against the reference goldens"""
+    from neuralsampleid_amd import functional as F_
+    from neuralsampleid_amd._lib import call, lib
+    F_.set_activation_dtype("bf16")
+    g = golden("e2e_b8_k3")
+    model = build()
+    model.load_state_dict(synth_state(model.state_dict()))
+    model.to(DEV).eval()
+    x_i, x_j = g.t("x_i").to(DEV), g.t("x_j").to(DEV)
+    n = len([k for k in g if k.startswith("knn.eval.")])
+    gold_idx = [g.t(f"knn.eval.{c}") for c in range(n)]
+    outs, launches = {}, {}
+    try:
+        for thr in (0, 1):
+            call("nsid_set_gemm_g256_min", thr)
+            n0 = lib.nsid_gemm_g256_launches()
+            F_.TAPE = F_.KnnTape(replay=gold_idx)
+            with torch.no_grad():
+                outs[thr] = model(x_i, x_j)
+            torch.cuda.synchronize()
+            launches[thr] = lib.nsid_gemm_g256_launches() - n0
+    finally:
+        F_.TAPE = None
+        call("nsid_set_gemm_g256_min", 512)
+    assert launches[0] == 0 and launches[1] >= 2 * 16, launches          # two views x (10 blocks with C >= 128: FFN fc1 + fc2 at least)
+    for a, b in zip(outs[1], outs[0]):
+        assert relerr(a, b) < 1e-2, relerr(a, b)                          # same operands and rounding points, another summation order
+    cos = torch.nn.functional.cosine_similarity(outs[1][2], outs[0][2], dim=1)
+    assert float(cos.min()) > 0.9998, float(cos.min())
+    assert relerr(outs[1][0], g.t("h_i_eval")) < 4e-2
+
+
 @pytest.mark.parametrize("M,Nout,K,affine,stat,res", [(16384, 1024, 256, False, True, False), (16384, 1024, 256, True, True, False),
                                                        (8192, 2048, 512, True, False, True), (32768, 512, 128, False, True, False)])
 def test_eight_wave_forward_tiles(ops, M, Nout, K, affine, stat, res):
