@@ -56,7 +56,8 @@ int nsid_get_gemm_precision(void);
 int nsid_set_gemm_w8_min(int tiles);
 /* tuning: smallest number of 256x256 output tiles for which nsid_linear_fwd / nsid_linear_fwd_res (bf16 storage, bf16 weights,
    one group, M % 256 == 0, Nout % 256 == 0, K % 128 == 0, no operand-load affine) take the LDS-DMA 256x256-tile kernel
-   (csrc/gemm256.hip); 0 = never; default 512 (env NSID_G256_MIN sets the initial value). nsid_gemm_g256_launches() = launches that took it. */
+   (csrc/gemm256.hip); 0 = never; default 512 for launches without a statistics epilogue (forward-only work); a threshold set here or by
+   env NSID_G256_MIN also applies to launches with statistics (training). nsid_gemm_g256_launches() = launches that took it. */
 int nsid_set_gemm_g256_min(int tiles);
 long nsid_gemm_g256_launches(void);
 /* number of NSID_ROW_TILE row tiles of an M-row matrix: size of the partial-statistics buffers */

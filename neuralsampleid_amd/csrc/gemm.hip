@@ -814,6 +814,9 @@ int g_gemm_precision = NSID_GEMM_FP32;     // process-wide (nsid_set_gemm_precis
 int g_w8_min = -1;
 // smallest number of 256x256 tiles for which the forward GEMM takes gemm256.hip (LDS-DMA staging); 0 = never
 int g_g256_min = -1;
+bool g_g256_explicit = false; // the threshold was set by NSID_G256_MIN / nsid_set_gemm_g256_min: only then do launches WITH a
+                              // statistics epilogue (training) take it — the default serves forward-only work, so that the
+                              // arithmetic of a training step does not depend on the batch size
 long g_g256_launches = 0;     // launches that took it (tests check that the kernel under test really ran)
 
 template <int BM, int BN, bool AR, bool BR, int NW = 4>
@@ -1068,6 +1071,7 @@ extern "C" int nsid_set_gemm_w8_min(int tiles) {
 extern "C" int nsid_set_gemm_g256_min(int tiles) {
   NSID_REQUIRE(tiles >= 0);
   g_g256_min = tiles;
+  g_g256_explicit = true;
   return NSID_OK;
 }
 extern "C" long nsid_gemm_g256_launches(void) { return g_g256_launches; }
@@ -1160,9 +1164,12 @@ static int linear_fwd_impl(const void* x, int ldx, const void* w, int w_dtype, c
   // default 512 (two tiles per CU and more: fingerprinting at micro-batch 2 048): 7.09 -> 6.56 ms per micro-batch. The training step
   // (<= 256 such tiles per launch) is neutral to slightly worse with it (8.30 vs 8.34 ms: a workgroup that owns 150 KB of a CU's LDS
   // keeps the other view's kernels off that CU), so it stays on gemm.hip.
-  if (g_g256_min < 0) g_g256_min = getenv("NSID_G256_MIN") ? atoi(getenv("NSID_G256_MIN")) : 512;
+  if (g_g256_min < 0) {
+    g_g256_explicit = getenv("NSID_G256_MIN") != nullptr;
+    g_g256_min = g_g256_explicit ? atoi(getenv("NSID_G256_MIN")) : 512;
+  }
   const int g256_min = g_g256_min;
-  if (g256_min > 0 && act_dtype == NSID_BF16 && wb && groups == 1 && in_scale == nullptr && ksplit == 1 &&
+  if (g256_min > 0 && (stat == nullptr || g_g256_explicit) && act_dtype == NSID_BF16 && wb && groups == 1 && in_scale == nullptr && ksplit == 1 &&
       (act_out == NSID_ACT_NONE || act_out == NSID_ACT_RELU) && act_in == NSID_ACT_NONE && ldx >= K &&
       (long)(M / 256) * (Nout / 256) >= g256_min) {
     const int rc256 = nsid_gemm256_fwd_launch(x, ldx, w, bias, addend, ldadd, out, ldo, M, Nout, K, act_out == NSID_ACT_RELU, stat,

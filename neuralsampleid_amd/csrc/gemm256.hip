@@ -368,9 +368,9 @@ int nsid_gemm256_fwd_launch(const void* x, int ldx, const void* w, const float* 
   p.trace = static_cast<unsigned long long*>(g_gemm_trace_host);
   static int n_cu = 0;
   if (n_cu == 0) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
+    int dev = 0, n = 0;               // an attribute query, not hipGetDeviceProperties: legal whatever the stream is doing (capture)
+    n_cu = (hipGetDevice(&dev) == hipSuccess &&
+            hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess) ? n : 256;
     if (const char* e = getenv("NSID_G256_GRID")) n_cu = atoi(e);        // experiments
     if (n_cu <= 0) n_cu = 256;
   }
