@@ -408,15 +408,29 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
   const float bc1 = (float)(1.0 - pow((double)b1, t));
   const float bc2_sqrt = (float)sqrt(1.0 - pow((double)b2, t));
   const float step_size = lr / bc1;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-    const float gi = g[i] * coef;
-    const float mi = m[i] * b1 + (1.f - b1) * gi;       // exp_avg.lerp_(grad, 1-beta1)
-    const float vi = v[i] * b2 + (1.f - b2) * gi * gi;
-    m[i] = mi;
-    v[i] = vi;
+  // 16 bytes per lane and access (seven streams of 73.5 MB: the scalar form ran at 3.7 TB/s); same per-element expressions
+  const long n4 = (reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) |
+                   reinterpret_cast<uintptr_t>(v)) % 16 == 0 ? n / 4 : 0;
+  auto upd = [&](float gi_, float& mi_, float& vi_, float& pi_) {
+    const float gi = gi_ * coef;
+    const float mi = mi_ * b1 + (1.f - b1) * gi;        // exp_avg.lerp_(grad, 1-beta1)
+    const float vi = vi_ * b2 + (1.f - b2) * gi * gi;
+    mi_ = mi;
+    vi_ = vi;
     const float denom = sqrtf(vi) / bc2_sqrt + eps;
-    p[i] -= step_size * (mi / denom);
+    pi_ -= step_size * (mi / denom);
+  };
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    const f32x4 g4 = reinterpret_cast<const f32x4*>(g)[i];
+    f32x4 m4 = reinterpret_cast<f32x4*>(m)[i], v4 = reinterpret_cast<f32x4*>(v)[i], p4 = reinterpret_cast<f32x4*>(p)[i];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) upd(g4[e], m4[e], v4[e], p4[e]);
+    reinterpret_cast<f32x4*>(m)[i] = m4;
+    reinterpret_cast<f32x4*>(v)[i] = v4;
+    reinterpret_cast<f32x4*>(p)[i] = p4;
   }
+  for (long i = 4 * n4 + (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    upd(g[i], m[i], v[i], p[i]);
 }
 __global__ void adam_tick_kernel(int64_t* step, const float* gnorm) {
   if (gnorm == nullptr || isfinite(gnorm[0])) *step += 1;
