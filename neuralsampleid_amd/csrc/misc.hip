@@ -424,7 +424,11 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     const f32x4 g4 = reinterpret_cast<const f32x4*>(g)[i];
     f32x4 m4 = reinterpret_cast<f32x4*>(m)[i], v4 = reinterpret_cast<f32x4*>(v)[i], p4 = reinterpret_cast<f32x4*>(p)[i];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) upd(g4[e], m4[e], v4[e], p4[e]);
+    for (int e = 0; e < 4; ++e) {          // (vector elements do not bind to references)
+      float me = m4[e], ve = v4[e], pe = p4[e];
+      upd(g4[e], me, ve, pe);
+      m4[e] = me; v4[e] = ve; p4[e] = pe;
+    }
     reinterpret_cast<f32x4*>(m)[i] = m4;
     reinterpret_cast<f32x4*>(v)[i] = v4;
     reinterpret_cast<f32x4*>(p)[i] = p4;
