@@ -400,12 +400,30 @@ def main():
                 step()
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
-            g = torch.cuda.CUDAGraph()
+            use_engine = world == 1 and os.environ.get("NSID_ENGINE", "0") != "0"
+            g = torch.cuda.CUDAGraph(keep_graph=True) if use_engine else torch.cuda.CUDAGraph()
             # world > 1: RCCL's helper threads may touch the HIP runtime while we capture; only calls made by the
             # capturing thread may invalidate the capture ("thread_local"), not theirs
             mode = os.environ.get("NSID_CAPTURE_MODE", "thread_local" if world > 1 else "global")
-            with torch.cuda.graph(g, capture_error_mode=mode):
-                step()
+            if use_engine:       # experiment: replay as plain stream launches, weight gradients floating (neuralsampleid_amd/engine.py)
+                from neuralsampleid_amd import engine as eng
+                keep = []
+                with eng.retain_allocations(keep), torch.cuda.graph(g, capture_error_mode=mode):
+                    step()
+                e = eng.StepEngine(g, keep, float_wgrad=os.environ.get("NSID_ENGINE") != "2")
+                log(f"{tag} step engine: {e.info}; {len(keep)} tensors retained")
+                e.replay(); torch.cuda.synchronize()
+                h0 = time.perf_counter()
+                for _ in range(5):
+                    e.replay()
+                h1 = time.perf_counter()
+                torch.cuda.synchronize()
+                log(f"engine host time per replay: {1e3 * (h1 - h0) / 5:.2f} ms (5 replays enqueued without waiting)")      # (these 6 replays advanced the model: harmless for a throughput run)
+                import types
+                g = types.SimpleNamespace(replay=e.replay, engine=e, graph=g)
+            else:
+                with torch.cuda.graph(g, capture_error_mode=mode):
+                    step()
             if rank == 0:
                 log(f"{tag} step captured in a hipGraph")
         except Exception as e:        # capture is an optimisation, never a requirement

@@ -60,6 +60,14 @@ int nsid_set_gemm_w8_min(int tiles);
    env NSID_G256_MIN also applies to launches with statistics (training). nsid_gemm_g256_launches() = launches that took it. */
 int nsid_set_gemm_g256_min(int tiles);
 long nsid_gemm_g256_launches(void);
+/* ---- step engine (csrc/engine.hip): replays a CAPTURED step (hipGraph_t of kernel nodes) as plain stream launches with its own
+   dependency plan — with float_wgrad != 0 the weight-gradient kernels leave the view chains for auxiliary streams and only the
+   optimiser tail waits for them (a hipGraph charges 15-20 us for every such fork on this ROCm, a stream event ~2 us). The caller keeps
+   the graph alive (the nodes' argument blocks are used in place) and guarantees that no buffer a weight gradient reads is freed or
+   overwritten before the step ends. `log` receives a one-line description or the reason for a refusal. */
+int nsid_engine_build(void* hip_graph, void** engine_out, int float_wgrad, char* log, size_t log_len);
+int nsid_engine_replay(void* engine, void* main_stream);
+int nsid_engine_destroy(void* engine);
 /* number of NSID_ROW_TILE row tiles of an M-row matrix: size of the partial-statistics buffers */
 int nsid_row_tiles(int M);
 

@@ -85,6 +85,12 @@ def _load():
     lib.nsid_get_gemm_precision.restype = ctypes.c_int
     lib.nsid_gemm_g256_launches.argtypes = []
     lib.nsid_gemm_g256_launches.restype = ctypes.c_long
+    lib.nsid_engine_build.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.c_char_p, ctypes.c_size_t]
+    lib.nsid_engine_build.restype = ctypes.c_int
+    lib.nsid_engine_replay.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    lib.nsid_engine_replay.restype = ctypes.c_int
+    lib.nsid_engine_destroy.argtypes = [ctypes.c_void_p]
+    lib.nsid_engine_destroy.restype = ctypes.c_int
     lib.nsid_row_tiles.argtypes = [ctypes.c_int]
     lib.nsid_row_tiles.restype = ctypes.c_int
     lib.nsid_sumsq_blocks.argtypes = [ctypes.c_long]
@@ -95,7 +101,7 @@ def _load():
 
 
 lib = _load()
-EXPORTS = list(SIGNATURES) + ["nsid_version", "nsid_debug_gemm_trace", "nsid_debug_knn_trace", "nsid_get_gemm_precision", "nsid_gemm_g256_launches", "nsid_row_tiles", "nsid_sumsq_blocks", "nsid_ntxent_ws_floats"]
+EXPORTS = list(SIGNATURES) + ["nsid_version", "nsid_debug_gemm_trace", "nsid_debug_knn_trace", "nsid_get_gemm_precision", "nsid_gemm_g256_launches", "nsid_engine_build", "nsid_engine_replay", "nsid_engine_destroy", "nsid_row_tiles", "nsid_sumsq_blocks", "nsid_ntxent_ws_floats"]
 
 _ERR = {-1: "NSID_EINVAL (unsupported shape, misaligned pointer or bad argument)",
         -2: "NSID_ELAUNCH (HIP runtime refused the launch)"}

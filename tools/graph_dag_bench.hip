@@ -8,6 +8,7 @@
 //   B  four streams: side kernels on an auxiliary stream per chain, one event edge per layer  (what lost)
 //   C  explicit graph (hipGraphAddKernelNode): same DAG as B, no event nodes
 //   D  explicit graph, chain kernels only                                     (lower bound: the side work is free)
+//   E / F  A and B launched directly on streams, no graph (one host thread: launch cost included)
 // Kernels are calibrated spin loops: `chain_us` on `chain_wgs` workgroups, `side_us` on `side_wgs`.
 //   hipcc --offload-arch=gfx950 -O2 -o /tmp/graph_dag_bench tools/graph_dag_bench.hip && /tmp/graph_dag_bench [layers chain_us side_us chain_wgs side_wgs]
 #include <hip/hip_runtime.h>
@@ -77,6 +78,48 @@ static hipGraphExec_t capture(const Cfg& c, bool aux) {
   return ex;
 }
 
+// the same work launched directly (no graph): host launch cost included, one host thread
+static float time_streams(const Cfg& c, bool aux, int reps) {
+  hipStream_t m, s2, a1, a2;
+  CK(hipStreamCreate(&m)); CK(hipStreamCreate(&s2)); CK(hipStreamCreate(&a1)); CK(hipStreamCreate(&a2));
+  std::vector<hipEvent_t> ev(2 * c.layers);
+  for (auto& e : ev) CK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  hipEvent_t j2, ja1, ja2, t0, t1;
+  CK(hipEventCreateWithFlags(&j2, hipEventDisableTiming)); CK(hipEventCreateWithFlags(&ja1, hipEventDisableTiming));
+  CK(hipEventCreateWithFlags(&ja2, hipEventDisableTiming));
+  CK(hipEventCreate(&t0)); CK(hipEventCreate(&t1));
+  float best = 1e30f;
+  for (int r = 0; r < reps + 1; ++r) {
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(t0, m));
+    CK(hipStreamWaitEvent(s2, t0, 0));
+    if (aux) { CK(hipStreamWaitEvent(a1, t0, 0)); CK(hipStreamWaitEvent(a2, t0, 0)); }
+    for (int l = 0; l < c.layers; ++l) {
+      hipStream_t chain[2] = {m, s2}, side[2] = {aux ? a1 : m, aux ? a2 : s2};
+      for (int v = 0; v < 2; ++v) {
+        launch(chain[v], c.chain_ticks, c.chain_wgs);
+        if (aux) {
+          CK(hipEventRecord(ev[2 * l + v], chain[v]));
+          CK(hipStreamWaitEvent(side[v], ev[2 * l + v], 0));
+        }
+        launch(side[v], c.side_ticks, c.side_wgs);
+      }
+    }
+    CK(hipEventRecord(j2, s2)); CK(hipStreamWaitEvent(m, j2, 0));
+    if (aux) {
+      CK(hipEventRecord(ja1, a1)); CK(hipStreamWaitEvent(m, ja1, 0));
+      CK(hipEventRecord(ja2, a2)); CK(hipStreamWaitEvent(m, ja2, 0));
+    }
+    launch(m, 100, 1);
+    CK(hipEventRecord(t1, m));
+    CK(hipStreamSynchronize(m));
+    float ms = 0;
+    CK(hipEventElapsedTime(&ms, t0, t1));
+    if (r > 0 && ms < best) best = ms;
+  }
+  return best * 1e3f;
+}
+
 static hipGraphExec_t explicit_graph(const Cfg& c, bool with_side) {
   hipGraph_t g;
   CK(hipGraphCreate(&g, 0));
@@ -126,5 +169,7 @@ int main(int argc, char** argv) {
   printf("  B four streams, event edge per layer      : %8.1f us per replay\n", time_graph(capture(c, true), s, 10));
   printf("  C explicit DAG, side kernels hang off     : %8.1f us per replay\n", time_graph(explicit_graph(c, true), s, 10));
   printf("  D explicit DAG, chains only               : %8.1f us per replay\n", time_graph(explicit_graph(c, false), s, 10));
+  printf("  E no graph, two streams inline            : %8.1f us (best of 5, host launches included)\n", time_streams(c, false, 5));
+  printf("  F no graph, four streams + events         : %8.1f us (best of 5, host launches included)\n", time_streams(c, true, 5));
   return 0;
 }
