@@ -297,7 +297,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=CFG["bsz_train"], help="clips (pairs) per GPU")
     ap.add_argument("--k", type=int, default=3, help="kNN neighbours (GraphEncoder default 3; train.py --k default 5)")
-    ap.add_argument("--precision", choices=["fp32", "bf16"], default=os.environ.get("NSID_BENCH_PRECISION", "bf16"),
+    ap.add_argument("--precision", choices=["fp32", "bf16"], default="bf16",
                     help="GEMM operand arithmetic: bf16 operands / fp32 storage+accumulate (BASELINE config 2, default) "
                          "or fp32 (exact fp32 MFMA, the strict-parity path); the other mode is timed as a side number")
     ap.add_argument("--storage", choices=["fp32", "bf16"], default=None,
@@ -318,6 +318,11 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="do not capture the step in a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-other", action="store_true",
+                    help="skip the side measurements of a default run (other precision, configs 4 and 5): A/B sweeps use this")
+    ap.add_argument("--tune", action="append", default=[], metavar="KEY=VALUE",
+                    help="set a tuning key of the kernel library (include/nsid.h nsid_set_tuning) for this run; recorded in "
+                         "config.tuning. The library never reads the environment.")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args.gpus))
@@ -342,6 +347,11 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
+    tuning = {}
+    for kv in args.tune:
+        key, _, val = kv.partition("=")
+        ops.set_tuning(key, int(val))
+        tuning[key] = int(val)
     from neuralsampleid_amd import functional as F_
     if args.storage is None:
         args.storage = "bf16" if args.precision == "bf16" else "fp32"
@@ -400,30 +410,12 @@ def main():
                 step()
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
-            use_engine = world == 1 and os.environ.get("NSID_ENGINE", "0") != "0"
-            g = torch.cuda.CUDAGraph(keep_graph=True) if use_engine else torch.cuda.CUDAGraph()
+            g = torch.cuda.CUDAGraph()
             # world > 1: RCCL's helper threads may touch the HIP runtime while we capture; only calls made by the
             # capturing thread may invalidate the capture ("thread_local"), not theirs
             mode = os.environ.get("NSID_CAPTURE_MODE", "thread_local" if world > 1 else "global")
-            if use_engine:       # experiment: replay as plain stream launches, weight gradients floating (neuralsampleid_amd/engine.py)
-                from neuralsampleid_amd import engine as eng
-                keep = []
-                with eng.retain_allocations(keep), torch.cuda.graph(g, capture_error_mode=mode):
-                    step()
-                e = eng.StepEngine(g, keep, float_wgrad=os.environ.get("NSID_ENGINE") != "2")
-                log(f"{tag} step engine: {e.info}; {len(keep)} tensors retained")
-                e.replay(); torch.cuda.synchronize()
-                h0 = time.perf_counter()
-                for _ in range(5):
-                    e.replay()
-                h1 = time.perf_counter()
-                torch.cuda.synchronize()
-                log(f"engine host time per replay: {1e3 * (h1 - h0) / 5:.2f} ms (5 replays enqueued without waiting)")      # (these 6 replays advanced the model: harmless for a throughput run)
-                import types
-                g = types.SimpleNamespace(replay=e.replay, engine=e, graph=g)
-            else:
-                with torch.cuda.graph(g, capture_error_mode=mode):
-                    step()
+            with torch.cuda.graph(g, capture_error_mode=mode):
+                step()
             if rank == 0:
                 log(f"{tag} step captured in a hipGraph")
         except Exception as e:        # capture is an optimisation, never a requirement
@@ -489,7 +481,7 @@ def main():
         roofline = roofline_entry(prof, args.precision, bracket_us, "_deep" if args.deep else "")
 
     other = None
-    if world == 1 and not args.no_roofline:
+    if world == 1 and not args.no_roofline and not args.no_other:
         # side number: the same step in the other arithmetic (eager; the GPU time dominates the host time)
         alt = "fp32" if args.precision == "bf16" else "bf16"
         ops.set_gemm_precision(alt)
@@ -547,6 +539,7 @@ def main():
                        "activation_storage": args.storage,
                        "views": "two HIP streams (parallel graph branches)" if not args.no_overlap else "sequential",
                        "hipgraph": graph is not None, "final_loss": round(final_loss, 5),
+                       "tuning": tuning or None, "lib": os.environ.get("NSID_LIB") or None,
                        "rccl": ({"ncclCommCount": parallel.COMM.count(), "collectives_per_step": per_step_calls,
                                  "gradient_buckets": len(reducer.bounds), "bucket_bytes": 16 << 20,
                                  "captured_on_every_rank": graph is not None}

@@ -51,23 +51,17 @@ int nsid_debug_knn_trace(void* device_buf);
 /* process-wide arithmetic of the nsid_linear_* GEMMs (BASELINE config 2 names bf16 compute); returns NSID_OK/EINVAL */
 int nsid_set_gemm_precision(int mode);
 int nsid_get_gemm_precision(void);
-/* tuning: smallest number of 128x128 output tiles for which nsid_linear_fwd (bf16 storage, bf16 weights, whole tiles) takes
-   the 8-wave 256x128-tile kernel; 0 = never (default; env NSID_W8_MIN sets the initial value) */
-int nsid_set_gemm_w8_min(int tiles);
-/* tuning: smallest number of 256x256 output tiles for which nsid_linear_fwd / nsid_linear_fwd_res (bf16 storage, bf16 weights,
-   one group, M % 256 == 0, Nout % 256 == 0, K % 128 == 0, no operand-load affine) take the LDS-DMA 256x256-tile kernel
-   (csrc/gemm256.hip); 0 = never; default 512 for launches without a statistics epilogue (forward-only work); a threshold set here or by
-   env NSID_G256_MIN also applies to launches with statistics (training). nsid_gemm_g256_launches() = launches that took it. */
-int nsid_set_gemm_g256_min(int tiles);
+/* ---- tuning: named launch-heuristic constants (tile-width thresholds, workgroup caps, split targets, kernel-family switches).
+   The library never reads the environment: defaults are compiled in (csrc/nsid_common.h NSID_TUNING_TABLE lists every key with
+   its default and meaning), and a run changes them only through these calls, so kernel selection and arithmetic depend on explicit
+   caller state alone. Keys used by the tests: "g256_min", "g256_train", "w8_min", "knn_strips". Unknown key -> NSID_EINVAL. */
+int nsid_set_tuning(const char* key, long value);
+int nsid_get_tuning(const char* key, long* value);
+int nsid_reset_tuning(void);                 /* every key back to its compiled-in default */
+int nsid_tuning_count(void);
+const char* nsid_tuning_key(int i);          /* i in [0, nsid_tuning_count()) */
+/* launches of nsid_linear_fwd / nsid_linear_fwd_res that took the 256x256-tile LDS-DMA kernel (csrc/gemm256.hip) so far */
 long nsid_gemm_g256_launches(void);
-/* ---- step engine (csrc/engine.hip): replays a CAPTURED step (hipGraph_t of kernel nodes) as plain stream launches with its own
-   dependency plan — with float_wgrad != 0 the weight-gradient kernels leave the view chains for auxiliary streams and only the
-   optimiser tail waits for them (a hipGraph charges 15-20 us for every such fork on this ROCm, a stream event ~2 us). The caller keeps
-   the graph alive (the nodes' argument blocks are used in place) and guarantees that no buffer a weight gradient reads is freed or
-   overwritten before the step ends. `log` receives a one-line description or the reason for a refusal. */
-int nsid_engine_build(void* hip_graph, void** engine_out, int float_wgrad, char* log, size_t log_len);
-int nsid_engine_replay(void* engine, void* main_stream);
-int nsid_engine_destroy(void* engine);
 /* number of NSID_ROW_TILE row tiles of an M-row matrix: size of the partial-statistics buffers */
 int nsid_row_tiles(int M);
 

@@ -9,13 +9,13 @@ import torch  # noqa: F401  -- must come first: torch bundles its own libamdhip6
 #                              would bind the system HIP runtime and leave two runtimes in one process
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("NSID_LIB") or os.path.join(_PKG, "libnsid_hip.so")     # NSID_LIB: an alternative build (kernel A/B experiments)
+# NSID_LIB: path of an alternative BUILD of the same library (one-box kernel A/B, tools/build_variant.sh). It selects which .so is
+# loaded, nothing inside the library reads the environment; bench.py records an override in its JSON line (config.lib).
+LIB_PATH = os.environ.get("NSID_LIB") or os.path.join(_PKG, "libnsid_hip.so")
 
 # signature letters: p = device pointer, i = int, l = long, z = size_t, f = float, s = stream (void*)
 SIGNATURES = {
     "nsid_set_gemm_precision": "i",
-    "nsid_set_gemm_w8_min": "i",
-    "nsid_set_gemm_g256_min": "i",
     "nsid_linear_fwd": "pipippiiiiippiipiis",
     "nsid_linear_fwd_res": "pipippipiiiiippiis",
     "nsid_linear_bwd_data": "pipipipiiiiiis",
@@ -85,12 +85,16 @@ def _load():
     lib.nsid_get_gemm_precision.restype = ctypes.c_int
     lib.nsid_gemm_g256_launches.argtypes = []
     lib.nsid_gemm_g256_launches.restype = ctypes.c_long
-    lib.nsid_engine_build.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.c_char_p, ctypes.c_size_t]
-    lib.nsid_engine_build.restype = ctypes.c_int
-    lib.nsid_engine_replay.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
-    lib.nsid_engine_replay.restype = ctypes.c_int
-    lib.nsid_engine_destroy.argtypes = [ctypes.c_void_p]
-    lib.nsid_engine_destroy.restype = ctypes.c_int
+    lib.nsid_set_tuning.argtypes = [ctypes.c_char_p, ctypes.c_long]
+    lib.nsid_set_tuning.restype = ctypes.c_int
+    lib.nsid_get_tuning.argtypes = [ctypes.c_char_p, ctypes.POINTER(ctypes.c_long)]
+    lib.nsid_get_tuning.restype = ctypes.c_int
+    lib.nsid_reset_tuning.argtypes = []
+    lib.nsid_reset_tuning.restype = ctypes.c_int
+    lib.nsid_tuning_count.argtypes = []
+    lib.nsid_tuning_count.restype = ctypes.c_int
+    lib.nsid_tuning_key.argtypes = [ctypes.c_int]
+    lib.nsid_tuning_key.restype = ctypes.c_char_p
     lib.nsid_row_tiles.argtypes = [ctypes.c_int]
     lib.nsid_row_tiles.restype = ctypes.c_int
     lib.nsid_sumsq_blocks.argtypes = [ctypes.c_long]
@@ -101,20 +105,34 @@ def _load():
 
 
 lib = _load()
-EXPORTS = list(SIGNATURES) + ["nsid_version", "nsid_debug_gemm_trace", "nsid_debug_knn_trace", "nsid_get_gemm_precision", "nsid_gemm_g256_launches", "nsid_engine_build", "nsid_engine_replay", "nsid_engine_destroy", "nsid_row_tiles", "nsid_sumsq_blocks", "nsid_ntxent_ws_floats"]
+EXPORTS = list(SIGNATURES) + ["nsid_version", "nsid_debug_gemm_trace", "nsid_debug_knn_trace", "nsid_get_gemm_precision", "nsid_gemm_g256_launches", "nsid_set_tuning", "nsid_get_tuning", "nsid_reset_tuning", "nsid_tuning_count", "nsid_tuning_key", "nsid_row_tiles", "nsid_sumsq_blocks", "nsid_ntxent_ws_floats"]
 
 _ERR = {-1: "NSID_EINVAL (unsupported shape, misaligned pointer or bad argument)",
         -2: "NSID_ELAUNCH (HIP runtime refused the launch)"}
 
 
-# NSID_ABLATE=name1,name2: timing experiments ONLY — the listed entry points return immediately without launching, so that
-# `bench.py` shows what a kernel family costs in the two-stream step (results are then garbage; tools/ablate.sh)
-_ABLATE = frozenset(n for n in os.environ.get("NSID_ABLATE", "").split(",") if n)
-
-
 def call(name, *args):
-    if _ABLATE and name in _ABLATE:
-        return
     rc = getattr(lib, name)(*args)
     if rc != 0:
         raise RuntimeError(f"{name} failed: {_ERR.get(rc, rc)}")
+
+
+def set_tuning(key: str, value: int) -> None:
+    """one launch-heuristic constant of the kernel library (include/nsid.h nsid_set_tuning; keys: tuning_keys())"""
+    if lib.nsid_set_tuning(key.encode(), int(value)) != 0:
+        raise KeyError(f"unknown tuning key {key!r}; known: {', '.join(tuning_keys())}")
+
+
+def get_tuning(key: str) -> int:
+    v = ctypes.c_long()
+    if lib.nsid_get_tuning(key.encode(), ctypes.byref(v)) != 0:
+        raise KeyError(f"unknown tuning key {key!r}")
+    return int(v.value)
+
+
+def reset_tuning() -> None:
+    lib.nsid_reset_tuning()
+
+
+def tuning_keys():
+    return [lib.nsid_tuning_key(i).decode() for i in range(lib.nsid_tuning_count())]

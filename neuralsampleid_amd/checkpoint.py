@@ -25,7 +25,15 @@ def load_reference_checkpoint(model: torch.nn.Module, path_or_dict, strict: bool
     dict (epoch / loss / optimizer / scheduler entries untouched) so a caller can resume as train.py:131-137 does."""
     ckpt = path_or_dict
     if not isinstance(ckpt, Mapping):
-        ckpt = torch.load(path_or_dict, map_location=map_location)
+        try:
+            ckpt = torch.load(path_or_dict, map_location=map_location)
+        except Exception as strict_err:      # torch >= 2.6 defaults to weights_only=True
+            import pickle
+            if not isinstance(strict_err, (pickle.UnpicklingError, RuntimeError)):
+                raise
+            # the reference's own checkpoints carry loss / hit-rate logs with numpy scalars and are loaded there with an
+            # unrestricted torch.load (util.py:149-158, generate.py:88-97): a LOCAL, TRUSTED file gets the same treatment
+            ckpt = torch.load(path_or_dict, map_location=map_location, weights_only=False)
     sd = ckpt["state_dict"] if "state_dict" in ckpt and isinstance(ckpt["state_dict"], Mapping) else ckpt
     model.load_state_dict(strip_data_parallel_prefix(sd), strict=strict)
     return ckpt if sd is not ckpt else {"state_dict": sd}
@@ -33,7 +41,10 @@ def load_reference_checkpoint(model: torch.nn.Module, path_or_dict, strict: bool
 
 def save_reference_checkpoint(path, model: torch.nn.Module, epoch: int = 0, loss=None, optimizer=None, scheduler=None,
                               hit_rate_log=None) -> None:
-    """the dict layout of train.py:150-158"""
-    torch.save({"epoch": epoch, "loss": loss, "hit_rate_log": hit_rate_log, "state_dict": model.state_dict(),
+    """the dict layout of train.py:150-158. hit_rate_log defaults to the empty list the reference always writes. A checkpoint that
+    the reference's util.load_ckp is to RESUME from needs `optimizer` and `scheduler` (it calls load_state_dict on both, util.py:152-153);
+    without them the file serves inference consumers (generate.py:88-97, test_fp.py:372-383), which read `state_dict` only."""
+    torch.save({"epoch": epoch, "loss": loss, "hit_rate_log": [] if hit_rate_log is None else hit_rate_log,
+                "state_dict": model.state_dict(),
                 "optimizer": None if optimizer is None else optimizer.state_dict(),
                 "scheduler": None if scheduler is None else scheduler.state_dict()}, path)

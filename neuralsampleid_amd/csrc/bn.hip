@@ -261,7 +261,7 @@ inline float bn_slope(int act) { return act == NSID_ACT_RELU ? 0.f : (act == NSI
 
 inline int stream_grid(long nchunks) {
   long b = (nchunks + 255) / 256;
-  static const long cap = getenv("NSID_STREAM_MAXWG") ? atol(getenv("NSID_STREAM_MAXWG")) : 2048;
+  const long cap = nsid_tune(NSID_T_stream_max_wg);
   return (int)(b > cap ? cap : (b < 1 ? 1 : b));   // cap and grid-stride (guide §6 G11)
 }
 
@@ -443,8 +443,8 @@ extern "C" int nsid_bn_bwd_apply(const void* dout, const void* r, int M, int C, 
     // At most 384 workgroups (1.5 per CU): with 2 048 the pass takes every wave slot and saturates HBM for its 9 us while the
     // OTHER view's branch of the step stalls (this pass was 88 % exposed in the two-stream step, tools/ablate.sh); fewer, longer
     // workgroups stream a little slower alone and leave room beside them. One-box A/B of the whole step, three repetitions each:
-    // 2 048: 8.31 / 8.28 / 8.28 ms, 512: 8.21 / 8.23 / 8.23, 384: 8.22 / 8.18 / 8.17 (NSID_BNBA_MAXWG overrides).
-    static const long max_wg = getenv("NSID_BNBA_MAXWG") ? atol(getenv("NSID_BNBA_MAXWG")) : 384;
+    // 2 048: 8.31 / 8.28 / 8.28 ms, 512: 8.21 / 8.23 / 8.23, 384: 8.22 / 8.18 / 8.17 (tuning key bn_bwd_apply_max_wg).
+    const long max_wg = nsid_tune(NSID_T_bn_bwd_apply_max_wg);
     if (want > max_wg) want = max_wg;
     const long grid = (want + g0 - 1) / g0 * g0;
     NSID_LAUNCH((bn_bwd_apply_kernel<T, U>), dim3((int)grid), dim3(256), 0, static_cast<hipStream_t>(stream),

@@ -62,7 +62,12 @@ template <int ROWS, bool RMAJOR, bool H, bool SRC16 = false, int KS = 1, int NT 
 struct TileGeom {
   static_assert(KS == 1 || H, "deeper stages exist on the bf16 path only");
   static constexpr int BK = Prec<H>::BK * KS, ESZ = Prec<H>::ESZ;
-  // Bank-conflict-free LDS images (MI355X_MICROARCH.md, LDS: banking is per instruction, over fixed lane groups):
+  // LDS images whose fragment READS are bank-conflict-free (MI355X_MICROARCH.md, LDS: banking is per instruction, over fixed lane
+  // groups). The staging WRITES are not: a ds_write_b128 is served 8 lanes at a time, and 8 consecutive 16-byte chunks of 96-byte rows
+  // (32-deep stages) fold 2-way onto the 32 write banks: SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.22-0.31 on the KS = 1 kernels,
+  // 0.04-0.08 with 160-byte rows (KS = 2) (profiles/r02d_final/pmc_sq_summary.txt). Those replays stay under the 13 cycles the write
+  // instruction spends moving its operands to the LDS anyway (guide: a store conflict costs time only once the array cycles exceed
+  // the instruction's own), so the row pitch is chosen for the reads:
   //  RMAJOR: lds[row][BK elements + 32 B pad] (row = i or j, R contiguous): 96-byte rows in both precisions (160-byte rows
   //          with KS = 2: 16-byte block (10*lr + rq) mod 16 is a bijection for the same lane split). A fragment
   //          read is one ds_read_b128 per lane at (row lr, 16-byte chunk rq); the hardware serves lanes {0-3,12-15,20-27}
@@ -808,16 +813,13 @@ __global__ void elu_inplace_kernel(float* __restrict__ x, long rows, int cols, l
 }
 
 int g_gemm_precision = NSID_GEMM_FP32;     // process-wide (nsid_set_gemm_precision)
-// smallest number of 128x128 tiles for which the forward GEMM takes the 8-wave 256x128 form (0 = never; nsid_set_gemm_w8_min).
+// Tuning key w8_min: smallest number of 128x128 tiles for which the forward GEMM takes the 8-wave 256x128 form (0 = never).
 // Cold-operand microbenchmark: -12 ... -20 % on every >= 1024-tile forward GEMM (24.6 -> 20.1 us at 16384x1024x256); whole
 // training step 8.31 / 8.33 ms without against 8.35 / 8.38 ms with it, inference 286 k against 282 k clips/s: off by default.
-int g_w8_min = -1;
-// smallest number of 256x256 tiles for which the forward GEMM takes gemm256.hip (LDS-DMA staging); 0 = never
-int g_g256_min = -1;
-bool g_g256_explicit = false; // the threshold was set by NSID_G256_MIN / nsid_set_gemm_g256_min: only then do launches WITH a
-                              // statistics epilogue (training) take it — the default serves forward-only work, so that the
-                              // arithmetic of a training step does not depend on the batch size
-long g_g256_launches = 0;     // launches that took it (tests check that the kernel under test really ran)
+// Tuning keys g256_min / g256_train: smallest number of 256x256 tiles for which the forward GEMM takes gemm256.hip (LDS-DMA
+// staging); launches WITH a statistics epilogue (training) take it only when g256_train = 1 — the default serves forward-only work,
+// so that the arithmetic of a training step does not depend on the batch size.
+long g_g256_launches = 0;     // launches that took gemm256.hip (tests check that the kernel under test really ran)
 
 template <int BM, int BN, bool AR, bool BR, int NW = 4>
 int launch(GemmArgs p, int groups, hipStream_t s, int act_dtype, bool w_bf16 = false) {
@@ -842,7 +844,7 @@ int launch(GemmArgs p, int groups, hipStream_t s, int act_dtype, bool w_bf16 = f
   const bool full = st16 && p.I % BM == 0 && p.J % BN == 0 && p.rchunk % (2 * bk) == 0 && p.R % p.rchunk == 0;
   // Deep pipeline (KS = 2: 64-deep stages; PD = 4: four stages in flight) for launches that put at most ~2 workgroups on a
   // CU: there the round-1 loop kept 16-32 KB per workgroup in flight and fetched at ~16 GB/s per CU (shape table of round 2:
-  // the 256-tile GEMMs of the C = 256 stage ran 32 us against a 7 us HBM/MFMA bound). NSID_GEMM_DEEP="ks,pd[,maxwg]".
+  // the 256-tile GEMMs of the C = 256 stage ran 32 us against a 7 us HBM/MFMA bound). Tuning keys gemm_deep_{ks,pd,max_wg,ec,kinds}.
   // Measured on MI355X with cold operands (tools/gemm_bench.py --cold, round 2), 256-512 workgroups per launch:
   //   forward        : KS = 2, two register sets, early commit with the interleaved schedule: 26.4 -> 18.2 us (16384x256x1024),
   //                    44.5 -> 27.0 us (8192x512x2048), 15.7 -> 11.9 us (16384x256x512);
@@ -852,21 +854,12 @@ int launch(GemmArgs p, int groups, hipStream_t s, int act_dtype, bool w_bf16 = f
   // stage buffers) keeps the other view's kernels off that CU, and what the step rewards is little resource-time per
   // tile, not latency. One-box A/B of the whole step (two repetitions each): round-1 loops 8.52 / 8.52 ms, KS = 2 for
   // forward + weight gradient 8.41 / 8.43 ms, the same with early commit 8.55 / 8.57 ms -> KS = 2 without early commit is the
-  // default; early commit (NSID_GEMM_DEEP=2,2,512,1) remains for single-stream use (inference, microbenchmarks).
-  static int deep_ks = -1, deep_pd = 0, deep_maxwg = 512, deep_ec = 0;
-  if (deep_ks < 0) {
-    deep_ks = 2; deep_pd = 2;
-    if (const char* e = getenv("NSID_GEMM_DEEP")) {
-      int a = 1, b = 0, c = 512, d = 0;
-      const int n = sscanf(e, "%d,%d,%d,%d", &a, &b, &c, &d);
-      if (n >= 1) deep_ks = a;
-      if (n >= 2) deep_pd = b;
-      if (n >= 3) deep_maxwg = c;
-      if (n >= 4) deep_ec = d;
-    }
-  }
+  // default; early commit (tuning key gemm_deep_ec = 1) remains for single-stream use (inference, microbenchmarks).
+  const int deep_ks = (int)nsid_tune(NSID_T_gemm_deep_ks), deep_pd = (int)nsid_tune(NSID_T_gemm_deep_pd);
+  const long deep_maxwg = nsid_tune(NSID_T_gemm_deep_max_wg);
+  const int deep_ec = (int)nsid_tune(NSID_T_gemm_deep_ec);
   // which GEMM kinds take the deep form: bit 0 forward, bit 1 backward-data, bit 2 weight gradient
-  static const int deep_kinds = getenv("NSID_GEMM_DEEP_KINDS") ? atoi(getenv("NSID_GEMM_DEEP_KINDS")) : 5;
+  const int deep_kinds = (int)nsid_tune(NSID_T_gemm_deep_kinds);
   constexpr int kind_bit = AR ? (BR ? 1 : 2) : 4;
   const long wgs = (long)tiles * p.rsplit * groups;
   int ks = 1, pd = 0;
@@ -1063,17 +1056,6 @@ extern "C" int nsid_set_gemm_precision(int mode) {
   return NSID_OK;
 }
 extern "C" int nsid_get_gemm_precision(void) { return g_gemm_precision; }
-extern "C" int nsid_set_gemm_w8_min(int tiles) {
-  if (tiles < 0) return NSID_EINVAL;
-  g_w8_min = tiles;
-  return NSID_OK;
-}
-extern "C" int nsid_set_gemm_g256_min(int tiles) {
-  NSID_REQUIRE(tiles >= 0);
-  g_g256_min = tiles;
-  g_g256_explicit = true;
-  return NSID_OK;
-}
 extern "C" long nsid_gemm_g256_launches(void) { return g_g256_launches; }
 extern "C" int nsid_row_tiles(int M) { return (M + NSID_ROW_TILE - 1) / NSID_ROW_TILE; }
 
@@ -1139,7 +1121,7 @@ static int linear_fwd_impl(const void* x, int ldx, const void* w, int w_dtype, c
   // halve the tile width to double the loads in flight (the statistics tile stays 128 rows)
   const long t128 = (long)nsid_row_tiles(M) * ((Nout + 127) / 128) * groups;
   const bool half = g_gemm_precision == NSID_GEMM_BF16 || act_dtype == NSID_BF16;
-  static const int force_narrow = getenv("NSID_FWD_NARROW") ? atoi(getenv("NSID_FWD_NARROW")) : -1;
+  const int force_narrow = (int)nsid_tune(NSID_T_fwd_narrow);
   // measured (tools/gemm_bench.py, bf16 path): the 128-wide tile wins from 256 output columns on, and always when the
   // left operand carries the producer's BatchNorm (every column tile re-applies it: fewer, wider tiles = less VALU)
   bool narrow = half ? (Nout <= 64 || (Nout <= 128 && K <= 256 && in_scale == nullptr)) : Nout <= 64;
@@ -1150,26 +1132,21 @@ static int linear_fwd_impl(const void* x, int ldx, const void* w, int w_dtype, c
   // tiles move a quarter fewer operand bytes L2 -> LDS, which is what bounds the main loop. The
   // training step never takes it (it needs the statistics epilogue; 256x128 measured neutral there), fingerprinting at micro-batch
   // 1 024 has 1 024 - 4 096 tiles per GEMM: +4 % clips/s.
-  static const int tall_min = getenv("NSID_TALL_MIN") ? atoi(getenv("NSID_TALL_MIN")) : 1024;
+  const long tall_min = nsid_tune(NSID_T_tall_min);
   const bool tall = stat == nullptr && act_dtype == NSID_BF16 && wb && !narrow && t128 >= tall_min && M % 256 == 0 &&
                     Nout % 128 == 0 && K % 64 == 0 && ksplit == 1;
   // 8 waves on 256x128 tiles (round 2): same per-wave work as the 128x128 kernel, a quarter fewer operand bytes per flop,
-  // statistics epilogue included (two 128-row statistics tiles per workgroup). NSID_W8_MIN = smallest number of 128x128
+  // statistics epilogue included (two 128-row statistics tiles per workgroup). Tuning key w8_min = smallest number of 128x128
   // tiles that takes it (0 = never).
-  if (g_w8_min < 0) g_w8_min = getenv("NSID_W8_MIN") ? atoi(getenv("NSID_W8_MIN")) : 0;
-  const int w8_min = g_w8_min;
+  const long w8_min = nsid_tune(NSID_T_w8_min);
   const bool w8 = w8_min > 0 && act_dtype == NSID_BF16 && wb && !narrow && t128 >= w8_min && M % 256 == 0 && Nout % 128 == 0 &&
                   K % 64 == 0 && ksplit == 1;
-  // 256x256 tiles with LDS-DMA staging (gemm256.hip): NSID_G256_MIN = smallest number of 256x256 tiles that takes it (0 = never)
+  // 256x256 tiles with LDS-DMA staging (gemm256.hip): tuning key g256_min = smallest number of 256x256 tiles that takes it (0 = never)
   // default 512 (two tiles per CU and more: fingerprinting at micro-batch 2 048): 7.09 -> 6.56 ms per micro-batch. The training step
   // (<= 256 such tiles per launch) is neutral to slightly worse with it (8.30 vs 8.34 ms: a workgroup that owns 150 KB of a CU's LDS
   // keeps the other view's kernels off that CU), so it stays on gemm.hip.
-  if (g_g256_min < 0) {
-    g_g256_explicit = getenv("NSID_G256_MIN") != nullptr;
-    g_g256_min = g_g256_explicit ? atoi(getenv("NSID_G256_MIN")) : 512;
-  }
-  const int g256_min = g_g256_min;
-  if (g256_min > 0 && (stat == nullptr || g_g256_explicit) && act_dtype == NSID_BF16 && wb && groups == 1 && in_scale == nullptr && ksplit == 1 &&
+  const long g256_min = nsid_tune(NSID_T_g256_min);
+  if (g256_min > 0 && (stat == nullptr || nsid_tune(NSID_T_g256_train) != 0) && act_dtype == NSID_BF16 && wb && groups == 1 && in_scale == nullptr && ksplit == 1 &&
       (act_out == NSID_ACT_NONE || act_out == NSID_ACT_RELU) && act_in == NSID_ACT_NONE && ldx >= K &&
       (long)(M / 256) * (Nout / 256) >= g256_min) {
     const int rc256 = nsid_gemm256_fwd_launch(x, ldx, w, bias, addend, ldadd, out, ldo, M, Nout, K, act_out == NSID_ACT_RELU, stat,
@@ -1237,13 +1214,13 @@ static int linear_bwd_data_impl(const void* dout, int ldd, const void* w, int w_
   hipStream_t s = static_cast<hipStream_t>(stream);
   const long t128 = (long)nsid_row_tiles(M) * ((K + 127) / 128) * groups;
   const bool half = g_gemm_precision == NSID_GEMM_BF16 || act_dtype == NSID_BF16;
-  static const int force_narrow = getenv("NSID_BWD_NARROW") ? atoi(getenv("NSID_BWD_NARROW")) : -1;
+  const int force_narrow = (int)nsid_tune(NSID_T_bwd_narrow);
   bool narrow = half ? (K <= 64 || (K <= 128 && Nout <= 256)) : K <= 64;
   if (half && t128 < 128) narrow = true;        // few row tiles (the projector head, M = batch)
   if (force_narrow >= 0 && K > 64) narrow = force_narrow != 0;
   // the 8-wave 256x128 form loses here (16384x256x1024: 21.8 -> 41.4 us cold): 169 registers = one workgroup per CU, and the
   // transposed weight reads + addend / BatchNorm-sum epilogue do not shrink with the tile. Kept for experiments only.
-  static const int w8_min = getenv("NSID_W8_BWD_MIN") ? atoi(getenv("NSID_W8_BWD_MIN")) : 0;
+  const long w8_min = nsid_tune(NSID_T_w8_bwd_min);
   if (w8_min > 0 && !narrow && act_dtype == NSID_BF16 && wb && t128 >= w8_min && M % 256 == 0 && K % 128 == 0 && Nout % 64 == 0)
     return launch<256, 128, true, false, 8>(p, groups, s, act_dtype, wb);
   if (narrow) return launch<128, 64, true, false>(p, groups, s, act_dtype, wb);
@@ -1268,7 +1245,7 @@ extern "C" int nsid_linear_bwd_weight(const void* dout, int ldd, const void* x, 
   // atomics that all XCDs resolve memory-side (~1.3 TB/s chip-wide), so the bytes of atomics = workgroups x tile bytes
   // decide the kernel: 64x64 tiles (16 KB) beat 128x128 (64 KB) at every shape of the encoder once >= 256 workgroups
   // are in flight. Splits: >= 1024 rows each, at most ~1024 workgroups, at least ~256.
-  static const bool use_wide = getenv("NSID_WGRAD_V1") == nullptr;
+  const bool use_wide = nsid_tune(NSID_T_wgrad_wide) != 0;
   if (use_wide && act_dtype == NSID_BF16 && nsid_aligned16(dout) && nsid_aligned16(x) &&
       (in_scale == nullptr || (nsid_aligned16(in_scale) && nsid_aligned16(in_shift)))) {
     const int rc = nsid_wgrad2_launch(dout, ldd, x, ldx, dw, M, Nout, K, groups, in_scale, in_shift, act_slope(act_in),
@@ -1279,15 +1256,15 @@ extern "C" int nsid_linear_bwd_weight(const void* dout, int ldd, const void* x, 
   // rows, i.e. without more splits = atomic bytes than the square tiles need
   // (a launch alone is ~8 % slower with them, the two-branch step 1 % faster: half the workgroups and LDS per CU leave the
   // other view's kernels more room — judged by one-box A/B of the whole step)
-  static const int rect = getenv("NSID_WGRAD_RECT") ? atoi(getenv("NSID_WGRAD_RECT")) : 1;
-  static const long wg_rect = getenv("NSID_WGRAD_WGS_RECT") ? atol(getenv("NSID_WGRAD_WGS_RECT")) : 256;    // workgroup targets: rect 512 -> 256 is worth
+  const long rect = nsid_tune(NSID_T_wgrad_rect);
+  const long wg_rect = nsid_tune(NSID_T_wgrad_wgs_rect);    // workgroup targets: rect 512 -> 256 is worth
   // 0.12 ms of the two-stream step (8.23 -> 8.11 ms, one-box A/B x2; 192 / 128 fall back to square tiles and lose 0.2 ms): half the splits =
   // half the atomic bytes, and a weight gradient is off the critical chain, so its own latency does not matter
-  static const long wg_sq = getenv("NSID_WGRAD_WGS_SQ") ? atol(getenv("NSID_WGRAD_WGS_SQ")) : 1024;
+  const long wg_sq = nsid_tune(NSID_T_wgrad_wgs_sq);
   if (rect && act_dtype == NSID_BF16 && Nout % 128 == 0 && K % 64 == 0 && M % 1024 == 0) {
     const long tiles_r = (long)(Nout / 128) * (K / 64) * groups;
     const long S = std::min<long>(M / 1024, std::max<long>(1, wg_rect / tiles_r));
-    static const long rect_min = getenv("NSID_WGRAD_RECT_MIN") ? atol(getenv("NSID_WGRAD_RECT_MIN")) : 256;
+    const long rect_min = nsid_tune(NSID_T_wgrad_rect_min);
     if (tiles_r * S >= rect_min) {
       p.rsplit = (int)S;
       p.rchunk = (int)(M / S);
@@ -1303,7 +1280,7 @@ extern "C" int nsid_linear_bwd_weight(const void* dout, int ldd, const void* x, 
   long S;
   if (half) {
     S = std::min<long>((M + 1023) / 1024, std::max<long>(1, wg_sq / tiles));
-    static const long sq_min = getenv("NSID_WGRAD_SQ_MIN") ? atol(getenv("NSID_WGRAD_SQ_MIN")) : 256;
+    const long sq_min = nsid_tune(NSID_T_wgrad_sq_min);
     S = std::max<long>(S, (sq_min + tiles - 1) / tiles);
     S = std::min<long>(S, (M + 255) / 256);
   } else {

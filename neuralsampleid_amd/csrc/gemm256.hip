@@ -371,11 +371,11 @@ int nsid_gemm256_fwd_launch(const void* x, int ldx, const void* w, const float* 
     int dev = 0, n = 0;               // an attribute query, not hipGetDeviceProperties: legal whatever the stream is doing (capture)
     n_cu = (hipGetDevice(&dev) == hipSuccess &&
             hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess) ? n : 256;
-    if (const char* e = getenv("NSID_G256_GRID")) n_cu = atoi(e);        // experiments
     if (n_cu <= 0) n_cu = 256;
   }
   const int ntiles = (M / 256) * (Nout / 256);
-  const dim3 grid(ntiles < n_cu ? ntiles : n_cu);       // one workgroup per CU (155 KB of LDS), persistent over the tiles
+  const int wgs = nsid_tune(NSID_T_g256_grid) > 0 ? (int)nsid_tune(NSID_T_g256_grid) : n_cu;
+  const dim3 grid(ntiles < wgs ? ntiles : wgs);       // one workgroup per CU (155 KB of LDS), persistent over the tiles
   if (addend && (stat || relu_out)) return 1;
   if (stat && relu_out) return 1;
   if (addend) NSID_LAUNCH(gemm256_fwd_kernel<G256_ADD>, grid, dim3(512), 0, stream, p);

@@ -908,7 +908,7 @@ extern "C" int nsid_knn_graph(const void* r, int ldr, const float* scale, const 
   NSID_REQUIRE(k * dilation <= N);
   NSID_REQUIRE((scale == nullptr) == (shift == nullptr));
   const int kd = k * dilation;
-  static const bool use_fast = getenv("NSID_KNN_STRIPS") == nullptr;
+  const bool use_fast = nsid_tune(NSID_T_knn_strips) == 0;
   const bool pow2 = C >= 64 && C <= 512 && (C & (C - 1)) == 0 && N >= 32 && (N & (N - 1)) == 0;
   if (use_fast && pow2 && kd > 8 && N <= 128) {              // deep configuration, small graphs: rank counting
     hipStream_t s = static_cast<hipStream_t>(stream);

@@ -280,7 +280,7 @@ extern "C" int nsid_mr_aggregate_fwd(const void* r, int ldr, const float* scale,
   NSID_REQUIRE(C % nv == 0 && ldr % nv == 0 && ldr >= C && nsid_aligned16(r) && nsid_aligned16(u));
   NSID_REQUIRE((scale == nullptr) == (shift == nullptr));
   // one workgroup per clip with the clip in LDS, whenever a clip fits (every stage of the GraFP encoder: N*C = 16384)
-  static const bool use_lds = getenv("NSID_MR_GRID_STRIDE") == nullptr;
+  const bool use_lds = nsid_tune(NSID_T_mr_grid_stride) == 0;
   const size_t clip_bytes = (size_t)N * C * (dtype == NSID_BF16 ? 2 : 4);
   if (use_lds && clip_bytes <= 64 * 1024) {
     static bool configured = false;
@@ -292,7 +292,7 @@ extern "C" int nsid_mr_aggregate_fwd(const void* r, int ldr, const float* scale,
         return NSID_ELAUNCH;
       configured = true;
     }
-    static const int force_split = getenv("NSID_MR_SPLIT") ? atoi(getenv("NSID_MR_SPLIT")) : 0;
+    const int force_split = (int)nsid_tune(NSID_T_mr_split);
     int split = force_split > 0 ? force_split : (B <= 256 ? 2 : 1);
     while (split > 1 && (C / nv) % split != 0) split >>= 1;
     NSID_DISPATCH_DTYPE(dtype, T, {

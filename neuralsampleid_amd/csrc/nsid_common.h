@@ -127,6 +127,47 @@ static inline bool nsid_aligned16(const void* p) { return (reinterpret_cast<uint
     if (!(cond)) return NSID_EINVAL; \
   } while (0)
 
+// ---- tuning table (include/nsid.h: nsid_set_tuning / nsid_get_tuning / nsid_reset_tuning; defined in tuning.hip) -----------
+// Every launch heuristic that has a number in it reads that number from here. The defaults are the values that won their one-box
+// A/B of the whole two-stream step (docs/experiments.md); the library never reads the environment, so the arithmetic and the kernel
+// selection of a run depend only on what the caller sets explicitly (bench.py --tune key=value records it in its JSON line).
+#define NSID_TUNING_TABLE(X)                                                                                                  \
+  X(stream_max_wg, 2048)       /* workgroup cap of the grid-stride streaming kernels (bn_apply, ...) */                       \
+  X(bn_bwd_apply_max_wg, 384)  /* BatchNorm-backward apply pass: 1.5 workgroups per CU leave room for the other view */      \
+  X(gemm_deep_ks, 2)           /* 32-deep MFMA sub-steps per LDS stage for launches of <= gemm_deep_max_wg workgroups */      \
+  X(gemm_deep_pd, 2)           /* register sets (= stages in flight) of those launches: 2 or 4 */                             \
+  X(gemm_deep_max_wg, 512)                                                                                                    \
+  X(gemm_deep_ec, 0)           /* early commit (three LDS stage buffers): wins alone, loses in the two-stream step */         \
+  X(gemm_deep_kinds, 5)        /* which GEMM kinds take the deep form: bit 0 forward, bit 1 backward-data, bit 2 weight gradient */ \
+  X(fwd_narrow, -1)            /* -1: shape heuristic; 0 / 1 force 128- / 64-wide forward tiles */                             \
+  X(bwd_narrow, -1)                                                                                                           \
+  X(tall_min, 1024)            /* forward-only GEMMs with >= this many 128x128 tiles take 256x128 tiles */                    \
+  X(w8_min, 0)                 /* >= this many 128x128 tiles: 8-wave 256x128 forward kernel (0 = never) */                    \
+  X(w8_bwd_min, 0)                                                                                                            \
+  X(g256_min, 512)             /* >= this many 256x256 tiles: gemm256.hip (LDS-DMA staging); 0 = never */                     \
+  X(g256_train, 0)             /* 1: launches WITH a statistics epilogue (training) may take gemm256.hip too */               \
+  X(g256_grid, 0)              /* workgroups of the persistent gemm256 launch (0 = one per CU) */                             \
+  X(wgrad_wide, 1)             /* 8-wave 128x128-tile weight gradients (wgrad.hip) where they apply */                        \
+  X(wgrad_rect, 1)             /* 128x64-tile weight gradients */                                                             \
+  X(wgrad_wgs_rect, 256)       /* workgroup target of the 128x64 form (fewer splits = fewer atomic bytes) */                  \
+  X(wgrad_wgs_sq, 1024)                                                                                                       \
+  X(wgrad_rect_min, 256)                                                                                                      \
+  X(wgrad_sq_min, 256)                                                                                                        \
+  X(w3_wgs, 256)                                                                                                              \
+  X(w3_min_tiles, 64)                                                                                                         \
+  X(knn_strips, 0)             /* 1: always the general strip kernel (tests of the fallback) */                               \
+  X(mr_grid_stride, 0)         /* 1: grid-stride aggregation instead of the LDS-staged per-clip kernel */                     \
+  X(mr_split, 0)               /* channel split of the LDS-staged aggregation (0 = heuristic) */
+
+enum NsidTuneKey {
+#define NSID_TUNE_ENUM(name, def) NSID_T_##name,
+  NSID_TUNING_TABLE(NSID_TUNE_ENUM)
+#undef NSID_TUNE_ENUM
+  NSID_T_COUNT
+};
+extern long g_nsid_tune[NSID_T_COUNT];
+static inline long nsid_tune(NsidTuneKey k) { return g_nsid_tune[k]; }
+
 // wgrad.hip: 128x128-tile form of the bf16 weight-gradient GEMM; returns 1 when the shape is outside its preconditions
 int nsid_wgrad2_launch(const void* dout, int ldd, const void* x, int ldx, float* dw, int M, int Nout, int K, int groups,
                        const float* in_scale, const float* in_shift, float slope, hipStream_t stream);

@@ -1,0 +1,44 @@
+// The tuning table of the kernel library (nsid_common.h NSID_TUNING_TABLE): named launch-heuristic constants with compiled-in
+// defaults, changed only through this entry point — never through the environment.
+#include <string.h>
+#include "nsid_common.h"
+
+namespace {
+struct TuneEntry { const char* name; long def; };
+const TuneEntry kTable[NSID_T_COUNT] = {
+#define NSID_TUNE_ROW(name, def) {#name, def},
+    NSID_TUNING_TABLE(NSID_TUNE_ROW)
+#undef NSID_TUNE_ROW
+};
+int find(const char* key) {
+  if (key == nullptr) return -1;
+  for (int i = 0; i < NSID_T_COUNT; ++i)
+    if (strcmp(kTable[i].name, key) == 0) return i;
+  return -1;
+}
+}  // namespace
+
+long g_nsid_tune[NSID_T_COUNT] = {
+#define NSID_TUNE_DEF(name, def) def,
+    NSID_TUNING_TABLE(NSID_TUNE_DEF)
+#undef NSID_TUNE_DEF
+};
+
+extern "C" int nsid_set_tuning(const char* key, long value) {
+  const int i = find(key);
+  if (i < 0) return NSID_EINVAL;
+  g_nsid_tune[i] = value;
+  return NSID_OK;
+}
+extern "C" int nsid_get_tuning(const char* key, long* value) {
+  const int i = find(key);
+  if (i < 0 || value == nullptr) return NSID_EINVAL;
+  *value = g_nsid_tune[i];
+  return NSID_OK;
+}
+extern "C" int nsid_reset_tuning(void) {
+  for (int i = 0; i < NSID_T_COUNT; ++i) g_nsid_tune[i] = kTable[i].def;
+  return NSID_OK;
+}
+extern "C" int nsid_tuning_count(void) { return NSID_T_COUNT; }
+extern "C" const char* nsid_tuning_key(int i) { return (i >= 0 && i < NSID_T_COUNT) ? kTable[i].name : nullptr; }

@@ -181,8 +181,8 @@ __global__ __launch_bounds__(W3_THREADS, 2) void wgrad3_kernel(const WgArgs p) {
 int nsid_wgrad2_launch(const void* dout, int ldd, const void* x, int ldx, float* dw, int M, int Nout, int K, int groups,
                        const float* in_scale, const float* in_shift, float slope, hipStream_t stream) {
   if (ldd % 8 != 0 || ldx % 8 != 0) return 1;
-  static const int w3_wgs = getenv("NSID_W3_WGS") ? atoi(getenv("NSID_W3_WGS")) : 256;
-  static const long w3_min_tiles = getenv("NSID_W3_MIN_TILES") ? atol(getenv("NSID_W3_MIN_TILES")) : 64;
+  const long w3_wgs = nsid_tune(NSID_T_w3_wgs);
+  const long w3_min_tiles = nsid_tune(NSID_T_w3_min_tiles);
   const long tiles3 = (long)(Nout / W3_T) * (K / W3_T) * groups;
   if (w3_wgs > 0 && Nout % W3_T == 0 && K % W3_T == 0 && M % 128 == 0 && tiles3 >= w3_min_tiles) {
     int rc3 = 0;

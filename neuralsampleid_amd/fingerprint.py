@@ -50,7 +50,11 @@ class GraphedFingerprinter:
         z = fp(specs)                                          # (S, n_mels, n_frames) -> (S, d); a ragged tail runs eagerly
 
     The captured kernels read the weights and the folded conv+BatchNorm constants in place: after a change of the weights
-    (training steps, load_state_dict) build a new GraphedFingerprinter."""
+    (training steps, load_state_dict, torch.optim, in-place edits) build a new GraphedFingerprinter — a call after such a change is
+    REFUSED: the guard compares the library's state epochs (writes made by our own kernels behind torch's back) AND the
+    (data_ptr, _version) of every parameter and buffer (torch-side writes). The constants the replayed kernels read (folded weights,
+    eval affines, bf16 shadows) are referenced from here, so a later eager forward that rebuilds the caches cannot free them under
+    the graph."""
 
     def __init__(self, model, micro_batch: int = 1024, example: torch.Tensor = None):
         from . import functional, ops
@@ -61,6 +65,7 @@ class GraphedFingerprinter:
         self.x = torch.zeros(shape, device=dev)
         self.d = model.projector[-1].out_features
         self.epochs = (ops.WEIGHT_EPOCH, ops.STATS_EPOCH)
+        self._held = None
         was_training = model.training
         model.eval()
         try:
@@ -77,13 +82,20 @@ class GraphedFingerprinter:
                 self.graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(self.graph):
                     _, self.z = model._embed(self.x)
+                # everything the captured kernels read in place, kept alive with the graph
+                self._held = (list(ops._FOLDED.values()), list(ops._EVAL_AFFINE.values()),
+                              [e[0] for e in ops.SHADOWS.entries.values()])
+                self._versions = self._state_versions()
         finally:
             model.train(was_training)
+
+    def _state_versions(self):
+        return tuple((t.data_ptr(), t._version) for t in list(self.model.parameters()) + list(self.model.buffers()))
 
     @torch.no_grad()
     def __call__(self, specs: torch.Tensor, out: torch.Tensor = None) -> torch.Tensor:
         from . import ops
-        if (ops.WEIGHT_EPOCH, ops.STATS_EPOCH) != self.epochs:
+        if (ops.WEIGHT_EPOCH, ops.STATS_EPOCH) != self.epochs or self._state_versions() != self._versions:
             raise RuntimeError("the model's weights or running statistics changed since this graph was captured: "
                                "build a new GraphedFingerprinter")
         S = specs.shape[0]

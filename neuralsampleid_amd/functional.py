@@ -42,9 +42,8 @@ TAPE: Optional[KnnTape] = None
 # A conv bias that feeds a training-mode BatchNorm directly has an analytically ZERO gradient (BN subtracts the batch
 # mean, so sum_m dL/dr[m, c] == 0).  The reference's autograd still evaluates that sum and gets +-1e-7 roundoff, which
 # Adam then normalises into a +-lr random walk of a parameter with no effect on the output.  By default the column sum
-# is skipped and the gradient left at exactly 0; NSID_EXACT_BIAS_GRAD=1 evaluates it like the reference does.
-import os as _os
-EXACT_BIAS_GRAD = _os.environ.get("NSID_EXACT_BIAS_GRAD", "0") == "1"
+# is skipped and the gradient left at exactly 0; setting functional.EXACT_BIAS_GRAD = True evaluates it like the reference does.
+EXACT_BIAS_GRAD = False
 
 # When every parameter of a block already owns a gradient buffer and this flag is set (optim.FusedClipAdam sets it),
 # backward accumulates straight into p.grad (views of the flat gradient buffer) instead of returning fresh tensors
@@ -164,7 +163,7 @@ def _bn(P, S, pre):
 # (ops.folded_conv_bn), so a conv+BN layer is ONE GEMM that writes normalised values, the residual shortcut rides in that GEMM's
 # epilogue (nsid_linear_fwd_res) and the bn_apply passes disappear. The strict-fp32 path keeps conv and BatchNorm apart,
 # as the parity tests state them.
-FOLD_EVAL_BN = _os.environ.get("NSID_FOLD_EVAL_BN", "1") == "1"
+FOLD_EVAL_BN = True
 
 
 def fold_eval(training: bool, S) -> bool:

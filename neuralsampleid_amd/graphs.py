@@ -23,10 +23,7 @@ class GraphedTrainStep:
     eager loop (tests/test_e2e_gpu.py::test_graphed_train_step_equals_eager)."""
 
     def __init__(self, model, optimizer, cfg: dict, x_i: torch.Tensor, x_j: torch.Tensor,
-                 loss_fn: Optional[Callable] = None, reducer=None, warmup: int = 2, capture_error_mode: str = "global",
-                 engine: bool = False):
-        """engine (experimental, single GPU): replay the captured kernels as plain stream launches with the weight gradients floating
-        on auxiliary streams (neuralsampleid_amd/engine.py) instead of replaying the hipGraph"""
+                 loss_fn: Optional[Callable] = None, reducer=None, warmup: int = 2, capture_error_mode: str = "global"):
         if not hasattr(optimizer, "flat_g"):
             raise TypeError("GraphedTrainStep needs optim.FusedClipAdam (device-side lr / step / NaN-batch skip)")
         self.model, self.opt, self.cfg, self.reducer = model, optimizer, cfg, reducer
@@ -42,20 +39,9 @@ class GraphedTrainStep:
                 self._step()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        self.engine = None
-        if engine:
-            if reducer is not None:
-                raise ValueError("the step engine replays kernel nodes only: no collectives (single GPU)")
-            from . import engine as eng
-            self.graph = torch.cuda.CUDAGraph(keep_graph=True)
-            keep = []
-            with eng.retain_allocations(keep), torch.cuda.graph(self.graph, capture_error_mode=capture_error_mode):
-                self._step()
-            self.engine = eng.StepEngine(self.graph, keep)
-        else:
-            self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph, capture_error_mode=capture_error_mode):
-                self._step()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph, capture_error_mode=capture_error_mode):
+            self._step()
         self._restore(snap)
 
     def _snapshot(self):
@@ -96,10 +82,7 @@ class GraphedTrainStep:
     def __call__(self, x_i: torch.Tensor, x_j: torch.Tensor) -> torch.Tensor:
         self.x_i.copy_(x_i, non_blocking=True)
         self.x_j.copy_(x_j, non_blocking=True)
-        if self.engine is not None:
-            self.engine.replay()
-        else:
-            self.graph.replay()
+        self.graph.replay()
         from . import ops
         ops.bump_state_epoch()           # the replay wrote weights and running statistics behind torch's version counters
         return self.loss

@@ -6,7 +6,7 @@ from typing import Optional, Tuple
 
 import torch
 
-from ._lib import call, lib
+from ._lib import call, get_tuning, lib, reset_tuning, set_tuning  # noqa: F401  (tuning: re-exported)
 
 ACT_NONE, ACT_RELU, ACT_LEAKY, ACT_ELU = 0, 1, 2, 3
 ROW_TILE = 128
@@ -282,7 +282,7 @@ def linear_fwd(x, w, bias, M, Nout, K, groups=1, in_scale=None, in_shift=None, a
     wop, wdt = _weight(w, dt, K)
     # csrc/gemm.hip linear_fwd_impl: forward-only work with >= NSID_TALL_MIN (1024) tiles of 128x128 takes 256x128 tiles
     tall = (not want_stat and dt == BF16 and wdt == BF16 and not narrow and ksplit == 1 and M % 256 == 0 and Nout % 128 == 0
-            and K % 64 == 0 and row_tiles(M) * ((Nout + 127) // 128) * groups >= int(os.environ.get("NSID_TALL_MIN", "1024")))
+            and K % 64 == 0 and row_tiles(M) * ((Nout + 127) // 128) * groups >= get_tuning("tall_min"))
     name_ = "gemm_kernel<%d,%d,true,true>" % (256 if tall else 128, 64 if narrow else 128)
     n256 = lib.nsid_gemm_g256_launches() if PROFILE is not None else 0
     # csrc/gemm.hip decides between the tile families; the launch counter of the 256x256-tile LDS-DMA kernel says which one ran
@@ -308,7 +308,7 @@ def linear_fwd(x, w, bias, M, Nout, K, groups=1, in_scale=None, in_shift=None, a
     return out, stat
 
 
-FUSE_BN_BWD_REDUCE = os.environ.get("NSID_FUSE_BN_BWD_REDUCE", "1") == "1"     # backward-data GEMMs emit the next BatchNorm-backward's column sums (bf16 storage only)
+FUSE_BN_BWD_REDUCE = True     # backward-data GEMMs emit the next BatchNorm-backward's column sums (bf16 storage only)
 
 
 def linear_bwd_data(dout, w, M, Nout, K, groups=1, addend=None, out=None, bn=None):
@@ -359,7 +359,7 @@ def linear_bwd_weight(dout, x, dw, M, Nout, K, groups=1, in_scale=None, in_shift
     name = "gemm_kernel<%s,false,false>" % ("64,64" if small else "128,128")
     if dt == BF16 and Nout % 128 == 0 and K % 64 == 0 and M % 1024 == 0:          # csrc/gemm.hip: 128x64 tiles
         tiles_r = (Nout // 128) * (K // 64) * groups
-        if tiles_r * min(M // 1024, max(1, 512 // tiles_r)) >= 256 and os.environ.get("NSID_WGRAD_RECT", "1") != "0":
+        if tiles_r * min(M // 1024, max(1, 512 // tiles_r)) >= 256 and get_tuning("wgrad_rect") != 0:
             name = "gemm_kernel<128,64,false,false>"
     if dt == BF16 and Nout % 128 == 0 and K % 128 == 0 and M % 128 == 0 and (Nout // 128) * (K // 128) * groups >= 64:
         name = "wgrad3_kernel"              # csrc/wgrad.hip: 128x128 tiles, 8 waves

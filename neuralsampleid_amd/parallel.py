@@ -268,8 +268,10 @@ class CollectiveTimeout(RuntimeError):
 
 
 def sync_with_deadline(seconds: Optional[float] = None, what: str = "device work", fatal: bool = True) -> None:
-    """torch.cuda.synchronize() with a host deadline: an event recorded on every known stream is polled (1 ms sleeps),
-    the communicator's asynchronous error state is checked meanwhile. fatal: abort the communicator and os._exit(1)."""
+    """torch.cuda.synchronize() with a host deadline: an event recorded on every known stream is polled, the communicator's
+    asynchronous error state is checked meanwhile. fatal: abort the communicator and os._exit(1).
+    Polling: 50 us sleeps for the first 5 s (a bench's timed region ends here: a 1 ms poll interval would add up to 0.6 % to a
+    160 ms measurement), 1 ms afterwards; the RCCL error query runs once per millisecond, not once per poll."""
     import os
     import sys
     import time
@@ -285,9 +287,15 @@ def sync_with_deadline(seconds: Optional[float] = None, what: str = "device work
         evs.append(e)
     t0 = time.monotonic()
     err = None
+    last_check = t0
     while True:
         if all(e.query() for e in evs):
             return
+        now = time.monotonic()
+        if now - t0 < 5.0 and now - last_check < 1e-3:
+            time.sleep(5e-5)
+            continue
+        last_check = now
         if COMM is not None and COMM._h is not None:
             try:
                 code = COMM.async_error()
@@ -299,7 +307,7 @@ def sync_with_deadline(seconds: Optional[float] = None, what: str = "device work
         if time.monotonic() - t0 > seconds:
             err = f"{what} did not finish within {seconds:.0f} s"
             break
-        time.sleep(0.001)
+        time.sleep(5e-5 if now - t0 < 5.0 else 1e-3)
     if not fatal:
         raise CollectiveTimeout(err)
     print(f"[nsid] rank {_rank_world()[0]}: {err}; aborting the communicator and exiting", file=sys.stderr, flush=True)

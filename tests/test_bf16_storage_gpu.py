@@ -4,7 +4,6 @@ upcast fp32 copy of the SAME bf16 values (so the only differences are the final 
 relative L2 <= 2.5e-3, i.e. bf16's 2^-9 half-ulp rms, and bit-exact for pure data movement / integer outputs)."""
 import numpy as np
 import pytest
-import os
 
 import torch
 
@@ -13,7 +12,6 @@ from synth import GRAFP_CFG, synth_randn, synth_state
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
 BF = torch.bfloat16
-G256_DEFAULT = int(os.environ.get("NSID_G256_MIN", "512"))     # csrc/gemm.hip: threshold of the 256-tile LDS-DMA kernel
 
 
 @pytest.fixture()
@@ -300,7 +298,7 @@ def test_lds_dma_gemm_inside_the_eval_forward(ops, golden):
     """the folded eval forward with EVERY eligible GEMM on csrc/gemm256.hip (threshold forced to one tile: the C >= 128 stages' fc1 / fc2 /
     FFN layers take the plain, ReLU and residual epilogues) against the same forward on csrc/gemm.hip and against the reference goldens"""
     from neuralsampleid_amd import functional as F_
-    from neuralsampleid_amd._lib import call, lib
+    from neuralsampleid_amd._lib import call, lib, reset_tuning, set_tuning
     F_.set_activation_dtype("bf16")
     g = golden("e2e_b8_k3")
     model = build()
@@ -312,7 +310,7 @@ def test_lds_dma_gemm_inside_the_eval_forward(ops, golden):
     outs, launches = {}, {}
     try:
         for thr in (0, 1):
-            call("nsid_set_gemm_g256_min", thr)
+            set_tuning("g256_min", thr)
             n0 = lib.nsid_gemm_g256_launches()
             F_.TAPE = F_.KnnTape(replay=gold_idx)
             with torch.no_grad():
@@ -321,7 +319,7 @@ def test_lds_dma_gemm_inside_the_eval_forward(ops, golden):
             launches[thr] = lib.nsid_gemm_g256_launches() - n0
     finally:
         F_.TAPE = None
-        call("nsid_set_gemm_g256_min", G256_DEFAULT)
+        reset_tuning()
     assert launches[0] == 0 and launches[1] >= 2 * 16, launches          # two views x (10 blocks with C >= 128: FFN fc1 + fc2 at least)
     for a, b in zip(outs[1], outs[0]):
         assert relerr(a, b) < 1e-2, relerr(a, b)                          # same operands and rounding points, another summation order
@@ -333,9 +331,9 @@ def test_lds_dma_gemm_inside_the_eval_forward(ops, golden):
 @pytest.mark.parametrize("M,Nout,K,affine,stat,res", [(16384, 1024, 256, False, True, False), (16384, 1024, 256, True, True, False),
                                                        (8192, 2048, 512, True, False, True), (32768, 512, 128, False, True, False)])
 def test_eight_wave_forward_tiles(ops, M, Nout, K, affine, stat, res):
-    """the 8-wave 256x128-tile forward kernel (nsid_set_gemm_w8_min; off by default): product, bias, operand-load affine +
+    """the 8-wave 256x128-tile forward kernel (tuning key w8_min; off by default): product, bias, operand-load affine +
     ReLU, residual addend, and the BatchNorm statistics epilogue with TWO 128-row statistics tiles per workgroup"""
-    from neuralsampleid_amd._lib import call, lib
+    from neuralsampleid_amd._lib import call, lib, reset_tuning, set_tuning
     g = torch.Generator().manual_seed(21)
     x = torch.randn(M, K, generator=g).to(BF).to(DEV)
     w = (torch.randn(Nout, K, generator=g) * K ** -0.5).to(DEV)
@@ -347,16 +345,15 @@ def test_eight_wave_forward_tiles(ops, M, Nout, K, affine, stat, res):
     xin = act_ref(x.float() * sc + sh, 1) if affine else x.float()
     ref = xin.to(BF).double() @ w.to(BF).double().t() + bias.double()
     trace = torch.zeros(4 * 8192, dtype=torch.int64, device=DEV)
-    call("nsid_set_gemm_w8_min", 1024)
-    call("nsid_set_gemm_g256_min", 0)                 # (whatever NSID_G256_MIN says: this test is about the 8-wave body)
+    set_tuning("w8_min", 1024)
+    set_tuning("g256_min", 0)                 # (this test is about the 8-wave body)
     assert lib.nsid_debug_gemm_trace(trace.data_ptr()) == 0
     try:
         out, st = ops.linear_fwd(x, w, bias, M, Nout, K, 1, sc, sh, 1 if affine else 0, 0, want_stat=stat, addend=add)
         torch.cuda.synchronize()
     finally:
         lib.nsid_debug_gemm_trace(None)
-        call("nsid_set_gemm_w8_min", 0)
-        call("nsid_set_gemm_g256_min", G256_DEFAULT)
+        reset_tuning()
     assert int((trace.view(-1, 4)[:, 0] != 0).sum()) == (M // 256) * (Nout // 128)      # 256x128 tiles really ran
     assert relerr(out, ref + (add.double() if res else 0)) < 2.5e-3
     if stat:
@@ -372,10 +369,10 @@ def test_eight_wave_forward_tiles(ops, M, Nout, K, affine, stat, res):
                                                           (1024, 256, 128, False, False, True, True), (1024, 256, 128, False, True, False, True),
                                                           (512, 512, 2048, True, False, False, False)])
 def test_lds_dma_256_tile_forward(ops, M, Nout, K, relu, stat, res, bias):
-    """csrc/gemm256.hip (nsid_set_gemm_g256_min): 256x256 tiles staged by LDS-DMA through a four-slot ring — product, bias,
+    """csrc/gemm256.hip (tuning keys g256_min / g256_train): 256x256 tiles staged by LDS-DMA through a four-slot ring — product, bias,
     ReLU in the epilogue, residual addend and the BatchNorm statistics epilogue against an fp64 product of the bf16 operands.
     K = 128 is the shortest ring (prologue + tail only), K = 2048 runs 15 steady-state rounds."""
-    from neuralsampleid_amd._lib import call, lib
+    from neuralsampleid_amd._lib import call, lib, reset_tuning, set_tuning
     g = torch.Generator().manual_seed(31)
     x = torch.randn(M, K, generator=g).to(BF).to(DEV)
     w = (torch.randn(Nout, K, generator=g) * K ** -0.5).to(DEV)
@@ -386,12 +383,12 @@ def test_lds_dma_256_tile_forward(ops, M, Nout, K, relu, stat, res, bias):
     if relu:
         ref = ref.clamp_min(0)
     n0 = lib.nsid_gemm_g256_launches()
-    call("nsid_set_gemm_g256_min", 1)
+    set_tuning("g256_min", 1); set_tuning("g256_train", 1)
     try:
         out, st = ops.linear_fwd(x, w, b, M, Nout, K, 1, None, None, 0, 1 if relu else 0, want_stat=stat, addend=add)
         torch.cuda.synchronize()
     finally:
-        call("nsid_set_gemm_g256_min", G256_DEFAULT)
+        reset_tuning()
     assert lib.nsid_gemm_g256_launches() == n0 + 1                       # the kernel under test really ran
     # the only rounding is the bf16 store of the fp32 result
     full = ref + (add.double() if res else 0)
@@ -434,16 +431,16 @@ def test_tall_tile_forward_without_statistics(ops, M, Nout, K, affine, res):
     ref = xin.to(BF).double() @ w.to(BF).double().t() + bias.double()
     if res:
         ref = ref + add.double()
-    from neuralsampleid_amd._lib import call, lib
+    from neuralsampleid_amd._lib import call, lib, reset_tuning, set_tuning
     trace = torch.zeros(4 * 4096, dtype=torch.int64, device=DEV)          # one record per workgroup (nsid_debug_gemm_trace)
-    call("nsid_set_gemm_g256_min", 0)                 # (whatever NSID_G256_MIN says: this test is about gemm.hip's 256x128 tiles)
+    set_tuning("g256_min", 0)                 # (this test is about gemm.hip's 256x128 tiles)
     assert lib.nsid_debug_gemm_trace(trace.data_ptr()) == 0
     try:
         out, stat = ops.linear_fwd(x, w, bias, M, Nout, K, 1, sc, sh, 1 if affine else 0, 0, want_stat=False, addend=add)
         torch.cuda.synchronize()
     finally:
         lib.nsid_debug_gemm_trace(None)
-        call("nsid_set_gemm_g256_min", G256_DEFAULT)
+        reset_tuning()
     assert int((trace.view(-1, 4)[:, 0] != 0).sum()) == (M // 256) * (Nout // 128)      # 256x128 tiles really ran
     assert stat is None and relerr(out, ref) < 2.5e-3
     # the statistics epilogue keeps the 128-row tiles (training path): per-tile sums still match

@@ -36,6 +36,26 @@ def test_binding_table_covers_header(libpath):
     assert _lib.lib.nsid_ntxent_ws_floats(256) >= 4 * 256
 
 
+def test_tuning_table_roundtrip(libpath):
+    """nsid_set_tuning / nsid_get_tuning / nsid_reset_tuning: the only way launch heuristics change (the library never reads
+    the environment); unknown keys are refused"""
+    import subprocess
+    from neuralsampleid_amd import _lib
+    keys = _lib.tuning_keys()
+    assert len(keys) == len(set(keys)) >= 20 and {"g256_min", "g256_train", "w8_min", "knn_strips", "bn_bwd_apply_max_wg"} <= set(keys)
+    defaults = {k: _lib.get_tuning(k) for k in keys}
+    assert defaults["g256_min"] == 512 and defaults["bn_bwd_apply_max_wg"] == 384
+    _lib.set_tuning("g256_min", 7)
+    assert _lib.get_tuning("g256_min") == 7
+    _lib.reset_tuning()
+    assert {k: _lib.get_tuning(k) for k in keys} == defaults
+    with pytest.raises(KeyError):
+        _lib.set_tuning("no_such_key", 1)
+    # no getenv left in the kernel library
+    syms = subprocess.run(["nm", "-D", "--undefined-only", libpath], capture_output=True, text=True).stdout
+    assert "getenv" not in syms
+
+
 def test_ops_refuse_cpu_tensors(libpath):
     """the product path has no CPU fallback: CPU tensors are rejected, not silently computed elsewhere"""
     import torch

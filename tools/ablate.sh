@@ -1,9 +1,9 @@
 #!/bin/bash
-# Marginal cost of each kernel family INSIDE the two-stream hipGraph step: bench.py with the family's launches skipped
-# (NSID_ABLATE, _lib.py). The arithmetic is wrong in these runs (NaN-guard may skip the optimiser update); only the step time
-# is read. Usage (GPU box): tools/ablate.sh > gpurun_out/ablate.txt
-run() { NSID_ABLATE=$2 python bench.py --no-cpu-baseline --no-roofline 2>&1 >/dev/null | grep timed | sed "s/^/$1: /"; }
-run "baseline" ""
+# Marginal cost of each kernel family INSIDE the two-stream hipGraph step: tools/ablate.py runs bench.py with the family's launches
+# skipped. The arithmetic is wrong in these runs (the NaN guard may skip the optimiser update); only the step time is read.
+# Usage (GPU box): tools/ablate.sh > gpurun_out/ablate.txt
+run() { python tools/ablate.py "$2" -- --no-cpu-baseline --no-roofline --no-other 2>&1 >/dev/null | grep timed | sed "s/^/$1: /"; }
+run "baseline" "nsid_version"
 run "no bn_finalize (fwd)" "nsid_bn_finalize,nsid_bn_finalize_deferred"
 run "no bn_bwd_finalize" "nsid_bn_bwd_finalize"
 run "no bn_bwd_apply" "nsid_bn_bwd_apply"
@@ -15,4 +15,4 @@ run "no kNN" "nsid_knn_graph"
 run "no aggregation fwd+bwd" "nsid_mr_aggregate_fwd,nsid_mr_aggregate_bwd"
 run "no col_reduce (bn_bwd_reduce)" "nsid_bn_bwd_reduce"
 run "no optimiser" "nsid_adam_step,nsid_sumsq_partial,nsid_fill_zero,nsid_f32_to_bf16"
-run "baseline again" ""
+run "baseline again" "nsid_version"

@@ -6,7 +6,7 @@ out=gpurun_out/batch_scaling; mkdir -p $out
 for b in 128 256 512 1024; do
   for ov in "" "--no-overlap"; do
     tag="b${b}${ov:+_single}"
-    python bench.py --batch $b $ov --no-cpu-baseline --no-roofline --steps 20 --warmup 3 > $out/$tag.json 2>$out/$tag.err || exit 1
+    python bench.py --batch $b $ov --no-cpu-baseline --no-roofline --no-other --steps 20 --warmup 3 > $out/$tag.json 2>$out/$tag.err || exit 1
     python - "$out/$tag.json" "$tag" <<'PY'
 import json,sys
 d=json.load(open(sys.argv[1])); print(sys.argv[2], "ms/step", d["ms_per_step"], "clips/s", d["value"])

@@ -2,9 +2,9 @@
 """GEMM-family microbench on the shapes of the 't' encoder at B=256 (one view): per shape and direction, average
 device time (the repetitions are captured in one hipGraph), TFLOP/s and algorithmic GB/s.
 Usage: python tools/gemm_bench.py [--reps 20] [--only fwd] [--shapes MxNxKxG,...]
-Tuning knobs read by the kernel library (experiments; the defaults are the measured winners): NSID_FWD_NARROW=0/1,
-NSID_BWD_NARROW=0/1 (64- vs 128-wide tiles), NSID_WGRAD_V1=1 (never use the 8-wave 128x128 weight-gradient form),
-NSID_W3_WGS / NSID_W3_MIN_TILES (its workgroup target / smallest layer), NSID_KNN_STRIPS=1 (strip kNN kernel)."""
+Tuning keys of the kernel library (--tune key=value; the defaults are the measured winners): fwd_narrow=0/1,
+bwd_narrow=0/1 (64- vs 128-wide tiles), wgrad_wide=0 (never use the 8-wave 128x128 weight-gradient form),
+w3_wgs / w3_min_tiles (its workgroup target / smallest layer), knn_strips=1 (strip kNN kernel)."""
 import argparse
 import os
 import sys
@@ -94,7 +94,11 @@ def main():
     ap.add_argument("--blas", action="store_true",
                     help="with --cold: time torch.mm (hipBLASLt / rocBLAS) on the same operands instead: a yardstick for the "
                          "plain product without the fused load transform / epilogues")
+    ap.add_argument("--tune", action="append", default=[], metavar="KEY=VALUE", help="tuning key of the kernel library")
     args = ap.parse_args()
+    for kv in args.tune:
+        k_, v_ = kv.split("=")
+        ops.set_tuning(k_, int(v_))
     dev = "cuda"
     ops.set_gemm_precision(args.precision)
     adt = torch.bfloat16 if args.storage == "bf16" else torch.float32
