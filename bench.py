@@ -203,12 +203,11 @@ def infer_bench(args, model, rank, world, dev, dist):
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         log("timing the CPU baseline (oracle, eval forward) ...")
         cpu = cpu_baseline_infer(args.k, deep=args.deep)
+    result = None
     if rank == 0:
         # 9.8 MB per view-clip forward at 2 B/element with every conv output materialised once
         fwd_bytes = 9.8e6 * (1.0 if args.precision == "bf16" else 2.0) * args.clips
-        print(json.dumps({
-            "roofline": roofline, "kernels": kernels, "cpu_baseline": cpu,
-            "step_hbm_frac_algorithmic": round(fwd_bytes / elapsed / 1e9 / HBM_PEAK_GBPS, 4),
+        result = {
             "metric": "audio clips/sec (forward-only fingerprint extraction, grafp encoder)",
             "value": round(args.clips / elapsed, 1), "unit": "clips/s", "n_gpus": world, "steps": n_mb,
             "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / n_mb, 3), "higher_is_better": True,
@@ -218,11 +217,12 @@ def infer_bench(args, model, rank, world, dev, dist):
                                    f"{' from 16 kHz waveforms (log-mel front end on the GPU)' if args.from_wave else ''}"
                                    f", eval-mode BN, micro-batch {mb}{' (one hipGraph replay each)' if graphed is not None else ''}, "
                                    f"GraphEncoder('t', k={args.k}{', deep' if args.deep else ''})",
-                       "parallelism": f"shard{world}"}}))
+                       "parallelism": f"shard{world}", "tuning": getattr(args, "tuning", None) or None},
+            "roofline": roofline, "step_hbm_frac_algorithmic": round(fwd_bytes / elapsed / 1e9 / HBM_PEAK_GBPS, 4),
+            "kernels": kernels, "cpu_baseline": cpu}
     if world > 1:
         dist.barrier()
-    from neuralsampleid_amd import parallel
-    parallel.shutdown()
+    return result
 
 
 def measured_traffic(kernel, precision, tag=""):
@@ -290,75 +290,17 @@ def spawn_ranks(n: int) -> int:
     return 0
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=CFG["bsz_train"], help="clips (pairs) per GPU")
-    ap.add_argument("--k", type=int, default=3, help="kNN neighbours (GraphEncoder default 3; train.py --k default 5)")
-    ap.add_argument("--precision", choices=["fp32", "bf16"], default="bf16",
-                    help="GEMM operand arithmetic: bf16 operands / fp32 storage+accumulate (BASELINE config 2, default) "
-                         "or fp32 (exact fp32 MFMA, the strict-parity path); the other mode is timed as a side number")
-    ap.add_argument("--storage", choices=["fp32", "bf16"], default=None,
-                    help="activation storage in HBM (default: bf16 with --precision bf16 = BASELINE config 2's "
-                         "'bf16 storage / fp32 accumulate'; fp32 with --precision fp32)")
-    ap.add_argument("--mode", choices=["train", "infer"], default="train",
-                    help="train: contrastive step (BASELINE config 2/3, default); infer: forward-only fingerprint "
-                         "extraction in eval mode (config 5), --clips per job sharded over the ranks")
-    ap.add_argument("--clips", type=int, default=100000, help="infer mode: total clips of the job")
-    ap.add_argument("--from-wave", action="store_true",
-                    help="infer mode: start from synthetic 16 kHz waveforms (log-mel front end on the GPU, SURVEY 8f-4)")
-    ap.add_argument("--deep", action="store_true",
-                    help="BASELINE config 4: blocks [4,4,12,4], k=18, intended dilation schedule (capped by N)")
-    ap.add_argument("--no-overlap", action="store_true", help="run the two views on one stream instead of two")
-    ap.add_argument("--micro-batch", type=int, default=2048,
-                    help="--mode infer: clips per forward call (config 5: >= 1024; measured on MI355X: 3.5 ms per 1 024 clips at "
-                         "2 048 and 4 096 against 4.1 ms at 1 024 — the 1 024-clip launches leave partial rounds of tiles)")
-    ap.add_argument("--no-graph", action="store_true", help="do not capture the step in a hipGraph")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--no-other", action="store_true",
-                    help="skip the side measurements of a default run (other precision, configs 4 and 5): A/B sweeps use this")
-    ap.add_argument("--tune", action="append", default=[], metavar="KEY=VALUE",
-                    help="set a tuning key of the kernel library (include/nsid.h nsid_set_tuning) for this run; recorded in "
-                         "config.tuning. The library never reads the environment.")
-    args = ap.parse_args()
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        sys.exit(spawn_ranks(args.gpus))
-
+def run_config(args, ctx, side=False):
+    """one bench line (a dict on rank 0, None elsewhere) for the configuration `args` names; side=True: a secondary configuration
+    of a default run (no other-precision side number)"""
     import torch.distributed as dist
+    from neuralsampleid_amd import functional as F_
     from neuralsampleid_amd import ops, parallel
     from neuralsampleid_amd.encoder.graph_encoder import GraphEncoder
     from neuralsampleid_amd.optim import FusedClipAdam
     from neuralsampleid_amd.simclr.simclr import SimCLR
-
-    # data-path collectives: direct RCCL communicator (neuralsampleid_amd/rccl.py) on its own HIP stream; the
-    # torch.distributed group (gloo) only carries the ncclUniqueId, the host barriers and the max-over-ranks of the time
-    # NSID_BENCH_REHEARSAL=gloo: rehearse the multi-rank orchestration on a box with fewer GPUs than ranks (RCCL refuses two
-    # ranks on one device): torch.distributed/gloo carries the data-path collectives, ranks share devices, no hipGraph
-    rehearsal = os.environ.get("NSID_BENCH_REHEARSAL", "") == "gloo"
-    rank, local, world = parallel.init_from_env("gloo" if rehearsal else "rccl")
-    if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
-    if rehearsal:
-        local %= torch.cuda.device_count()
-        args.no_graph = True
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-
-    tuning = {}
-    for kv in args.tune:
-        key, _, val = kv.partition("=")
-        ops.set_tuning(key, int(val))
-        tuning[key] = int(val)
-    from neuralsampleid_amd import functional as F_
-    if args.storage is None:
-        args.storage = "bf16" if args.precision == "bf16" else "fp32"
-    if args.storage == "bf16" and args.precision != "bf16":
-        raise SystemExit("--storage bf16 needs --precision bf16 (bf16 tensors feed the bf16 MFMA path)")
-    ops.set_gemm_precision(args.precision)
-    F_.set_activation_dtype(args.storage)
+    rank, world, dev, tuning, rehearsal = ctx["rank"], ctx["world"], ctx["dev"], ctx["tuning"], ctx["rehearsal"]
+    args.tuning = tuning
     torch.manual_seed(42)                                   # identical initial weights on every rank
     enc_kw = dict(blocks=[4, 4, 12, 4], use_dilation=True) if args.deep else {}
     if args.deep:
@@ -481,7 +423,7 @@ def main():
         roofline = roofline_entry(prof, args.precision, bracket_us, "_deep" if args.deep else "")
 
     other = None
-    if world == 1 and not args.no_roofline and not args.no_other:
+    if world == 1 and not args.no_roofline and not args.no_other and not side:
         # side number: the same step in the other arithmetic (eager; the GPU time dominates the host time)
         alt = "fp32" if args.precision == "bf16" else "bf16"
         ops.set_gemm_precision(alt)
@@ -550,6 +492,113 @@ def main():
             "other_precision": other,
             "cpu_baseline": cpu,
         }
+        return out
+    return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=CFG["bsz_train"], help="clips (pairs) per GPU")
+    ap.add_argument("--k", type=int, default=3, help="kNN neighbours (GraphEncoder default 3; train.py --k default 5)")
+    ap.add_argument("--precision", choices=["fp32", "bf16"], default="bf16",
+                    help="GEMM operand arithmetic: bf16 operands / fp32 storage+accumulate (BASELINE config 2, default) "
+                         "or fp32 (exact fp32 MFMA, the strict-parity path); the other mode is timed as a side number")
+    ap.add_argument("--storage", choices=["fp32", "bf16"], default=None,
+                    help="activation storage in HBM (default: bf16 with --precision bf16 = BASELINE config 2's "
+                         "'bf16 storage / fp32 accumulate'; fp32 with --precision fp32)")
+    ap.add_argument("--mode", choices=["train", "infer"], default="train",
+                    help="train: contrastive step (BASELINE config 2/3, default); infer: forward-only fingerprint "
+                         "extraction in eval mode (config 5), --clips per job sharded over the ranks")
+    ap.add_argument("--clips", type=int, default=100000, help="infer mode: total clips of the job")
+    ap.add_argument("--from-wave", action="store_true",
+                    help="infer mode: start from synthetic 16 kHz waveforms (log-mel front end on the GPU, SURVEY 8f-4)")
+    ap.add_argument("--deep", action="store_true",
+                    help="BASELINE config 4: blocks [4,4,12,4], k=18, intended dilation schedule (capped by N)")
+    ap.add_argument("--no-overlap", action="store_true", help="run the two views on one stream instead of two")
+    ap.add_argument("--micro-batch", type=int, default=2048,
+                    help="--mode infer: clips per forward call (config 5: >= 1024; measured on MI355X: 3.5 ms per 1 024 clips at "
+                         "2 048 and 4 096 against 4.1 ms at 1 024 — the 1 024-clip launches leave partial rounds of tiles)")
+    ap.add_argument("--no-graph", action="store_true", help="do not capture the step in a hipGraph")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-other", action="store_true",
+                    help="skip the side measurements of a default run (other precision, configs 4 and 5): A/B sweeps use this")
+    ap.add_argument("--flag", action="append", default=[], metavar="MODULE.NAME=VALUE",
+                    help="set a module-level switch of the host side for this run, e.g. ops.FUSE_BN_BWD_APPLY=0 (one-box A/B); "
+                         "recorded in config.flags")
+    ap.add_argument("--tune", action="append", default=[], metavar="KEY=VALUE",
+                    help="set a tuning key of the kernel library (include/nsid.h nsid_set_tuning) for this run; recorded in "
+                         "config.tuning. The library never reads the environment.")
+    args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))
+
+    import torch.distributed as dist
+    from neuralsampleid_amd import ops, parallel
+    from neuralsampleid_amd.encoder.graph_encoder import GraphEncoder
+    from neuralsampleid_amd.optim import FusedClipAdam
+    from neuralsampleid_amd.simclr.simclr import SimCLR
+
+    # data-path collectives: direct RCCL communicator (neuralsampleid_amd/rccl.py) on its own HIP stream; the
+    # torch.distributed group (gloo) only carries the ncclUniqueId, the host barriers and the max-over-ranks of the time
+    # NSID_BENCH_REHEARSAL=gloo: rehearse the multi-rank orchestration on a box with fewer GPUs than ranks (RCCL refuses two
+    # ranks on one device): torch.distributed/gloo carries the data-path collectives, ranks share devices, no hipGraph
+    rehearsal = os.environ.get("NSID_BENCH_REHEARSAL", "") == "gloo"
+    rank, local, world = parallel.init_from_env("gloo" if rehearsal else "rccl")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if rehearsal:
+        local %= torch.cuda.device_count()
+        args.no_graph = True
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    tuning = {}
+    for kv in args.tune:
+        key, _, val = kv.partition("=")
+        ops.set_tuning(key, int(val))
+        tuning[key] = int(val)
+    from neuralsampleid_amd import functional as F_
+    for kv in args.flag:
+        target, _, val = kv.partition("=")
+        mod, _, name = target.partition(".")
+        module = {"ops": ops, "functional": F_}[mod]
+        if not hasattr(module, name):
+            raise SystemExit(f"--flag: {mod} has no switch {name}")
+        setattr(module, name, type(getattr(module, name))(int(val)))
+        tuning[target] = int(val)
+    if args.storage is None:
+        args.storage = "bf16" if args.precision == "bf16" else "fp32"
+    if args.storage == "bf16" and args.precision != "bf16":
+        raise SystemExit("--storage bf16 needs --precision bf16 (bf16 tensors feed the bf16 MFMA path)")
+    ops.set_gemm_precision(args.precision)
+    F_.set_activation_dtype(args.storage)
+    ctx = {"rank": rank, "world": world, "dev": dev, "tuning": tuning, "rehearsal": rehearsal}
+    default_run = (args.mode == "train" and not args.deep and world == 1 and not args.no_other and not args.no_roofline
+                   and args.batch == CFG["bsz_train"] and args.precision == "bf16")
+    out = run_config(args, ctx)
+    if default_run and rank == 0:
+        # BASELINE configs 4 and 5 at their NAMED sizes, timed in the same (driver-run) invocation: the deep step at batch 256 and
+        # forward-only extraction of 100 000 clips; each entry is a complete bench line of its own (roofline, traffic, cpu_baseline)
+        import copy
+        others = {}
+        for name, changes in (("config4_deep_step", {"deep": True}),
+                              ("config5_fingerprint_100k", {"mode": "infer", "clips": 100000})):
+            a2 = copy.copy(args)
+            for k_, v_ in changes.items():
+                setattr(a2, k_, v_)
+            log(f"other configuration: {name}")
+            try:
+                others[name] = run_config(a2, ctx, side=True)
+            except Exception as e:      # a side configuration must never take the headline down
+                others[name] = {"error": f"{type(e).__name__}: {e}"}
+            torch.cuda.synchronize()
+            torch.cuda.empty_cache()
+        out["other_configs"] = others
+    if rank == 0:
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

@@ -60,6 +60,12 @@ int nsid_get_tuning(const char* key, long* value);
 int nsid_reset_tuning(void);                 /* every key back to its compiled-in default */
 int nsid_tuning_count(void);
 const char* nsid_tuning_key(int i);          /* i in [0, nsid_tuning_count()) */
+/* debug: launch counters per kernel VARIANT since the last reset (csrc/nsid_common.h NSID_COUNTER_TABLE lists the keys, e.g.
+   "gemm_full", "gemm_ks2", "wgrad_rect", "wgrad3", "gemm_bn_sums", "knn2"); -1 for an unknown key. Host-side: counted when enqueued. */
+long nsid_debug_counter(const char* key);
+int nsid_debug_counters_reset(void);
+int nsid_debug_counter_count(void);
+const char* nsid_debug_counter_key(int i);
 /* launches of nsid_linear_fwd / nsid_linear_fwd_res that took the 256x256-tile LDS-DMA kernel (csrc/gemm256.hip) so far */
 long nsid_gemm_g256_launches(void);
 /* number of NSID_ROW_TILE row tiles of an M-row matrix: size of the partial-statistics buffers */
@@ -102,6 +108,17 @@ int nsid_linear_bwd_data_bn(const void* dout, int ldd, const void* w, int w_dtyp
                             void* din, int ldi, int M, int Nout, int K, int groups, int act_dtype, const void* bn_r,
                             const float* bn_scale, const float* bn_shift, const float* bn_mean, const float* bn_invstd,
                             int bn_act, float* bn_partial, void* stream);
+/* backward-data of a conv+BatchNorm(+act) layer whose BatchNorm backward is evaluated ON THE OPERAND LOAD: with dy = dL/d act(BN(r))
+ * and r that layer's raw conv output (both M x groups*Nout, bf16, contiguous), dr = BN-backward(dy, r) = sc*g + P*r + Q,
+ * g = dy*act'(sc*r + sh), coef4[4][groups*Nout] = {sc, sh, P, Q} from nsid_bn_bwd_finalize_fused, the call computes
+ * din = addend + dr w  and writes dr (bf16, M x groups*Nout) once for nsid_linear_bwd_weight. It replaces the
+ * nsid_bn_bwd_apply pass + nsid_linear_bwd_data[_bn] pair of a Conv2d+BatchNorm2d(+ReLU) site (encoder/graph_encoder.py:74-77,
+ * gcn_lib/torch_nn.py:56-60, torch_vertex.py:152-155). bn_* as in nsid_linear_bwd_data_bn (bn_r NULL: none).
+ * Returns 1, having launched nothing, when the shape is outside the fused form (caller: run the two-call form). */
+int nsid_linear_bwd_data_bnapply(const void* dy, const void* r, const float* coef4, int act, void* dr, const void* w, int w_dtype,
+                                 const void* addend, int ldadd, void* din, int ldi, int M, int Nout, int K, int groups,
+                                 int act_dtype, const void* bn_r, const float* bn_scale, const float* bn_shift,
+                                 const float* bn_mean, const float* bn_invstd, int bn_act, float* bn_partial, void* stream);
 /* backward-weight: dw[g*Nout+n, k] += sum_m dout[m, g*Nout+n] * f(x[m, g*K+k])   (f as in forward; atomic) */
 int nsid_linear_bwd_weight(const void* dout, int ldd, const void* x, int ldx, float* dw, int M, int Nout, int K,
                            int groups, const float* in_scale, const float* in_shift, int act_in,
@@ -137,6 +154,11 @@ int nsid_bn_bwd_reduce(const void* dout, const void* r, int M, int C, const floa
 /* step 2: dgamma += sum g*xhat; dbeta += sum g; coef[2][C] = {sum g / M, sum g*xhat / M} */
 int nsid_bn_bwd_finalize(const float* partial, int tiles, int C, int M, float* dgamma, float* dbeta, float* coef,
                          void* stream);
+/* step 2 for a consumer that evaluates step 3 on its operand load (nsid_linear_bwd_data_bnapply): additionally
+   coef4[4][C] = {scale, shift, P, Q} with dr = scale*g + P*r + Q, P = -scale*coef1*invstd, Q = scale*(coef1*invstd*mean - coef0) */
+int nsid_bn_bwd_finalize_fused(const float* partial, int tiles, int C, int M, float* dgamma, float* dbeta, float* coef,
+                               const float* scale, const float* shift, const float* mean, const float* invstd, float* coef4,
+                               void* stream);
 /* step 3: dr = scale * (g - coef0 - xhat*coef1)   (dr may alias dout) */
 int nsid_bn_bwd_apply(const void* dout, const void* r, int M, int C, const float* scale, const float* shift,
                       const float* mean, const float* invstd, int act, const float* coef, void* dr, int dtype,

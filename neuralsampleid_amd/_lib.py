@@ -30,6 +30,7 @@ SIGNATURES = {
     "nsid_bn_bwd_reduce": "ppiippppipis",
     "nsid_bn_bwd_finalize": "piiippps",
     "nsid_bn_bwd_apply": "ppiippppippis",
+    "nsid_bn_bwd_finalize_fused": "piiipppppppps",
     "nsid_knn_graph": "pippiiiiipis",
     "nsid_mr_aggregate_fwd": "pipppiiiippis",
     "nsid_mr_aggregate_bwd": "pppiiiipis",
@@ -95,6 +96,17 @@ def _load():
     lib.nsid_tuning_count.restype = ctypes.c_int
     lib.nsid_tuning_key.argtypes = [ctypes.c_int]
     lib.nsid_tuning_key.restype = ctypes.c_char_p
+    lib.nsid_debug_counter.argtypes = [ctypes.c_char_p]
+    lib.nsid_debug_counter.restype = ctypes.c_long
+    lib.nsid_debug_counters_reset.argtypes = []
+    lib.nsid_debug_counters_reset.restype = ctypes.c_int
+    lib.nsid_debug_counter_count.argtypes = []
+    lib.nsid_debug_counter_count.restype = ctypes.c_int
+    lib.nsid_debug_counter_key.argtypes = [ctypes.c_int]
+    lib.nsid_debug_counter_key.restype = ctypes.c_char_p
+    # returns 1 (nothing launched) for shapes outside the fused form: bound directly, not through call()
+    lib.nsid_linear_bwd_data_bnapply.argtypes = [_CT[c] for c in "pppippipipiiiiiipppppips"]
+    lib.nsid_linear_bwd_data_bnapply.restype = ctypes.c_int
     lib.nsid_row_tiles.argtypes = [ctypes.c_int]
     lib.nsid_row_tiles.restype = ctypes.c_int
     lib.nsid_sumsq_blocks.argtypes = [ctypes.c_long]
@@ -105,7 +117,7 @@ def _load():
 
 
 lib = _load()
-EXPORTS = list(SIGNATURES) + ["nsid_version", "nsid_debug_gemm_trace", "nsid_debug_knn_trace", "nsid_get_gemm_precision", "nsid_gemm_g256_launches", "nsid_set_tuning", "nsid_get_tuning", "nsid_reset_tuning", "nsid_tuning_count", "nsid_tuning_key", "nsid_row_tiles", "nsid_sumsq_blocks", "nsid_ntxent_ws_floats"]
+EXPORTS = list(SIGNATURES) + ["nsid_version", "nsid_debug_gemm_trace", "nsid_debug_knn_trace", "nsid_get_gemm_precision", "nsid_gemm_g256_launches", "nsid_linear_bwd_data_bnapply", "nsid_debug_counter", "nsid_debug_counters_reset", "nsid_debug_counter_count", "nsid_debug_counter_key", "nsid_set_tuning", "nsid_get_tuning", "nsid_reset_tuning", "nsid_tuning_count", "nsid_tuning_key", "nsid_row_tiles", "nsid_sumsq_blocks", "nsid_ntxent_ws_floats"]
 
 _ERR = {-1: "NSID_EINVAL (unsupported shape, misaligned pointer or bad argument)",
         -2: "NSID_ELAUNCH (HIP runtime refused the launch)"}
@@ -132,6 +144,17 @@ def get_tuning(key: str) -> int:
 
 def reset_tuning() -> None:
     lib.nsid_reset_tuning()
+
+
+def launch_counters(reset: bool = False) -> dict:
+    """launches per kernel variant since the last reset (include/nsid.h nsid_debug_counter)"""
+    out = {}
+    for i in range(lib.nsid_debug_counter_count()):
+        k = lib.nsid_debug_counter_key(i)
+        out[k.decode()] = int(lib.nsid_debug_counter(k))
+    if reset:
+        lib.nsid_debug_counters_reset()
+    return out
 
 
 def tuning_keys():

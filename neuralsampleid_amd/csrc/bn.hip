@@ -191,9 +191,17 @@ __global__ __launch_bounds__(256) void col_reduce_kernel(const T* __restrict__ d
   }
 }
 
+// coef4 (optional): the BatchNorm backward as ONE affine of its two sources for a consumer that evaluates it on its operand load
+// (gemm.hip ABN): dr = sc*(g - c0 - xhat*c1) = sc*g + P*r + Q with P = -sc*c1*invstd, Q = sc*(c1*invstd*mean - c0);
+// coef4[4][C] = {sc, sh, P, Q} (sc, sh: the forward affine, needed for the activation mask g = dy * act'(sc*r + sh)).
 __global__ __launch_bounds__(FIN_CH * FIN_TG) void bn_bwd_finalize_kernel(const float* __restrict__ partial,
                                                                            int tiles, int C, int M, float* dgamma,
-                                                                           float* dbeta, float* coef) {
+                                                                           float* dbeta, float* coef,
+                                                                           const float* __restrict__ scale,
+                                                                           const float* __restrict__ shift,
+                                                                           const float* __restrict__ mean,
+                                                                           const float* __restrict__ invstd,
+                                                                           float* __restrict__ coef4) {
   __shared__ double red0[FIN_CH * FIN_TG], red1[FIN_CH * FIN_TG];
   const int c = blockIdx.x * FIN_CH + (threadIdx.x & (FIN_CH - 1)), tg = threadIdx.x / FIN_CH;
   double sg, sgx;
@@ -202,8 +210,18 @@ __global__ __launch_bounds__(FIN_CH * FIN_TG) void bn_bwd_finalize_kernel(const 
   // atomic: the two views of a step may run this concurrently on different streams for the same layer
   if (dbeta) atomicAdd(dbeta + c, (float)sg);
   if (dgamma) atomicAdd(dgamma + c, (float)sgx);
-  coef[c] = (float)(sg / M);
-  coef[C + c] = (float)(sgx / M);
+  const float c0 = (float)(sg / M), c1 = (float)(sgx / M);
+  if (coef != nullptr) {
+    coef[c] = c0;
+    coef[C + c] = c1;
+  }
+  if (coef4 != nullptr) {
+    const float sc = scale[c], is = invstd[c];
+    coef4[c] = sc;
+    coef4[C + c] = shift[c];
+    coef4[2 * C + c] = -sc * c1 * is;
+    coef4[3 * C + c] = sc * (c1 * is * mean[c] - c0);
+  }
 }
 
 // Every thread keeps ONE column chunk for the whole kernel (the launch makes the thread count a multiple of the chunks per
@@ -422,7 +440,18 @@ extern "C" int nsid_bn_bwd_finalize(const float* partial, int tiles, int C, int 
                                     float* coef, void* stream) {
   NSID_REQUIRE(partial && coef && C > 0 && M > 0 && tiles == nsid_row_tiles(M));
   NSID_LAUNCH(bn_bwd_finalize_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_TG), 0,
-              static_cast<hipStream_t>(stream), partial, tiles, C, M, dgamma, dbeta, coef);
+              static_cast<hipStream_t>(stream), partial, tiles, C, M, dgamma, dbeta, coef, static_cast<const float*>(nullptr),
+              static_cast<const float*>(nullptr), static_cast<const float*>(nullptr), static_cast<const float*>(nullptr),
+              static_cast<float*>(nullptr));
+  return nsid_launch_status();
+}
+
+extern "C" int nsid_bn_bwd_finalize_fused(const float* partial, int tiles, int C, int M, float* dgamma, float* dbeta,
+                                          float* coef, const float* scale, const float* shift, const float* mean,
+                                          const float* invstd, float* coef4, void* stream) {
+  NSID_REQUIRE(partial && coef && coef4 && scale && shift && mean && invstd && C > 0 && M > 0 && tiles == nsid_row_tiles(M));
+  NSID_LAUNCH(bn_bwd_finalize_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_TG), 0,
+              static_cast<hipStream_t>(stream), partial, tiles, C, M, dgamma, dbeta, coef, scale, shift, mean, invstd, coef4);
   return nsid_launch_status();
 }
 
@@ -445,7 +474,8 @@ extern "C" int nsid_bn_bwd_apply(const void* dout, const void* r, int M, int C, 
     // workgroups stream a little slower alone and leave room beside them. One-box A/B of the whole step, three repetitions each:
     // 2 048: 8.31 / 8.28 / 8.28 ms, 512: 8.21 / 8.23 / 8.23, 384: 8.22 / 8.18 / 8.17 (tuning key bn_bwd_apply_max_wg).
     const long max_wg = nsid_tune(NSID_T_bn_bwd_apply_max_wg);
-    if (want > max_wg) want = max_wg;
+    nsid_count(NSID_C_bn_bwd_apply);
+    if (want > max_wg) { want = max_wg; nsid_count(NSID_C_bn_bwd_apply_capped); }
     const long grid = (want + g0 - 1) / g0 * g0;
     NSID_LAUNCH((bn_bwd_apply_kernel<T, U>), dim3((int)grid), dim3(256), 0, static_cast<hipStream_t>(stream),
                 static_cast<const T*>(dout), static_cast<const T*>(r), (long)M, CV, scale, shift, mean,

@@ -48,6 +48,12 @@ struct GemmArgs {
   // reduction index (i/j-major B); pad_safe = an element offset that is always inside the operand.
   int pad_period, pad_phase, pad_c0, pad_c1; long pad_safe;
   int relu_out;   // forward, non-atomic store path: out = max(acc + bias, 0) (eval mode: the consumer then needs no activation on load)
+  // ABN (backward-data, bf16 storage, full tiles): the left operand is the BatchNorm BACKWARD of the layer in front, evaluated on
+  // the operand load from TWO tensors of the same layout — A = dy (gradient w.r.t. that layer's activated output) and abn_r = r (its
+  // raw conv output): dr = sc*g + P*r + Q with g = dy * act'(sc*r + sh); abn_coef[4][abn_plane] = {sc, sh, P, Q} per channel
+  // (nsid_bn_bwd_finalize_fused). The workgroups of column tile 0 also write dr (abn_dr, row stride abn_lddr) for the weight
+  // gradient: the separate bn_bwd_apply pass (read dy, read r, write dr) disappears.
+  const void* abn_r; const float* abn_coef; long abn_plane; float abn_slope; void* abn_dr; long abn_lddr;
 };
 
 // Precision H = false: fp32 operands, v_mfma_f32_16x16x4_f32, BK = 16 (exact fp32 — the parity path).
@@ -230,6 +236,40 @@ __device__ __forceinline__ void stage_store(char* lds, const StageRegs<ROWS, RMA
   }
 }
 
+// ABN staging of an R-major bf16 tile: dr = sc*g + (P*r + Q), g = z > 0 ? dy : dy*slope, z = sc*r + sh, rounded to bf16 once (the value
+// bn_bwd_apply would have stored), written to the LDS image and — for the workgroups of column tile 0 — to the dr side output.
+// Every chunk of a thread covers the SAME 8 reduction channels (NT % CPR == 0), so the four coefficient vectors are 8 registers each.
+template <int ROWS, int KS, int NT>
+__device__ __forceinline__ void stage_store_abn(char* lds, const StageRegs<ROWS, true, true, true, KS, NT>& dy,
+                                                const StageRegs<ROWS, true, true, true, KS, NT>& rr, const f32x4* cf, float slope,
+                                                char* side, long side_ld) {
+  using G = TileGeom<ROWS, true, true, true, KS, NT>;
+  static_assert(NT % G::CPR == 0, "a thread keeps its reduction channels over the chunks of a stage");
+  const int t = threadIdx.x;
+#pragma unroll
+  for (int q = 0; q < G::VEC; ++q) {
+    const int idx = t + NT * q;
+    const int row = idx / G::CPR, kc = idx % G::CPR;
+    const bf16x8 hd = __builtin_bit_cast(bf16x8, dy.v[q]), hr = __builtin_bit_cast(bf16x8, rr.v[q]);
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; e += 2) {
+      const f32x4 sc4 = cf[0 + (e >> 2)], sh4 = cf[2 + (e >> 2)], p4 = cf[4 + (e >> 2)], q4 = cf[6 + (e >> 2)];
+      const int l = e & 3;
+      const f32x2 x = {(float)hr[e], (float)hr[e + 1]}, d = {(float)hd[e], (float)hd[e + 1]};
+      const f32x2 sc = {sc4[l], sc4[l + 1]};
+      const f32x2 z = sc * x + f32x2{sh4[l], sh4[l + 1]};
+      const f32x2 ds = d * slope;
+      const f32x2 g = {z[0] > 0.f ? d[0] : ds[0], z[1] > 0.f ? d[1] : ds[1]};
+      const f32x2 v = sc * g + (f32x2{p4[l], p4[l + 1]} * x + f32x2{q4[l], q4[l + 1]});
+      o[e] = (__bf16)v[0];
+      o[e + 1] = (__bf16)v[1];
+    }
+    *reinterpret_cast<bf16x8*>(lds + row * G::STRIDE + kc * 16) = o;
+    if (side != nullptr) *reinterpret_cast<bf16x8*>(side + ((long)row * side_ld + kc * 8) * 2) = o;
+  }
+}
+
 // fp32 fragment of one 16-row tile: element s feeds MFMA sub-step s (reduction index 4*(lane>>4)+s of the chunk)
 template <int ROWS, bool RMAJOR>
 __device__ __forceinline__ f32x4 frag_read_f32(const char* lds, int row, int rq) {
@@ -297,8 +337,8 @@ __device__ unsigned long long* g_gemm_trace = nullptr;
 // of the 4-wave 128x128 kernel while a stage moves a quarter fewer operand bytes per flop, at two workgroups = 16 waves
 // per CU (the 4-wave 256x128 form needs 201 registers: 8 waves per CU).
 template <int BM, int BN, bool A_RMAJOR, bool B_RMAJOR, bool H, bool ST, bool AAFF, bool WB = false, bool FULL = false,
-          bool ARELU = false, int KS = 1, int PD = 0, bool EC = false, int PADX = 0, int NW = 4>
-__global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : ((KS > 1 || PD > 2) ? 1 : ((FULL && WB && BM == 128 && BN == 128 && !AAFF) ? 3 : 2)))   // waves per SIMD
+          bool ARELU = false, int KS = 1, int PD = 0, bool EC = false, int PADX = 0, int NW = 4, bool ABN = false>
+__global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : ((KS > 1 || PD > 2) ? 1 : ((FULL && WB && BM == 128 && BN == 128 && !AAFF && !ABN) ? 3 : 2)))   // waves per SIMD
 void gemm_kernel(const GemmArgs p) {
   unsigned long long* const trace = g_gemm_trace;
   unsigned long long t_start = 0, t_loop = 0;
@@ -309,6 +349,8 @@ void gemm_kernel(const GemmArgs p) {
   static_assert((KS == 1 && PD == 0) || (FULL && H && ST), "the deep pipelines are full-tile bf16-storage variants");
   static_assert(!EC || PD >= 2, "early commit rides with the deep pipelines");
   static_assert(NW == 4 || NW == 8, "4 waves as 2x2 or 8 waves as 4x2");
+  static_assert(!ABN || (FULL && H && ST && WB && A_RMAJOR && !B_RMAJOR && !AAFF && !ARELU && !EC && PADX == 0 && NW == 4),
+                "the BatchNorm-backward operand load is a full-tile bf16 backward-data variant");
   constexpr int NT = 64 * NW, WROWS = NW / 2;
   using GA = TileGeom<BM, A_RMAJOR, H, SA, KS, NT>;
   using GB = TileGeom<BN, B_RMAJOR, H, SB, KS, NT>;
@@ -383,6 +425,9 @@ void gemm_kernel(const GemmArgs p) {
   static_assert(DEPTH == 1 || DEPTH == 2 || DEPTH == 4, "the unrolled loop body needs an even number of register sets");
   StageRegs<BM, A_RMAJOR, H, SA, KS, NT> ra[DEPTH];
   StageRegs<BN, B_RMAJOR, H, SB, KS, NT> rb[DEPTH];
+  StageRegs<BM, A_RMAJOR, H, SA, KS, NT> ra2[ABN ? DEPTH : 1];     // ABN: the second source tensor (r) of the left operand
+  f32x4 abn_cf[ABN ? 8 : 1];                                        // ABN: {sc, sh, P, Q} x 8 channels of the stage being committed
+  const char* A2 = ABN ? reinterpret_cast<const char*>(p.abn_r) + g * p.a_goff * GA::SSZ : nullptr;
 
   f32x4 acs[GA::VEC * GA::EPC / 4], ach[GA::VEC * GA::EPC / 4];   // reduction-indexed affine of the stage being committed
   // FULL tiles address a stage as (uniform 64-bit base in SGPRs) + (32-bit lane offset fixed for the whole kernel): the
@@ -404,7 +449,7 @@ void gemm_kernel(const GemmArgs p) {
                         : (unsigned)(((idx / GB::CPC) * (int)p.ldb + (idx % GB::CPC) * GB::EPC) * GB::SSZ);
     }
   }
-  auto issue = [&](auto& sa, auto& sb, int st) {
+  auto issue = [&](auto& sa, auto& sb, auto& sa2, int st) {
     int r0 = rbeg + st * BK;
     if constexpr (FULL) {
       r0 = min(r0, rend - BK);      // the two prefetches past the last stage re-read it (never computed on)
@@ -414,6 +459,11 @@ void gemm_kernel(const GemmArgs p) {
       for (int q = 0; q < GA::VEC; ++q) {
         sa.v[q] = *reinterpret_cast<const f32x4*>(pa + voa[q]);
         sa.ok[q] = true;
+      }
+      if constexpr (ABN) {
+        const char* pa2 = A2 + ((long)i0 * p.lda + r0) * GA::SSZ;       // same layout and row stride as A (host-checked)
+#pragma unroll
+        for (int q = 0; q < GA::VEC; ++q) sa2.v[q] = *reinterpret_cast<const f32x4*>(pa2 + voa[q]);
       }
 #pragma unroll
       for (int q = 0; q < GB::VEC; ++q) {
@@ -427,9 +477,24 @@ void gemm_kernel(const GemmArgs p) {
   };
   auto aff_fetch = [&](int st) {
     if constexpr (AAFF) affine_prefetch<BM, H, SA, KS, NT>(acs, ach, rbeg + st * BK, rend, a_sc, a_sh);
+    if constexpr (ABN) {       // the 8 channels of this thread's chunks in stage st (past the end: the last stage again, unused)
+      const int r0 = min(rbeg + st * BK, rend - BK) + (int)(threadIdx.x % GA::CPR) * 8;
+      const float* c = p.abn_coef + g * p.a_goff + r0;
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        abn_cf[2 * v] = *reinterpret_cast<const f32x4*>(c + v * p.abn_plane);
+        abn_cf[2 * v + 1] = *reinterpret_cast<const f32x4*>(c + v * p.abn_plane + 4);
+      }
+    }
   };
-  auto commit = [&](const auto& sa, const auto& sb, int st) {
+  auto commit = [&](const auto& sa, const auto& sb, const auto& sa2, int st) {
     char* dst = lds_raw + (EC ? st % 3 : (st & 1)) * STAGE;
+    if constexpr (ABN) {
+      // column tile 0 of every row panel also stores dr (each stage exactly once: phantom stages past the end write LDS only)
+      char* side = (tj == 0 && st < nstage && p.abn_dr != nullptr)
+                       ? reinterpret_cast<char*>(p.abn_dr) + ((long)i0 * p.abn_lddr + g * p.a_goff + rbeg + st * BK) * 2 : nullptr;
+      stage_store_abn<BM, KS, NT>(dst, sa, sa2, abn_cf, p.abn_slope, side, p.abn_lddr);
+    } else
     stage_store<BM, A_RMAJOR, H, SA, ARELU, KS, NT>(dst, sa, a_aff, p.a_slope, acs, ach);
     stage_store<BN, B_RMAJOR, H, SB, false, KS, NT>(dst + GA::BYTES, sb, b_aff, p.b_slope, bcs, bch);
   };
@@ -505,18 +570,18 @@ void gemm_kernel(const GemmArgs p) {
   if (DEPTH == 1) {
     if (nstage > 0) {
       aff_fetch(0);
-      issue(ra[0], rb[0], 0);
-      commit(ra[0], rb[0], 0);
+      issue(ra[0], rb[0], ra2[ABN ? (0) : 0], 0);
+      commit(ra[0], rb[0], ra2[ABN ? (0) : 0], 0);
     }
     __syncthreads();
     for (int st = 0; st < nstage; ++st) {
       const bool more = st + 1 < nstage;
       if (more) {                                   // lands under the MFMA block below
         aff_fetch(st + 1);
-        issue(ra[0], rb[0], st + 1);
+        issue(ra[0], rb[0], ra2[ABN ? (0) : 0], st + 1);
       }
       compute(st);
-      if (more) commit(ra[0], rb[0], st + 1);
+      if (more) commit(ra[0], rb[0], ra2[ABN ? (0) : 0], st + 1);
       __syncthreads();
     }
   } else {
@@ -530,25 +595,25 @@ void gemm_kernel(const GemmArgs p) {
     // DEPTH register sets: at the top of sub-step u of an iteration, LDS[s&1] holds stage s = st+u, set u is free (it held
     // stage s) and the other DEPTH-1 sets hold stages s+1 .. s+DEPTH-1 in flight.
     aff_fetch(0);
-    issue(ra[0], rb[0], 0);
-    commit(ra[0], rb[0], 0);
+    issue(ra[0], rb[0], ra2[ABN ? (0) : 0], 0);
+    commit(ra[0], rb[0], ra2[ABN ? (0) : 0], 0);
 #pragma unroll
-    for (int d = 1; d < DEPTH; ++d) issue(ra[d], rb[d], d);
+    for (int d = 1; d < DEPTH; ++d) issue(ra[d], rb[d], ra2[ABN ? (d) : 0], d);
     __syncthreads();
     for (int st = 0; st < nstage; st += DEPTH) {
 #pragma unroll
       for (int u = 0; u < DEPTH; ++u) {
         if constexpr (EC) {
           aff_fetch(st + u + 1);
-          compute_ec(st + u, [&] { issue(ra[u], rb[u], st + u + DEPTH); },
-                     [&] { commit(ra[(u + 1) % DEPTH], rb[(u + 1) % DEPTH], st + u + 1); });
+          compute_ec(st + u, [&] { issue(ra[u], rb[u], ra2[ABN ? (u) : 0], st + u + DEPTH); },
+                     [&] { commit(ra[(u + 1) % DEPTH], rb[(u + 1) % DEPTH], ra2[ABN ? ((u + 1) % DEPTH) : 0], st + u + 1); });
         } else {
           aff_fetch(st + u + 1);
-          issue(ra[u], rb[u], st + u + DEPTH);
+          issue(ra[u], rb[u], ra2[ABN ? (u) : 0], st + u + DEPTH);
           __builtin_amdgcn_sched_barrier(0);
           compute(st + u);
           __builtin_amdgcn_sched_barrier(0);
-          commit(ra[(u + 1) % DEPTH], rb[(u + 1) % DEPTH], st + u + 1);
+          commit(ra[(u + 1) % DEPTH], rb[(u + 1) % DEPTH], ra2[ABN ? ((u + 1) % DEPTH) : 0], st + u + 1);
         }
         __syncthreads();
       }
@@ -875,6 +940,27 @@ int launch(GemmArgs p, int groups, hipStream_t s, int act_dtype, bool w_bf16 = f
     }
   }
   const bool ec = deep_ec != 0 && BM * BN <= 128 * 128 && (AR && BR);   // forward only; three buffers of a 256x128 tile do not fit LDS
+  if (p.abn_r != nullptr) {     // outside the fused BatchNorm-backward form: 1 = nothing launched, the caller runs the unfused pair
+    if (!(AR && !BR && NW == 4 && BM == 128)) return NSID_EINVAL;
+    if (!(st16 && w_bf16 && full)) return 1;
+  }
+  nsid_count(AR ? (BR ? NSID_C_gemm_fwd : NSID_C_gemm_bwd_data) : NSID_C_gemm_bwd_weight);
+  if (p.split_major) nsid_count(NSID_C_gemm_split_major);
+  if (aff) nsid_count(NSID_C_gemm_affine_load);
+  if (NW == 8) nsid_count(NSID_C_gemm_w8);
+  if (BM == 256 && NW == 4) nsid_count(NSID_C_gemm_tall);
+  if (AR && !BR && p.bn_r != nullptr) nsid_count(NSID_C_gemm_bn_sums);
+  if (!AR) nsid_count(BM == BN ? NSID_C_wgrad_square : NSID_C_wgrad_rect);
+  {
+    // the deep / full-tile forms exist for bf16 storage only (and bf16 weights in the forward / backward-data kinds)
+    const bool deep_path = st16 && full && (AR ? w_bf16 : true);
+    if (deep_path) {
+      nsid_count(NSID_C_gemm_full);
+      if (NW == 4 && ks == 2) nsid_count(NSID_C_gemm_ks2);
+      if (NW == 4 && pd == 4) nsid_count(NSID_C_gemm_pd4);
+      if (NW == 4 && ec && (ks == 2 || pd == 4)) nsid_count(NSID_C_gemm_ec);
+    }
+  }
 #define NSID_GEMM_DEEP_GO(AFF_, WB_, RELU_)                                                                       \
   do {                                                                                                            \
     if constexpr (NW == 8) {                                                                                      \
@@ -891,6 +977,15 @@ int launch(GemmArgs p, int groups, hipStream_t s, int act_dtype, bool w_bf16 = f
     else if (pd == 4) NSID_LAUNCH((gemm_kernel<BM, BN, AR, BR, true, true, AFF_, WB_, true, RELU_, 1, 4>), grid, dim3(256), 0, s, p);       \
     else NSID_LAUNCH((gemm_kernel<BM, BN, AR, BR, true, true, AFF_, WB_, true, RELU_>), grid, dim3(256), 0, s, p);                           \
   } while (0)
+  if (p.abn_r != nullptr) {     // backward-data with the BatchNorm backward on the operand load: one full-tile bf16 form
+    if constexpr (AR && !BR && NW == 4 && BM == 128) {
+      nsid_count(NSID_C_gemm_bn_apply_load);
+      NSID_LAUNCH((gemm_kernel<BM, BN, AR, BR, true, true, false, true, true, false, 1, 0, false, 0, 4, true>), grid, dim3(256), 0, s, p);
+      return nsid_launch_status();
+    } else {
+      return NSID_EINVAL;
+    }
+  }
   if constexpr (NW == 8) {
     if (!(st16 && full && (w_bf16 || !AR))) return NSID_EINVAL;      // the 8-wave form exists for full bf16 tiles only
   }
@@ -1151,7 +1246,7 @@ static int linear_fwd_impl(const void* x, int ldx, const void* w, int w_dtype, c
       (long)(M / 256) * (Nout / 256) >= g256_min) {
     const int rc256 = nsid_gemm256_fwd_launch(x, ldx, w, bias, addend, ldadd, out, ldo, M, Nout, K, act_out == NSID_ACT_RELU, stat,
                                               p.stat_plane, p.stat_ld, s);
-    if (rc256 != 1) { ++g_g256_launches; return rc256; }
+    if (rc256 != 1) { ++g_g256_launches; nsid_count(NSID_C_gemm256); return rc256; }
   }
   const int rc = w8 ? launch<256, 128, true, true, 8>(p, groups, s, act_dtype, wb)
                     : tall ? launch<256, 128, true, true>(p, groups, s, act_dtype, wb)
@@ -1164,10 +1259,13 @@ static int linear_fwd_impl(const void* x, int ldx, const void* w, int w_dtype, c
   return nsid_launch_status();
 }
 
+struct AbnArgs {          // BatchNorm backward of the layer in front, applied on the operand load (GemmArgs::abn_*)
+  const void* r; const float* coef4; int act; void* dr;
+};
 static int linear_bwd_data_impl(const void* dout, int ldd, const void* w, int w_dtype, const void* addend, int ldadd,
                                 void* din, int ldi, int M, int Nout, int K, int groups, int act_dtype, void* stream,
                                 const void* bn_r, const float* bn_scale, const float* bn_shift, const float* bn_mean,
-                                const float* bn_invstd, int bn_act, float* bn_partial);
+                                const float* bn_invstd, int bn_act, float* bn_partial, const AbnArgs* abn = nullptr);
 
 extern "C" int nsid_linear_bwd_data(const void* dout, int ldd, const void* w, int w_dtype, const void* addend, int ldadd,
                                     void* din, int ldi, int M, int Nout, int K, int groups, int act_dtype,
@@ -1188,10 +1286,33 @@ extern "C" int nsid_linear_bwd_data_bn(const void* dout, int ldd, const void* w,
                               bn_r, bn_scale, bn_shift, bn_mean, bn_invstd, bn_act, bn_partial);
 }
 
+// Backward-data of a conv whose OUTPUT gradient still has to go through the BatchNorm(+activation) backward of that conv's own
+// BatchNorm: din = addend + dr w with dr = BN-backward(dy, r) evaluated on the operand load (no bn_bwd_apply pass), dr written once as
+// a side output for the weight gradient. coef4[4][groups*Nout] = {sc, sh, P, Q} from nsid_bn_bwd_finalize_fused. The optional bn_*
+// arguments are nsid_linear_bwd_data_bn's (column sums for the NEXT BatchNorm backward). Returns 1 (nothing launched) when the shape is
+// outside the fused form: bf16 storage and weights, M % 128 == 0, Nout % 64 == 0, K a multiple of the tile width, ldd == groups*Nout.
+extern "C" int nsid_linear_bwd_data_bnapply(const void* dy, const void* r, const float* coef4, int act, void* dr, const void* w,
+                                            int w_dtype, const void* addend, int ldadd, void* din, int ldi, int M, int Nout, int K,
+                                            int groups, int act_dtype, const void* bn_r, const float* bn_scale,
+                                            const float* bn_shift, const float* bn_mean, const float* bn_invstd, int bn_act,
+                                            float* bn_partial, void* stream) {
+  NSID_REQUIRE(dy && r && coef4 && dr && nsid_aligned16(r) && nsid_aligned16(dr) && nsid_aligned16(coef4));
+  NSID_REQUIRE(act == NSID_ACT_NONE || act == NSID_ACT_RELU || act == NSID_ACT_LEAKY);
+  if (act_dtype != NSID_BF16 || w_dtype != NSID_BF16 || (groups * Nout) % 8 != 0) return 1;
+  if (bn_r != nullptr) {
+    NSID_REQUIRE(bn_scale && bn_shift && bn_mean && bn_invstd && bn_partial && ldi == groups * K && (groups * K) % 8 == 0 &&
+                 nsid_aligned16(bn_r));
+    NSID_REQUIRE(bn_act == NSID_ACT_NONE || bn_act == NSID_ACT_RELU || bn_act == NSID_ACT_LEAKY);
+  }
+  const AbnArgs abn{r, coef4, act, dr};
+  return linear_bwd_data_impl(dy, groups * Nout, w, w_dtype, addend, ldadd, din, ldi, M, Nout, K, groups, act_dtype, stream, bn_r,
+                              bn_scale, bn_shift, bn_mean, bn_invstd, bn_act, bn_partial, &abn);
+}
+
 static int linear_bwd_data_impl(const void* dout, int ldd, const void* w, int w_dtype, const void* addend, int ldadd,
                                 void* din, int ldi, int M, int Nout, int K, int groups, int act_dtype, void* stream,
                                 const void* bn_r, const float* bn_scale, const float* bn_shift, const float* bn_mean,
-                                const float* bn_invstd, int bn_act, float* bn_partial) {
+                                const float* bn_invstd, int bn_act, float* bn_partial, const AbnArgs* abn) {
   NSID_REQUIRE(dout && w && din && M > 0 && Nout > 0 && K > 0 && groups > 0 && NSID_DTYPE_OK(act_dtype));
   NSID_REQUIRE(NSID_DTYPE_OK(w_dtype) && (w_dtype == NSID_F32 || (act_dtype == NSID_BF16 && K % 8 == 0)));
   const bool wb = w_dtype == NSID_BF16;
@@ -1218,6 +1339,13 @@ static int linear_bwd_data_impl(const void* dout, int ldd, const void* w, int w_
   bool narrow = half ? (K <= 64 || (K <= 128 && Nout <= 256)) : K <= 64;
   if (half && t128 < 128) narrow = true;        // few row tiles (the projector head, M = batch)
   if (force_narrow >= 0 && K > 64) narrow = force_narrow != 0;
+  if (abn != nullptr) {
+    // every column tile re-evaluates the BatchNorm backward of its row panel: as few column tiles as the tile family offers
+    narrow = K <= 64;
+    p.abn_r = abn->r; p.abn_coef = abn->coef4; p.abn_plane = (long)groups * Nout; p.abn_slope = act_slope(abn->act);
+    p.abn_dr = abn->dr; p.abn_lddr = (long)groups * Nout;
+    if (K % (narrow ? 64 : 128) != 0 || M % 128 != 0 || Nout % 64 != 0) return 1;
+  }
   // the 8-wave 256x128 form loses here (16384x256x1024: 21.8 -> 41.4 us cold): 169 registers = one workgroup per CU, and the
   // transposed weight reads + addend / BatchNorm-sum epilogue do not shrink with the tile. Kept for experiments only.
   const long w8_min = nsid_tune(NSID_T_w8_bwd_min);

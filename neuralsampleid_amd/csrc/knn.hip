@@ -911,6 +911,7 @@ extern "C" int nsid_knn_graph(const void* r, int ldr, const float* scale, const 
   const bool use_fast = nsid_tune(NSID_T_knn_strips) == 0;
   const bool pow2 = C >= 64 && C <= 512 && (C & (C - 1)) == 0 && N >= 32 && (N & (N - 1)) == 0;
   if (use_fast && pow2 && kd > 8 && N <= 128) {              // deep configuration, small graphs: rank counting
+    nsid_count(NSID_C_knn_rank);
     hipStream_t s = static_cast<hipStream_t>(stream);
     return dtype == NSID_BF16 ? launch_knn_rank<__bf16>(r, ldr, scale, shift, B, N, C, k, dilation, idx, s)
                               : launch_knn_rank<float>(r, ldr, scale, shift, B, N, C, k, dilation, idx, s);
@@ -919,9 +920,10 @@ extern "C" int nsid_knn_graph(const void* r, int ldr, const float* scale, const 
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int rc = dtype == NSID_BF16 ? launch_knn_sel<__bf16>(r, ldr, scale, shift, B, N, C, k, dilation, idx, s)
                                       : launch_knn_sel<float>(r, ldr, scale, shift, B, N, C, k, dilation, idx, s);
-    if (rc != 1) return rc;
+    if (rc != 1) { nsid_count(NSID_C_knn_sel); return rc; }
   }
   if (use_fast && kd <= 8 && pow2) {
+    nsid_count(NSID_C_knn2);
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (dtype == NSID_BF16) {
       if (kd <= 3) return launch_knn2<__bf16, 3>(r, ldr, scale, shift, B, N, C, k, dilation, idx, s);
@@ -934,6 +936,7 @@ extern "C" int nsid_knn_graph(const void* r, int ldr, const float* scale, const 
   }
   const size_t bytes = ((size_t)N * (C + 4) + N + (size_t)KNN_WAVES * 16 * (N + 4)) * sizeof(float);
   NSID_REQUIRE(bytes <= 160 * 1024);
+  nsid_count(NSID_C_knn_strips);
   static size_t configured = 0;       // raise the dynamic-LDS cap once per size step (not a per-call sync)
   if (bytes > configured) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(knn_kernel<float>),

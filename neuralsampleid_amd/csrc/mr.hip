@@ -293,6 +293,7 @@ extern "C" int nsid_mr_aggregate_fwd(const void* r, int ldr, const float* scale,
       configured = true;
     }
     const int force_split = (int)nsid_tune(NSID_T_mr_split);
+    nsid_count(NSID_C_mr_fwd_lds);
     int split = force_split > 0 ? force_split : (B <= 256 ? 2 : 1);
     while (split > 1 && (C / nv) % split != 0) split >>= 1;
     NSID_DISPATCH_DTYPE(dtype, T, {
@@ -304,6 +305,7 @@ extern "C" int nsid_mr_aggregate_fwd(const void* r, int ldr, const float* scale,
   const long total = (long)B * N * (C / nv);
   long blocks = (total + 255) / 256;
   if (blocks > 4096) blocks = 4096;
+  nsid_count(NSID_C_mr_fwd_grid);
   NSID_DISPATCH_DTYPE(dtype, T, {
     NSID_LAUNCH((mr_fwd_kernel<T>), dim3((int)blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
                 static_cast<const T*>(r), (long)ldr, scale, shift, idx, (long)B * N, N, C, k, static_cast<T*>(u), argmax);

@@ -168,6 +168,34 @@ enum NsidTuneKey {
 extern long g_nsid_tune[NSID_T_COUNT];
 static inline long nsid_tune(NsidTuneKey k) { return g_nsid_tune[k]; }
 
+// ---- launch counters (include/nsid.h nsid_debug_counter): how many launches took each kernel VARIANT since the last reset. Host
+// side, incremented when a launch is enqueued (also under stream capture). Tests use them to prove that the variants the bench
+// times (full-tile, 64-deep stages, rectangular weight-gradient tiles, ...) are the ones a parity test exercised.
+#define NSID_COUNTER_TABLE(X)                                                                  \
+  X(gemm_fwd) X(gemm_bwd_data) X(gemm_bwd_weight)        /* launches of gemm.hip by kind */      \
+  X(gemm_full)            /* predication-free full-tile instantiation */                        \
+  X(gemm_ks2)             /* 64-deep LDS stages */                                              \
+  X(gemm_pd4) X(gemm_ec) X(gemm_w8) X(gemm_tall)                                                \
+  X(gemm_split_major)     /* split index fastest in the grid (a split stays on one XCD) */      \
+  X(gemm_affine_load)     /* producer BatchNorm + activation applied on the operand load */     \
+  X(gemm_relu_load)                                                                             \
+  X(gemm_bn_sums)         /* backward-data epilogue emits BatchNorm-backward column sums */     \
+  X(gemm_bn_apply_load)   /* backward-data applies a BatchNorm backward on its operand load */  \
+  X(gemm256)              /* gemm256.hip */                                                     \
+  X(wgrad_rect) X(wgrad_square) X(wgrad3)                                                       \
+  X(bn_bwd_apply) X(bn_bwd_apply_capped)                                                        \
+  X(knn2) X(knn_rank) X(knn_sel) X(knn_strips)                                                  \
+  X(mr_fwd_lds) X(mr_fwd_grid)
+
+enum NsidCounterKey {
+#define NSID_CNT_ENUM(name) NSID_C_##name,
+  NSID_COUNTER_TABLE(NSID_CNT_ENUM)
+#undef NSID_CNT_ENUM
+  NSID_C_COUNT
+};
+extern long g_nsid_counter[NSID_C_COUNT];
+static inline void nsid_count(NsidCounterKey k) { ++g_nsid_counter[k]; }
+
 // wgrad.hip: 128x128-tile form of the bf16 weight-gradient GEMM; returns 1 when the shape is outside its preconditions
 int nsid_wgrad2_launch(const void* dout, int ldd, const void* x, int ldx, float* dw, int M, int Nout, int K, int groups,
                        const float* in_scale, const float* in_shift, float slope, hipStream_t stream);

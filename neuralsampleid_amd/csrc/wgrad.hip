@@ -200,6 +200,7 @@ int nsid_wgrad2_launch(const void* dout, int ldd, const void* x, int ldx, float*
       p.R = M; p.rchunk = rc3; p.tiles_j = K / W3_T;
       p.b_scale = in_scale; p.b_shift = in_shift; p.b_slope = slope; p.b_aff_goff = K;
       dim3 grid(M / rc3, (Nout / W3_T) * (K / W3_T), groups);
+      nsid_count(NSID_C_wgrad3);
       if (in_scale != nullptr) NSID_LAUNCH((wgrad3_kernel<true>), grid, dim3(W3_THREADS), 0, stream, p);
       else NSID_LAUNCH((wgrad3_kernel<false>), grid, dim3(W3_THREADS), 0, stream, p);
       return nsid_launch_status();

@@ -274,17 +274,18 @@ def grapher_backward(dx1: Tensor, P, S, G) -> Tensor:
     # dv is dL/d(relu(BN(r2))): the GEMM that writes it also emits that BatchNorm's backward column sums
     dv, part2 = ops.linear_bwd_data(dr3, ops.w2d(P["fc2.0.weight"]), M, C, 2 * C, bn=(r2, a2, ACT_RELU))
     # grouped conv (+BN+ReLU), input = u
-    dr2 = ops.bn_backward(dv, r2, a2, ACT_RELU, G[pre + "1.weight"], G[pre + "1.bias"], inplace=True, partial=part2)
+    # (the BatchNorm-backward apply is evaluated on the backward-data GEMM's operand load where the shape allows: ops.py)
+    dr2, du, _ = ops.bn_backward_linear_bwd_data(dv, r2, a2, ACT_RELU, G[pre + "1.weight"], G[pre + "1.bias"], part2,
+                                                 ops.w2d(P[pre + "0.weight"]), M, C // 2, C // 2, 4)
     _bias_grad_before_bn(dr2, G[pre + "0.bias"])
     ops.linear_bwd_weight(dr2, u, ops.w2d(G[pre + "0.weight"]), M, C // 2, C // 2, 4)
-    du = ops.linear_bwd_data(dr2, ops.w2d(P[pre + "0.weight"]), M, C // 2, C // 2, 4)
     # max-relative aggregation: route to arg-max neighbour and centre; kNN itself carries no gradient
     dy = ops.mr_aggregate_bwd(du, idx, amax, B, N, C)
     # fc1 (+BN), input = x0
-    dr1 = ops.bn_backward(dy, r1, a1, ACT_NONE, G["fc1.1.weight"], G["fc1.1.bias"], inplace=True)
+    dr1, dx0, part = ops.bn_backward_linear_bwd_data(dy, r1, a1, ACT_NONE, G["fc1.1.weight"], G["fc1.1.bias"], None,
+                                                     ops.w2d(P["fc1.0.weight"]), M, C, C, 1, addend=dx1, bn=_link_in(S) or False)
     _bias_grad_before_bn(dr1, G["fc1.0.bias"])
     ops.linear_bwd_weight(dr1, x0, ops.w2d(G["fc1.0.weight"]), M, C, C)
-    dx0, part = ops.linear_bwd_data(dr1, ops.w2d(P["fc1.0.weight"]), M, C, C, 1, addend=dx1, bn=_link_in(S) or False)
     _store_partial(S, part)
     return dx0
 
@@ -314,9 +315,9 @@ def ffn_backward(dx2: Tensor, P, S, G) -> Tensor:
     dr5 = ops.bn_backward(dx2, r5, a5, ACT_NONE, G["fc2.1.weight"], G["fc2.1.bias"], partial=_link_partial(S))
     ops.linear_bwd_weight(dr5, r4, ops.w2d(G["fc2.0.weight"]), M, C, H, 1, a4.scale, a4.shift, ACT_RELU)
     dh, part4 = ops.linear_bwd_data(dr5, ops.w2d(P["fc2.0.weight"]), M, C, H, bn=(r4, a4, ACT_RELU))
-    dr4 = ops.bn_backward(dh, r4, a4, ACT_RELU, G["fc1.1.weight"], G["fc1.1.bias"], inplace=True, partial=part4)
+    dr4, dx1, part = ops.bn_backward_linear_bwd_data(dh, r4, a4, ACT_RELU, G["fc1.1.weight"], G["fc1.1.bias"], part4,
+                                                     ops.w2d(P["fc1.0.weight"]), M, H, C, 1, addend=dx2, bn=_link_in(S) or False)
     ops.linear_bwd_weight(dr4, x1, ops.w2d(G["fc1.0.weight"]), M, H, C)
-    dx1, part = ops.linear_bwd_data(dr4, ops.w2d(P["fc1.0.weight"]), M, H, C, 1, addend=dx2, bn=_link_in(S) or False)
     _store_partial(S, part)
     return dx1
 

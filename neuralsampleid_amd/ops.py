@@ -349,6 +349,64 @@ def linear_bwd_data(dout, w, M, Nout, K, groups=1, addend=None, out=None, bn=Non
     return (out, None) if want_pair else out
 
 
+FUSE_BN_BWD_APPLY = True      # BatchNorm-backward apply evaluated on the operand load of the backward-data GEMM (bf16 storage)
+
+
+def bn_backward_linear_bwd_data(dy, r, aff: "BNAffine", act, dgamma, dbeta, partial, w, M, Nout, K, groups=1, addend=None,
+                                bn=None):
+    """BatchNorm(+act) backward of a conv+BN layer FOLLOWED by that conv's backward-data GEMM, the two fused where the shape allows:
+        dr  = BN-backward(dy, r)        (dy = dL/d act(BN(r)); dgamma / dbeta accumulated)
+        din = addend + dr @ w           (+ the column sums for the next BatchNorm backward when bn=(r', aff', act'))
+    Returns (dr, din, partial_out). Fused form (csrc/gemm.hip ABN): the GEMM evaluates dr on its operand load from dy and r and
+    writes it once for the weight gradient — no bn_bwd_apply pass. `partial` = this layer's column sums (from the GEMM that wrote dy,
+    or None: a reduce launch). Falls back to bn_backward + linear_bwd_data (same results up to one fp32 rounding before the bf16
+    store) for fp32 storage and shapes outside the fused form."""
+    dt = _act(dy, r, addend)
+    C = r.shape[1]
+    tiles = row_tiles(M)
+    s = _stream()
+    wop, wdt = _weight(w, dt, K)
+    fusable = (FUSE_BN_BWD_APPLY and dt == BF16 and wdt == BF16 and tuple(r.shape) == (M, groups * Nout) and
+               tuple(dy.shape) == (M, groups * Nout) and M % 128 == 0 and Nout % 64 == 0 and K % 64 == 0 and (K <= 64 or K % 128 == 0))
+    if not fusable:
+        dr = bn_backward(dy, r, aff, act, dgamma, dbeta, inplace=True, partial=partial)
+        return (dr,) + linear_bwd_data(dr, w, M, Nout, K, groups, addend=addend, bn=bn if bn is not None else False)
+    if partial is None:
+        partial = torch.empty((2, tiles, C), device=r.device, dtype=torch.float32)
+        call("nsid_bn_bwd_reduce", _p(dy), _p(r), M, C, _p(aff.scale), _p(aff.shift), _p(aff.mean), _p(aff.invstd), act, _p(partial),
+             dt, s)
+    coef = torch.empty((6, C), device=r.device, dtype=torch.float32)        # [0:2] = (c0, c1) for the unfused apply, [2:6] = coef4
+    call("nsid_bn_bwd_finalize_fused", _p(partial), tiles, C, M, _p(dgamma), _p(dbeta), _p(coef), _p(aff.scale), _p(aff.shift),
+         _p(aff.mean), _p(aff.invstd), _p(coef[2]), s)
+    dr = torch.empty_like(dy)
+    din = torch.empty((M, groups * K), device=dy.device, dtype=dy.dtype)
+    want_pair = bn is not None
+    bn = bn or None
+    fuse_sums = bn is not None and FUSE_BN_BWD_REDUCE and (groups * K) % 8 == 0 and tuple(bn[0].shape) == (M, groups * K)
+    part_out = torch.empty((2, tiles, groups * K), device=dy.device, dtype=torch.float32) if fuse_sums else None
+    br, baff, bact = bn if fuse_sums else (None, None, ACT_NONE)
+    esz = dy.element_size()
+    nbytes = groups * (3 * esz * M * Nout + float(wop.element_size()) * Nout * K
+                       + esz * M * K * ((2 if addend is not None else 1) + (1 if fuse_sums else 0)))
+    rc = [0]
+
+    def launch():
+        rc[0] = lib.nsid_linear_bwd_data_bnapply(
+            _p(dy), _p(r), _p(coef[2]), act, _p(dr), _p(wop), wdt, _p(addend), 0 if addend is None else addend.shape[-1], _p(din),
+            din.shape[-1], M, Nout, K, groups, dt, _p(br), _p(baff.scale) if baff else None, _p(baff.shift) if baff else None,
+            _p(baff.mean) if baff else None, _p(baff.invstd) if baff else None, bact, _p(part_out), s)
+    _timed("gemm_kernel<128,%d,true,false> +bn_apply_load" % (64 if K <= 64 else 128), 2.0 * M * Nout * K * groups, nbytes, launch,
+           (M, Nout, K, groups))
+    if rc[0] == 1:             # outside the fused form after all: apply with the coefficients already computed, then the plain GEMM
+        call("nsid_bn_bwd_apply", _p(dy), _p(r), M, C, _p(aff.scale), _p(aff.shift), _p(aff.mean), _p(aff.invstd), act, _p(coef),
+             _p(dr), dt, s)
+        res = linear_bwd_data(dr, w, M, Nout, K, groups, addend=addend, out=din, bn=bn if bn is not None else False)
+        return (dr,) + res
+    if rc[0] != 0:
+        raise RuntimeError(f"nsid_linear_bwd_data_bnapply failed: {rc[0]}")
+    return dr, din, part_out
+
+
 def linear_bwd_weight(dout, x, dw, M, Nout, K, groups=1, in_scale=None, in_shift=None, act_in=ACT_NONE) -> None:
     """dw += dout^T f(x)"""
     _chk(dw, in_scale, in_shift)

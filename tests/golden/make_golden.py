@@ -308,6 +308,112 @@ def gold_e2e():
         print("   losses", losses, "gnorm", gnorms)
 
 
+def bench_clips(batch, seed):
+    """bench.py's synth_clips — the inputs of the TIMED step: seeds (seed, seed + 1)"""
+    gi = torch.Generator().manual_seed(seed)
+    gj = torch.Generator().manual_seed(seed + 1)
+    x_i = torch.randn(batch, CFG["n_mels"], CFG["n_frames"], generator=gi) * 20.0 - 40.0
+    x_j = x_i + 3.0 * torch.randn(batch, CFG["n_mels"], CFG["n_frames"], generator=gj)
+    return x_i, x_j
+
+
+def _per_clip(t):
+    """(B, D) -> (B, 2) float64 [sum, norm] per clip: pins every clip's embedding without storing it"""
+    t = t.detach().double()
+    return torch.stack([t.sum(1), t.norm(dim=1)], 1)
+
+
+def _b256_run(x_i, x_j, threads=8):
+    """step 0 of train.py:53-75 on the reference, seed-42 default initialisation; returns everything the fixtures need"""
+    torch.set_num_threads(threads)
+    torch.manual_seed(42)
+    model = SimCLR(CFG, GraphEncoder(CFG, in_channels=CFG["n_filters"], k=3, size="t"))
+    tape = KnnTape(model)
+    model.train()
+    model.zero_grad()
+    h_i, h_j, z_i, z_j = model(x_i, x_j)
+    loss = ntxent_loss(z_i, z_j, CFG)
+    loss.backward()
+    grads = {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+    gn = float(torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=1.0))
+    torch.set_num_threads(8)
+    return model, tape, (h_i.detach(), h_j.detach(), z_i.detach(), z_j.detach()), float(loss.detach()), gn, grads
+
+
+def _pack_tape(tape_dict, tag, n_calls):
+    """neighbour ids of every call as uint8 (N <= 256) + the near-tie rows (k-th / (k+1)-th gap < 1e-4) as packed bits"""
+    out = {}
+    for c in range(n_calls):
+        idx = tape_dict[f"knn.{tag}.{c}"]
+        assert int(idx.max()) < 256 and int(idx.min()) >= 0
+        out[f"knn.{tag}.{c}"] = idx.to(torch.uint8)
+        out[f"near.{tag}.{c}"] = np.packbits((tape_dict[f"gap.{tag}.{c}"] < 1e-4).numpy().reshape(-1))
+    return out
+
+
+def gold_b256():
+    """The TIMED configuration (BASELINE config 2 as bench.py runs it): seed-42 default initialisation, the bench's own 256 clip
+    pairs (seeds 1000 / 1001), k = 3. One eval forward, then step 0 of train.py:53-75 (forward in train mode, NT-Xent, backward,
+    clip_grad_norm_(1.0)), with the neighbour ids of all 24 graph builds of each pass.
+
+    Also measured here, on the reference itself: HOW CHAOTIC the training-mode step is at this batch. VERDICT r2 expected that
+    with BatchNorm averaging over 65 536 rows a flipped kNN near-tie would stop mattering; the reference says otherwise — scaling
+    x_i by (1 + 1e-7) (view j untouched) flips neighbours from block 1 on (rows with identical ids per block: 1.0, 0.9999, ...,
+    0.67 at block 12) and moves the loss by 2e-2, the gradient norm by 6 % and single gradients by 25-40 %, while a different
+    thread count (another summation order, same graphs) moves nothing. So the numbers below pin the HIP path with the
+    reference's neighbour ids teacher-forced, exactly like the B = 8 goldens, and the free-running comparison is bounded by the
+    reference's own response (b256_seed42_k3_chaos.json)."""
+    print("b256")
+    B = 256
+    x_i, x_j = bench_clips(B, 1000)
+    torch.manual_seed(42)
+    model = SimCLR(CFG, GraphEncoder(CFG, in_channels=CFG["n_filters"], k=3, size="t"))
+    tape = KnnTape(model)
+    model.eval()
+    with torch.no_grad():
+        h_i, h_j, z_i, z_j = model(x_i, x_j)
+        loss_eval = ntxent_loss(z_i, z_j, CFG)
+    ev_knn = tape.take("eval")
+    out = dict(z_i_eval=z_i, z_j_eval=z_j, h_i_eval_clip=_per_clip(h_i), h_j_eval_clip=_per_clip(h_j), h_i_eval_head=h_i[:8],
+               loss_eval=loss_eval.reshape(1).double())
+    out["near_ties_eval"] = np.array([int((ev_knn[f"gap.eval.{c}"] < 1e-4).sum()) for c in range(24)], np.int64)
+    del model, tape
+    model, tape, (h_i, h_j, z_i, z_j), loss, gn, grads = _b256_run(x_i, x_j)
+    tr_knn = tape.take("s0")
+    out["near_ties_train"] = np.array([int((tr_knn[f"gap.s0.{c}"] < 1e-4).sum()) for c in range(24)], np.int64)
+    out.update(_pack_tape(tr_knn, "s0", 24))
+    out.update(z_i_train=z_i, z_j_train=z_j, h_i_train_clip=_per_clip(h_i), h_j_train_clip=_per_clip(h_j),
+               h_i_train_head=h_i[:8], loss_train=np.array([loss], np.float64), gnorm=np.array([gn], np.float64))
+    sums = _checksums(grads.items())
+    out.update({"grad." + n: grads[n] for n in (
+        "peak_extractor.convs.0.weight", "encoder.stem.0.weight", "encoder.backbone.0.0.fc1.0.weight",
+        "encoder.backbone.0.0.graph_conv.gconv.nn.0.weight", "encoder.backbone.2.conv.0.bias",
+        "encoder.backbone.7.1.fc1.1.weight", "encoder.backbone.14.1.fc2.1.weight", "encoder.proj.bias", "projector.2.bias")})
+    stats1 = _checksums((n, t.float()) for n, t in model.state_dict().items() if n.endswith(("running_mean", "running_var")))
+    save("b256_seed42_k3", **out)
+    with open(os.path.join(HERE, "b256_seed42_k3_checksums.json"), "w") as f:
+        json.dump({"grad": sums, "bn_after_step1": stats1}, f, indent=0)
+    print("   loss eval", float(loss_eval), "train", loss, "gnorm", gn,
+          "near ties eval/train", int(out["near_ties_eval"].sum()), int(out["near_ties_train"].sum()))
+
+    # ---- the reference's own sensitivity at this batch (see the docstring)
+    def response(other):
+        _, tp, (_, _, zi, zj), l_, g_, gr = other
+        rows = [float((a == b).all(-1).float().mean()) for a, b in zip(tape_idx, tp.idx)]
+        rel = {n: float((gr[n] - grads[n]).norm() / grads[n].norm()) for n in (
+            "encoder.stem.0.weight", "encoder.backbone.7.1.fc1.0.weight", "encoder.backbone.14.1.fc2.0.weight", "projector.2.weight")}
+        flat = torch.cat([(gr[n] - grads[n]).reshape(-1) for n in grads])
+        return {"dloss": abs(l_ - loss), "gnorm_rel": abs(g_ - gn) / gn, "max_dz": float(max((zi - z_i).abs().max(), (zj - z_j).abs().max())),
+                "flat_grad_rel": float(flat.norm() / gn), "grad_rel": rel, "rows_with_equal_ids_per_graph_build": rows}
+    tape_idx = [tr_knn[f"knn.s0.{c}"] for c in range(24)]
+    chaos = {"perturbation x_i*(1+1e-7)": response(_b256_run(x_i * (1.0 + 1e-7), x_j)),
+             "3 threads instead of 8 (summation order only)": response(_b256_run(x_i, x_j, threads=3))}
+    with open(os.path.join(HERE, "b256_seed42_k3_chaos.json"), "w") as f:
+        json.dump(chaos, f, indent=1)
+    for k_, v in chaos.items():
+        print("   ", k_, {a: b for a, b in v.items() if a != "rows_with_equal_ids_per_graph_build"})
+
+
 def deep_reference_encoder(k=18, blocks=(4, 4, 12, 4)):
     """BASELINE config 4 built from the REFERENCE's own classes. The reference's GraphEncoder never advances its block
     counter (graph_encoder.py:161-173: every Grapher gets dilation 1) and has no [4,4,12,4] size, so the backbone is
@@ -466,6 +572,6 @@ def gold_relpos():
 if __name__ == "__main__":
     torch.manual_seed(0)
     only = sys.argv[1:] or ["shapes", "init", "relpos", "knn", "mrconv", "block", "downsample", "peak", "ntxent", "e2e",
-                            "deep", "fpdb"]
+                            "deep", "fpdb", "b256"]
     for name in only:
         globals()["gold_" + name]()

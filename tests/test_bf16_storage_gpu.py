@@ -243,6 +243,75 @@ def test_bwd_data_emits_bn_backward_sums(ops, M, Nout, K, groups, act, add):
 
 
 
+@pytest.mark.parametrize("M,Nout,K,groups,act,add,link,fused_expected", [
+    (16384, 1024, 256, 1, 1, True, True, True),     # FFN hidden layer at C = 256: two column tiles, side output from tile 0
+    (8192, 2048, 512, 1, 1, True, False, True),     # C = 512: four column tiles
+    (65536, 256, 64, 1, 1, True, True, True),       # C = 64: 64-wide tiles
+    (16384, 128, 128, 4, 1, False, False, True),    # grouped layer at C = 256
+    (32768, 128, 128, 1, 0, True, True, True),      # Grapher fc1 (no activation) at C = 128: one 128-wide column tile
+    (2048, 64, 64, 1, 0, True, True, True),         # the batch-8 goldens' stage 0
+    (2048, 32, 32, 4, 1, False, False, False),      # grouped layer at C = 64: outside the fused form -> two-call fallback
+    (200, 64, 256, 1, 2, True, False, False)])      # ragged rows: fallback
+def test_bn_backward_on_the_backward_data_operand_load(ops, M, Nout, K, groups, act, add, link, fused_expected):
+    """ops.bn_backward_linear_bwd_data: BatchNorm(+act) backward evaluated on the backward-data GEMM's operand load (csrc/gemm.hip
+    ABN) against the two-call form (bn_bwd_apply pass + plain GEMM): same dr up to one fp32 rounding before the bf16 store, same din,
+    same column sums for the next BatchNorm backward, same dgamma / dbeta; the launch counter says which form ran"""
+    from neuralsampleid_amd._lib import launch_counters
+    C = groups * Nout
+    dy = synth_randn(f"ady{M}{C}", M, C).to(BF).to(DEV)
+    r = (synth_randn(f"ar{M}{C}", M, C) * 1.3 + 0.2).to(BF).to(DEV)
+    w = (synth_randn(f"aw{Nout}{K}{groups}", groups * Nout, K) * Nout ** -0.5).to(DEV)
+    ops.SHADOWS.register(w, ops.f32_to_bf16(w), owner=w)
+    addend = synth_randn(f"aa{M}{K}", M, groups * K).to(BF).to(DEV) if add else None
+    mean, var = r.float().mean(0), r.float().var(0, unbiased=False)
+    invstd = 1 / torch.sqrt(var + 1e-5)
+    gamma, beta = (1 + 0.2 * synth_randn("ag", C)).to(DEV), (0.1 * synth_randn("ab", C)).to(DEV)
+    aff = ops.BNAffine(gamma * invstd, beta - mean * gamma * invstd, mean, invstd)
+    bn = False
+    if link:           # din is dL/dy of an upstream BatchNorm layer with raw input r_up
+        CK = groups * K
+        r_up = (synth_randn(f"au{M}{CK}", M, CK) * 0.8 - 0.1).to(BF).to(DEV)
+        mu, vu = r_up.float().mean(0), r_up.float().var(0, unbiased=False)
+        iu = 1 / torch.sqrt(vu + 1e-5)
+        bn = (r_up, ops.BNAffine(iu, -mu * iu, mu, iu), 1)
+    out = {}
+    for fuse in (False, True):
+        ops.FUSE_BN_BWD_APPLY = fuse
+        dg, db = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+        launch_counters(reset=True)
+        try:
+            dr, din, part = ops.bn_backward_linear_bwd_data(dy.clone(), r, aff, act, dg, db, None, w, M, Nout, K, groups,
+                                                            addend=addend, bn=bn)
+        finally:
+            ops.FUSE_BN_BWD_APPLY = True
+        torch.cuda.synchronize()
+        out[fuse] = (dr.float(), din.float(), part, dg, db, launch_counters())
+    (dr0, din0, p0, dg0, db0, c0), (dr1, din1, p1, dg1, db1, c1) = out[False], out[True]
+    assert c0["gemm_bn_apply_load"] == 0 and c0["bn_bwd_apply"] == 1
+    assert c1["gemm_bn_apply_load"] == (1 if fused_expected else 0) and c1["bn_bwd_apply"] == (0 if fused_expected else 1), c1
+    assert relerr(dg1, dg0) < 1e-6 and relerr(db1, db0) < 1e-6                    # same reduce + finalize
+    # dr: the same fp32 value up to the association of three terms, rounded to bf16 once: rare one-ulp (2^-8 relative) differences
+    assert relerr(dr1, dr0) < 1e-3, relerr(dr1, dr0)
+    assert float(((dr1 - dr0).abs() > 2 ** -7 * dr0.abs().clamp_min(1e-3)).float().mean()) < 1e-4
+    assert relerr(din1, din0) < 2.5e-3, relerr(din1, din0)                        # the GEMM sums those dr values; bf16 store
+    if link:
+        assert p1.shape == p0.shape and relerr(p1, p0) < 5e-3
+    else:
+        assert p0 is None and p1 is None
+    # against an fp64 evaluation of the textbook formula on the same bf16 inputs
+    x, d = r.double(), dy.double()
+    z = aff.scale.double() * x + aff.shift.double()
+    g = d * {0: torch.ones_like(z), 1: (z > 0).double(), 2: torch.where(z > 0, 1.0, 0.2)}[act]
+    xh = (x - mean.double()) * invstd.double()
+    dr_ref = aff.scale.double() * (g - g.mean(0) - xh * (g * xh).mean(0))
+    assert relerr(dr1, dr_ref) < 3e-3                                             # one bf16 rounding
+    G_ = range(groups)
+    din_ref = torch.cat([bfr(dr_ref[:, q * Nout:(q + 1) * Nout]) @ bfr(w[q * Nout:(q + 1) * Nout]) for q in G_], 1)
+    if add:
+        din_ref = din_ref + addend.double()
+    assert relerr(din1, din_ref) < 6e-3, relerr(din1, din_ref)
+
+
 @pytest.mark.parametrize("M,Nout,K,groups,affine", [(512, 256, 512, 1, True), (200, 64, 64, 1, False), (384, 128, 128, 4, True)])
 def test_linear_fwd_with_residual_addend(ops, M, Nout, K, groups, affine):
     """nsid_linear_fwd_res: out = f(x) W^T + bias + addend in one launch (eval path: conv + folded BatchNorm + shortcut)"""

@@ -154,9 +154,11 @@ def test_bf16_train_step_vs_oracle_and_goldens(bf16_mode, golden, k):
     # (a) measured on MI355X (k = 3 / 5): see the numbers recorded below each bound
     assert a["rel_h"] < TOL["rel_h"] and a["max_z"] < TOL["max_z"] and a["cos_z_min"] > TOL["cos_z_min"]
     assert a["dloss"] < TOL["dloss"] and a["gnorm_rel"] < TOL["gnorm_rel"]
-    assert a["grad_rel_late"] < TOL["grad_rel_late"] and a["grad_rel_median"] < TOL["grad_rel_median"]
-    assert a["grad_rel_worst"] < TOL["grad_rel_worst"], a["grad_rel_worst_name"]
     assert a["bn_stat_worst"] < TOL["bn_stat_worst"]
+    # per-parameter gradients at batch 8 are recorded, not bounded (bounds of 3x the measured 0.65 / 0.40 / 0.34 relative
+    # L2 cannot fail): the per-parameter statement of the timed arithmetic is made where train-mode BatchNorm does not amplify a
+    # rounding 20-40x — one block deep (test_block_train_bf16_vs_emulation, four shapes) and at the timed batch of 256
+    # (tests/test_b256_gpu.py)
     # (b) no further from the reference than the emulated arithmetic is
     assert b_hip["rel_h"] < 1.3 * b_em["rel_h"] + 1e-3 and b_hip["dloss"] < 1.5 * b_em["dloss"] + 2e-2
     assert b_hip["cos_z_min"] > 1.0 - 1.5 * (1.0 - b_em["cos_z_min"]) - 1e-3
@@ -171,11 +173,11 @@ def test_bf16_train_step_vs_oracle_and_goldens(bf16_mode, golden, k):
 # near-identical neighbours and ReLU masks gate the rest; a one-ulp difference in a bf16-stored activation flips such a
 # choice, and train-mode BatchNorm at batch 8 then spreads it over every clip. The global norm (0.3 %) and the loss are
 # the well-conditioned quantities; test_block_train_bf16_vs_emulation states the per-block (un-amplified) agreement.
-TOL = {"rel_h": 0.15, "max_z": 0.05, "cos_z_min": 0.993, "dloss": 0.04, "gnorm_rel": 0.01, "grad_rel_late": 0.8,
-       "grad_rel_median": 0.9, "grad_rel_worst": 1.5, "bn_stat_worst": 0.025}
+TOL = {"rel_h": 0.15, "max_z": 0.05, "cos_z_min": 0.993, "dloss": 0.04, "gnorm_rel": 0.01, "bn_stat_worst": 0.025}
 
 
-BLOCKS = [("c64n256_k3d1", 64, 256, 3, 1), ("c256n64_k18d3", 256, 64, 18, 3), ("c512n32_k3d1", 512, 32, 3, 1)]
+BLOCKS = [("c64n256_k3d1", 64, 256, 3, 1), ("c128n128_k5d1", 128, 128, 5, 1), ("c256n64_k18d3", 256, 64, 18, 3),
+          ("c512n32_k3d1", 512, 32, 3, 1)]
 
 
 @pytest.mark.parametrize("tag,C,N,k,d", BLOCKS)
