@@ -568,7 +568,7 @@ def main():
         module = {"ops": ops, "functional": F_}[mod]
         if not hasattr(module, name):
             raise SystemExit(f"--flag: {mod} has no switch {name}")
-        setattr(module, name, type(getattr(module, name))(int(val)))
+        setattr(module, name, int(val))
         tuning[target] = int(val)
     if args.storage is None:
         args.storage = "bf16" if args.precision == "bf16" else "fp32"

@@ -276,14 +276,15 @@ def grapher_backward(dx1: Tensor, P, S, G) -> Tensor:
     # grouped conv (+BN+ReLU), input = u
     # (the BatchNorm-backward apply is evaluated on the backward-data GEMM's operand load where the shape allows: ops.py)
     dr2, du, _ = ops.bn_backward_linear_bwd_data(dv, r2, a2, ACT_RELU, G[pre + "1.weight"], G[pre + "1.bias"], part2,
-                                                 ops.w2d(P[pre + "0.weight"]), M, C // 2, C // 2, 4)
+                                                 ops.w2d(P[pre + "0.weight"]), M, C // 2, C // 2, 4, site=ops.SITE_GCONV)
     _bias_grad_before_bn(dr2, G[pre + "0.bias"])
     ops.linear_bwd_weight(dr2, u, ops.w2d(G[pre + "0.weight"]), M, C // 2, C // 2, 4)
     # max-relative aggregation: route to arg-max neighbour and centre; kNN itself carries no gradient
     dy = ops.mr_aggregate_bwd(du, idx, amax, B, N, C)
     # fc1 (+BN), input = x0
     dr1, dx0, part = ops.bn_backward_linear_bwd_data(dy, r1, a1, ACT_NONE, G["fc1.1.weight"], G["fc1.1.bias"], None,
-                                                     ops.w2d(P["fc1.0.weight"]), M, C, C, 1, addend=dx1, bn=_link_in(S) or False)
+                                                     ops.w2d(P["fc1.0.weight"]), M, C, C, 1, addend=dx1, bn=_link_in(S) or False,
+                                                     site=ops.SITE_FC1)
     _bias_grad_before_bn(dr1, G["fc1.0.bias"])
     ops.linear_bwd_weight(dr1, x0, ops.w2d(G["fc1.0.weight"]), M, C, C)
     _store_partial(S, part)

@@ -349,11 +349,14 @@ def linear_bwd_data(dout, w, M, Nout, K, groups=1, addend=None, out=None, bn=Non
     return (out, None) if want_pair else out
 
 
-FUSE_BN_BWD_APPLY = True      # BatchNorm-backward apply evaluated on the operand load of the backward-data GEMM (bf16 storage)
+# BatchNorm-backward apply evaluated on the operand load of the backward-data GEMM (bf16 storage): bit mask over the call sites
+# (1: FFN hidden layer, 2: grouped conv, 4: Grapher fc1); True = all, False / 0 = none
+FUSE_BN_BWD_APPLY = 4        # measured in the two-stream step (round 3, one-box A/B x2): none 8.09 / 8.06 ms, FFN 8.35 / 8.35, grouped 8.14 / 8.13, fc1 8.08 / 8.09, all 8.33 / 8.32
+SITE_FFN, SITE_GCONV, SITE_FC1 = 1, 2, 4
 
 
 def bn_backward_linear_bwd_data(dy, r, aff: "BNAffine", act, dgamma, dbeta, partial, w, M, Nout, K, groups=1, addend=None,
-                                bn=None):
+                                bn=None, site=SITE_FFN):
     """BatchNorm(+act) backward of a conv+BN layer FOLLOWED by that conv's backward-data GEMM, the two fused where the shape allows:
         dr  = BN-backward(dy, r)        (dy = dL/d act(BN(r)); dgamma / dbeta accumulated)
         din = addend + dr @ w           (+ the column sums for the next BatchNorm backward when bn=(r', aff', act'))
@@ -366,7 +369,8 @@ def bn_backward_linear_bwd_data(dy, r, aff: "BNAffine", act, dgamma, dbeta, part
     tiles = row_tiles(M)
     s = _stream()
     wop, wdt = _weight(w, dt, K)
-    fusable = (FUSE_BN_BWD_APPLY and dt == BF16 and wdt == BF16 and tuple(r.shape) == (M, groups * Nout) and
+    enabled = FUSE_BN_BWD_APPLY is True or (FUSE_BN_BWD_APPLY and (int(FUSE_BN_BWD_APPLY) & site))
+    fusable = (enabled and dt == BF16 and wdt == BF16 and tuple(r.shape) == (M, groups * Nout) and
                tuple(dy.shape) == (M, groups * Nout) and M % 128 == 0 and Nout % 64 == 0 and K % 64 == 0 and (K <= 64 or K % 128 == 0))
     if not fusable:
         dr = bn_backward(dy, r, aff, act, dgamma, dbeta, inplace=True, partial=partial)

@@ -161,11 +161,17 @@ def test_fp32_hip_vs_reference_at_b256(golden, restore_mode):
     assert same[0] > 0.999 and same[12] > 0.999                       # the first graph of each view sees identical features
 
 
-# bounds: VERDICT r2's targets (loss 1e-4, global norm 1 %) where the measurement allows, else <= 3x the measured value
-# (gpurun_out/b256_measured.json of round 3; numbers next to each key)
-TOL32 = {"eval_max_dz": 5e-4, "eval_h_clip_norm_rel": 5e-4,
-         "dloss": 1e-4, "gnorm_rel": 1e-2, "max_dz": 2e-4, "h_clip_norm_rel": 5e-4, "bn_norm_rel": 1e-4, "knn_soft": 1500,
-         "grad_late": 5e-4, "grad_early": 4e-2, "grad_norm_late": 2e-3, "grad_norm_worst": 4e-2}
+# bounds: <= 3x the values measured on MI355X in round 3 (gpurun_out/c1/b256_measured.json) — all far inside VERDICT r2's targets
+# (loss 1e-4, global norm 1 %). Measured: eval max |dz| 8.0e-5 (the CPU oracle with its own search: 7.7e-5), per-clip |h| 3.6e-5;
+# forced step 0: |dloss| 9.5e-7 (two float32 ulps of 4.64), global gradient norm 3.5e-4, max |dz| 5.4e-6, per-clip |h| 2.6e-6,
+# running statistics 3e-8, neighbour sets: 0 hard mismatches, 10 rows on recorded near-ties of 622 592; fully stored gradients:
+# late layers 1.7-2.6e-5, early layers 4.3-6.5e-3 (the reference's own fp32 floor there: the CPU oracle sits at 5.2-7.5e-3);
+# per-parameter gradient norms: late 2.2e-4, worst 1.9e-3. Free-running step (nothing forced): |dloss| 9.0e-3, norm 0.7 %,
+# max |dz| 0.27, rows with equal neighbour sets falling from 1.0 to 0.73 over the 12 blocks of a view — the same decay the
+# reference shows under a 1e-7 input perturbation (0.67).
+TOL32 = {"eval_max_dz": 2.5e-4, "eval_h_clip_norm_rel": 1.2e-4,
+         "dloss": 5e-6, "gnorm_rel": 1.1e-3, "max_dz": 2e-5, "h_clip_norm_rel": 1e-5, "bn_norm_rel": 1e-6, "knn_soft": 40,
+         "grad_late": 1e-4, "grad_early": 2e-2, "grad_norm_late": 7e-4, "grad_norm_worst": 6e-3}
 
 
 def emulation_fixture(golden):
@@ -242,6 +248,14 @@ def test_bf16_hip_vs_emulation_at_b256_and_timed_variants_ran(golden, restore_mo
         assert e < 1.3 * b_em["full_grads"][n] + 0.05, (n, e, b_em["full_grads"][n])
 
 
-# <= 3x the values measured on MI355X in round 3 (gpurun_out/b256_measured.json), numbers in DESIGN.md section 4
-TOL16 = {"h_clip_norm_rel": 0.05, "max_dz": 0.05, "cos_z_min": 0.993, "dloss": 0.04, "gnorm_rel": 0.02, "bn_norm_rel": 0.025,
-         "grad_rel_late": 0.8, "grad_rel_early": 1.5, "grad_norm_rel_median": 0.5, "grad_norm_rel_worst": 1.5}
+# <= 3x the values measured on MI355X in round 3 (gpurun_out/c1/b256_measured.json). HIP bf16 against the emulation: per-clip |h|
+# 1.5 %, max |dz| 0.026, min cos z 0.9969, |dloss| 8.1e-3, running statistics 5e-5, per-parameter gradient NORMS: median 0.45 %,
+# worst 25 % (the peak extractor's bias); fully stored gradients: late layers 6-9 %, early layers 29-36 % relative L2; global norm
+# 9.4 %. The global norm is NOT the well-conditioned quantity it is at batch 8: with the default initialisation 116 of its 157 come
+# from the peak extractor's conv weight, the first layer of the net and the most sensitive gradient there is (the fp32 reference
+# itself moves it by 40 % under a 1e-7 input perturbation). Against the fp32 goldens both sit equally far: |dloss| 0.046 (HIP) /
+# 0.038 (emulation), early gradients 0.60-0.69 / 0.64-0.69, late 0.19-0.26 / 0.18-0.26, min cos z 0.977 / 0.978 — bf16 storage of
+# 60 activation tensors per view costs that much in a train-mode step; the loss curve of 30 steps is what test_training_curve
+# judges it on.
+TOL16 = {"h_clip_norm_rel": 0.045, "max_dz": 0.08, "cos_z_min": 0.9908, "dloss": 0.025, "gnorm_rel": 0.29, "bn_norm_rel": 1.6e-4,
+         "grad_rel_late": 0.28, "grad_rel_early": 1.1, "grad_norm_rel_median": 0.014, "grad_norm_rel_worst": 0.77}
