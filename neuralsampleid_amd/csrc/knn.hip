@@ -230,6 +230,154 @@ __device__ __forceinline__ float row16_sum(float v) {
 // debug timeline, as in gemm.hip: {start, features staged, normalised, end} on the 100 MHz clock per workgroup
 __device__ unsigned long long* g_knn_trace = nullptr;
 
+// ---- bf16 x 6 distance products (round 3) -------------------------------------------------------------------------------------
+// The f32-input MFMA runs at the f32 VECTOR rate (64 flop/clk/SIMD, 1/16 of the bf16 rate), and in knn2_kernel it competes with the
+// top-list insertions for the same issue cycles: 13.7 us of a 25.6 us clip at N = 256. A normalised feature y (|y| <= 1) is split
+// EXACTLY into three bf16 values y = h + m + l (three 8-bit significands cover fp32's 24: h = bf16(y), m = bf16(y - h),
+// l = bf16(y - h - m), every difference exact in fp32), and a product keeps the six terms down to 2^-16 of the leading one:
+//   y_i y_j = h_i h_j + (h_i m_j + m_i h_j) + (h_i l_j + l_i h_j + m_i m_j) + O(2^-24 |y_i y_j|)
+// i.e. the dropped terms are of the size of ONE fp32 rounding of the product — what any fp32 evaluation (the reference's CPU GEMM, the
+// fp32 MFMA, this) already differs in. Six v_mfma_f32_16x16x32_bf16 per 32 channels (96 cycles) replace eight v_mfma_f32_16x16x4_f32
+// (256 cycles); the leading term and the five small ones go to separate fp32 accumulators and are added once per tile.
+// LDS image: img[s][kc][n][8] bf16 (s = h, m, l; kc = 8-channel chunk; 16 bytes per (kc, n)): a fragment read (lane (lr, rq) takes
+// node row lr, chunk 4*ks + rq) is conflict-free without padding — ds_read_b128 serves lanes {0-3,12-15,20-27} together, i.e. two
+// COMPLEMENTARY halves of the 16 rows at chunks rq and rq + 1, 16 different 16-byte slots of a 256-byte bank row (N % 16 == 0).
+__device__ __forceinline__ char* knn_img(char* img, int s, int kc, int n, int KC, int N) {
+  return img + ((((long)s * KC + kc) * N + n) << 4);
+}
+
+template <typename T> __device__ __forceinline__ void knn_load8(const T* p, float* v);
+template <> __device__ __forceinline__ void knn_load8<float>(const float* p, float* v) {
+  const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { v[e] = a[e]; v[4 + e] = b[e]; }
+}
+template <> __device__ __forceinline__ void knn_load8<__bf16>(const __bf16* p, float* v) {
+  const bf16x8 x = *reinterpret_cast<const bf16x8*>(p);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] = (float)x[e];
+}
+
+// Stage + BatchNorm-apply + F.normalize + exact three-way bf16 split of one clip, straight from global memory (no fp32 LDS image).
+// A wave takes 8 rows per pass: lane (nl = lane & 7, kl = lane >> 3) owns the chunks kc = kl + 8 j (j < JN = C / 64) of row nl, so
+// that the 8 lanes the LDS serves together write 8 consecutive rows of one chunk (128 contiguous bytes: conflict-free), and a row's
+// sum of squares is three xor-shuffles (8, 16, 32) away. The quotient is the correctly rounded y / max(|y|, 1e-12) of F.normalize.
+template <typename T, int JN>
+__device__ __forceinline__ void knn_stage_split(const T* __restrict__ src, long ldr, const float* __restrict__ scale,
+                                                const float* __restrict__ shift, int N, int nwaves, char* img, float* sq) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nl = lane & 7, kl = lane >> 3;
+  constexpr int KC = 8 * JN;
+  constexpr int RU = JN <= 2 ? 2 : 1;                      // row passes in flight (independent chains of ~2 000 cycles each)
+  for (int n0 = wave * 8; n0 < N; n0 += RU * nwaves * 8) {
+    float v[RU][JN][8];
+    int nn[RU];
+#pragma unroll
+    for (int u = 0; u < RU; ++u) {
+      const int n = n0 + u * nwaves * 8 + nl;
+      nn[u] = n < N ? n : -1;
+      const T* rowp = src + (long)(n < N ? n : N - 1) * ldr;
+#pragma unroll
+      for (int j = 0; j < JN; ++j) knn_load8<T>(rowp + (kl + 8 * j) * 8, v[u][j]);
+    }
+    if (scale != nullptr) {
+#pragma unroll
+      for (int j = 0; j < JN; ++j) {
+        float sc[8], sh[8];
+        load_channels<8>(scale, (kl + 8 * j) * 8, sc);
+        load_channels<8>(shift, (kl + 8 * j) * 8, sh);
+#pragma unroll
+        for (int u = 0; u < RU; ++u)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[u][j][e] = sc[e] * v[u][j][e] + sh[e];
+      }
+    }
+    float ss[RU];
+#pragma unroll
+    for (int u = 0; u < RU; ++u) {
+      ss[u] = 0.f;
+#pragma unroll
+      for (int j = 0; j < JN; ++j)
+        ss[u] += ((v[u][j][0] * v[u][j][0] + v[u][j][1] * v[u][j][1]) + (v[u][j][2] * v[u][j][2] + v[u][j][3] * v[u][j][3])) +
+                 ((v[u][j][4] * v[u][j][4] + v[u][j][5] * v[u][j][5]) + (v[u][j][6] * v[u][j][6] + v[u][j][7] * v[u][j][7]));
+    }
+#pragma unroll
+    for (int o = 8; o < 64; o <<= 1)
+#pragma unroll
+      for (int u = 0; u < RU; ++u) ss[u] += __shfl_xor(ss[u], o, 64);
+#pragma unroll
+    for (int u = 0; u < RU; ++u) {
+      const float denom = fmaxf(sqrtf(ss[u]), 1e-12f), rden = 1.f / denom;
+      ss[u] = 0.f;
+#pragma unroll
+      for (int j = 0; j < JN; ++j) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[u][j][e] = div_shared(v[u][j][e], denom, rden);
+        ss[u] += ((v[u][j][0] * v[u][j][0] + v[u][j][1] * v[u][j][1]) + (v[u][j][2] * v[u][j][2] + v[u][j][3] * v[u][j][3])) +
+                 ((v[u][j][4] * v[u][j][4] + v[u][j][5] * v[u][j][5]) + (v[u][j][6] * v[u][j][6] + v[u][j][7] * v[u][j][7]));
+      }
+    }
+#pragma unroll
+    for (int o = 8; o < 64; o <<= 1)
+#pragma unroll
+      for (int u = 0; u < RU; ++u) ss[u] += __shfl_xor(ss[u], o, 64);
+#pragma unroll
+    for (int u = 0; u < RU; ++u) {
+      if (nn[u] < 0) continue;
+      if (kl == 0) sq[nn[u]] = ss[u];
+#pragma unroll
+      for (int j = 0; j < JN; ++j) {
+        bf16x8 h, m, l;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float y = v[u][j][e];
+          h[e] = (__bf16)y;
+          const float r1 = y - (float)h[e];              // exact: y and h share the leading 8 bits
+          m[e] = (__bf16)r1;
+          l[e] = (__bf16)(r1 - (float)m[e]);             // exact remainder, itself at most 8 significant bits
+        }
+        *reinterpret_cast<bf16x8*>(knn_img(img, 0, kl + 8 * j, nn[u], KC, N)) = h;
+        *reinterpret_cast<bf16x8*>(knn_img(img, 1, kl + 8 * j, nn[u], KC, N)) = m;
+        *reinterpret_cast<bf16x8*>(knn_img(img, 2, kl + 8 * j, nn[u], KC, N)) = l;
+      }
+    }
+  }
+}
+
+template <typename T>
+__device__ __forceinline__ void knn_stage_split_any(const T* src, long ldr, const float* scale, const float* shift, int N, int C,
+                                                    int nwaves, char* img, float* sq) {
+  switch (C) {            // uniform; C is 64, 128, 256 or 512 on these paths (host-checked)
+    case 64: knn_stage_split<T, 1>(src, ldr, scale, shift, N, nwaves, img, sq); break;
+    case 128: knn_stage_split<T, 2>(src, ldr, scale, shift, N, nwaves, img, sq); break;
+    case 256: knn_stage_split<T, 4>(src, ldr, scale, shift, N, nwaves, img, sq); break;
+    default: knn_stage_split<T, 8>(src, ldr, scale, shift, N, nwaves, img, sq); break;
+  }
+}
+
+// one 32-channel step of NT 16x16 distance tiles: the three fragments of the lane's ROW node (fa*) against those of NT column-node
+// tiles (fb*). `SW` swaps the MFMA operands (knn2: the C/D layout then hands a lane one row's distances in increasing column order).
+struct KnnFrag { bf16x8 h, m, l; };
+__device__ __forceinline__ KnnFrag knn_frag(const char* img, int kc, int n, int KC, int N) {
+  KnnFrag f;
+  f.h = *reinterpret_cast<const bf16x8*>(knn_img(const_cast<char*>(img), 0, kc, n, KC, N));
+  f.m = *reinterpret_cast<const bf16x8*>(knn_img(const_cast<char*>(img), 1, kc, n, KC, N));
+  f.l = *reinterpret_cast<const bf16x8*>(knn_img(const_cast<char*>(img), 2, kc, n, KC, N));
+  return f;
+}
+template <bool SW>
+__device__ __forceinline__ void knn_mfma6(const KnnFrag& a, const KnnFrag& b, f32x4& lead, f32x4& corr) {
+#define NSID_KNN_MM(X, Y, ACC) ACC = SW ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(Y, X, ACC, 0, 0, 0) \
+                                        : __builtin_amdgcn_mfma_f32_16x16x32_bf16(X, Y, ACC, 0, 0, 0)
+  NSID_KNN_MM(a.h, b.h, lead);
+  NSID_KNN_MM(a.m, b.m, corr);          // smallest terms first
+  NSID_KNN_MM(a.h, b.l, corr);
+  NSID_KNN_MM(a.l, b.h, corr);
+  NSID_KNN_MM(a.h, b.m, corr);
+  NSID_KNN_MM(a.m, b.h, corr);
+#undef NSID_KNN_MM
+}
+
 // NT = column tiles per MFMA pass (4 for N >= 128, 2 for N = 64, 1 for N = 32) is a template parameter: as a run-time
 // value every MFMA sat behind its own scalar branch (tools/asm_profile.py: 187 branches, one MFMA per basic block).
 template <typename T, int KD, int NT>
@@ -238,10 +386,9 @@ __global__ __launch_bounds__(KNN2_THREADS) void knn2_kernel(const T* __restrict_
                                                             const float* __restrict__ shift, int N, int C, int k,
                                                             int dilation, int32_t* __restrict__ idx) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int LD = C + 4;
-  float* yn = smem;                      // [N][LD] normalised features, fp32
-  float* sq = yn + (long)N * LD;         // [N]
-  float* xkey = sq + N;                  // [4 row tiles][16 rows][KD] lists handed over by the second column group
+  char* img = reinterpret_cast<char*>(smem);          // [3][C/8][N][8] bf16: the h / m / l images of the normalised features
+  float* sq = smem + 3 * (N * C / 2);                 // [N]
+  float* xkey = sq + N;                               // [4 row tiles][16 rows][KD] lists handed over by the second column group
   int* xid = reinterpret_cast<int*>(xkey + 4 * 16 * KD);
   unsigned long long* const trace = g_knn_trace;
   unsigned long long tt[3] = {0, 0, 0};
@@ -250,102 +397,11 @@ __global__ __launch_bounds__(KNN2_THREADS) void knn2_kernel(const T* __restrict_
   const int b = blockIdx.x;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const T* src = r + (long)b * N * ldr;
-  constexpr int NV = Chunk<T>::N;
-  const int CV = C / NV;
+  const int KC = C >> 3;
 
-  // ---- phase 1a: y = scale*r + shift into LDS as fp32; the loads of a batch are all issued before the first use (a clip
-  // is 4 chunks per thread at bf16: as a plain loop that was 4 serial HBM round trips at one workgroup per CU)
-  constexpr int UB = 4;
-  for (int q0 = t; q0 < N * CV; q0 += UB * KNN2_THREADS) {
-    float v[UB][NV];
-#pragma unroll
-    for (int u = 0; u < UB; ++u) {
-      const int q = q0 + u * KNN2_THREADS;
-      if (q < N * CV) Chunk<T>::load(src + (long)(q / CV) * ldr + (q % CV) * NV, v[u]);
-    }
-#pragma unroll
-    for (int u = 0; u < UB; ++u) {
-      const int q = q0 + u * KNN2_THREADS;
-      if (q < N * CV) {
-        const int n = q / CV, c = (q % CV) * NV;
-        if (scale != nullptr) {
-          float sc[NV], sh[NV];
-          load_channels<NV>(scale, c, sc);
-          load_channels<NV>(shift, c, sh);
-#pragma unroll
-          for (int e = 0; e < NV; ++e) v[u][e] = sc[e] * v[u][e] + sh[e];
-        }
-#pragma unroll
-        for (int e = 0; e < NV; e += 4)
-          *reinterpret_cast<f32x4*>(yn + n * LD + c + e) = f32x4{v[u][e], v[u][e + 1], v[u][e + 2], v[u][e + 3]};
-      }
-    }
-  }
-  __syncthreads();
+  // ---- phase 1: y = scale*r + shift, F.normalize, |y^|^2, three-way bf16 split — one pass from global memory into the LDS images
+  knn_stage_split_any<T>(src, ldr, scale, shift, N, C, KNN2_WAVES, img, sq);
   if (trace) tt[1] = __builtin_amdgcn_s_memrealtime();
-  // ---- phase 1b: F.normalize(p=2, dim=channels, eps=1e-12) and |y^|^2 of the normalised rows; a row is handled by
-  // LPR = min(64, C/4) lanes with one or two float4 each
-  {
-    const int LPR = C / 4 < 64 ? C / 4 : 64;     // 16, 32 or 64
-    const int RPP = 64 / LPR;                     // rows per wave pass
-    const int CPL = C / 4 / LPR;                  // float4 chunks per lane (1 or 2)
-    const int cl = lane % LPR;
-    // RU independent rows per lane group and iteration: the chain load -> reduce -> sqrt -> 8 divisions -> reduce ->
-    // store is ~2 000 cycles of latency per row at two waves per SIMD (this phase took 7 of the kernel's 20 us)
-    constexpr int RU = 4;
-    for (int n0 = wave * RPP; n0 < N; n0 += RU * KNN2_WAVES * RPP) {
-      f32x4 v0[RU], v1[RU];
-      float ss[RU];
-      int nn[RU];
-#pragma unroll
-      for (int u = 0; u < RU; ++u) {
-        const int n = n0 + u * KNN2_WAVES * RPP + lane / LPR;
-        nn[u] = n < N ? n : -1;                  // surplus lane groups read row N-1 and store nothing
-        const int nr = n < N ? n : N - 1;
-        v0[u] = *reinterpret_cast<const f32x4*>(yn + nr * LD + 4 * cl);
-        v1[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (CPL > 1) v1[u] = *reinterpret_cast<const f32x4*>(yn + nr * LD + 4 * (cl + LPR));
-      }
-#pragma unroll
-      for (int u = 0; u < RU; ++u) {
-        ss[u] = (v0[u][0] * v0[u][0] + v0[u][1] * v0[u][1]) + (v0[u][2] * v0[u][2] + v0[u][3] * v0[u][3]);
-        ss[u] += (v1[u][0] * v1[u][0] + v1[u][1] * v1[u][1]) + (v1[u][2] * v1[u][2] + v1[u][3] * v1[u][3]);
-        ss[u] = row16_sum(ss[u]);
-      }
-      if (LPR >= 32) {
-#pragma unroll
-        for (int u = 0; u < RU; ++u) ss[u] += __shfl_xor(ss[u], 16, 64);
-      }
-      if (LPR >= 64) {
-#pragma unroll
-        for (int u = 0; u < RU; ++u) ss[u] += __shfl_xor(ss[u], 32, 64);
-      }
-#pragma unroll
-      for (int u = 0; u < RU; ++u) {
-        const float denom = fmaxf(sqrtf(ss[u]), 1e-12f), rden = 1.f / denom;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { v0[u][e] = div_shared(v0[u][e], denom, rden); v1[u][e] = div_shared(v1[u][e], denom, rden); }
-        ss[u] = (v0[u][0] * v0[u][0] + v0[u][1] * v0[u][1]) + (v0[u][2] * v0[u][2] + v0[u][3] * v0[u][3]);
-        ss[u] += (v1[u][0] * v1[u][0] + v1[u][1] * v1[u][1]) + (v1[u][2] * v1[u][2] + v1[u][3] * v1[u][3]);
-        ss[u] = row16_sum(ss[u]);
-      }
-      if (LPR >= 32) {
-#pragma unroll
-        for (int u = 0; u < RU; ++u) ss[u] += __shfl_xor(ss[u], 16, 64);
-      }
-      if (LPR >= 64) {
-#pragma unroll
-        for (int u = 0; u < RU; ++u) ss[u] += __shfl_xor(ss[u], 32, 64);
-      }
-#pragma unroll
-      for (int u = 0; u < RU; ++u) {
-        if (nn[u] < 0) continue;
-        *reinterpret_cast<f32x4*>(yn + nn[u] * LD + 4 * cl) = v0[u];
-        if (CPL > 1) *reinterpret_cast<f32x4*>(yn + nn[u] * LD + 4 * (cl + LPR)) = v1[u];
-        if (cl == 0) sq[nn[u]] = ss[u];
-      }
-    }
-  }
   __syncthreads();
 
   if (trace) tt[2] = __builtin_amdgcn_s_memrealtime();
@@ -361,37 +417,33 @@ __global__ __launch_bounds__(KNN2_THREADS) void knn2_kernel(const T* __restrict_
     top.init();
     const int i = 16 * rt + lr;                           // this lane's row node
     const float si = sq[i];
-    const float* arow = yn + i * LD + 4 * rq;
     for (int ct0 = cg * CTG; ct0 < (cg + 1) * CTG; ct0 += NT) {
-      f32x4 acc[NT];
+      f32x4 lead[NT], corr[NT];
 #pragma unroll
-      for (int u = 0; u < NT; ++u) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-      const float* brow = yn + (16 * ct0 + lr) * LD + 4 * rq;
-      // the fragments of the next 16 channels are read while the MFMAs of the current ones run
-      f32x4 fa = *reinterpret_cast<const f32x4*>(arow), fb[NT];
+      for (int u = 0; u < NT; ++u) lead[u] = corr[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+      // the fragments of the next 32 channels are read while the MFMAs of the current ones run
+      KnnFrag fa = knn_frag(img, rq, i, KC, N), fb[NT];
 #pragma unroll
-      for (int u = 0; u < NT; ++u) fb[u] = *reinterpret_cast<const f32x4*>(brow + u * 16 * LD);
-      for (int ch = 0; ch < C; ch += 16) {
-        const int chn = ch + 16 < C ? ch + 16 : ch;       // the last prefetch re-reads the current chunk (unused)
-        const f32x4 na = *reinterpret_cast<const f32x4*>(arow + chn);
-        f32x4 nb[NT];
+      for (int u = 0; u < NT; ++u) fb[u] = knn_frag(img, rq, 16 * (ct0 + u) + lr, KC, N);
+      for (int kc = 0; kc < KC; kc += 4) {
+        const int kn = (kc + 4 < KC ? kc + 4 : kc) + rq;   // the last prefetch re-reads the current chunk (unused)
+        const KnnFrag na = knn_frag(img, kn, i, KC, N);
+        KnnFrag nb[NT];
 #pragma unroll
-        for (int u = 0; u < NT; ++u) nb[u] = *reinterpret_cast<const f32x4*>(brow + u * 16 * LD + chn);
+        for (int u = 0; u < NT; ++u) nb[u] = knn_frag(img, kn, 16 * (ct0 + u) + lr, KC, N);
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-#pragma unroll
-          for (int u = 0; u < NT; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(fb[u][e], fa[e], acc[u], 0, 0, 0);
+        for (int u = 0; u < NT; ++u) knn_mfma6<false>(fb[u], fa, lead[u], corr[u]);     // A = column nodes, B = this lane's row node
         fa = na;
 #pragma unroll
         for (int u = 0; u < NT; ++u) fb[u] = nb[u];
       }
-      // acc[u][e] = y_j . y_i with j = 16*(ct0+u) + 4*rq + e, i = this lane's row: D = (|i|^2 - 2 i.j) + |j|^2
+      // lead + corr = y_j . y_i with j = 16*(ct0+u) + 4*rq + e, i = this lane's row: D = (|i|^2 - 2 i.j) + |j|^2
 #pragma unroll
       for (int u = 0; u < NT; ++u) {
         const int j0 = 16 * (ct0 + u) + 4 * rq;
         const f32x4 sj = *reinterpret_cast<const f32x4*>(sq + j0);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) top.push_ordered((si + (-2.f * acc[u][e])) + sj[e], j0 + e);
+        for (int e = 0; e < 4; ++e) top.push_ordered((si + (-2.f * (lead[u][e] + corr[u][e]))) + sj[e], j0 + e);
       }
     }
     // ---- merge the four quarter lists of every row (lanes lr + 16q): two butterfly exchanges, after which all four
@@ -873,7 +925,7 @@ int launch_knn_rank(const void* r, int ldr, const float* scale, const float* shi
 template <typename T, int KD, int NT>
 int launch_knn2_nt(const void* r, int ldr, const float* scale, const float* shift, int B, int N, int C, int k,
                    int dilation, int32_t* idx, hipStream_t s) {
-  const size_t bytes = ((size_t)N * (C + 4) + N + 2 * 4 * 16 * KD) * sizeof(float);
+  const size_t bytes = (size_t)3 * N * C * 2 + ((size_t)N + 2 * 4 * 16 * KD) * sizeof(float);      // three bf16 images + |y|^2 + hand-over lists
   static bool configured = false;      // raise the dynamic-LDS cap once per instantiation (not a per-call sync)
   if (!configured) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(knn2_kernel<T, KD, NT>),
