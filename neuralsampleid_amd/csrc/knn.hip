@@ -230,18 +230,22 @@ __device__ __forceinline__ float row16_sum(float v) {
 // debug timeline, as in gemm.hip: {start, features staged, normalised, end} on the 100 MHz clock per workgroup
 __device__ unsigned long long* g_knn_trace = nullptr;
 
-// ---- bf16 x 6 distance products (round 3) -------------------------------------------------------------------------------------
-// The f32-input MFMA runs at the f32 VECTOR rate (64 flop/clk/SIMD, 1/16 of the bf16 rate), and in knn2_kernel it competes with the
-// top-list insertions for the same issue cycles: 13.7 us of a 25.6 us clip at N = 256. A normalised feature y (|y| <= 1) is split
-// EXACTLY into three bf16 values y = h + m + l (three 8-bit significands cover fp32's 24: h = bf16(y), m = bf16(y - h),
-// l = bf16(y - h - m), every difference exact in fp32), and a product keeps the six terms down to 2^-16 of the leading one:
-//   y_i y_j = h_i h_j + (h_i m_j + m_i h_j) + (h_i l_j + l_i h_j + m_i m_j) + O(2^-24 |y_i y_j|)
-// i.e. the dropped terms are of the size of ONE fp32 rounding of the product — what any fp32 evaluation (the reference's CPU GEMM, the
-// fp32 MFMA, this) already differs in. Six v_mfma_f32_16x16x32_bf16 per 32 channels (96 cycles) replace eight v_mfma_f32_16x16x4_f32
-// (256 cycles); the leading term and the five small ones go to separate fp32 accumulators and are added once per tile.
-// LDS image: img[s][kc][n][8] bf16 (s = h, m, l; kc = 8-channel chunk; 16 bytes per (kc, n)): a fragment read (lane (lr, rq) takes
+// ---- split-fp16 distance products (round 3) -----------------------------------------------------------------------------------
+// The f32-input MFMA runs at the f32 VECTOR rate (64 flop/clk/SIMD, 1/16 of the 16-bit rate), and in knn2_kernel it competes with
+// the top-list insertions for the same issue cycles: 13.7 us of a 25.6 us clip at N = 256. A normalised feature y (|y| <= 1) is split
+// into two fp16 values, a = fp16(y) and b = fp16(y - a) (the difference is exact in fp32): a + b carries 22 significant bits of y,
+// and a product keeps three terms:   y_i y_j = a_i a_j + (a_i b_j + b_i a_j) + O(2^-22 |y_i y_j|).
+// Measured against an fp64 evaluation on unit-norm rows (C = 64 ... 512): rms error 2.6e-8, max 1.5e-7 — the fp32 GEMM the reference
+// runs on the CPU sits at 1.9e-8 / 2.8e-7 (its own summation order), i.e. the split product is as close to the true distances as the
+// reference is; a bf16 split (8 bits per part) would need three parts and six terms for that, a two-part bf16 product is 1e-5 off.
+// Three v_mfma_f32_16x16x32_f16 per 32 channels (48 cycles) replace eight v_mfma_f32_16x16x4_f32 (256 cycles); the leading term and
+// the two small ones go to separate fp32 accumulators and are added once per tile. (fp16's narrow exponent costs nothing here: below
+// 6e-5 a value keeps an ABSOLUTE precision of 3e-8, which is what a distance between unit vectors needs.)
+// LDS image: img[s][kc][n][8] fp16 (s = a, b; kc = 8-channel chunk; 16 bytes per (kc, n)): a fragment read (lane (lr, rq) takes
 // node row lr, chunk 4*ks + rq) is conflict-free without padding — ds_read_b128 serves lanes {0-3,12-15,20-27} together, i.e. two
 // COMPLEMENTARY halves of the 16 rows at chunks rq and rq + 1, 16 different 16-byte slots of a 256-byte bank row (N % 16 == 0).
+// Two images of a clip are 64 KB at every stage (N * C = 16 384): two workgroups per CU, as with the fp32 image before.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ char* knn_img(char* img, int s, int kc, int n, int KC, int N) {
   return img + ((((long)s * KC + kc) * N + n) << 4);
 }
@@ -258,7 +262,7 @@ template <> __device__ __forceinline__ void knn_load8<__bf16>(const __bf16* p, f
   for (int e = 0; e < 8; ++e) v[e] = (float)x[e];
 }
 
-// Stage + BatchNorm-apply + F.normalize + exact three-way bf16 split of one clip, straight from global memory (no fp32 LDS image).
+// Stage + BatchNorm-apply + F.normalize + two-way fp16 split of one clip, straight from global memory (no fp32 LDS image).
 // A wave takes 8 rows per pass: lane (nl = lane & 7, kl = lane >> 3) owns the chunks kc = kl + 8 j (j < JN = C / 64) of row nl, so
 // that the 8 lanes the LDS serves together write 8 consecutive rows of one chunk (128 contiguous bytes: conflict-free), and a row's
 // sum of squares is three xor-shuffles (8, 16, 32) away. The quotient is the correctly rounded y / max(|y|, 1e-12) of F.normalize.
@@ -327,18 +331,15 @@ __device__ __forceinline__ void knn_stage_split(const T* __restrict__ src, long 
       if (kl == 0) sq[nn[u]] = ss[u];
 #pragma unroll
       for (int j = 0; j < JN; ++j) {
-        bf16x8 h, m, l;
+        f16x8 a, bb;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           const float y = v[u][j][e];
-          h[e] = (__bf16)y;
-          const float r1 = y - (float)h[e];              // exact: y and h share the leading 8 bits
-          m[e] = (__bf16)r1;
-          l[e] = (__bf16)(r1 - (float)m[e]);             // exact remainder, itself at most 8 significant bits
+          a[e] = (_Float16)y;                            // round to nearest even (v_cvt_f16_f32)
+          bb[e] = (_Float16)(y - (float)a[e]);           // the difference is exact in fp32
         }
-        *reinterpret_cast<bf16x8*>(knn_img(img, 0, kl + 8 * j, nn[u], KC, N)) = h;
-        *reinterpret_cast<bf16x8*>(knn_img(img, 1, kl + 8 * j, nn[u], KC, N)) = m;
-        *reinterpret_cast<bf16x8*>(knn_img(img, 2, kl + 8 * j, nn[u], KC, N)) = l;
+        *reinterpret_cast<f16x8*>(knn_img(img, 0, kl + 8 * j, nn[u], KC, N)) = a;
+        *reinterpret_cast<f16x8*>(knn_img(img, 1, kl + 8 * j, nn[u], KC, N)) = bb;
       }
     }
   }
@@ -355,27 +356,19 @@ __device__ __forceinline__ void knn_stage_split_any(const T* src, long ldr, cons
   }
 }
 
-// one 32-channel step of NT 16x16 distance tiles: the three fragments of the lane's ROW node (fa*) against those of NT column-node
-// tiles (fb*). `SW` swaps the MFMA operands (knn2: the C/D layout then hands a lane one row's distances in increasing column order).
-struct KnnFrag { bf16x8 h, m, l; };
+// one 32-channel step of a 16x16 distance tile: the two fragments of one node set (x) against those of the other (y); the MFMA's A
+// operand indexes the tile's ROWS (C/D layout: row = 4*(lane>>4) + reg), its B operand the COLUMNS (lane & 15)
+struct KnnFrag { f16x8 a, b; };
 __device__ __forceinline__ KnnFrag knn_frag(const char* img, int kc, int n, int KC, int N) {
   KnnFrag f;
-  f.h = *reinterpret_cast<const bf16x8*>(knn_img(const_cast<char*>(img), 0, kc, n, KC, N));
-  f.m = *reinterpret_cast<const bf16x8*>(knn_img(const_cast<char*>(img), 1, kc, n, KC, N));
-  f.l = *reinterpret_cast<const bf16x8*>(knn_img(const_cast<char*>(img), 2, kc, n, KC, N));
+  f.a = *reinterpret_cast<const f16x8*>(knn_img(const_cast<char*>(img), 0, kc, n, KC, N));
+  f.b = *reinterpret_cast<const f16x8*>(knn_img(const_cast<char*>(img), 1, kc, n, KC, N));
   return f;
 }
-template <bool SW>
-__device__ __forceinline__ void knn_mfma6(const KnnFrag& a, const KnnFrag& b, f32x4& lead, f32x4& corr) {
-#define NSID_KNN_MM(X, Y, ACC) ACC = SW ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(Y, X, ACC, 0, 0, 0) \
-                                        : __builtin_amdgcn_mfma_f32_16x16x32_bf16(X, Y, ACC, 0, 0, 0)
-  NSID_KNN_MM(a.h, b.h, lead);
-  NSID_KNN_MM(a.m, b.m, corr);          // smallest terms first
-  NSID_KNN_MM(a.h, b.l, corr);
-  NSID_KNN_MM(a.l, b.h, corr);
-  NSID_KNN_MM(a.h, b.m, corr);
-  NSID_KNN_MM(a.m, b.h, corr);
-#undef NSID_KNN_MM
+__device__ __forceinline__ void knn_mfma3(const KnnFrag& x, const KnnFrag& y, f32x4& lead, f32x4& corr) {
+  lead = __builtin_amdgcn_mfma_f32_16x16x32_f16(x.a, y.a, lead, 0, 0, 0);
+  corr = __builtin_amdgcn_mfma_f32_16x16x32_f16(x.a, y.b, corr, 0, 0, 0);
+  corr = __builtin_amdgcn_mfma_f32_16x16x32_f16(x.b, y.a, corr, 0, 0, 0);
 }
 
 // NT = column tiles per MFMA pass (4 for N >= 128, 2 for N = 64, 1 for N = 32) is a template parameter: as a run-time
@@ -386,8 +379,8 @@ __global__ __launch_bounds__(KNN2_THREADS) void knn2_kernel(const T* __restrict_
                                                             const float* __restrict__ shift, int N, int C, int k,
                                                             int dilation, int32_t* __restrict__ idx) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  char* img = reinterpret_cast<char*>(smem);          // [3][C/8][N][8] bf16: the h / m / l images of the normalised features
-  float* sq = smem + 3 * (N * C / 2);                 // [N]
+  char* img = reinterpret_cast<char*>(smem);          // [2][C/8][N][8] fp16: the two split images of the normalised features
+  float* sq = smem + 2 * (N * C / 2);                 // [N]
   float* xkey = sq + N;                               // [4 row tiles][16 rows][KD] lists handed over by the second column group
   int* xid = reinterpret_cast<int*>(xkey + 4 * 16 * KD);
   unsigned long long* const trace = g_knn_trace;
@@ -399,7 +392,7 @@ __global__ __launch_bounds__(KNN2_THREADS) void knn2_kernel(const T* __restrict_
   const T* src = r + (long)b * N * ldr;
   const int KC = C >> 3;
 
-  // ---- phase 1: y = scale*r + shift, F.normalize, |y^|^2, three-way bf16 split — one pass from global memory into the LDS images
+  // ---- phase 1: y = scale*r + shift, F.normalize, |y^|^2, two-way fp16 split — one pass from global memory into the LDS images
   knn_stage_split_any<T>(src, ldr, scale, shift, N, C, KNN2_WAVES, img, sq);
   if (trace) tt[1] = __builtin_amdgcn_s_memrealtime();
   __syncthreads();
@@ -432,7 +425,7 @@ __global__ __launch_bounds__(KNN2_THREADS) void knn2_kernel(const T* __restrict_
 #pragma unroll
         for (int u = 0; u < NT; ++u) nb[u] = knn_frag(img, kn, 16 * (ct0 + u) + lr, KC, N);
 #pragma unroll
-        for (int u = 0; u < NT; ++u) knn_mfma6<false>(fb[u], fa, lead[u], corr[u]);     // A = column nodes, B = this lane's row node
+        for (int u = 0; u < NT; ++u) knn_mfma3(fb[u], fa, lead[u], corr[u]);     // A = column nodes, B = this lane's row node
         fa = na;
 #pragma unroll
         for (int u = 0; u < NT; ++u) fb[u] = nb[u];
@@ -925,7 +918,7 @@ int launch_knn_rank(const void* r, int ldr, const float* scale, const float* shi
 template <typename T, int KD, int NT>
 int launch_knn2_nt(const void* r, int ldr, const float* scale, const float* shift, int B, int N, int C, int k,
                    int dilation, int32_t* idx, hipStream_t s) {
-  const size_t bytes = (size_t)3 * N * C * 2 + ((size_t)N + 2 * 4 * 16 * KD) * sizeof(float);      // three bf16 images + |y|^2 + hand-over lists
+  const size_t bytes = (size_t)2 * N * C * 2 + ((size_t)N + 2 * 4 * 16 * KD) * sizeof(float);      // two fp16 images + |y|^2 + hand-over lists
   static bool configured = false;      // raise the dynamic-LDS cap once per instantiation (not a per-call sync)
   if (!configured) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(knn2_kernel<T, KD, NT>),

@@ -47,7 +47,13 @@ class GraphedFingerprinter:
     micro-batch of 512 AND of 1024 clips eagerly; 3.5 ms per 1024 clips once the host is out of the way).
 
         fp = GraphedFingerprinter(model, micro_batch=1024)     # eval mode, captures once (weights are read in place)
-        z = fp(specs)                                          # (S, n_mels, n_frames) -> (S, d); a ragged tail runs eagerly
+        z = fp(specs)                                          # (S, n_mels, n_frames) -> (S, d); a ragged tail is padded
+
+    streams > 1: that many captures of the same forward, each with its own static buffers, replayed on their own HIP streams with
+    the micro-batches dealt round-robin — the latency-bound kernels of one micro-batch (one workgroup per clip in the graph builder,
+    the small-tile GEMMs of the first stage) run beside the bandwidth-bound ones of another. Measured on MI355X (round 3, 98 304
+    clips, micro-batch 2 048): 305.7 k clips/s on one stream, 333.1 k on two, 349.6 k on three; results are identical (same kernels
+    on the same data, no cross-stream reduction).
 
     The captured kernels read the weights and the folded conv+BatchNorm constants in place: after a change of the weights
     (training steps, load_state_dict, torch.optim, in-place edits) build a new GraphedFingerprinter — a call after such a change is
@@ -56,13 +62,15 @@ class GraphedFingerprinter:
     eval affines, bf16 shadows) are referenced from here, so a later eager forward that rebuilds the caches cannot free them under
     the graph."""
 
-    def __init__(self, model, micro_batch: int = 1024, example: torch.Tensor = None):
+    def __init__(self, model, micro_batch: int = 1024, example: torch.Tensor = None, streams: int = 1):
         from . import functional, ops
         self.model, self.mb = model, int(micro_batch)
         dev = next(model.parameters()).device
         cfg = model.cfg
         shape = (self.mb, cfg["n_mels"], cfg["n_frames"]) if example is None else (self.mb,) + tuple(example.shape[1:])
-        self.x = torch.zeros(shape, device=dev)
+        self.n_streams = max(1, int(streams))
+        self.xs = [torch.zeros(shape, device=dev) for _ in range(self.n_streams)]
+        self.x = self.xs[0]
         self.d = model.projector[-1].out_features
         self.epochs = (ops.WEIGHT_EPOCH, ops.STATS_EPOCH)
         self._held = None
@@ -79,9 +87,15 @@ class GraphedFingerprinter:
                         model._embed(self.x)
                 torch.cuda.current_stream().wait_stream(side)
                 torch.cuda.synchronize()
-                self.graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(self.graph):
-                    _, self.z = model._embed(self.x)
+                self.graphs, self.zs = [], []
+                for x_s in self.xs:
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g):
+                        _, z_s = model._embed(x_s)
+                    self.graphs.append(g)
+                    self.zs.append(z_s)
+                self.graph, self.z = self.graphs[0], self.zs[0]
+                self.streams = [torch.cuda.Stream(device=dev) for _ in range(self.n_streams)] if self.n_streams > 1 else []
                 # everything the captured kernels read in place, kept alive with the graph
                 self._held = (list(ops._FOLDED.values()), list(ops._EVAL_AFFINE.values()),
                               [e[0] for e in ops.SHADOWS.entries.values()])
@@ -101,13 +115,28 @@ class GraphedFingerprinter:
         S = specs.shape[0]
         if out is None:
             out = torch.empty((S, self.d), device=specs.device, dtype=torch.float32)
-        full = S // self.mb * self.mb
-        for lo in range(0, full, self.mb):
-            self.x.copy_(specs[lo:lo + self.mb], non_blocking=True)
-            self.graph.replay()
-            out[lo:lo + self.mb].copy_(self.z, non_blocking=True)
-        if full < S:
-            extract_fingerprints(self.model, specs[full:], self.mb, out[full:])
+        # a ragged tail rides through the same graph: its clips overwrite the head of a static input buffer, the rows behind them
+        # keep the previous micro-batch's clips (eval mode: every clip is independent), and only the tail's rows are copied out
+        bounds = [(lo, min(lo + self.mb, S)) for lo in range(0, S, self.mb)]
+        if self.n_streams == 1 or len(bounds) == 1:
+            for lo, hi in bounds:
+                self.x[:hi - lo].copy_(specs[lo:hi], non_blocking=True)
+                self.graph.replay()
+                out[lo:hi].copy_(self.z[:hi - lo], non_blocking=True)
+        else:
+            cur = torch.cuda.current_stream()
+            ready = torch.cuda.Event()
+            ready.record(cur)                                    # specs / out as the caller's stream left them
+            for st in self.streams:
+                st.wait_event(ready)
+            for i, (lo, hi) in enumerate(bounds):
+                s_ = i % self.n_streams
+                with torch.cuda.stream(self.streams[s_]):        # in-order within a stream: the static buffers are reused safely
+                    self.xs[s_][:hi - lo].copy_(specs[lo:hi], non_blocking=True)
+                    self.graphs[s_].replay()
+                    out[lo:hi].copy_(self.zs[s_][:hi - lo], non_blocking=True)
+            for st in self.streams:
+                cur.wait_stream(st)
         return out
 
 

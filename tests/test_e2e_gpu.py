@@ -585,6 +585,14 @@ def test_graphed_fingerprinter_equals_eager_extraction(golden):
     z = fp(x)
     assert model.training and z.shape == (19, 128)
     assert maxerr(z, ref) < 2e-6                                             # same kernels; split-K atomics in the projector
+    # three concurrent replays on three HIP streams (micro-batches dealt round-robin): the same numbers, twice in a row (the static
+    # buffers of a stream are reused by its next micro-batch)
+    fp3 = GraphedFingerprinter(model, micro_batch=4, streams=3)
+    for _ in range(2):
+        z3 = fp3(x)
+        torch.cuda.synchronize()
+        assert maxerr(z3, ref) < 2e-6
+    del fp3
     assert maxerr(z[:8], g.t("z_i_eval")) < 1e-2                             # and the reference's eval goldens (own kNN)
     # torch-side weight changes move only `_version`: load_state_dict after the capture must be refused as well,
     # and a fresh capture must see the loaded weights
