@@ -497,66 +497,15 @@ __global__ __launch_bounds__(KNN2_THREADS) void knn_rank_kernel(const T* __restr
                                                                 const float* __restrict__ shift, int N, int C, int k,
                                                                 int dilation, int32_t* __restrict__ idx) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int LD = C + 4, SLD = N + 4;
-  float* yn = smem;                      // [N][LD]
-  float* sq = yn + (long)N * LD;         // [N]
-  float* strips = sq + N;                // [8 waves][16][SLD]
+  const int SLD = N + 4;
+  char* img = reinterpret_cast<char*>(smem);   // [2][C/8][N][8] fp16 split images (see knn2_kernel)
+  float* sq = smem + 2 * (N * C / 2);          // [N]
+  float* strips = sq + N;                      // [8 waves][16][SLD]
   const int b = blockIdx.x;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const T* src = r + (long)b * N * ldr;
-  constexpr int NV = Chunk<T>::N;
-  const int CV = C / NV;
-  constexpr int UB = 4;
-  for (int q0 = t; q0 < N * CV; q0 += UB * KNN2_THREADS) {
-    float v[UB][NV];
-#pragma unroll
-    for (int u = 0; u < UB; ++u) {
-      const int q = q0 + u * KNN2_THREADS;
-      if (q < N * CV) Chunk<T>::load(src + (long)(q / CV) * ldr + (q % CV) * NV, v[u]);
-    }
-#pragma unroll
-    for (int u = 0; u < UB; ++u) {
-      const int q = q0 + u * KNN2_THREADS;
-      if (q < N * CV) {
-        const int n = q / CV, c = (q % CV) * NV;
-        if (scale != nullptr) {
-          float sc[NV], sh[NV];
-          load_channels<NV>(scale, c, sc);
-          load_channels<NV>(shift, c, sh);
-#pragma unroll
-          for (int e = 0; e < NV; ++e) v[u][e] = sc[e] * v[u][e] + sh[e];
-        }
-#pragma unroll
-        for (int e = 0; e < NV; e += 4)
-          *reinterpret_cast<f32x4*>(yn + n * LD + c + e) = f32x4{v[u][e], v[u][e + 1], v[u][e + 2], v[u][e + 3]};
-      }
-    }
-  }
-  __syncthreads();
-  {  // F.normalize + |y^|^2 (same arithmetic as knn2_kernel)
-    const int LPR = C / 4 < 64 ? C / 4 : 64, RPP = 64 / LPR, CPL = C / 4 / LPR, cl = lane % LPR;
-    for (int n0 = wave * RPP; n0 < N; n0 += KNN2_WAVES * RPP) {
-      const int n = n0 + lane / LPR;
-      f32x4 v0 = *reinterpret_cast<const f32x4*>(yn + n * LD + 4 * cl), v1 = {0.f, 0.f, 0.f, 0.f};
-      if (CPL > 1) v1 = *reinterpret_cast<const f32x4*>(yn + n * LD + 4 * (cl + LPR));
-      float ss = (v0[0] * v0[0] + v0[1] * v0[1]) + (v0[2] * v0[2] + v0[3] * v0[3]);
-      ss += (v1[0] * v1[0] + v1[1] * v1[1]) + (v1[2] * v1[2] + v1[3] * v1[3]);
-      ss = row16_sum(ss);
-      if (LPR >= 32) ss += __shfl_xor(ss, 16, 64);
-      if (LPR >= 64) ss += __shfl_xor(ss, 32, 64);
-      const float denom = fmaxf(sqrtf(ss), 1e-12f), rden = 1.f / denom;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) { v0[e] = div_shared(v0[e], denom, rden); v1[e] = div_shared(v1[e], denom, rden); }
-      float s2 = (v0[0] * v0[0] + v0[1] * v0[1]) + (v0[2] * v0[2] + v0[3] * v0[3]);
-      s2 += (v1[0] * v1[0] + v1[1] * v1[1]) + (v1[2] * v1[2] + v1[3] * v1[3]);
-      s2 = row16_sum(s2);
-      if (LPR >= 32) s2 += __shfl_xor(s2, 16, 64);
-      if (LPR >= 64) s2 += __shfl_xor(s2, 32, 64);
-      *reinterpret_cast<f32x4*>(yn + n * LD + 4 * cl) = v0;
-      if (CPL > 1) *reinterpret_cast<f32x4*>(yn + n * LD + 4 * (cl + LPR)) = v1;
-      if (cl == 0) sq[n] = s2;
-    }
-  }
+  const int KC = C >> 3;
+  knn_stage_split_any<T>(src, ldr, scale, shift, N, C, KNN2_WAVES, img, sq);
   __syncthreads();
 
   const int lr = lane & 15, rq = lane >> 4;
@@ -564,26 +513,22 @@ __global__ __launch_bounds__(KNN2_THREADS) void knn_rank_kernel(const T* __restr
   const int kd = k * dilation;
   float* strip = strips + wave * 16 * SLD;
   for (int s = wave; s < NS; s += KNN2_WAVES) {      // no workgroup barrier below: a wave owns its strip buffer
-    const float* arow = yn + (16 * s + lr) * LD + 4 * rq;
     for (int tn = 0; tn < NS; tn += NT) {
-      f32x4 acc[NT];
+      f32x4 lead[NT], corr[NT];
 #pragma unroll
-      for (int u = 0; u < NT; ++u) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-      const float* brow = yn + (16 * tn + lr) * LD + 4 * rq;
-      // the fragments of the next 16 channels are read while the MFMAs of the current ones run
-      f32x4 fa = *reinterpret_cast<const f32x4*>(arow), fb[NT];
+      for (int u = 0; u < NT; ++u) lead[u] = corr[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+      // the fragments of the next 32 channels are read while the MFMAs of the current ones run
+      KnnFrag fa = knn_frag(img, rq, 16 * s + lr, KC, N), fb[NT];
 #pragma unroll
-      for (int u = 0; u < NT; ++u) fb[u] = *reinterpret_cast<const f32x4*>(brow + u * 16 * LD);
-      for (int ch = 0; ch < C; ch += 16) {
-        const int chn = ch + 16 < C ? ch + 16 : ch;
-        const f32x4 na = *reinterpret_cast<const f32x4*>(arow + chn);
-        f32x4 nb[NT];
+      for (int u = 0; u < NT; ++u) fb[u] = knn_frag(img, rq, 16 * (tn + u) + lr, KC, N);
+      for (int kc = 0; kc < KC; kc += 4) {
+        const int kn = (kc + 4 < KC ? kc + 4 : kc) + rq;
+        const KnnFrag na = knn_frag(img, kn, 16 * s + lr, KC, N);
+        KnnFrag nb[NT];
 #pragma unroll
-        for (int u = 0; u < NT; ++u) nb[u] = *reinterpret_cast<const f32x4*>(brow + u * 16 * LD + chn);
+        for (int u = 0; u < NT; ++u) nb[u] = knn_frag(img, kn, 16 * (tn + u) + lr, KC, N);
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-#pragma unroll
-          for (int u = 0; u < NT; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[e], fb[u][e], acc[u], 0, 0, 0);
+        for (int u = 0; u < NT; ++u) knn_mfma3(fa, fb[u], lead[u], corr[u]);      // A = the strip's row nodes, B = column nodes
         fa = na;
 #pragma unroll
         for (int u = 0; u < NT; ++u) fb[u] = nb[u];
@@ -595,7 +540,7 @@ __global__ __launch_bounds__(KNN2_THREADS) void knn_rank_kernel(const T* __restr
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const float si = sq[16 * s + 4 * rq + e];
-          strip[(4 * rq + e) * SLD + 16 * (tn + u) + lr] = (si + (-2.f * acc[u][e])) + sj;
+          strip[(4 * rq + e) * SLD + 16 * (tn + u) + lr] = (si + (-2.f * (lead[u][e] + corr[u][e]))) + sj;
         }
       }
     }
@@ -714,67 +659,16 @@ __global__ __launch_bounds__(KNN2_THREADS) void knn_sel_kernel(const T* __restri
                                                                const float* __restrict__ shift, int N, int C, int k,
                                                                int dilation, int32_t* __restrict__ idx) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int LD = C + 4, SLD = N + 4;
-  float* yn = smem;                                  // [N][LD]
-  float* sq = yn + (long)N * LD;                     // [N]
+  const int SLD = N + 4;
+  char* img = reinterpret_cast<char*>(smem);         // [2][C/8][N][8] fp16 split images (see knn2_kernel)
+  float* sq = smem + 2 * (N * C / 2);                // [N]
   float* strips = sq + N;                            // [KSEL_STRIPS][16][SLD]
   float* scratch = strips + KSEL_STRIPS * 16 * SLD;  // [8 waves][64 lane minima + 2*N candidate (value, index)]
   const int b = blockIdx.x;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const T* src = r + (long)b * N * ldr;
-  constexpr int NV = Chunk<T>::N;
-  const int CV = C / NV;
-  constexpr int UB = 4;
-  for (int q0 = t; q0 < N * CV; q0 += UB * KNN2_THREADS) {
-    float v[UB][NV];
-#pragma unroll
-    for (int u = 0; u < UB; ++u) {
-      const int q = q0 + u * KNN2_THREADS;
-      if (q < N * CV) Chunk<T>::load(src + (long)(q / CV) * ldr + (q % CV) * NV, v[u]);
-    }
-#pragma unroll
-    for (int u = 0; u < UB; ++u) {
-      const int q = q0 + u * KNN2_THREADS;
-      if (q < N * CV) {
-        const int n = q / CV, c = (q % CV) * NV;
-        if (scale != nullptr) {
-          float sc[NV], sh[NV];
-          load_channels<NV>(scale, c, sc);
-          load_channels<NV>(shift, c, sh);
-#pragma unroll
-          for (int e = 0; e < NV; ++e) v[u][e] = sc[e] * v[u][e] + sh[e];
-        }
-#pragma unroll
-        for (int e = 0; e < NV; e += 4)
-          *reinterpret_cast<f32x4*>(yn + n * LD + c + e) = f32x4{v[u][e], v[u][e + 1], v[u][e + 2], v[u][e + 3]};
-      }
-    }
-  }
-  __syncthreads();
-  {  // F.normalize + |y^|^2 (same arithmetic as knn2_kernel)
-    const int LPR = C / 4 < 64 ? C / 4 : 64, RPP = 64 / LPR, CPL = C / 4 / LPR, cl = lane % LPR;
-    for (int n0 = wave * RPP; n0 < N; n0 += KNN2_WAVES * RPP) {
-      const int n = n0 + lane / LPR;
-      f32x4 v0 = *reinterpret_cast<const f32x4*>(yn + n * LD + 4 * cl), v1 = {0.f, 0.f, 0.f, 0.f};
-      if (CPL > 1) v1 = *reinterpret_cast<const f32x4*>(yn + n * LD + 4 * (cl + LPR));
-      float ss = (v0[0] * v0[0] + v0[1] * v0[1]) + (v0[2] * v0[2] + v0[3] * v0[3]);
-      ss += (v1[0] * v1[0] + v1[1] * v1[1]) + (v1[2] * v1[2] + v1[3] * v1[3]);
-      ss = row16_sum(ss);
-      if (LPR >= 32) ss += __shfl_xor(ss, 16, 64);
-      if (LPR >= 64) ss += __shfl_xor(ss, 32, 64);
-      const float denom = fmaxf(sqrtf(ss), 1e-12f), rden = 1.f / denom;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) { v0[e] = div_shared(v0[e], denom, rden); v1[e] = div_shared(v1[e], denom, rden); }
-      float s2 = (v0[0] * v0[0] + v0[1] * v0[1]) + (v0[2] * v0[2] + v0[3] * v0[3]);
-      s2 += (v1[0] * v1[0] + v1[1] * v1[1]) + (v1[2] * v1[2] + v1[3] * v1[3]);
-      s2 = row16_sum(s2);
-      if (LPR >= 32) s2 += __shfl_xor(s2, 16, 64);
-      if (LPR >= 64) s2 += __shfl_xor(s2, 32, 64);
-      *reinterpret_cast<f32x4*>(yn + n * LD + 4 * cl) = v0;
-      if (CPL > 1) *reinterpret_cast<f32x4*>(yn + n * LD + 4 * (cl + LPR)) = v1;
-      if (cl == 0) sq[n] = s2;
-    }
-  }
+  const int KC = C >> 3;
+  knn_stage_split_any<T>(src, ldr, scale, shift, N, C, KNN2_WAVES, img, sq);
   __syncthreads();
 
   const int lr = lane & 15, rq = lane >> 4;
@@ -789,21 +683,17 @@ __global__ __launch_bounds__(KNN2_THREADS) void knn_sel_kernel(const T* __restri
   for (int s0 = 0; s0 < NS; s0 += KSEL_STRIPS) {     // uniform trip count: workgroup barriers inside
     const int s = s0 + pair;
     {  // ---- phase A: this wave's half of the column tiles of strip s
-      const float* arow = yn + (16 * s + lr) * LD + 4 * rq;
       for (int tn = hw * (NS / 2); tn < (hw + 1) * (NS / 2); tn += 4) {
-        f32x4 acc[4];
+        f32x4 lead[4], corr[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const float* brow = yn + (16 * tn + lr) * LD + 4 * rq;
-        for (int ch = 0; ch < C; ch += 16) {
-          const f32x4 fa = *reinterpret_cast<const f32x4*>(arow + ch);
-          f32x4 fb[4];
+        for (int u = 0; u < 4; ++u) lead[u] = corr[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int kc = 0; kc < KC; kc += 4) {
+          const KnnFrag fa = knn_frag(img, kc + rq, 16 * s + lr, KC, N);
+          KnnFrag fb[4];
 #pragma unroll
-          for (int u = 0; u < 4; ++u) fb[u] = *reinterpret_cast<const f32x4*>(brow + u * 16 * LD + ch);
+          for (int u = 0; u < 4; ++u) fb[u] = knn_frag(img, kc + rq, 16 * (tn + u) + lr, KC, N);
 #pragma unroll
-          for (int e = 0; e < 4; ++e)
-#pragma unroll
-            for (int u = 0; u < 4; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[e], fb[u][e], acc[u], 0, 0, 0);
+          for (int u = 0; u < 4; ++u) knn_mfma3(fa, fb[u], lead[u], corr[u]);
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -811,7 +701,7 @@ __global__ __launch_bounds__(KNN2_THREADS) void knn_sel_kernel(const T* __restri
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             const float si = sq[16 * s + 4 * rq + e];
-            strip[(4 * rq + e) * SLD + 16 * (tn + u) + lr] = (si + (-2.f * acc[u][e])) + sj;
+            strip[(4 * rq + e) * SLD + 16 * (tn + u) + lr] = (si + (-2.f * (lead[u][e] + corr[u][e]))) + sj;
           }
         }
       }
@@ -878,8 +768,8 @@ __global__ __launch_bounds__(KNN2_THREADS) void knn_sel_kernel(const T* __restri
 template <typename T>
 int launch_knn_sel(const void* r, int ldr, const float* scale, const float* shift, int B, int N, int C, int k,
                    int dilation, int32_t* idx, hipStream_t s) {
-  const size_t bytes = ((size_t)N * (C + 4) + N + (size_t)KSEL_STRIPS * 16 * (N + 4) + (size_t)KNN2_WAVES * (64 + 2 * N + 8)) *
-                       sizeof(float);
+  const size_t bytes = (size_t)2 * N * C * 2 + ((size_t)N + (size_t)KSEL_STRIPS * 16 * (N + 4) + (size_t)KNN2_WAVES * (64 + 2 * N + 8)) *
+                                               sizeof(float);
   if (bytes > 160 * 1024) return 1;
   static bool configured = false;
   if (!configured) {
@@ -896,7 +786,7 @@ int launch_knn_sel(const void* r, int ldr, const float* scale, const float* shif
 template <typename T, int NT>
 int launch_knn_rank_nt(const void* r, int ldr, const float* scale, const float* shift, int B, int N, int C, int k,
                        int dilation, int32_t* idx, hipStream_t s) {
-  const size_t bytes = ((size_t)N * (C + 4) + N + (size_t)KNN2_WAVES * 16 * (N + 4)) * sizeof(float);
+  const size_t bytes = (size_t)2 * N * C * 2 + ((size_t)N + (size_t)KNN2_WAVES * 16 * (N + 4)) * sizeof(float);
   static bool configured = false;
   if (!configured) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(knn_rank_kernel<T, NT>),
