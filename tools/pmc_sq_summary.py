@@ -4,8 +4,10 @@ SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE G
 
     mfma_busy  = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 * 1024)   # busy matrix-pipe cycles / (kernel cycles x SIMDs):
                  GRBM_GUI_ACTIVE is summed over the 8 XCDs (MI355X_MICROARCH.md, DVFS give-back), 256 CUs x 4 SIMDs
+    mfma_wall  = SQ_VALU_MFMA_BUSY_CYCLES / (duration x 2.4 GHz x 1024)    # the same against the kernel's wall time at the MAXIMUM
+                 clock: a lower bound that does not depend on GRBM_GUI_ACTIVE, which over-counts on dispatches shorter than ~0.3 ms
+                 (the guide's caveat; GRBM / 8 / duration read 3-14 "GHz" on these 5-30 us kernels, so that column is gone)
     lds_confl  = SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE                  # share of LDS-array cycles that are conflict replays
-    clock_GHz  = GRBM_GUI_ACTIVE / 8 / kernel duration                    # reads high below ~0.3 ms (guide), indicative only
 
 Usage: pmc_sq_summary.py counter_collection.csv[.gz] kernel_trace.csv > profiles/<name>/pmc_sq_summary.txt"""
 import collections, csv, gzip, re, sys
@@ -41,8 +43,9 @@ for k, c in acc.items():
         continue
     cyc = gui / 8.0
     rows.append((dur[k], k, cnt[k], dur[k] / cnt[k] / 1e3, c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (cyc * 1024),
-                 c.get("SQ_LDS_BANK_CONFLICT", 0.0) / max(c.get("SQ_LDS_IDX_ACTIVE", 0.0), 1.0), cyc / max(dur[k], 1.0)))
+                 c.get("SQ_LDS_BANK_CONFLICT", 0.0) / max(c.get("SQ_LDS_IDX_ACTIVE", 0.0), 1.0),
+                 c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (max(dur[k], 1.0) * 2.4 * 1024)))
 rows.sort(reverse=True)
-print(f"{'kernel':100s} {'launches':>8s} {'avg us':>8s} {'mfma_busy':>9s} {'lds_confl':>9s} {'clock GHz':>9s}")
-for d, k, n, us, mf, lc, ghz in rows[:40]:
-    print(f"{k[:100]:100s} {n:8d} {us:8.1f} {mf:9.3f} {lc:9.3f} {ghz:9.2f}")
+print(f"{'kernel':100s} {'launches':>8s} {'avg us':>8s} {'mfma_busy':>9s} {'mfma_wall':>9s} {'lds_confl':>9s}")
+for d, k, n, us, mf, lc, mw in rows[:40]:
+    print(f"{k[:100]:100s} {n:8d} {us:8.1f} {mf:9.3f} {mw:9.3f} {lc:9.3f}")

@@ -11,11 +11,11 @@ modes=${@:-train infer deep}
 out=gpurun_out/$name
 mkdir -p $out
 export TMPDIR=/tmp
-common="--no-cpu-baseline --no-roofline"
+common="--no-cpu-baseline --no-roofline --no-other"
 for mode in $modes; do
   case $mode in
     train) flags=""; tag="" ;;
-    infer) flags="--mode infer --clips 20480"; tag="_infer" ;;
+    infer) flags="--mode infer --clips 20480 --infer-streams 1"; tag="_infer" ;;
     deep)  flags="--deep"; tag="_deep" ;;
   esac
   eager="--no-graph --no-overlap"; [ $mode = infer ] && eager=""
@@ -33,6 +33,7 @@ for mode in $modes; do
     python3 tools/trace_summary.py $out/stats$tag 8 > $out/trace_summary$tag.txt || true
   fi
   rm -rf $out/stats$tag
-  python3 bench.py $flags > $out/bench$tag.json 2> $out/bench$tag.log
+  [ $mode = infer ] && flags="--mode infer"
+  python3 bench.py --no-other $flags > $out/bench$tag.json 2> $out/bench$tag.log
   tail -c 400 $out/bench$tag.json; echo
 done
