@@ -246,6 +246,7 @@ __device__ __forceinline__ void stage_store_abn(char* lds, const StageRegs<ROWS,
   using G = TileGeom<ROWS, true, true, true, KS, NT>;
   static_assert(NT % G::CPR == 0, "a thread keeps its reduction channels over the chunks of a stage");
   const int t = threadIdx.x;
+  const bool masked = slope != 1.f;          // uniform: a BatchNorm without an activation behind it needs no mask (g = dy)
 #pragma unroll
   for (int q = 0; q < G::VEC; ++q) {
     const int idx = t + NT * q;
@@ -258,15 +259,24 @@ __device__ __forceinline__ void stage_store_abn(char* lds, const StageRegs<ROWS,
       const int l = e & 3;
       const f32x2 x = {(float)hr[e], (float)hr[e + 1]}, d = {(float)hd[e], (float)hd[e + 1]};
       const f32x2 sc = {sc4[l], sc4[l + 1]};
-      const f32x2 z = sc * x + f32x2{sh4[l], sh4[l + 1]};
-      const f32x2 ds = d * slope;
-      const f32x2 g = {z[0] > 0.f ? d[0] : ds[0], z[1] > 0.f ? d[1] : ds[1]};
+      f32x2 g = d;
+      if (masked) {
+        const f32x2 z = sc * x + f32x2{sh4[l], sh4[l + 1]};
+        const f32x2 ds = d * slope;
+        g = f32x2{z[0] > 0.f ? d[0] : ds[0], z[1] > 0.f ? d[1] : ds[1]};
+      }
       const f32x2 v = sc * g + (f32x2{p4[l], p4[l + 1]} * x + f32x2{q4[l], q4[l + 1]});
       o[e] = (__bf16)v[0];
       o[e + 1] = (__bf16)v[1];
     }
+#ifdef NSID_ABN_NOMATH      // diagnosis builds (tools/build_variant.sh): what the operand transform / the side store cost
+    o = __builtin_bit_cast(bf16x8, dy.v[q]) ;
+    asm volatile("" :: "v"(rr.v[q]));
+#endif
     *reinterpret_cast<bf16x8*>(lds + row * G::STRIDE + kc * 16) = o;
+#ifndef NSID_ABN_NOSIDE
     if (side != nullptr) *reinterpret_cast<bf16x8*>(side + ((long)row * side_ld + kc * 8) * 2) = o;
+#endif
   }
 }
 
@@ -648,7 +658,11 @@ void gemm_kernel(const GemmArgs p) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int i = i0 + wm0 + 16 * a + 4 * rq + r;
+#ifdef NSID_WGRAD_PLAINSTORE        // diagnosis build: what the fp32 atomics of the split reduction cost inside the step (results wrong)
+          if ((FULL || i < p.I) && jok) crow[(long)(16 * a + r) * p.ldc + 16 * b] = acc[a][b][r];
+#else
           if ((FULL || i < p.I) && jok) atomicAdd(crow + (long)(16 * a + r) * p.ldc + 16 * b, acc[a][b][r]);
+#endif
         }
     }
   } else {
