@@ -197,3 +197,40 @@ def test_rccl_step_captured_in_hipgraph(rccl_comm):
     for k, v in ref[3].items():
         if k.endswith(("running_mean", "running_var")):
             assert float((m.state_dict()[k] - v).abs().max()) < 1e-4, k
+
+
+def _run_bench_rehearsal(n, extra):
+    """the whole N-rank orchestration of bench.py on this one-GPU box: torch.distributed.run starts N fresh ranks that share the
+    device, torch.distributed/gloo carries the data-path collectives (RCCL refuses two ranks on one GPU)"""
+    import json
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["NSID_BENCH_REHEARSAL"] = "gloo"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", str(n), "--no-cpu-baseline", "--no-roofline"] + extra
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert len(lines) == 1, (len(lines), r.stdout[-500:])            # exactly one JSON line, from rank 0
+    return json.loads(lines[0])
+
+
+def test_bench_orchestration_rehearsal_two_and_four_ranks():
+    """`bench.py --gpus N` end to end before the driver's first multi-GPU run — sharded inputs, z all-gather +
+    global NT-Xent, bucketed gradient all-reduce through the reducer hooks, barrier + max-over-ranks timing, ONE JSON line.
+    (What only the 8-GPU node can show stays untested: ncclCommInitRank across processes, RCCL kernels in a captured graph.)"""
+    for n in (2, 4):                                                   # at most 4 processes on the card (the box allows 6)
+        d = _run_bench_rehearsal(n, ["--steps", "2", "--warmup", "1", "--batch", "16"])
+        assert d["n_gpus"] == n and d["steps"] == 2 and d["scaling"] == "weak"
+        assert d["config"]["global_batch"] == 16 * n and d["config"]["parallelism"] == f"dp{n}"
+        assert "REHEARSAL" in d["config"]["collectives"] and d["config"]["hipgraph"] is False
+        assert d["value"] > 0 and abs(d["value"] - 16 * n * 2 / (d["ms_per_step"] * 2e-3)) < 0.02 * d["value"]
+        assert 0 < d["config"]["final_loss"] < 10
+    d = _run_bench_rehearsal(2, ["--mode", "infer", "--clips", "4096", "--micro-batch", "1024", "--warmup", "1"])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["parallelism"] == "shard2" and d["value"] > 0
