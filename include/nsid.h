@@ -96,6 +96,12 @@ int nsid_linear_fwd(const void* x, int ldx, const void* w, int w_dtype, const fl
 int nsid_linear_fwd_res(const void* x, int ldx, const void* w, int w_dtype, const float* bias, const void* addend, int ldadd,
                         void* out, int ldo, int M, int Nout, int K, int groups, const float* in_scale,
                         const float* in_shift, int act_in, int act_dtype, void* stream);
+/* eval-mode FFN in ONE launch: out = x + W2 relu(W1 x + b1) + b2 with both BatchNorms folded into (W1, b1) (H x C) and (W2, b2)
+   (C x H) — FFN.forward, encoder/graph_encoder.py:82-89, in eval mode. x, out: M x C bf16 contiguous; W1, W2: bf16 row-major;
+   b1, b2 fp32. The M x H hidden tensor never reaches HBM. Returns 1 (nothing launched) outside C in {64, 128}, H = 4C, M % 128 == 0:
+   the caller then runs nsid_linear_fwd + nsid_linear_fwd_res. */
+int nsid_ffn_fused_fwd(const void* x, const void* w1, const float* b1, const void* w2, const float* b2, void* out, int M, int C,
+                       int H, void* stream);
 /* backward-data: din[m, g*K+k] = addend[m, g*K+k] + sum_n dout[m, g*Nout+n] * w[g*Nout+n, k]   (addend optional) */
 int nsid_linear_bwd_data(const void* dout, int ldd, const void* w, int w_dtype, const void* addend, int ldadd,
                          void* din, int ldi, int M, int Nout, int K, int groups,

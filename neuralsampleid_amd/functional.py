@@ -295,6 +295,15 @@ def grapher_backward(dx1: Tensor, P, S, G) -> Tensor:
 def ffn_forward(x1: Tensor, P, S: Optional[dict], training: bool) -> Tensor:
     M, C = x1.shape
     H = P["fc1.0.weight"].shape[0]
+    if fold_eval(training, S) and C in (64, 128) and H == 4 * C and M % 128 == 0:
+        # forward-only, both BatchNorms folded into their convs: one launch, the hidden tensor never leaves the CU (csrc/ffn_fused.hip)
+        g1, be1, rm1, rv1, _, _ = _bn(P, S, "fc1.1.")
+        g2, be2, rm2, rv2, _, _ = _bn(P, S, "fc2.1.")
+        w1f, b1f = ops.folded_conv_bn(ops.w2d(P["fc1.0.weight"]), None, g1, be1, rm1, rv1)
+        w2f, b2f = ops.folded_conv_bn(ops.w2d(P["fc2.0.weight"]), None, g2, be2, rm2, rv2)
+        out = ops.ffn_fused_fwd(x1, w1f, b1f, w2f, b2f, M, C, H)
+        if out is not None:
+            return out
     r4, a4 = conv_bn(x1, M, C, H, P["fc1.0.weight"], None, _bn(P, S, "fc1.1."), training, folded_act=ACT_RELU)
     if fold_eval(training, S):     # r4 already is relu(BN(conv)) (a4 is None)
         return conv_bn(r4, M, H, C, P["fc2.0.weight"], None, _bn(P, S, "fc2.1."), training, in_aff=a4, act_in=ACT_RELU,

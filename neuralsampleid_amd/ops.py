@@ -308,6 +308,33 @@ def linear_fwd(x, w, bias, M, Nout, K, groups=1, in_scale=None, in_shift=None, a
     return out, stat
 
 
+FUSE_EVAL_FFN = True          # eval-mode FFN (BatchNorms folded) as one launch for the C = 64 / 128 stages (csrc/ffn_fused.hip)
+
+
+def ffn_fused_fwd(x, w1f, b1f, w2f, b2f, M, C, H):
+    """out = x + w2f relu(w1f x + b1f) + b2f in one launch (folded eval-mode FFN); None when the shape is outside the fused form"""
+    _chk(w1f, b1f, w2f, b2f)
+    if _act(x) != BF16 or x.shape != (M, C) or not FUSE_EVAL_FFN:
+        return None
+    w1, d1 = _weight(w1f, BF16, C)
+    w2, d2 = _weight(w2f, BF16, H)
+    if d1 != BF16 or d2 != BF16:
+        return None
+    out = torch.empty_like(x)
+    rc = [0]
+
+    def launch():
+        rc[0] = lib.nsid_ffn_fused_fwd(_p(x), _p(w1), _p(b1f), _p(w2), _p(b2f), _p(out), M, C, H, _stream())
+    _timed("ffn_fused_kernel", 4.0 * M * C * H, 2.0 * x.element_size() * M * C + 4.0 * C * H, launch, (M, C, H, 1))
+    if rc[0] == 1:
+        if PROFILE is not None:
+            PROFILE.records.pop()
+        return None
+    if rc[0] != 0:
+        raise RuntimeError(f"nsid_ffn_fused_fwd failed: {rc[0]}")
+    return out
+
+
 FUSE_BN_BWD_REDUCE = True     # backward-data GEMMs emit the next BatchNorm-backward's column sums (bf16 storage only)
 
 

@@ -312,6 +312,35 @@ def test_bn_backward_on_the_backward_data_operand_load(ops, M, Nout, K, groups, 
     assert relerr(din1, din_ref) < 6e-3, relerr(din1, din_ref)
 
 
+@pytest.mark.parametrize("M,C", [(2048, 64), (128, 64), (4096, 128), (65536, 64)])
+def test_eval_ffn_in_one_launch(ops, M, C):
+    """csrc/ffn_fused.hip: out = x + W2 relu(W1 x + b1) + b2 (FFN.forward in eval mode with both BatchNorms folded) in one launch,
+    the M x 4C hidden tensor never written: against an fp64 evaluation with the same two bf16 rounding points (hidden, output) and
+    against the two-launch form (nsid_linear_fwd with the ReLU epilogue + nsid_linear_fwd_res)"""
+    from neuralsampleid_amd._lib import launch_counters
+    H = 4 * C
+    x = synth_randn(f"ffx{M}{C}", M, C).to(BF).to(DEV)
+    w1 = (synth_randn(f"ffw1{C}", H, C) * C ** -0.5).to(DEV)
+    w2 = (synth_randn(f"ffw2{C}", C, H) * H ** -0.5).to(DEV)
+    b1, b2 = (0.3 * synth_randn(f"ffb1{C}", H)).to(DEV), (0.3 * synth_randn(f"ffb2{C}", C)).to(DEV)
+    for w in (w1, w2):
+        ops.SHADOWS.register(w, ops.f32_to_bf16(w), owner=w)
+    launch_counters(reset=True)
+    out = ops.ffn_fused_fwd(x, w1, b1, w2, b2, M, C, H)
+    torch.cuda.synchronize()
+    assert out is not None and launch_counters()["ffn_fused"] == 1
+    hid = torch.relu(x.double() @ bfr(w1).t() + b1.double())
+    ref = x.double() + bfr(hid.float()) @ bfr(w2).t() + b2.double()
+    assert relerr(out, ref) < 2.5e-3, relerr(out, ref)                       # one bf16 rounding of the output
+    err = (out.double() - ref).abs() / (ref.abs() + 1.0)
+    assert float(err.max()) < 1.2e-2                                        # no stray element (a mis-indexed tile would be O(1))
+    h2, _ = ops.linear_fwd(x, w1, b1, M, H, C, act_out=ops.ACT_RELU)
+    two, _ = ops.linear_fwd(h2, w2, b2, M, C, H, addend=x)
+    assert relerr(out, two) < 1e-3 and float((out != two).float().mean()) < 0.02      # same rounding points, another summation order
+    assert ops.ffn_fused_fwd(x[:, :32].contiguous(), w1[:128, :32].contiguous(), b1[:128], w2[:32, :128].contiguous(), b2[:32],
+                             M, 32, 128) is None                            # outside the fused form: the caller falls back
+
+
 @pytest.mark.parametrize("M,Nout,K,groups,affine", [(512, 256, 512, 1, True), (200, 64, 64, 1, False), (384, 128, 128, 4, True)])
 def test_linear_fwd_with_residual_addend(ops, M, Nout, K, groups, affine):
     """nsid_linear_fwd_res: out = f(x) W^T + bias + addend in one launch (eval path: conv + folded BatchNorm + shortcut)"""
