@@ -102,6 +102,13 @@ int nsid_linear_fwd_res(const void* x, int ldx, const void* w, int w_dtype, cons
    the caller then runs nsid_linear_fwd + nsid_linear_fwd_res. */
 int nsid_ffn_fused_fwd(const void* x, const void* w1, const float* b1, const void* w2, const float* b2, void* out, int M, int C,
                        int H, void* stream);
+/* eval-mode MRConv2d in ONE launch, one workgroup per clip: v = relu(W (*)_4 [y, max_j(y[idx_j] - y)] + b) with the BatchNorm folded
+   into (W, b) — MRConv2d.forward (gcn_lib/torch_vertex.py:19-34) + BasicConv (torch_nn.py:52-76) in eval mode. y: (B*N, C) bf16 plain
+   values (the producer's BatchNorm folded too), idx: (B, N, k) clip-local, w: (2C, C/2) bf16, bias: (2C) fp32, out: (B*N, 2C) bf16.
+   The interleaved (B*N, 2C) tensor of nsid_mr_aggregate_fwd is never formed. Returns 1 (nothing launched) outside C in {64, 128, 256},
+   N*C = 16384, k <= 64: the caller then runs nsid_mr_aggregate_fwd + nsid_linear_fwd. */
+int nsid_mrconv_fused_fwd(const void* y, const int32_t* idx, int B, int N, int C, int k, const void* w, const float* bias, void* out,
+                          void* stream);
 /* backward-data: din[m, g*K+k] = addend[m, g*K+k] + sum_n dout[m, g*Nout+n] * w[g*Nout+n, k]   (addend optional) */
 int nsid_linear_bwd_data(const void* dout, int ldd, const void* w, int w_dtype, const void* addend, int ldadd,
                          void* din, int ldi, int M, int Nout, int K, int groups,

@@ -1,0 +1,196 @@
+// Eval-mode max-relative aggregation + grouped conv (+ folded BatchNorm + ReLU) in ONE launch, one workgroup per clip
+// (MRConv2d.forward, encoder/gcn_lib/torch_vertex.py:19-34 + BasicConv, torch_nn.py:52-76, in eval mode; forward-only extraction):
+//     v[n, g*K + j] = relu( sum_k W[g*K + j][k] * u[n, g*K + k] + b ),   u[n, 2c] = y[n, c],  u[n, 2c+1] = max_j (y[idx[n,j], c] - y[n, c])
+// The interleaved tensor u (M x 2C: 134 MB written and read back per launch pair at a 2 048-clip micro-batch) is never formed: a lane
+// builds the MFMA operand fragment it needs — 4 channels of its node and of the node's neighbours, gathered from the clip's LDS image,
+// max-relative in fp32, rounded to bf16 exactly where the two-launch form rounds u — and feeds it to the matrix core directly.
+// HBM sees y once in and v once out.
+//
+// Tiling: N * C = 16 384 at every stage, so a clip is always 32 KB; 4 waves share the clip's 16-node tiles. The MFMA operands are
+// swapped (A = weight rows, B = nodes) so that a lane ends up with 4 CONSECUTIVE output channels of one node: bias + ReLU + bf16 pack,
+// one 8-byte store into a per-group staging image, then 16-byte coalesced stores. Per group: weights -> LDS (the next group's are in
+// flight meanwhile), barrier, fragments + MFMA for all of the wave's node tiles, epilogue, barrier, copy-out.
+#include "nsid_common.h"
+
+namespace {
+
+struct MrcArgs {
+  const __bf16* y; const int32_t* idx; const __bf16* w; const float* bias; __bf16* out;
+  int k;
+};
+
+// NW waves: min(NW, N/16) groups of node tiles x (NW / that) splits of a group's output tiles. DIRECT: the epilogue stores 8 bytes per
+// lane straight to global memory (32 contiguous bytes per node and instruction; the group's other tiles complete the lines) instead of
+// staging the group's slab in LDS: one barrier and 17-20 KB of LDS less per workgroup (more workgroups per CU).
+template <int C, int NW, bool DIRECT>
+__global__ __launch_bounds__(64 * NW) void mrconv_fused_kernel(const MrcArgs p) {
+  constexpr int MRC_THREADS = 64 * NW;
+  constexpr int N = 16384 / C;               // nodes per clip
+  constexpr int K = C / 2;                   // per group: input (interleaved) channels = output channels
+  constexpr int JT = K / 16, KS = K / 32;    // 16-channel output tiles, 32-deep MFMA steps per group
+  constexpr int WN = (N / 16 < NW) ? N / 16 : NW;      // wave groups across the node tiles
+  constexpr int JS = NW / WN;                // splits of a group's output tiles
+  constexpr int NTW = N / 16 / WN;           // node tiles per wave
+  constexpr int JW = JT / JS;                // output tiles per wave
+  static_assert(JT % JS == 0 && (N / 16) % WN == 0, "whole tiles per wave");
+  constexpr int SY = C * 2 + 16;             // clip image rows: consecutive nodes land on disjoint banks for the 8-byte gathers
+  constexpr int SW = K * 2 + 32;             // weight image rows (fragment reads by ds_read_b128: conflict-free)
+  constexpr int SO = K * 2 + 16;             // staging rows
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* yimg = smem;                         // [N][SY]
+  char* wimg = yimg + N * SY;                // [K][SW]
+  char* oimg = wimg + K * SW;                // [N][SO]  (absent when DIRECT)
+  int* idxl = reinterpret_cast<int*>(oimg + (DIRECT ? 0 : N * SO));     // [N][k]
+  const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int lr = lane & 15, rq = lane >> 4;
+  const int wn = wave % WN, wjs = wave / WN;
+  const long row0 = (long)blockIdx.x * N;
+  const int k = p.k;
+
+  // ---- the clip, its neighbour lists, and the first group's weights
+  constexpr int YV = N * C / 8 / MRC_THREADS;            // 16-byte chunks of the clip per thread (8)
+  constexpr int WV = K * K / 8 / MRC_THREADS > 0 ? K * K / 8 / MRC_THREADS : 1;
+  constexpr int WCH = K * K / 8;                         // 16-byte chunks of one group's weights
+  f32x4 wreg[WV];
+  auto wload = [&](int g) {
+#pragma unroll
+    for (int q = 0; q < WV; ++q) {
+      const int i = t + MRC_THREADS * q;
+      if (WCH % MRC_THREADS == 0 || i < WCH) wreg[q] = *reinterpret_cast<const f32x4*>(p.w + (long)g * K * K + (long)i * 8);
+    }
+  };
+  auto wstore = [&]() {
+#pragma unroll
+    for (int q = 0; q < WV; ++q) {
+      const int i = t + MRC_THREADS * q;
+      if (WCH % MRC_THREADS == 0 || i < WCH) *reinterpret_cast<f32x4*>(wimg + (i / (K / 8)) * SW + (i % (K / 8)) * 16) = wreg[q];
+    }
+  };
+  {
+    f32x4 v[YV];
+#pragma unroll
+    for (int q = 0; q < YV; ++q) {
+      const int i = t + MRC_THREADS * q;
+      v[q] = *reinterpret_cast<const f32x4*>(p.y + (row0 + i / (C / 8)) * C + (i % (C / 8)) * 8);
+    }
+    wload(0);
+    for (int i = t; i < N * k; i += MRC_THREADS) {
+      const int m = p.idx[row0 * k + i];
+      idxl[i] = m < 0 ? 0 : (m >= N ? N - 1 : m);        // ids come from the caller: never read outside the clip
+    }
+#pragma unroll
+    for (int q = 0; q < YV; ++q) {
+      const int i = t + MRC_THREADS * q;
+      *reinterpret_cast<f32x4*>(yimg + (i / (C / 8)) * SY + (i % (C / 8)) * 16) = v[q];
+    }
+  }
+
+  for (int g = 0; g < 4; ++g) {
+    wstore();                                 // (every wave left the previous group's MFMAs behind the barrier below)
+    if (g + 1 < 4) wload(g + 1);
+    __syncthreads();
+    f32x4 acc[NTW][JW];
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+      for (int a = 0; a < JW; ++a) acc[nt][a] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt) {
+      const int n = 16 * (wn + WN * nt) + lr;
+      const int* nb = idxl + n * k;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        // this lane's B fragment: interleaved channels 32 ks + 8 rq .. + 7 of group g = original channels c0 .. c0 + 3
+        const int c0 = g * (C / 4) + 16 * ks + 4 * rq;
+        const bf16x4 own = *reinterpret_cast<const bf16x4*>(yimg + n * SY + c0 * 2);
+        float ys[4], best[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { ys[e] = (float)own[e]; best[e] = -__builtin_inff(); }
+        for (int j = 0; j < k; ++j) {
+          const bf16x4 v = *reinterpret_cast<const bf16x4*>(yimg + nb[j] * SY + c0 * 2);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float d = (float)v[e] - ys[e];
+            best[e] = d > best[e] ? d : best[e];          // strict: the first maximum wins, NaN never enters (as torch.max / mr.hip)
+          }
+        }
+        bf16x8 fb;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { fb[2 * e] = own[e]; fb[2 * e + 1] = (__bf16)best[e]; }
+#pragma unroll
+        for (int a = 0; a < JW; ++a) {
+          const bf16x8 fa = *reinterpret_cast<const bf16x8*>(wimg + (16 * (wjs * JW + a) + lr) * SW + (4 * ks + rq) * 16);
+          acc[nt][a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb, acc[nt][a], 0, 0, 0);
+        }
+      }
+    }
+    // ---- epilogue: D[j = 16 a + 4 rq + e][node lr] + bias, ReLU, bf16: 4 consecutive channels of one node per lane
+#pragma unroll
+    for (int a = 0; a < JW; ++a) {
+      const int j0 = 16 * (wjs * JW + a) + 4 * rq;
+      const f32x4 bj = *reinterpret_cast<const f32x4*>(p.bias + g * K + j0);
+#pragma unroll
+      for (int nt = 0; nt < NTW; ++nt) {
+        const int n = 16 * (wn + WN * nt) + lr;
+        bf16x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (__bf16)fmaxf(acc[nt][a][e] + bj[e], 0.f);
+        if constexpr (DIRECT) *reinterpret_cast<bf16x4*>(p.out + (row0 + n) * (2 * C) + g * K + j0) = o;
+        else *reinterpret_cast<bf16x4*>(oimg + n * SO + j0 * 2) = o;
+      }
+    }
+    __syncthreads();                          // (DIRECT: every wave is done with this group's weight image)
+    if constexpr (!DIRECT) {
+      constexpr int OCH = N * K / 8;          // 16-byte chunks of the group's output slab
+#pragma unroll
+      for (int q = 0; q < OCH / MRC_THREADS; ++q) {
+        const int i = t + MRC_THREADS * q;
+        const int n = i / (K / 8), ch = i % (K / 8);
+        *reinterpret_cast<f32x4*>(p.out + (row0 + n) * (2 * C) + g * K + ch * 8) = *reinterpret_cast<const f32x4*>(oimg + n * SO + ch * 16);
+      }
+    }
+  }
+}
+
+template <int C, int NW, bool DIRECT>
+int mrc_launch_v(const MrcArgs& p, int B, hipStream_t s) {
+  constexpr int N = 16384 / C, K = C / 2;
+  const size_t bytes = (size_t)N * (C * 2 + 16) + (size_t)K * (K * 2 + 32) + (DIRECT ? 0 : (size_t)N * (K * 2 + 16)) + (size_t)N * p.k * 4;
+  if (bytes > 160 * 1024) return 1;
+  static bool configured = false;
+  if (!configured) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(mrconv_fused_kernel<C, NW, DIRECT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            160 * 1024) != hipSuccess)
+      return NSID_ELAUNCH;
+    configured = true;
+  }
+  NSID_LAUNCH((mrconv_fused_kernel<C, NW, DIRECT>), dim3(B), dim3(64 * NW), bytes, s, p);
+  return nsid_launch_status();
+}
+
+template <int C>
+int mrc_launch(const MrcArgs& p, int B, hipStream_t s) {
+  const int v = (int)nsid_tune(NSID_T_mrconv_variant);         // bit 0: 8 waves, bit 1: direct stores
+  switch (v & 3) {
+    case 0: return mrc_launch_v<C, 4, false>(p, B, s);
+    case 1: return mrc_launch_v<C, 8, false>(p, B, s);
+    case 2: return mrc_launch_v<C, 4, true>(p, B, s);
+    default: return mrc_launch_v<C, 8, true>(p, B, s);
+  }
+}
+
+}  // namespace
+// y: (B*N, C) bf16 contiguous node-major features (BatchNorm already folded: plain values); idx: (B, N, k) clip-local int32;
+// w: (2C, C/2) bf16 = the grouped conv's weight with its BatchNorm folded in, bias: (2C) fp32; out: (B*N, 2C) bf16.
+// Returns 1 (nothing launched) outside the fused form: C in {64, 128, 256} with N * C = 16 384, k <= 64.
+extern "C" int nsid_mrconv_fused_fwd(const void* y, const int32_t* idx, int B, int N, int C, int k, const void* w, const float* bias,
+                                     void* out, void* stream) {
+  NSID_REQUIRE(y && idx && w && bias && out && B > 0 && k > 0);
+  if (!(C == 64 || C == 128 || C == 256) || (long)N * C != 16384 || k > 64) return 1;
+  NSID_REQUIRE(nsid_aligned16(y) && nsid_aligned16(w) && nsid_aligned16(bias) && nsid_aligned16(out));
+  MrcArgs p{static_cast<const __bf16*>(y), idx, static_cast<const __bf16*>(w), bias, static_cast<__bf16*>(out), k};
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int rc = C == 64 ? mrc_launch<64>(p, B, s) : (C == 128 ? mrc_launch<128>(p, B, s) : mrc_launch<256>(p, B, s));
+  if (rc == NSID_OK) nsid_count(NSID_C_mrconv_fused);
+  return rc;
+}

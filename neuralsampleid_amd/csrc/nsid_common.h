@@ -158,7 +158,8 @@ static inline bool nsid_aligned16(const void* p) { return (reinterpret_cast<uint
   X(knn_strips, 0)             /* 1: always the general strip kernel (tests of the fallback) */                               \
   X(mr_grid_stride, 0)         /* 1: grid-stride aggregation instead of the LDS-staged per-clip kernel */                     \
   X(mr_split, 0)               /* channel split of the LDS-staged aggregation (0 = heuristic) */                              \
-  X(ffn_waves, 8)              /* waves per workgroup of the fused eval-mode FFN (4 or 8) */
+  X(ffn_waves, 8)              /* waves per workgroup of the fused eval-mode FFN (4 or 8) */                                  \
+  X(mrconv_variant, 3)         /* fused eval-mode aggregation + grouped conv: bit 0 = 8 waves, bit 1 = direct 8-byte stores */
 
 enum NsidTuneKey {
 #define NSID_TUNE_ENUM(name, def) NSID_T_##name,
@@ -187,7 +188,8 @@ static inline long nsid_tune(NsidTuneKey k) { return g_nsid_tune[k]; }
   X(bn_bwd_apply) X(bn_bwd_apply_capped)                                                        \
   X(knn2) X(knn_rank) X(knn_sel) X(knn_strips)                                                  \
   X(mr_fwd_lds) X(mr_fwd_grid)                                                                  \
-  X(ffn_fused)            /* eval-mode FFN in one launch (ffn_fused.hip) */
+  X(ffn_fused)            /* eval-mode FFN in one launch (ffn_fused.hip) */                     \
+  X(mrconv_fused)         /* eval-mode max-relative aggregation + grouped conv in one launch (mrconv_fused.hip) */
 
 enum NsidCounterKey {
 #define NSID_CNT_ENUM(name) NSID_C_##name,

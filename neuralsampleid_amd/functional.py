@@ -243,10 +243,17 @@ def grapher_forward(x0: Tensor, P, S: Optional[dict], B: int, N: int, k: int, di
         if TAPE.replay is not None:
             idx = TAPE.replay[TAPE.pos].to(device=idx.device, dtype=torch.int32).contiguous()
             TAPE.pos = (TAPE.pos + 1) % len(TAPE.replay) if TAPE.cyclic else TAPE.pos + 1
-    u, amax = ops.mr_aggregate_fwd(r1, idx, B, N, C, a1, want_argmax=S is not None)
     pre = "graph_conv.gconv.nn."
-    r2, a2 = conv_bn(u, M, C // 2, C // 2, P[pre + "0.weight"], P[pre + "0.bias"], _bn(P, S, pre + "1."), training,
-                     groups=4, folded_act=ACT_RELU)
+    r2 = None
+    if fold_eval(training, S) and a1 is not None and a1.identity:
+        # forward-only, BatchNorms folded: aggregation + grouped conv in one launch per clip, the interleaved tensor u never formed
+        gg, gb, grm, grv, _, _ = _bn(P, S, pre + "1.")
+        wgf, bgf = ops.folded_conv_bn(ops.w2d(P[pre + "0.weight"]), P[pre + "0.bias"], gg, gb, grm, grv)
+        r2, a2 = ops.mrconv_fused_fwd(r1, idx, B, N, C, wgf, bgf), None
+    if r2 is None:
+        u, amax = ops.mr_aggregate_fwd(r1, idx, B, N, C, a1, want_argmax=S is not None)
+        r2, a2 = conv_bn(u, M, C // 2, C // 2, P[pre + "0.weight"], P[pre + "0.bias"], _bn(P, S, pre + "1."), training,
+                         groups=4, folded_act=ACT_RELU)
     if fold_eval(training, S):   # conv + BatchNorm + shortcut in one launch; r2 already is relu(BN(conv)) (a2 is None)
         return conv_bn(r2, M, 2 * C, C, P["fc2.0.weight"], P["fc2.0.bias"], _bn(P, S, "fc2.1."), training,
                        in_aff=a2, act_in=ACT_RELU, residual=x0)[0]

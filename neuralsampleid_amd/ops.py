@@ -335,6 +335,35 @@ def ffn_fused_fwd(x, w1f, b1f, w2f, b2f, M, C, H):
     return out
 
 
+FUSE_EVAL_MRCONV = True       # eval-mode max-relative aggregation + grouped conv as one launch (csrc/mrconv_fused.hip)
+
+
+def mrconv_fused_fwd(y, idx, B, N, C, wf, bf):
+    """relu(grouped conv([y, max-relative(y)]) + b) with the BatchNorm folded into (wf, bf), one workgroup per clip; the interleaved
+    (B*N, 2C) tensor is never formed. None when the shape is outside the fused form."""
+    _chk(wf, bf)
+    if not FUSE_EVAL_MRCONV or _act(y) != BF16 or y.shape != (B * N, C) or idx.dtype != torch.int32 or not idx.is_contiguous():
+        return None
+    w, dw = _weight(wf, BF16, C // 2)
+    if dw != BF16:
+        return None
+    k = idx.shape[-1]
+    out = torch.empty((B * N, 2 * C), device=y.device, dtype=y.dtype)
+    rc = [0]
+
+    def launch():
+        rc[0] = lib.nsid_mrconv_fused_fwd(_p(y), _p(idx), B, N, C, k, _p(w), _p(bf), _p(out), _stream())
+    _timed("mrconv_fused_kernel", 2.0 * B * N * (C // 2) * (C // 2) * 4, float(B) * N * (3 * C * y.element_size() + k * 4), launch,
+           (B * N, C // 2, C // 2, 4))
+    if rc[0] == 1:
+        if PROFILE is not None:
+            PROFILE.records.pop()
+        return None
+    if rc[0] != 0:
+        raise RuntimeError(f"nsid_mrconv_fused_fwd failed: {rc[0]}")
+    return out
+
+
 FUSE_BN_BWD_REDUCE = True     # backward-data GEMMs emit the next BatchNorm-backward's column sums (bf16 storage only)
 
 

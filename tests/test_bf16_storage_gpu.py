@@ -312,6 +312,43 @@ def test_bn_backward_on_the_backward_data_operand_load(ops, M, Nout, K, groups, 
     assert relerr(din1, din_ref) < 6e-3, relerr(din1, din_ref)
 
 
+@pytest.mark.parametrize("B,C,k", [(5, 64, 3), (3, 128, 5), (4, 256, 3), (2, 256, 18), (64, 64, 3)])
+def test_eval_mrconv_in_one_launch(ops, B, C, k):
+    """csrc/mrconv_fused.hip: max-relative aggregation + grouped conv (+ folded BatchNorm + ReLU) in one launch per clip, the
+    interleaved (B*N, 2C) tensor never formed: against the two-launch form (nsid_mr_aggregate_fwd + grouped nsid_linear_fwd with the
+    ReLU epilogue: same bf16 rounding of the aggregated values, same MFMA) and against an fp64 evaluation"""
+    from neuralsampleid_amd._lib import launch_counters
+    N = 16384 // C
+    y = synth_randn(f"mcy{B}{C}", B * N, C).to(BF).to(DEV)
+    g = torch.Generator().manual_seed(C + k)
+    idx = torch.randint(0, N, (B, N, k), generator=g, dtype=torch.int32)
+    idx[:, :, 0] = torch.arange(N, dtype=torch.int32)                      # self first, as the graph builder emits it
+    idx = idx.to(DEV)
+    w = (synth_randn(f"mcw{C}", 2 * C, C // 2) * (C // 2) ** -0.5).to(DEV)
+    b = (0.2 * synth_randn(f"mcb{C}", 2 * C)).to(DEV)
+    ops.SHADOWS.register(w, ops.f32_to_bf16(w), owner=w)
+    u, _ = ops.mr_aggregate_fwd(y, idx, B, N, C, None, want_argmax=False)
+    two, _ = ops.linear_fwd(u, w, b, B * N, C // 2, C // 2, groups=4, act_out=ops.ACT_RELU)
+    try:
+        for variant in (0, 1, 2, 3):              # 4 / 8 waves x staged / direct stores (tuning key mrconv_variant; default 3)
+            ops.set_tuning("mrconv_variant", variant)
+            launch_counters(reset=True)
+            out = ops.mrconv_fused_fwd(y, idx, B, N, C, w, b)
+            torch.cuda.synchronize()
+            assert out is not None and launch_counters()["mrconv_fused"] == 1
+            assert relerr(out, two) < 1e-3 and float((out != two).float().mean()) < 0.02, variant
+    finally:
+        ops.reset_tuning()
+    yd = y.double().reshape(B, N, C).cpu()
+    nbr = torch.gather(yd.unsqueeze(2).expand(B, N, k, C), 1, idx.cpu().long().unsqueeze(-1).expand(B, N, k, C))
+    m = (nbr - yd.unsqueeze(2)).max(2).values
+    ud = torch.stack([yd, bfr(m.float())], -1).reshape(B * N, 2 * C)        # interleave, aggregated half rounded to bf16
+    K = C // 2
+    ref = torch.cat([ud[:, q * K:(q + 1) * K] @ bfr(w[q * K:(q + 1) * K]).cpu().t() for q in range(4)], 1) + b.double().cpu()
+    assert relerr(out, ref.clamp_min(0)) < 2.5e-3
+    assert ops.mrconv_fused_fwd(y[:, :32].contiguous(), idx, B, N, 32, w[:64, :16].contiguous(), b[:64]) is None
+
+
 @pytest.mark.parametrize("M,C", [(2048, 64), (128, 64), (4096, 128), (65536, 64)])
 def test_eval_ffn_in_one_launch(ops, M, C):
     """csrc/ffn_fused.hip: out = x + W2 relu(W1 x + b1) + b2 (FFN.forward in eval mode with both BatchNorms folded) in one launch,

@@ -6,7 +6,7 @@ set -e
 name=$1; shift
 root=$(cd "$(dirname "$0")/.." && pwd)
 obj=/tmp/nsid_variant_$name; mkdir -p $obj
-all="tuning gemm gemm256 ffn_fused wgrad bn knn mr ntxent misc"
+all="tuning gemm gemm256 ffn_fused mrconv_fused wgrad bn knn mr ntxent misc"
 for s in $all; do
   if [ -n "$ONLY" ] && ! echo " $ONLY " | grep -q " $s "; then
     cp $root/neuralsampleid_amd/csrc/_obj/$s.o $obj/$s.o
