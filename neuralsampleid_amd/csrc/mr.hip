@@ -88,6 +88,10 @@ __global__ __launch_bounds__(MRF_THREADS) void mr_fwd_lds_kernel(const T* __rest
   const int b = blockIdx.x / split, part = blockIdx.x % split, t = threadIdx.x;
   const long row0 = (long)b * N;
   const int CV = C / NV, CVp = CV / split, Cp = CVp * NV, c_lo = part * Cp, total = N * CVp;
+  // the clip's neighbour lists go to LDS too (coalesced, clamped once): read from global inside the neighbour loop they were k
+  // dependent L1 round trips per chunk (k = 18 in the deep configuration)
+  int* nbl = reinterpret_cast<int*>(mrf_smem + (size_t)N * Cp * sizeof(T));
+  for (int q = t; q < N * k; q += MRF_THREADS) nbl[q] = min(max(idx[row0 * k + q], 0), N - 1);
   for (int q = t; q < total; q += MRF_THREADS) {
     const int n = q / CVp, cl = (q % CVp) * NV;
     *reinterpret_cast<f32x4*>(clip + (long)n * Cp + cl) = *reinterpret_cast<const f32x4*>(r + (row0 + n) * ldr + c_lo + cl);
@@ -106,9 +110,9 @@ __global__ __launch_bounds__(MRF_THREADS) void mr_fwd_lds_kernel(const T* __rest
     Chunk<T>::load(clip + (long)n * Cp + cl, y);
 #pragma unroll
     for (int e = 0; e < NV; ++e) y[e] = sc[e] * y[e] + sh[e];
-    const int32_t* nb = idx + (row0 + n) * k;
+    const int* nb = nbl + n * k;
     for (int j = 0; j < k; ++j) {
-      const int m = min(max(nb[j], 0), N - 1);                    // ids come from the caller: never read outside the clip
+      const int m = nb[j];                                        // (clamped when staged: never read outside the clip)
       float v[NV];
       Chunk<T>::load(clip + (long)m * Cp + cl, v);
 #pragma unroll
@@ -282,13 +286,13 @@ extern "C" int nsid_mr_aggregate_fwd(const void* r, int ldr, const float* scale,
   // one workgroup per clip with the clip in LDS, whenever a clip fits (every stage of the GraFP encoder: N*C = 16384)
   const bool use_lds = nsid_tune(NSID_T_mr_grid_stride) == 0;
   const size_t clip_bytes = (size_t)N * C * (dtype == NSID_BF16 ? 2 : 4);
-  if (use_lds && clip_bytes <= 64 * 1024) {
+  if (use_lds && clip_bytes <= 64 * 1024 && (size_t)N * k * 4 <= 64 * 1024) {
     static bool configured = false;
     if (!configured) {
       if (hipFuncSetAttribute(reinterpret_cast<const void*>(mr_fwd_lds_kernel<float>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024) != hipSuccess ||
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess ||
           hipFuncSetAttribute(reinterpret_cast<const void*>(mr_fwd_lds_kernel<__bf16>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024) != hipSuccess)
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess)
         return NSID_ELAUNCH;
       configured = true;
     }
@@ -297,7 +301,7 @@ extern "C" int nsid_mr_aggregate_fwd(const void* r, int ldr, const float* scale,
     int split = force_split > 0 ? force_split : (B <= 256 ? 2 : 1);
     while (split > 1 && (C / nv) % split != 0) split >>= 1;
     NSID_DISPATCH_DTYPE(dtype, T, {
-      NSID_LAUNCH((mr_fwd_lds_kernel<T>), dim3(B * split), dim3(MRF_THREADS), clip_bytes / split, static_cast<hipStream_t>(stream),
+      NSID_LAUNCH((mr_fwd_lds_kernel<T>), dim3(B * split), dim3(MRF_THREADS), clip_bytes / split + (size_t)N * k * 4, static_cast<hipStream_t>(stream),
                   static_cast<const T*>(r), (long)ldr, scale, shift, idx, N, C, k, static_cast<T*>(u), argmax, split);
     });
     return nsid_launch_status();

@@ -26,5 +26,5 @@ for s, e, name in sel:
     name = re.sub(r"\((GemmArgs|WgArgs|.*)\)$", "", name).replace(" ", "")
     acc[name][0] += 1
     acc[name][1] += e - s
-for name, (c, t) in sorted(acc.items(), key=lambda kv: -kv[1][1])[:40]:
+for name, (c, t) in sorted(acc.items(), key=lambda kv: -kv[1][1])[:int(sys.argv[3]) if len(sys.argv) > 3 else 40]:
     print(f"  {name[:110]:110s} x{c / n:6.1f} avg {t / c / 1e3:7.1f} us  per-step {t / 1e3 / n:8.1f} us")
