@@ -221,6 +221,10 @@ def infer_bench(args, model, rank, world, dev, dist):
     if rank == 0:
         # 9.8 MB per view-clip forward at 2 B/element with every conv output materialised once
         fwd_bytes = 9.8e6 * (1.0 if args.precision == "bf16" else 2.0) * args.clips
+        dealt = ""
+        if graphed is not None:          # --from-wave hands over one waveform (= one micro-batch) per call: one stream in use
+            dealt = (f" (one hipGraph replay each, dealt over {graphed.n_streams} HIP streams)" if big is not None
+                     else " (one hipGraph replay per extraction call)")
         result = {
             "metric": "audio clips/sec (forward-only fingerprint extraction, grafp encoder)",
             "value": round(args.clips / elapsed, 1), "unit": "clips/s", "n_gpus": world, "steps": n_mb,
@@ -229,7 +233,7 @@ def infer_bench(args, model, rank, world, dev, dist):
             "data": "synthetic",
             "config": {"workload": f"fingerprint inference, {args.clips} synthetic clips"
                                    f"{' from 16 kHz waveforms (log-mel front end on the GPU)' if args.from_wave else ''}"
-                                   f", eval-mode BN, micro-batch {mb}{f' (one hipGraph replay each, dealt over {graphed.n_streams} HIP streams)' if graphed is not None else ''}, "
+                                   f", eval-mode BN, micro-batch {mb}{dealt}, "
                                    f"GraphEncoder('t', k={args.k}{', deep' if args.deep else ''})",
                        "parallelism": f"shard{world}", "tuning": getattr(args, "tuning", None) or None},
             "roofline": roofline, "step_hbm_frac_algorithmic": round(fwd_bytes / elapsed / 1e9 / HBM_PEAK_GBPS, 4),
