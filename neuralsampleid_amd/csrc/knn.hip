@@ -646,12 +646,31 @@ __global__ __launch_bounds__(KNN2_THREADS) void knn_rank_kernel(const T* __restr
 // ------------------------------------------------------------------------------------------------------------------
 // Large k*dilation on the 256-node graphs (deep configuration, stage 0: the 18 nearest of 256): THRESHOLD SELECT.
 // A pair of waves computes a 16-row distance strip into LDS; then a wave takes a row at a time, 4 values per lane:
-//   1. every lane's minimum, and the rank of that minimum among the 64 lane minima (64 compares on an LDS broadcast);
-//   2. T = the (k*d)-th smallest lane minimum: at least k*d entries are <= T, so every wanted neighbour is <= T;
-//   3. the entries <= T (about k*d .. 4*k*d of them) are compacted into LDS with ballots;
-//   4. each candidate's exact rank among the candidates, (distance, index) order -> neighbour rank/dilation.
-// ~500 instructions per row instead of k*d rounds of a dependent 64-lane arg-min (the strip kernel: 480 us per call here).
+//   1. the values become order-preserving u32 keys (NaN -> largest);
+//   2. T = a key with k*d <= #{key <= T} <= k*d + KSEL_SLACK, by bisection of the key space: one step is four compares, four
+//      ballots and scalar popcounts — no LDS, no cross-lane traffic (about a dozen steps for distances of unit vectors; the search
+//      ends at the exact (k*d)-th smallest key when ties keep the count above the slack);
+//   3. the entries <= T are compacted into LDS with ballots as packed (key << 32 | index) words;
+//   4. each candidate's exact rank among the candidates is one 64-bit compare per other candidate on 16-byte LDS broadcasts,
+//      eight candidates per trip -> neighbour rank / dilation.
+// History: k*d rounds of a dependent 64-lane arg-min (the strip kernel) took 480 us per call here; ranking the 64 lane MINIMA against
+// each other to find a threshold 157 us (tools/knn_sel_trace.py: 5 500 of a row's 9 100 cycles went to those 64 compares on LDS
+// broadcasts, 2 700 to the candidate ranks); this form ~2 700 cycles per row.
 constexpr int KSEL_STRIPS = 4;            // strip buffers per workgroup (8 waves = 4 pairs)
+constexpr int KSEL_SLACK = 3;             // surplus candidates accepted instead of another bisection step
+constexpr int KSEL_CH = 8;                // candidates per ranking trip (four 16-byte broadcasts)
+
+__device__ __forceinline__ unsigned knn_key(float x) {
+  const unsigned b = __float_as_uint(x + 0.f);                       // -0 -> +0: equal distances must get equal keys
+  const unsigned key = b ^ ((unsigned)((int)b >> 31) | 0x80000000u);
+  return x != x ? 0xffffffffu : key;
+}
+__device__ __forceinline__ int knn_count_le(const unsigned (&key)[4], unsigned t) {
+  int c = 0;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) c += __popcll(__ballot(key[e] <= t));
+  return c;
+}
 
 template <typename T>
 __global__ __launch_bounds__(KNN2_THREADS) void knn_sel_kernel(const T* __restrict__ r, long ldr,
@@ -663,7 +682,7 @@ __global__ __launch_bounds__(KNN2_THREADS) void knn_sel_kernel(const T* __restri
   char* img = reinterpret_cast<char*>(smem);         // [2][C/8][N][8] fp16 split images (see knn2_kernel)
   float* sq = smem + 2 * (N * C / 2);                // [N]
   float* strips = sq + N;                            // [KSEL_STRIPS][16][SLD]
-  float* scratch = strips + KSEL_STRIPS * 16 * SLD;  // [8 waves][64 lane minima + 2*N candidate (value, index)]
+  unsigned long long* scratch = reinterpret_cast<unsigned long long*>(strips + KSEL_STRIPS * 16 * SLD);   // [8 waves][N + KSEL_CH]
   const int b = blockIdx.x;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const T* src = r + (long)b * N * ldr;
@@ -672,14 +691,18 @@ __global__ __launch_bounds__(KNN2_THREADS) void knn_sel_kernel(const T* __restri
   __syncthreads();
 
   const int lr = lane & 15, rq = lane >> 4;
-  const int NS = N >> 4;                             // strips == column tiles (a multiple of 8 here: N % 128 == 0)
+  const int NS = N >> 4;                             // strips == column tiles (16 here: N == 256, host-checked)
   const int kd = k * dilation;
+  const unsigned dinv = (65536u + dilation - 1) / dilation;          // rank / dilation == rank * dinv >> 16 for rank < 256
   const int pair = wave >> 1, hw = wave & 1;         // two waves per strip: column halves in phase A, row halves in phase B
   float* strip = strips + pair * 16 * SLD;
-  float* lmins = scratch + wave * (64 + 2 * N + 8);
-  float* cval = lmins + 64;                          // [N + 4]: room for the float4 padding behind the last candidate
-  int* cidx = reinterpret_cast<int*>(cval + N + 4);  // [N + 4]
-  const int NE = N >> 6;                             // entries per lane (2 or 4)
+  unsigned long long* ckeys = scratch + wave * (N + KSEL_CH);
+#ifdef NSID_KSEL_TRACE          // diagnosis build: cycles of wave 0 per section of the loop (tools/knn_sel_trace.py)
+  unsigned long long ksel_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ksel_last = __builtin_amdgcn_s_memtime();
+#define KSEL_MARK(i) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); ksel_acc[i] += now_ - ksel_last; ksel_last = now_; }
+#else
+#define KSEL_MARK(i)
+#endif
   for (int s0 = 0; s0 < NS; s0 += KSEL_STRIPS) {     // uniform trip count: workgroup barriers inside
     const int s = s0 + pair;
     {  // ---- phase A: this wave's half of the column tiles of strip s
@@ -709,67 +732,72 @@ __global__ __launch_bounds__(KNN2_THREADS) void knn_sel_kernel(const T* __restri
     __syncthreads();
     // ---- phase B: rows 8*hw .. 8*hw+7 of the strip, one row at a time
     for (int rr = 8 * hw; rr < 8 * hw + 8; ++rr) {
+      KSEL_MARK(0);
       const float* drow = strip + rr * SLD;
-      float v[4];
-      float lmin = __builtin_inff();
+      unsigned key[4];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        v[e] = e < NE ? drow[lane + 64 * e] : __builtin_inff();
-        lmin = (v[e] < lmin) ? v[e] : lmin;                    // NaN never becomes the minimum
+      for (int e = 0; e < 4; ++e) key[e] = knn_key(drow[lane + 64 * e]);
+      KSEL_MARK(1);
+      // bisection: #{key <= lo} < kd <= #{key <= hi} = chi throughout (key 0 belongs to no value: it would be a negative NaN)
+      unsigned lo = 0u, hi = 0xff800000u;                      // +inf: everything but NaN
+      int chi = knn_count_le(key, hi);
+      int32_t* out = idx + ((long)b * N + 16 * s + rr) * k;
+      if (chi < kd) {                                          // NaN-poisoned row: fewer comparable entries than wanted
+        if (lane < k) out[lane] = lane;
+      } else {
+        while (chi > kd + KSEL_SLACK && hi - lo > 1u) {
+          const unsigned mid = lo + ((hi - lo) >> 1);
+          const int c = knn_count_le(key, mid);
+          if (c >= kd) { hi = mid; chi = c; } else { lo = mid; }
+        }
       }
-      lmins[lane] = lmin;
-      int mrank = 0;                                           // rank of this lane's minimum among the 64 minima
-      for (int m = 0; m < 64; m += 4) {
-        const f32x4 o = *reinterpret_cast<const f32x4*>(lmins + m);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) mrank += (o[e] < lmin || (o[e] == lmin && m + e < lane)) ? 1 : 0;
-      }
-      const unsigned long long pick = __ballot(mrank == kd - 1);
-      const int src_lane = pick ? (__ffsll((long long)pick) - 1) : 0;
-      const float T_ = __shfl(lmin, src_lane, 64);             // (k*d)-th smallest lane minimum
+      KSEL_MARK(2);
       int base = 0;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const bool cand = e < NE && v[e] <= T_;
+        const bool cand = key[e] <= hi;
         const unsigned long long mask = __ballot(cand);
         if (cand) {
-          const int pos = base + __popcll(mask & ((1ull << lane) - 1ull));
-          cval[pos] = v[e];
-          cidx[pos] = lane + 64 * e;
+          const int pos = base + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+          ckeys[pos] = ((unsigned long long)key[e] << 32) | (unsigned)(lane + 64 * e);
         }
         base += __popcll(mask);
       }
-      int32_t* out = idx + ((long)b * N + 16 * s + rr) * k;
-      if (base < kd) {                                         // NaN-poisoned row: fewer finite entries than wanted
-        if (lane < k) out[lane] = lane;
-      }
-      if (lane < 4) cval[base + lane] = __builtin_inff();      // pad to whole float4 groups: +inf precedes nothing
-      for (int c0 = lane; c0 < base; c0 += 64) {
-        const float dv = cval[c0];
-        const int di = cidx[c0];
+      if (lane < KSEL_CH) ckeys[base + lane] = ~0ull;          // pad to whole trips: the largest word precedes nothing
+      KSEL_MARK(3);
+      for (int c0 = lane; c0 < base; c0 += 64) {               // one trip unless ties push more than 64 entries under the threshold
+        const unsigned long long mine = ckeys[c0];
         int rank = 0;
-        // four candidates per pair of 16-byte LDS broadcasts (one element per iteration was two dependent LDS round trips per
-        // candidate: ~9 000 cycles per row, most of the kernel's 7 us per row)
-        for (int m = 0; m < base; m += 4) {
-          const f32x4 ov = *reinterpret_cast<const f32x4*>(cval + m);
-          const int4 oi = *reinterpret_cast<const int4*>(cidx + m);
-          rank += (ov[0] < dv || (ov[0] == dv && oi.x < di)) ? 1 : 0;
-          rank += (ov[1] < dv || (ov[1] == dv && oi.y < di)) ? 1 : 0;
-          rank += (ov[2] < dv || (ov[2] == dv && oi.z < di)) ? 1 : 0;
-          rank += (ov[3] < dv || (ov[3] == dv && oi.w < di)) ? 1 : 0;
+        for (int m = 0; m < base; m += KSEL_CH) {
+          typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+          u64x2 o[KSEL_CH / 2];
+#pragma unroll
+          for (int q = 0; q < KSEL_CH / 2; ++q) o[q] = *reinterpret_cast<const u64x2*>(ckeys + m + 2 * q);
+#pragma unroll
+          for (int q = 0; q < KSEL_CH / 2; ++q) rank += (o[q][0] < mine ? 1 : 0) + (o[q][1] < mine ? 1 : 0);
         }
-        if (rank < kd && rank % dilation == 0) out[rank / dilation] = di;
+        if (rank < kd) {
+          const int q = (int)(((unsigned)rank * dinv) >> 16);
+          if (q * dilation == rank) out[q] = (int)(unsigned)mine;
+        }
       }
+      KSEL_MARK(4);
     }
+    KSEL_MARK(5);
     __syncthreads();
+    KSEL_MARK(6);
   }
+#ifdef NSID_KSEL_TRACE
+  if (g_knn_trace && t == 0)
+    for (int i = 0; i < 8; ++i) g_knn_trace[8 * blockIdx.x + i] = ksel_acc[i];
+#endif
 }
 
 template <typename T>
 int launch_knn_sel(const void* r, int ldr, const float* scale, const float* shift, int B, int N, int C, int k,
                    int dilation, int32_t* idx, hipStream_t s) {
-  const size_t bytes = (size_t)2 * N * C * 2 + ((size_t)N + (size_t)KSEL_STRIPS * 16 * (N + 4) + (size_t)KNN2_WAVES * (64 + 2 * N + 8)) *
-                                               sizeof(float);
+  const size_t bytes = (size_t)2 * N * C * 2 + ((size_t)N + (size_t)KSEL_STRIPS * 16 * (N + 4)) * sizeof(float) +
+                       (size_t)KNN2_WAVES * (N + KSEL_CH) * sizeof(unsigned long long);
   if (bytes > 160 * 1024) return 1;
   static bool configured = false;
   if (!configured) {
