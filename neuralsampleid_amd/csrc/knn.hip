@@ -644,32 +644,42 @@ __global__ __launch_bounds__(KNN2_THREADS) void knn_rank_kernel(const T* __restr
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// Large k*dilation on the 256-node graphs (deep configuration, stage 0: the 18 nearest of 256): THRESHOLD SELECT.
-// A pair of waves computes a 16-row distance strip into LDS; then a wave takes a row at a time, 4 values per lane:
-//   1. the values become order-preserving u32 keys (NaN -> largest);
-//   2. T = a key with k*d <= #{key <= T} <= k*d + KSEL_SLACK, by bisection of the key space: one step is four compares, four
-//      ballots and scalar popcounts — no LDS, no cross-lane traffic (about a dozen steps for distances of unit vectors; the search
+// Large k*dilation on the 256-node graphs (deep configuration, stage 0: the 18 nearest of 256): THRESHOLD SELECT IN REGISTERS.
+// A wave owns a 16-row distance strip and never writes it anywhere: the MFMA C/D layout leaves row 4*(lane>>4)+e of the strip in
+// register e of the 16 accumulator tiles of ONE 16-lane group (lane&15 = column within a tile), i.e. a row's 256 distances are 16
+// registers x 16 lanes, and the four groups of a wave work on four rows at once (e = 0..3 in turn):
+//   1. the distances become order-preserving u32 keys (NaN -> largest);
+//   2. T = a key with k*d <= #{key <= T} <= k*d + KSEL_SLACK, by bisection of the key space: one step is 16 compares per lane and a
+//      4-step DPP sum over the group — no LDS, no scalar round trips (about a dozen steps for distances of unit vectors; the search
 //      ends at the exact (k*d)-th smallest key when ties keep the count above the slack);
-//   3. the entries <= T are compacted into LDS with ballots as packed (key << 32 | index) words;
-//   4. each candidate's exact rank among the candidates is one 64-bit compare per other candidate on 16-byte LDS broadcasts,
-//      eight candidates per trip -> neighbour rank / dilation.
-// History: k*d rounds of a dependent 64-lane arg-min (the strip kernel) took 480 us per call here; ranking the 64 lane MINIMA against
-// each other to find a threshold 157 us (tools/knn_sel_trace.py: 5 500 of a row's 9 100 cycles went to those 64 compares on LDS
-// broadcasts, 2 700 to the candidate ranks); this form ~2 700 cycles per row.
-constexpr int KSEL_STRIPS = 4;            // strip buffers per workgroup (8 waves = 4 pairs)
+//   3. the entries <= T are compacted into the group's LDS slot as packed (key << 32 | column) words (DPP prefix sum);
+//   4. each candidate's exact rank among the candidates is one 64-bit compare per other candidate on 16-byte LDS reads, eight
+//      candidates per trip -> neighbour rank / dilation.
+// No workgroup barrier after staging. History: k*d rounds of a dependent 64-lane arg-min (the strip kernel) took 480 us per call
+// here; a strip in LDS + the 64 lane minima ranked against each other for a threshold 157 us (tools/knn_sel_trace.py: 5 500 of a
+// row's 9 100 cycles went to those 64 compares on LDS broadcasts); the same with a wave-wide bisection on ballots 91 us.
 constexpr int KSEL_SLACK = 3;             // surplus candidates accepted instead of another bisection step
-constexpr int KSEL_CH = 8;                // candidates per ranking trip (four 16-byte broadcasts)
+constexpr int KSEL_CH = 8;                // candidates per ranking trip (four 16-byte reads)
+constexpr int KSEL_TILES = 16;            // column tiles of a strip: N == 256 only (host-checked)
 
 __device__ __forceinline__ unsigned knn_key(float x) {
   const unsigned b = __float_as_uint(x + 0.f);                       // -0 -> +0: equal distances must get equal keys
   const unsigned key = b ^ ((unsigned)((int)b >> 31) | 0x80000000u);
   return x != x ? 0xffffffffu : key;
 }
-__device__ __forceinline__ int knn_count_le(const unsigned (&key)[4], unsigned t) {
-  int c = 0;
-#pragma unroll
-  for (int e = 0; e < 4; ++e) c += __popcll(__ballot(key[e] <= t));
-  return c;
+__device__ __forceinline__ int row16_sum(int v) {                    // every lane of a 16-lane row gets the row's total
+  v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true);      // quad_perm [1,0,3,2]
+  v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true);      // quad_perm [2,3,0,1]
+  v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, true);     // row_half_mirror
+  v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, true);     // row_mirror
+  return v;
+}
+__device__ __forceinline__ int row16_scan(int v) {                   // inclusive prefix sum within a 16-lane row
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, true);     // row_shr:1, zeros shifted in
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, true);
+  return v;
 }
 
 template <typename T>
@@ -678,11 +688,10 @@ __global__ __launch_bounds__(KNN2_THREADS) void knn_sel_kernel(const T* __restri
                                                                const float* __restrict__ shift, int N, int C, int k,
                                                                int dilation, int32_t* __restrict__ idx) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int SLD = N + 4;
+  constexpr int SLOT = 256 + 2 * KSEL_CH;            // candidates of a row + padding + the dump word
   char* img = reinterpret_cast<char*>(smem);         // [2][C/8][N][8] fp16 split images (see knn2_kernel)
   float* sq = smem + 2 * (N * C / 2);                // [N]
-  float* strips = sq + N;                            // [KSEL_STRIPS][16][SLD]
-  unsigned long long* scratch = reinterpret_cast<unsigned long long*>(strips + KSEL_STRIPS * 16 * SLD);   // [8 waves][N + KSEL_CH]
+  unsigned long long* slots = reinterpret_cast<unsigned long long*>(sq + N);      // [8 waves][4 groups][SLOT]
   const int b = blockIdx.x;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const T* src = r + (long)b * N * ldr;
@@ -691,88 +700,106 @@ __global__ __launch_bounds__(KNN2_THREADS) void knn_sel_kernel(const T* __restri
   __syncthreads();
 
   const int lr = lane & 15, rq = lane >> 4;
-  const int NS = N >> 4;                             // strips == column tiles (16 here: N == 256, host-checked)
   const int kd = k * dilation;
   const unsigned dinv = (65536u + dilation - 1) / dilation;          // rank / dilation == rank * dinv >> 16 for rank < 256
-  const int pair = wave >> 1, hw = wave & 1;         // two waves per strip: column halves in phase A, row halves in phase B
-  float* strip = strips + pair * 16 * SLD;
-  unsigned long long* ckeys = scratch + wave * (N + KSEL_CH);
+  unsigned long long* slot = slots + (wave * 4 + rq) * SLOT;
 #ifdef NSID_KSEL_TRACE          // diagnosis build: cycles of wave 0 per section of the loop (tools/knn_sel_trace.py)
   unsigned long long ksel_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ksel_last = __builtin_amdgcn_s_memtime();
 #define KSEL_MARK(i) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); ksel_acc[i] += now_ - ksel_last; ksel_last = now_; }
 #else
 #define KSEL_MARK(i)
 #endif
-  for (int s0 = 0; s0 < NS; s0 += KSEL_STRIPS) {     // uniform trip count: workgroup barriers inside
-    const int s = s0 + pair;
-    {  // ---- phase A: this wave's half of the column tiles of strip s
-      for (int tn = hw * (NS / 2); tn < (hw + 1) * (NS / 2); tn += 4) {
-        f32x4 lead[4], corr[4];
+  for (int s = wave; s < KSEL_TILES; s += KNN2_WAVES) {
+    KSEL_MARK(0);
+    unsigned key[KSEL_TILES][4];
+    // ---- phase A: the strip's 16 x 256 distances, four column tiles per pass, straight into keys
 #pragma unroll
-        for (int u = 0; u < 4; ++u) lead[u] = corr[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-        for (int kc = 0; kc < KC; kc += 4) {
-          const KnnFrag fa = knn_frag(img, kc + rq, 16 * s + lr, KC, N);
-          KnnFrag fb[4];
+    for (int t0 = 0; t0 < KSEL_TILES; t0 += 4) {
+      f32x4 lead[4], corr[4];
 #pragma unroll
-          for (int u = 0; u < 4; ++u) fb[u] = knn_frag(img, kc + rq, 16 * (tn + u) + lr, KC, N);
+      for (int u = 0; u < 4; ++u) lead[u] = corr[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int kc = 0; kc < KC; kc += 4) {
+        const KnnFrag fa = knn_frag(img, kc + rq, 16 * s + lr, KC, N);
+        KnnFrag fb[4];
 #pragma unroll
-          for (int u = 0; u < 4; ++u) knn_mfma3(fa, fb[u], lead[u], corr[u]);
-        }
+        for (int u = 0; u < 4; ++u) fb[u] = knn_frag(img, kc + rq, 16 * (t0 + u) + lr, KC, N);
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const float sj = sq[16 * (tn + u) + lr];
+        for (int u = 0; u < 4; ++u) knn_mfma3(fa, fb[u], lead[u], corr[u]);      // A = the strip's row nodes, B = column nodes
+      }
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const float si = sq[16 * s + 4 * rq + e];
-            strip[(4 * rq + e) * SLD + 16 * (tn + u) + lr] = (si + (-2.f * (lead[u][e] + corr[u][e]))) + sj;
-          }
+      for (int u = 0; u < 4; ++u) {
+        const float sj = sq[16 * (t0 + u) + lr];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float si = sq[16 * s + 4 * rq + e];
+          // 2 x as x + x, not -2.f * x: hipcc contracts the product form into v_pk_fma_f32 (pairs of tiles) with the literal 2.0 and
+          // op_sel on the |y_i|^2 pair, and on MI355X / ROCm 7.2 that instruction intermittently (0.1-1 % of launches, same rows each
+          // time, lanes 48-63 of the low half) dropped the |y_i|^2 term: distances exactly 1.0 too small in one tile of one row
+          // (tools/knn_sel_repro.py; docs/experiments.md). Same value either way: doubling is exact.
+          const float x_ = lead[u][e] + corr[u][e];
+          key[t0 + u][e] = knn_key((si - (x_ + x_)) + sj);
         }
       }
     }
-    __syncthreads();
-    // ---- phase B: rows 8*hw .. 8*hw+7 of the strip, one row at a time
-    for (int rr = 8 * hw; rr < 8 * hw + 8; ++rr) {
-      KSEL_MARK(0);
-      const float* drow = strip + rr * SLD;
-      unsigned key[4];
+#ifdef NSID_KSEL_DUMP       // diagnosis build: dump every key (tools/knn_sel_repro.py): [clip][row][column]
+    if (g_knn_trace) {
+      unsigned* dump = reinterpret_cast<unsigned*>(g_knn_trace);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) key[e] = knn_key(drow[lane + 64 * e]);
-      KSEL_MARK(1);
+      for (int u = 0; u < KSEL_TILES; ++u)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dump[((long)b * 256 + 16 * s + 4 * rq + e) * 256 + 16 * u + lr] = key[u][e];
+    }
+#endif
+    KSEL_MARK(1);
+    // ---- phase B: row 16 s + 4 rq + e in this lane's group
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      int32_t* out = idx + ((long)b * N + 16 * s + 4 * rq + e) * k;
       // bisection: #{key <= lo} < kd <= #{key <= hi} = chi throughout (key 0 belongs to no value: it would be a negative NaN)
       unsigned lo = 0u, hi = 0xff800000u;                      // +inf: everything but NaN
-      int chi = knn_count_le(key, hi);
-      int32_t* out = idx + ((long)b * N + 16 * s + rr) * k;
-      if (chi < kd) {                                          // NaN-poisoned row: fewer comparable entries than wanted
-        if (lane < k) out[lane] = lane;
-      } else {
-        while (chi > kd + KSEL_SLACK && hi - lo > 1u) {
-          const unsigned mid = lo + ((hi - lo) >> 1);
-          const int c = knn_count_le(key, mid);
-          if (c >= kd) { hi = mid; chi = c; } else { lo = mid; }
-        }
+      int chi;
+      {
+        int c = 0;
+#pragma unroll
+        for (int u = 0; u < KSEL_TILES; ++u) c += key[u][e] <= hi ? 1 : 0;
+        chi = row16_sum(c);
+      }
+      if (chi < kd)                                            // NaN-poisoned row: fewer comparable entries than wanted
+        for (int j = lr; j < k; j += 16) out[j] = j;
+      bool act = chi > kd + KSEL_SLACK;
+      while (__any(act)) {
+        const unsigned mid = lo + ((hi - lo) >> 1);
+        int c = 0;
+#pragma unroll
+        for (int u = 0; u < KSEL_TILES; ++u) c += key[u][e] <= mid ? 1 : 0;
+        c = row16_sum(c);
+        const bool down = act && c >= kd, up = act && c < kd;
+        hi = down ? mid : hi;
+        chi = down ? c : chi;
+        lo = up ? mid : lo;
+        act = act && chi > kd + KSEL_SLACK && hi - lo > 1u;
       }
       KSEL_MARK(2);
-      int base = 0;
+      int n = 0;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const bool cand = key[e] <= hi;
-        const unsigned long long mask = __ballot(cand);
-        if (cand) {
-          const int pos = base + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
-          ckeys[pos] = ((unsigned long long)key[e] << 32) | (unsigned)(lane + 64 * e);
-        }
-        base += __popcll(mask);
+      for (int u = 0; u < KSEL_TILES; ++u) n += key[u][e] <= hi ? 1 : 0;
+      int pos = row16_scan(n) - n;
+#pragma unroll
+      for (int u = 0; u < KSEL_TILES; ++u) {
+        const bool cand = key[u][e] <= hi;
+        slot[cand ? pos : 256 + KSEL_CH] = ((unsigned long long)key[u][e] << 32) | (unsigned)(16 * u + lr);
+        pos += cand ? 1 : 0;
       }
-      if (lane < KSEL_CH) ckeys[base + lane] = ~0ull;          // pad to whole trips: the largest word precedes nothing
+      if (lr < KSEL_CH) slot[chi + lr] = ~0ull;                // pad to whole trips: the largest word precedes nothing
       KSEL_MARK(3);
-      for (int c0 = lane; c0 < base; c0 += 64) {               // one trip unless ties push more than 64 entries under the threshold
-        const unsigned long long mine = ckeys[c0];
+      for (int c0 = lr; c0 < chi; c0 += 16) {
+        const unsigned long long mine = slot[c0];
         int rank = 0;
-        for (int m = 0; m < base; m += KSEL_CH) {
+        for (int m = 0; m < chi; m += KSEL_CH) {
           typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
           u64x2 o[KSEL_CH / 2];
 #pragma unroll
-          for (int q = 0; q < KSEL_CH / 2; ++q) o[q] = *reinterpret_cast<const u64x2*>(ckeys + m + 2 * q);
+          for (int q = 0; q < KSEL_CH / 2; ++q) o[q] = *reinterpret_cast<const u64x2*>(slot + m + 2 * q);
 #pragma unroll
           for (int q = 0; q < KSEL_CH / 2; ++q) rank += (o[q][0] < mine ? 1 : 0) + (o[q][1] < mine ? 1 : 0);
         }
@@ -783,9 +810,6 @@ __global__ __launch_bounds__(KNN2_THREADS) void knn_sel_kernel(const T* __restri
       }
       KSEL_MARK(4);
     }
-    KSEL_MARK(5);
-    __syncthreads();
-    KSEL_MARK(6);
   }
 #ifdef NSID_KSEL_TRACE
   if (g_knn_trace && t == 0)
@@ -796,8 +820,8 @@ __global__ __launch_bounds__(KNN2_THREADS) void knn_sel_kernel(const T* __restri
 template <typename T>
 int launch_knn_sel(const void* r, int ldr, const float* scale, const float* shift, int B, int N, int C, int k,
                    int dilation, int32_t* idx, hipStream_t s) {
-  const size_t bytes = (size_t)2 * N * C * 2 + ((size_t)N + (size_t)KSEL_STRIPS * 16 * (N + 4)) * sizeof(float) +
-                       (size_t)KNN2_WAVES * (N + KSEL_CH) * sizeof(unsigned long long);
+  const size_t bytes = (size_t)2 * N * C * 2 + (size_t)N * sizeof(float) +
+                       (size_t)KNN2_WAVES * 4 * (256 + 2 * KSEL_CH) * sizeof(unsigned long long);
   if (bytes > 160 * 1024) return 1;
   static bool configured = false;
   if (!configured) {

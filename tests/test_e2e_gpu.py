@@ -204,9 +204,14 @@ def tape_of(g, tag):
 
 def check_tape(recorded, gold_idx, gaps):
     hard = soft = rows = 0
-    for r, gi, gp in zip(recorded, gold_idx, gaps):
+    for c, (r, gi, gp) in enumerate(zip(recorded, gold_idx, gaps)):
         h, s_ = knn_mismatch(r, gi, gp)
         hard, soft, rows = hard + h, soft + s_, rows + gp.size
+        if h:                                                    # say which call / row, for the assertion's captured output
+            a, b = np.sort(r.cpu().numpy(), axis=-1), np.sort(np.asarray(gi), axis=-1)
+            for pos in np.argwhere((a != b).any(-1) & (np.asarray(gp) >= 1e-4))[:4]:
+                pos = tuple(pos)
+                print(f"kNN call {c} {a.shape} row {pos} gap {float(np.asarray(gp)[pos]):.3g}\n  got  {r.cpu().numpy()[pos]}\n  gold {np.asarray(gi)[pos]}")
     return hard, soft, rows
 
 

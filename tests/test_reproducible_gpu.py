@@ -1,0 +1,128 @@
+"""Run-to-run reproducibility: the same kNN launch repeated on the same operands must give the same bits, and the forward passes
+(whose only atomics are the head's fp32 accumulations) the same values to an ulp or two. This is the hazard detector of the suite:
+a missing wait state, an LDS ordering assumption or an instruction that misbehaves under load shows up as a launch that differs
+from the first one, typically 0.1-1 % of the time on a handful of rows.
+Motivation (round 3): the register-resident `knn_sel_kernel` passed every golden and still returned a wrong neighbour row in about
+1 launch of 150 — hipcc had contracted `|y_i|^2 - 2 x` into `v_pk_fma_f32 ..., 2.0, v[si:si+1] op_sel:[0,0,1]`, and that instruction
+intermittently dropped the |y_i|^2 term in lanes 48-63 (docs/experiments.md, tools/knn_sel_repro.py)."""
+import pytest
+import torch
+
+from synth import GRAFP_CFG
+from test_e2e_gpu import build_model, load_synth, tape_of
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+REPEATS = 150
+
+
+@pytest.fixture(autouse=True)
+def _fp32_after():
+    yield
+    from neuralsampleid_amd import functional as F_
+    F_.set_activation_dtype("fp32")
+    F_.TAPE = None
+
+
+def _capture_knn_calls(run):
+    """every ops.knn_graph call of `run()` with its operands cloned"""
+    from neuralsampleid_amd import ops
+    calls, orig = [], ops.knn_graph
+
+    def capture(r, B, N, C, k, dilation=1, aff=None):
+        calls.append((r.clone(), B, N, C, k, dilation,
+                      None if aff is None else ops.BNAffine(aff.scale.clone(), aff.shift.clone())))
+        return orig(r, B, N, C, k, dilation, aff)
+    ops.knn_graph = capture
+    try:
+        run()
+    finally:
+        ops.knn_graph = orig
+    return calls
+
+
+def _repeat_knn(calls):
+    from neuralsampleid_amd import ops
+    bad = []
+    for ci, (r, B, N, C, k, d, aff) in enumerate(calls):
+        first = ops.knn_graph(r, B, N, C, k, d, aff)
+        differ = torch.zeros((), dtype=torch.int32, device=DEV)
+        for _ in range(REPEATS):
+            differ += (ops.knn_graph(r, B, N, C, k, d, aff) != first).any().int()
+        if int(differ):
+            bad.append((ci, N, C, k, d, int(differ)))
+    return bad
+
+
+def test_deep_configuration_knn_kernels_repeat_bitwise(golden):
+    """knn_sel_kernel (N = 256, k d = 18) and knn_rank_kernel (k d = 36 / 54 / 18) on the deep configuration's own train-mode
+    features (teacher-forced forward of tests/golden/deep_b4_k18): 48 calls x 150 launches"""
+    from neuralsampleid_amd import functional as F_
+    from neuralsampleid_amd.encoder.graph_encoder import GraphEncoder
+    from neuralsampleid_amd.simclr.simclr import SimCLR
+    g = golden("deep_b4_k18")
+    model = load_synth(SimCLR(GRAFP_CFG, GraphEncoder(GRAFP_CFG, in_channels=GRAFP_CFG["n_filters"], k=18, size="t",
+                                                      blocks=[4, 4, 12, 4], use_dilation=True))).train()
+    x_i, x_j = g.t("x_i").to(DEV), g.t("x_j").to(DEV)
+    gold_idx, _ = tape_of(g, "s0")
+
+    def run():
+        F_.TAPE = F_.KnnTape(replay=gold_idx)
+        with torch.no_grad():
+            model(x_i, x_j)
+        F_.TAPE = None
+    calls = _capture_knn_calls(run)
+    assert len(calls) == 48 and {c[2] for c in calls} == {256, 128, 64, 32}
+    assert _repeat_knn(calls) == []
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+def test_knn2_kernel_repeats_bitwise(golden, mode):
+    """the k = 3 kernels of the timed configuration, on the B = 8 golden's train-mode features, both storage types"""
+    from neuralsampleid_amd import functional as F_
+    F_.set_activation_dtype(mode)
+    g = golden("e2e_b8_k3")
+    model = build_model(3).train()
+    x_i, x_j = g.t("x_i").to(DEV), g.t("x_j").to(DEV)
+
+    def run():
+        with torch.no_grad():
+            model(x_i, x_j)
+    calls = _capture_knn_calls(run)
+    assert len(calls) == 24
+    assert _repeat_knn(calls) == []
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+def test_forward_only_extraction_repeats_to_an_ulp(mode):
+    """eval-mode forward of 512 clips (GEMMs incl. the 256x256-tile and fused FFN / aggregation forms, kNN, aggregation, head).
+    Only the head accumulates with fp32 atomics (node mean / split reductions: +-1 ulp run to run, measured 6e-8 on unit-norm
+    fingerprints); everything upstream — in particular what the kNN graphs are built from — is order-fixed, so 40 passes must
+    agree to 1e-6: a dropped term or a stale tile moves a fingerprint by 1e-3 or more"""
+    from neuralsampleid_amd import fingerprint, functional as F_
+    F_.set_activation_dtype(mode)
+    model = build_model(3).eval()
+    gen = torch.Generator().manual_seed(5)
+    x = (torch.randn(512, GRAFP_CFG["n_mels"], GRAFP_CFG["n_frames"], generator=gen) * 20 - 40).to(DEV)
+    first = fingerprint.extract_fingerprints(model, x, 512).clone()
+    worst = torch.zeros((), device=DEV)
+    for _ in range(40):
+        worst = torch.maximum(worst, (fingerprint.extract_fingerprints(model, x, 512) - first).abs().max())
+    assert float(worst) <= 1e-6
+
+
+def test_train_mode_forward_repeats_to_an_ulp():
+    """train-mode forward (batch statistics from per-tile partial sums in a fixed order) at B = 64, bf16 storage: z of 30 passes
+    within 2e-6 of the first (the head's atomics again)"""
+    from neuralsampleid_amd import functional as F_
+    F_.set_activation_dtype("bf16")
+    model = build_model(3).train()
+    gen = torch.Generator().manual_seed(6)
+    x_i = (torch.randn(64, GRAFP_CFG["n_mels"], GRAFP_CFG["n_frames"], generator=gen) * 20 - 40).to(DEV)
+    x_j = x_i + 3 * torch.randn(x_i.shape, generator=gen).to(DEV)
+    with torch.no_grad():
+        first = torch.cat(model(x_i, x_j)[2:]).clone()
+        worst = torch.zeros((), device=DEV)
+        for _ in range(30):
+            worst = torch.maximum(worst, (torch.cat(model(x_i, x_j)[2:]) - first).abs().max())
+    assert float(worst) <= 2e-6

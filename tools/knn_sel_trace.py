@@ -30,8 +30,7 @@ ops.knn_graph(r, a.B, N, a.C, a.k, a.d, aff)
 torch.cuda.synchronize()
 lib.nsid_debug_knn_trace(None)
 t = buf.cpu().numpy().reshape(-1, 8).astype(np.float64)
-names = ["phase A (MFMA strip) + barrier", "row: load 4 values, lane minimum", "row: rank of the lane minimum (64 compares)",
-         "row: threshold + compaction", "row: candidate ranks + store", "(loop end)", "closing barrier"]
+names = ["(loop head)", "phase A (MFMA strip -> keys)", "rows: bisection", "rows: compaction", "rows: candidate ranks + store", "-", "-"]
 tot = t[:, :7].sum(1)
 print(f"  cycles of wave 0, median over workgroups; total {np.median(tot):.0f}")
 for i, n in enumerate(names):
