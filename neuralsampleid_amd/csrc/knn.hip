@@ -373,11 +373,14 @@ __device__ __forceinline__ void knn_mfma3(const KnnFrag& x, const KnnFrag& y, f3
 
 // NT = column tiles per MFMA pass (4 for N >= 128, 2 for N = 64, 1 for N = 32) is a template parameter: as a run-time
 // value every MFMA sat behind its own scalar branch (tools/asm_profile.py: 187 branches, one MFMA per basic block).
-template <typename T, int KD, int NT>
-__global__ __launch_bounds__(KNN2_THREADS) void knn2_kernel(const T* __restrict__ r, long ldr,
-                                                            const float* __restrict__ scale,
-                                                            const float* __restrict__ shift, int N, int C, int k,
-                                                            int dilation, int32_t* __restrict__ idx) {
+// PF = read the fragments of the next 32 channels while the MFMAs of the current ones run (ten fragments live: 146 VGPRs, one
+// workgroup per CU). Without it the kernel fits 128 VGPRs and TWO workgroups share a CU, which is what hides latency when a launch
+// has more clips than CUs (fingerprint extraction: 2 048 clips per micro-batch); with one clip per CU (a training step) the
+// prefetch wins. The launcher picks by the clip count.
+template <typename T, int KD, int NT, bool PF>
+__device__ __forceinline__ void knn2_body(const T* __restrict__ r, long ldr, const float* __restrict__ scale,
+                                          const float* __restrict__ shift, int N, int C, int k, int dilation,
+                                          int32_t* __restrict__ idx) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   char* img = reinterpret_cast<char*>(smem);          // [2][C/8][N][8] fp16: the two split images of the normalised features
   float* sq = smem + 2 * (N * C / 2);                 // [N]
@@ -414,21 +417,28 @@ __global__ __launch_bounds__(KNN2_THREADS) void knn2_kernel(const T* __restrict_
       f32x4 lead[NT], corr[NT];
 #pragma unroll
       for (int u = 0; u < NT; ++u) lead[u] = corr[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-      // the fragments of the next 32 channels are read while the MFMAs of the current ones run
-      KnnFrag fa = knn_frag(img, rq, i, KC, N), fb[NT];
+      if constexpr (PF) {
+        KnnFrag fa = knn_frag(img, rq, i, KC, N), fb[NT];
 #pragma unroll
-      for (int u = 0; u < NT; ++u) fb[u] = knn_frag(img, rq, 16 * (ct0 + u) + lr, KC, N);
-      for (int kc = 0; kc < KC; kc += 4) {
-        const int kn = (kc + 4 < KC ? kc + 4 : kc) + rq;   // the last prefetch re-reads the current chunk (unused)
-        const KnnFrag na = knn_frag(img, kn, i, KC, N);
-        KnnFrag nb[NT];
+        for (int u = 0; u < NT; ++u) fb[u] = knn_frag(img, rq, 16 * (ct0 + u) + lr, KC, N);
+        for (int kc = 0; kc < KC; kc += 4) {
+          const int kn = (kc + 4 < KC ? kc + 4 : kc) + rq;   // the last prefetch re-reads the current chunk (unused)
+          const KnnFrag na = knn_frag(img, kn, i, KC, N);
+          KnnFrag nb[NT];
 #pragma unroll
-        for (int u = 0; u < NT; ++u) nb[u] = knn_frag(img, kn, 16 * (ct0 + u) + lr, KC, N);
+          for (int u = 0; u < NT; ++u) nb[u] = knn_frag(img, kn, 16 * (ct0 + u) + lr, KC, N);
 #pragma unroll
-        for (int u = 0; u < NT; ++u) knn_mfma3(fb[u], fa, lead[u], corr[u]);     // A = column nodes, B = this lane's row node
-        fa = na;
+          for (int u = 0; u < NT; ++u) knn_mfma3(fb[u], fa, lead[u], corr[u]);     // A = column nodes, B = this lane's row node
+          fa = na;
 #pragma unroll
-        for (int u = 0; u < NT; ++u) fb[u] = nb[u];
+          for (int u = 0; u < NT; ++u) fb[u] = nb[u];
+        }
+      } else {
+        for (int kc = 0; kc < KC; kc += 4) {
+          const KnnFrag fa = knn_frag(img, kc + rq, i, KC, N);
+#pragma unroll
+          for (int u = 0; u < NT; ++u) knn_mfma3(knn_frag(img, kc + rq, 16 * (ct0 + u) + lr, KC, N), fa, lead[u], corr[u]);
+        }
       }
       // lead + corr = y_j . y_i with j = 16*(ct0+u) + 4*rq + e, i = this lane's row: D = (|i|^2 - 2 i.j) + |j|^2
 #pragma unroll
@@ -482,6 +492,21 @@ __global__ __launch_bounds__(KNN2_THREADS) void knn2_kernel(const T* __restrict_
     trace[4 * blockIdx.x + 2] = tt[2];
     trace[4 * blockIdx.x + 3] = __builtin_amdgcn_s_memrealtime();
   }
+}
+
+template <typename T, int KD, int NT>
+__global__ __launch_bounds__(KNN2_THREADS) void knn2_kernel(const T* __restrict__ r, long ldr,
+                                                            const float* __restrict__ scale,
+                                                            const float* __restrict__ shift, int N, int C, int k,
+                                                            int dilation, int32_t* __restrict__ idx) {
+  knn2_body<T, KD, NT, true>(r, ldr, scale, shift, N, C, k, dilation, idx);
+}
+// the two-workgroups-per-CU form: four waves per SIMD = at most 128 VGPRs
+template <typename T, int KD, int NT>
+__global__ __launch_bounds__(KNN2_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4)))
+void knn2_pair_kernel(const T* __restrict__ r, long ldr, const float* __restrict__ scale, const float* __restrict__ shift,
+                      int N, int C, int k, int dilation, int32_t* __restrict__ idx) {
+  knn2_body<T, KD, NT, false>(r, ldr, scale, shift, N, C, k, dilation, idx);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -867,6 +892,20 @@ int launch_knn2_nt(const void* r, int ldr, const float* scale, const float* shif
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
       return NSID_ELAUNCH;
     configured = true;
+  }
+  const int pair_min = nsid_tune(NSID_T_knn_pair_min);      // clips from which two workgroups share a CU (0 = never)
+  if (pair_min > 0 && B >= pair_min && 2 * bytes <= 160 * 1024) {
+    static bool configured2 = false;
+    if (!configured2) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(knn2_pair_kernel<T, KD, NT>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+        return NSID_ELAUNCH;
+      configured2 = true;
+    }
+    nsid_count(NSID_C_knn2_pair);
+    NSID_LAUNCH((knn2_pair_kernel<T, KD, NT>), dim3(B), dim3(KNN2_THREADS), bytes, s, static_cast<const T*>(r), (long)ldr,
+                scale, shift, N, C, k, dilation, idx);
+    return nsid_launch_status();
   }
   NSID_LAUNCH((knn2_kernel<T, KD, NT>), dim3(B), dim3(KNN2_THREADS), bytes, s, static_cast<const T*>(r), (long)ldr, scale,
               shift, N, C, k, dilation, idx);

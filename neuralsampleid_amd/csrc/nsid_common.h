@@ -156,6 +156,7 @@ static inline bool nsid_aligned16(const void* p) { return (reinterpret_cast<uint
   X(w3_wgs, 256)                                                                                                              \
   X(w3_min_tiles, 64)                                                                                                         \
   X(knn_strips, 0)             /* 1: always the general strip kernel (tests of the fallback) */                               \
+  X(knn_pair_min, 512)         /* clips per launch from which knn2 runs as two 128-VGPR workgroups per CU; 0 = never */        \
   X(mr_grid_stride, 0)         /* 1: grid-stride aggregation instead of the LDS-staged per-clip kernel */                     \
   X(mr_split, 0)               /* channel split of the LDS-staged aggregation (0 = heuristic) */                              \
   X(ffn_waves, 8)              /* waves per workgroup of the fused eval-mode FFN (4 or 8) */                                  \
@@ -186,7 +187,7 @@ static inline long nsid_tune(NsidTuneKey k) { return g_nsid_tune[k]; }
   X(gemm256)              /* gemm256.hip */                                                     \
   X(wgrad_rect) X(wgrad_square) X(wgrad3)                                                       \
   X(bn_bwd_apply) X(bn_bwd_apply_capped)                                                        \
-  X(knn2) X(knn_rank) X(knn_sel) X(knn_strips)                                                  \
+  X(knn2) X(knn2_pair) X(knn_rank) X(knn_sel) X(knn_strips)                                                  \
   X(mr_fwd_lds) X(mr_fwd_grid)                                                                  \
   X(ffn_fused)            /* eval-mode FFN in one launch (ffn_fused.hip) */                     \
   X(mrconv_fused)         /* eval-mode max-relative aggregation + grouped conv in one launch (mrconv_fused.hip) */

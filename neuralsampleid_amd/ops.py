@@ -6,7 +6,7 @@ from typing import Optional, Tuple
 
 import torch
 
-from ._lib import call, get_tuning, lib, reset_tuning, set_tuning  # noqa: F401  (tuning: re-exported)
+from ._lib import call, get_tuning, launch_counters, lib, reset_tuning, set_tuning  # noqa: F401  (tuning, counters: re-exported)
 
 ACT_NONE, ACT_RELU, ACT_LEAKY, ACT_ELU = 0, 1, 2, 3
 ROW_TILE = 128

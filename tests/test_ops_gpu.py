@@ -276,6 +276,28 @@ def test_knn_graph_affine(ops):
     assert same.mean() > 0.995
 
 
+@pytest.mark.parametrize("N,C", [(256, 64), (128, 128), (64, 256), (32, 512)])
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_knn2_pair_variant_equals_the_default(ops, N, C, dt):
+    """knn2_pair_kernel (128 VGPRs, two workgroups per CU, no fragment prefetch; picked from `knn_pair_min` clips per launch)
+    computes the same distances in the same order as knn2_kernel: identical ids for every k*d of the fast path, and the launch
+    counter says which one ran"""
+    B = 24
+    r = rnd(f"knnpair{N}", B * N, C).to(DEV).to(dt)
+    aff = ops.BNAffine(torch.rand(C, device=DEV) + 0.5, torch.randn(C, device=DEV) * 0.1)
+    try:
+        for k, d in ((3, 1), (5, 1), (4, 2), (2, 3)):
+            ops.set_tuning("knn_pair_min", 0)
+            want = ops.knn_graph(r, B, N, C, k, d, aff)
+            ops.set_tuning("knn_pair_min", 1)
+            c0 = ops.launch_counters()["knn2_pair"]
+            got = ops.knn_graph(r, B, N, C, k, d, aff)
+            assert ops.launch_counters()["knn2_pair"] == c0 + 1
+            assert (got == want).all(), (k, d)
+    finally:
+        ops.reset_tuning()
+
+
 def test_mr_aggregate_golden(ops, golden):
     g = golden("mragg_c64n256")
     y = to_rows(g.t("x"))
