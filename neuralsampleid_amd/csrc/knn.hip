@@ -760,7 +760,7 @@ __global__ __launch_bounds__(KNN2_THREADS) void knn_sel_kernel(const T* __restri
           // 2 x as x + x, not -2.f * x: hipcc contracts the product form into v_pk_fma_f32 (pairs of tiles) with the literal 2.0 and
           // op_sel on the |y_i|^2 pair, and on MI355X / ROCm 7.2 that instruction intermittently (0.1-1 % of launches, same rows each
           // time, lanes 48-63 of the low half) dropped the |y_i|^2 term: distances exactly 1.0 too small in one tile of one row
-          // (tools/knn_sel_repro.py; docs/experiments.md). Same value either way: doubling is exact.
+          // (tools/knn_sel_repro.py; docs/experiments.md; guarded by tests/test_cabi.py). Same value either way: doubling is exact.
           const float x_ = lead[u][e] + corr[u][e];
           key[t0 + u][e] = knn_key((si - (x_ + x_)) + sj);
         }

@@ -62,3 +62,51 @@ def test_ops_refuse_cpu_tensors(libpath):
     from neuralsampleid_amd import ops
     with pytest.raises(RuntimeError):
         ops.bn_apply(torch.zeros(4, 4), ops.BNAffine(torch.ones(4), torch.zeros(4)))
+
+
+def _gfx950_disassembly(libpath, tmp_path):
+    """llvm-objdump of every gfx950 code object bundled in the library's .hip_fatbin section (one offload bundle per source)"""
+    import struct
+    import subprocess
+    llvm = "/opt/rocm/lib/llvm/bin"
+    if not os.path.exists(f"{llvm}/llvm-objdump"):
+        pytest.skip("no llvm-objdump in this image")
+    fat = str(tmp_path / "fat.bin")
+    subprocess.run([f"{llvm}/llvm-objcopy", f"--dump-section=.hip_fatbin={fat}", libpath, str(tmp_path / "null")], check=True)
+    blob = open(fat, "rb").read()
+    texts = []
+    for bi, m in enumerate(re.finditer(re.escape(b"__CLANG_OFFLOAD_BUNDLE__"), blob)):
+        o = m.start()
+        p = o + 32
+        for _ in range(struct.unpack_from("<Q", blob, o + 24)[0]):
+            eo, es, tl = struct.unpack_from("<QQQ", blob, p)
+            triple = blob[p + 24:p + 24 + tl].decode()
+            p += 24 + tl
+            if "gfx950" in triple and es:
+                co = str(tmp_path / f"co{bi}.o")
+                with open(co, "wb") as f:
+                    f.write(blob[o + eo:o + eo + es])
+                texts.append(subprocess.run([f"{llvm}/llvm-objdump", "-d", "--mcpu=gfx950", co], capture_output=True,
+                                            text=True, check=True).stdout)
+    return texts
+
+
+def test_no_packed_fma_with_a_constant_multiplier(libpath, tmp_path):
+    """`v_pk_fma_f32 d, x, 2.0, v[s:s+1] op_sel:[0,0,1] ...` (hipcc's contraction of `s - 2 x` over two tiles) intermittently lost
+    its addend in lanes 48-63 on MI355X / ROCm 7.2 (docs/experiments.md, round 3: one wrong kNN row in 0.1-1 % of launches; the
+    source now doubles with x + x). A packed FMA whose MULTIPLIER is an inline constant or literal must not come back in any
+    kernel; a constant ADDEND (`..., 0`: a canonicalising multiply) is everywhere and has never misbehaved."""
+    texts = _gfx950_disassembly(libpath, tmp_path)
+    assert len(texts) >= 10                                   # one code object per source file
+    const = re.compile(r"-?\d+(\.\d+)?|0x[0-9a-f]+")
+    seen, bad = 0, []
+    for text in texts:
+        for line in text.splitlines():
+            if "v_pk_fma_f32" not in line:
+                continue
+            seen += 1
+            body = line.split("//")[0].split(None, 1)[1]
+            args = [a.strip() for a in re.split(r",(?![^\[]*\])", body)]
+            if any(const.fullmatch(a) for a in args[1:3]):
+                bad.append(line.strip()[:120])
+    assert seen > 1000 and not bad, bad[:5]
