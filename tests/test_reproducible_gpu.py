@@ -126,3 +126,35 @@ def test_train_mode_forward_repeats_to_an_ulp():
         for _ in range(30):
             worst = torch.maximum(worst, (torch.cat(model(x_i, x_j)[2:]) - first).abs().max())
     assert float(worst) <= 2e-6
+
+
+def _repeat_bitwise(fn, n=100):
+    """fn() -> tuple of tensors; the number of repeats (of n) in which any output differs from the first call's"""
+    first = [t.clone() for t in fn()]
+    differ = torch.zeros((), dtype=torch.int32, device=DEV)
+    for _ in range(n):
+        for a, b in zip(fn(), first):
+            differ += (a != b).any().int()
+    return int(differ)
+
+
+@pytest.mark.parametrize("M,Nout,K,groups", [(32768, 512, 128, 1), (32768, 128, 512, 1), (16384, 128, 128, 4), (8192, 2048, 512, 1)])
+def test_gemm_family_repeats_bitwise_at_the_timed_shapes(M, Nout, K, groups):
+    """forward (BatchNorm + ReLU on the operand load, statistics epilogue), backward-data (plain, and with the BatchNorm-backward
+    column sums in the epilogue) and the BatchNorm-backward passes on bf16 activations at the step's own shapes: none of these
+    accumulates with atomics, so 100 launches must agree bit for bit (the weight gradients do use atomics and are not here)"""
+    from neuralsampleid_amd import functional as F_, ops
+    F_.set_activation_dtype("bf16")
+    g = torch.Generator(device=DEV).manual_seed(M + K)
+    x = torch.randn(M, groups * K, device=DEV, generator=g).bfloat16()
+    dy = torch.randn(M, groups * Nout, device=DEV, generator=g).bfloat16()
+    w = torch.randn(groups * Nout, K, device=DEV, generator=g) * K ** -0.5
+    sc = 1 + 0.1 * torch.randn(groups * K, device=DEV, generator=g)
+    sh = 0.1 * torch.randn(groups * K, device=DEV, generator=g)
+    aff = ops.BNAffine(sc, sh, mean=torch.zeros_like(sc), invstd=torch.ones_like(sc))
+    assert _repeat_bitwise(lambda: ops.linear_fwd(x, w, None, M, Nout, K, groups, sc, sh, ops.ACT_RELU, 0, want_stat=True)) == 0
+    assert _repeat_bitwise(lambda: (ops.linear_bwd_data(dy, w, M, Nout, K, groups),)) == 0
+    assert _repeat_bitwise(lambda: ops.linear_bwd_data(dy, w, M, Nout, K, groups, bn=(x, aff, ops.ACT_RELU))) == 0
+    dgamma, dbeta = torch.zeros(groups * K, device=DEV), torch.zeros(groups * K, device=DEV)
+    dx = torch.randn(M, groups * K, device=DEV, generator=g).bfloat16()
+    assert _repeat_bitwise(lambda: (ops.bn_backward(dx, x, aff, ops.ACT_RELU, dgamma, dbeta),)) == 0
