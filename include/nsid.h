@@ -70,6 +70,14 @@ const char* nsid_debug_counter_key(int i);
 long nsid_gemm_g256_launches(void);
 /* number of NSID_ROW_TILE row tiles of an M-row matrix: size of the partial-statistics buffers */
 int nsid_row_tiles(int M);
+/* Bytes of caller-provided scratch an op needs, or -1 for an unknown op name ("a nsid_workspace_bytes(op, dims)
+ * query per op"; the reference has no counterpart — its ops allocate through torch). No entry point allocates; the kernels keep
+ * their working sets in LDS and registers, so every op answers 0 ("knn_graph", "mr_aggregate", "linear", "linear_bwd_data",
+ * "linear_bwd_weight", "downsample3", "peak_patchify", "bn_apply", "node_mean", "l2norm", "adam", "ffn_fused", "mrconv_fused")
+ * except: "bn_stat" (rows x cols layer: the [2][nsid_row_tiles(rows)][cols] fp32 partial sums between a GEMM's statistics
+ * epilogue / nsid_bn_bwd_reduce and the finalize kernels), "ntxent" (rows = pairs of the global batch: nsid_ntxent_ws_floats),
+ * "sumsq" (rows = gradient elements: nsid_sumsq_blocks partial sums). */
+long nsid_workspace_bytes(const char* op, long rows, long cols);
 
 /* ---- 1x1 convolution / Linear as a row GEMM on MFMA (fp32 accumulate) ------------------------------------
  * act_dtype = NSID_BF16: the activation operands/outputs are bf16 in HBM (bias, statistics, weight gradients stay

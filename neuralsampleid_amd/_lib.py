@@ -92,6 +92,8 @@ def _load():
     lib.nsid_get_tuning.restype = ctypes.c_int
     lib.nsid_reset_tuning.argtypes = []
     lib.nsid_reset_tuning.restype = ctypes.c_int
+    lib.nsid_workspace_bytes.argtypes = [ctypes.c_char_p, ctypes.c_long, ctypes.c_long]
+    lib.nsid_workspace_bytes.restype = ctypes.c_long
     lib.nsid_tuning_count.argtypes = []
     lib.nsid_tuning_count.restype = ctypes.c_int
     lib.nsid_tuning_key.argtypes = [ctypes.c_int]
@@ -121,7 +123,7 @@ def _load():
 
 
 lib = _load()
-EXPORTS = list(SIGNATURES) + ["nsid_version", "nsid_debug_gemm_trace", "nsid_debug_knn_trace", "nsid_get_gemm_precision", "nsid_gemm_g256_launches", "nsid_linear_bwd_data_bnapply", "nsid_ffn_fused_fwd", "nsid_mrconv_fused_fwd", "nsid_debug_counter", "nsid_debug_counters_reset", "nsid_debug_counter_count", "nsid_debug_counter_key", "nsid_set_tuning", "nsid_get_tuning", "nsid_reset_tuning", "nsid_tuning_count", "nsid_tuning_key", "nsid_row_tiles", "nsid_sumsq_blocks", "nsid_ntxent_ws_floats"]
+EXPORTS = list(SIGNATURES) + ["nsid_version", "nsid_debug_gemm_trace", "nsid_debug_knn_trace", "nsid_get_gemm_precision", "nsid_gemm_g256_launches", "nsid_linear_bwd_data_bnapply", "nsid_ffn_fused_fwd", "nsid_mrconv_fused_fwd", "nsid_debug_counter", "nsid_debug_counters_reset", "nsid_debug_counter_count", "nsid_debug_counter_key", "nsid_set_tuning", "nsid_get_tuning", "nsid_reset_tuning", "nsid_tuning_count", "nsid_tuning_key", "nsid_row_tiles", "nsid_sumsq_blocks", "nsid_ntxent_ws_floats", "nsid_workspace_bytes"]
 
 _ERR = {-1: "NSID_EINVAL (unsupported shape, misaligned pointer or bad argument)",
         -2: "NSID_ELAUNCH (HIP runtime refused the launch)"}

@@ -64,3 +64,23 @@ extern "C" const char* nsid_debug_counter_key(int i) { return (i >= 0 && i < NSI
 
 extern "C" int nsid_tuning_count(void) { return NSID_T_COUNT; }
 extern "C" const char* nsid_tuning_key(int i) { return (i >= 0 && i < NSID_T_COUNT) ? kTable[i].name : nullptr; }
+
+// ---- one size query for the caller-provided scratch of every op. The kernels keep their working sets in LDS and
+// registers, so most ops need none; the three that hand partial results from one launch to the next say how much here.
+extern "C" int nsid_row_tiles(int M);
+extern "C" int nsid_sumsq_blocks(long n);
+extern "C" size_t nsid_ntxent_ws_floats(int Bg);
+extern "C" long nsid_workspace_bytes(const char* op, long rows, long cols) {
+  if (op == nullptr || rows < 0 || cols < 0) return -1;
+  static const char* const kNone[] = {"knn_graph", "mr_aggregate", "linear", "linear_bwd_data", "linear_bwd_weight", "downsample3",
+                                      "peak_patchify", "bn_apply", "node_mean", "l2norm", "adam", "ffn_fused", "mrconv_fused"};
+  for (const char* n : kNone)
+    if (strcmp(op, n) == 0) return 0;
+  if (strcmp(op, "bn_stat") == 0)            // [2][row tiles][cols] fp32 partial sums of a rows x cols layer (forward and backward)
+    return 2L * nsid_row_tiles((int)rows) * cols * (long)sizeof(float);
+  if (strcmp(op, "ntxent") == 0)             // rows = pairs of the GLOBAL batch
+    return (long)(nsid_ntxent_ws_floats((int)rows) * sizeof(float));
+  if (strcmp(op, "sumsq") == 0)              // rows = elements of the flat gradient
+    return (long)nsid_sumsq_blocks(rows) * (long)sizeof(float);
+  return -1;
+}

@@ -110,3 +110,18 @@ def test_no_packed_fma_with_a_constant_multiplier(libpath, tmp_path):
             if any(const.fullmatch(a) for a in args[1:3]):
                 bad.append(line.strip()[:120])
     assert seen > 1000 and not bad, bad[:5]
+
+
+def test_workspace_query(libpath):
+    """SURVEY 8b's per-op scratch query: 0 for the ops that live in LDS, the partial-sum buffers for the three that do not"""
+    lib = ctypes.CDLL(libpath)
+    lib.nsid_workspace_bytes.argtypes = [ctypes.c_char_p, ctypes.c_long, ctypes.c_long]
+    lib.nsid_workspace_bytes.restype = ctypes.c_long
+    lib.nsid_row_tiles.restype = ctypes.c_int
+    lib.nsid_ntxent_ws_floats.restype = ctypes.c_size_t
+    for op in (b"knn_graph", b"mr_aggregate", b"linear", b"downsample3", b"peak_patchify"):
+        assert lib.nsid_workspace_bytes(op, 32768, 128) == 0
+    assert lib.nsid_workspace_bytes(b"bn_stat", 32768, 512) == 2 * lib.nsid_row_tiles(32768) * 512 * 4
+    assert lib.nsid_workspace_bytes(b"ntxent", 2048, 0) == lib.nsid_ntxent_ws_floats(2048) * 4
+    assert lib.nsid_workspace_bytes(b"sumsq", 18_562_664, 0) > 0
+    assert lib.nsid_workspace_bytes(b"no_such_op", 1, 1) == -1 and lib.nsid_workspace_bytes(None, 1, 1) == -1
