@@ -5,6 +5,8 @@ from the first one, typically 0.1-1 % of the time on a handful of rows.
 Motivation (round 3): the register-resident `knn_sel_kernel` passed every golden and still returned a wrong neighbour row in about
 1 launch of 150 — hipcc had contracted `|y_i|^2 - 2 x` into `v_pk_fma_f32 ..., 2.0, v[si:si+1] op_sel:[0,0,1]`, and that instruction
 intermittently dropped the |y_i|^2 term in lanes 48-63 (docs/experiments.md, tools/knn_sel_repro.py)."""
+import os
+
 import pytest
 import torch
 
@@ -13,7 +15,7 @@ from test_e2e_gpu import build_model, load_synth, tape_of
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
-REPEATS = 150
+REPEATS = int(os.environ.get("NSID_REPEATS", "150"))     # a soak run raises it (tools/gpu_fulltests.sh does not)
 
 
 @pytest.fixture(autouse=True)
