@@ -168,14 +168,36 @@ __global__ __launch_bounds__(MRB_THREADS) void mr_bwd_kernel(const T* __restrict
   const int E = N * k;
 
   for (int n = t; n < N; n += MRB_THREADS) cnt[n] = 0;
-  // ---- A: stage du_odd and argmax
-  for (int q = t; q < total; q += MRB_THREADS) {
+  // ---- A: stage du_odd and argmax. A thread meets the same (node, chunk) items again in phase C: their own-row term
+  // du_even - du_odd stays in registers across the graph reversal (KEEP items: every stage of the encoder has N*C = 16 384, i.e.
+  // 2 items per thread in bf16 and 4 in fp32), so du is read from memory ONCE (the second read was 1.36x the algorithmic bytes)
+  constexpr int KEEP = 16384 / (NV * MRB_THREADS);
+  float own[KEEP][NV];
+#pragma unroll
+  for (int it = 0; it < KEEP; ++it) {
+    const int q = t + it * MRB_THREADS;
+    if (q >= total) break;
+    float g0[NV], g1[NV], o[NV];
+    Chunk<T>::load(dub + (long)q * 2 * NV, g0);
+    Chunk<T>::load(dub + (long)q * 2 * NV + NV, g1);
+#pragma unroll
+    for (int e = 0; e < NV / 2; ++e) {
+      o[e] = g0[2 * e + 1]; o[NV / 2 + e] = g1[2 * e + 1];
+      own[it][e] = g0[2 * e] - g0[2 * e + 1];
+      own[it][NV / 2 + e] = g1[2 * e] - g1[2 * e + 1];
+    }
+    Chunk<T>::store(odd + (long)q * NV, o);                  // exact: a copy in the storage type
+#pragma unroll
+    for (int e = 0; e < NV; e += 4)
+      *reinterpret_cast<uint32_t*>(am + (long)q * NV + e) = *reinterpret_cast<const uint32_t*>(amb + (long)q * NV + e);
+  }
+  for (int q = t + KEEP * MRB_THREADS; q < total; q += MRB_THREADS) {     // larger clips (not in this encoder): LDS only
     float g0[NV], g1[NV], o[NV];
     Chunk<T>::load(dub + (long)q * 2 * NV, g0);
     Chunk<T>::load(dub + (long)q * 2 * NV + NV, g1);
 #pragma unroll
     for (int e = 0; e < NV / 2; ++e) { o[e] = g0[2 * e + 1]; o[NV / 2 + e] = g1[2 * e + 1]; }
-    Chunk<T>::store(odd + (long)q * NV, o);                  // exact: a copy in the storage type
+    Chunk<T>::store(odd + (long)q * NV, o);
 #pragma unroll
     for (int e = 0; e < NV; e += 4)
       *reinterpret_cast<uint32_t*>(am + (long)q * NV + e) = *reinterpret_cast<const uint32_t*>(amb + (long)q * NV + e);
@@ -206,16 +228,8 @@ __global__ __launch_bounds__(MRB_THREADS) void mr_bwd_kernel(const T* __restrict
   }
   __syncthreads();
   // ---- C: gather
-  for (int q = t; q < total; q += MRB_THREADS) {
+  auto gather = [&](int q, float (&v)[NV]) {
     const int n = q / CV, c = (q % CV) * NV;
-    float g0[NV], g1[NV], v[NV];
-    Chunk<T>::load(dub + (long)q * 2 * NV, g0);             // second read of du: L2
-    Chunk<T>::load(dub + (long)q * 2 * NV + NV, g1);
-#pragma unroll
-    for (int e = 0; e < NV / 2; ++e) {
-      v[e] = g0[2 * e] - g0[2 * e + 1];
-      v[NV / 2 + e] = g1[2 * e] - g1[2 * e + 1];
-    }
     const int p1 = start[n + 1];
     for (int p = start[n]; p < p1; ++p) {
       const int s2 = src[p];
@@ -231,6 +245,23 @@ __global__ __launch_bounds__(MRB_THREADS) void mr_bwd_kernel(const T* __restrict
       }
     }
     Chunk<T>::store(dy + row0 * C + (long)q * NV, v);
+  };
+#pragma unroll
+  for (int it = 0; it < KEEP; ++it) {
+    const int q = t + it * MRB_THREADS;
+    if (q >= total) break;
+    gather(q, own[it]);
+  }
+  for (int q = t + KEEP * MRB_THREADS; q < total; q += MRB_THREADS) {
+    float g0[NV], g1[NV], v[NV];
+    Chunk<T>::load(dub + (long)q * 2 * NV, g0);             // second read of du: L2
+    Chunk<T>::load(dub + (long)q * 2 * NV + NV, g1);
+#pragma unroll
+    for (int e = 0; e < NV / 2; ++e) {
+      v[e] = g0[2 * e] - g0[2 * e + 1];
+      v[NV / 2 + e] = g1[2 * e] - g1[2 * e + 1];
+    }
+    gather(q, v);
   }
 }
 
