@@ -515,6 +515,11 @@ def run_config(args, ctx, side=False):
 
 
 def main():
+    try:      # past four hardware queues the step's streams share a pipe and the two view branches stop overlapping (docs/experiments.md)
+        if int(os.environ.get("GPU_MAX_HW_QUEUES", "4")) > 4:
+            print("[bench] GPU_MAX_HW_QUEUES > 4 in the environment: expect ~2.4x the step time (measured 7.9 -> 19 ms)", file=sys.stderr)
+    except ValueError:
+        pass
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
