@@ -56,10 +56,13 @@ def _repeat_knn(calls):
     return bad
 
 
-def test_deep_configuration_knn_kernels_repeat_bitwise(golden):
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+def test_deep_configuration_knn_kernels_repeat_bitwise(golden, mode):
     """knn_sel_kernel (N = 256, k d = 18) and knn_rank_kernel (k d = 36 / 54 / 18) on the deep configuration's own train-mode
-    features (teacher-forced forward of tests/golden/deep_b4_k18): 48 calls x 150 launches"""
+    features (forward of tests/golden/deep_b4_k18, the reference's neighbour ids teacher-forced so that the fp32 features are the
+    golden's; bf16 storage = the instantiations bench.py --deep times): 48 calls x 150 launches"""
     from neuralsampleid_amd import functional as F_
+    F_.set_activation_dtype(mode)
     from neuralsampleid_amd.encoder.graph_encoder import GraphEncoder
     from neuralsampleid_amd.simclr.simclr import SimCLR
     g = golden("deep_b4_k18")
