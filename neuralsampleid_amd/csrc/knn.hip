@@ -685,7 +685,6 @@ __global__ __launch_bounds__(KNN2_THREADS) void knn_rank_kernel(const T* __restr
 // row's 9 100 cycles went to those 64 compares on LDS broadcasts); the same with a wave-wide bisection on ballots 91 us.
 constexpr int KSEL_SLACK = 3;             // surplus candidates accepted instead of another bisection step
 constexpr int KSEL_CH = 8;                // candidates per ranking trip (four 16-byte reads)
-constexpr int KSEL_TILES = 16;            // column tiles of a strip: N == 256 only (host-checked)
 
 __device__ __forceinline__ unsigned knn_key(float x) {
   const unsigned b = __float_as_uint(x + 0.f);                       // -0 -> +0: equal distances must get equal keys
@@ -707,13 +706,15 @@ __device__ __forceinline__ int row16_scan(int v) {                   // inclusiv
   return v;
 }
 
-template <typename T>
+// TILES = column tiles of a strip = N / 16 (16: the 256-node graphs; 8: the 128-node graphs, where k*d = 36 of 128 still leaves
+// rank counting 12x more compares than ranking the candidates)
+template <typename T, int TILES>
 __global__ __launch_bounds__(KNN2_THREADS) void knn_sel_kernel(const T* __restrict__ r, long ldr,
                                                                const float* __restrict__ scale,
                                                                const float* __restrict__ shift, int N, int C, int k,
                                                                int dilation, int32_t* __restrict__ idx) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  constexpr int SLOT = 256 + 2 * KSEL_CH;            // candidates of a row + padding + the dump word
+  constexpr int SLOT = 16 * TILES + 2 * KSEL_CH;            // candidates of a row + padding + the dump word
   char* img = reinterpret_cast<char*>(smem);         // [2][C/8][N][8] fp16 split images (see knn2_kernel)
   float* sq = smem + 2 * (N * C / 2);                // [N]
   unsigned long long* slots = reinterpret_cast<unsigned long long*>(sq + N);      // [8 waves][4 groups][SLOT]
@@ -734,25 +735,26 @@ __global__ __launch_bounds__(KNN2_THREADS) void knn_sel_kernel(const T* __restri
 #else
 #define KSEL_MARK(i)
 #endif
-  for (int s = wave; s < KSEL_TILES; s += KNN2_WAVES) {
+  for (int s = wave; s < TILES; s += KNN2_WAVES) {
     KSEL_MARK(0);
-    unsigned key[KSEL_TILES][4];
-    // ---- phase A: the strip's 16 x 256 distances, four column tiles per pass, straight into keys
+    unsigned key[TILES][4];
+    // ---- phase A: the strip's 16 x N distances, up to four column tiles per pass, straight into keys
+    constexpr int TP = TILES < 4 ? TILES : 4;
 #pragma unroll
-    for (int t0 = 0; t0 < KSEL_TILES; t0 += 4) {
-      f32x4 lead[4], corr[4];
+    for (int t0 = 0; t0 < TILES; t0 += TP) {
+      f32x4 lead[TP], corr[TP];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) lead[u] = corr[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int u = 0; u < TP; ++u) lead[u] = corr[u] = f32x4{0.f, 0.f, 0.f, 0.f};
       for (int kc = 0; kc < KC; kc += 4) {
         const KnnFrag fa = knn_frag(img, kc + rq, 16 * s + lr, KC, N);
-        KnnFrag fb[4];
+        KnnFrag fb[TP];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) fb[u] = knn_frag(img, kc + rq, 16 * (t0 + u) + lr, KC, N);
+        for (int u = 0; u < TP; ++u) fb[u] = knn_frag(img, kc + rq, 16 * (t0 + u) + lr, KC, N);
 #pragma unroll
-        for (int u = 0; u < 4; ++u) knn_mfma3(fa, fb[u], lead[u], corr[u]);      // A = the strip's row nodes, B = column nodes
+        for (int u = 0; u < TP; ++u) knn_mfma3(fa, fb[u], lead[u], corr[u]);      // A = the strip's row nodes, B = column nodes
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < TP; ++u) {
         const float sj = sq[16 * (t0 + u) + lr];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -770,9 +772,9 @@ __global__ __launch_bounds__(KNN2_THREADS) void knn_sel_kernel(const T* __restri
     if (g_knn_trace) {
       unsigned* dump = reinterpret_cast<unsigned*>(g_knn_trace);
 #pragma unroll
-      for (int u = 0; u < KSEL_TILES; ++u)
+      for (int u = 0; u < TILES; ++u)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) dump[((long)b * 256 + 16 * s + 4 * rq + e) * 256 + 16 * u + lr] = key[u][e];
+        for (int e = 0; e < 4; ++e) dump[((long)b * 16 * TILES + 16 * s + 4 * rq + e) * 16 * TILES + 16 * u + lr] = key[u][e];
     }
 #endif
     KSEL_MARK(1);
@@ -786,7 +788,7 @@ __global__ __launch_bounds__(KNN2_THREADS) void knn_sel_kernel(const T* __restri
       {
         int c = 0;
 #pragma unroll
-        for (int u = 0; u < KSEL_TILES; ++u) c += key[u][e] <= hi ? 1 : 0;
+        for (int u = 0; u < TILES; ++u) c += key[u][e] <= hi ? 1 : 0;
         chi = row16_sum(c);
       }
       if (chi < kd)                                            // NaN-poisoned row: fewer comparable entries than wanted
@@ -796,7 +798,7 @@ __global__ __launch_bounds__(KNN2_THREADS) void knn_sel_kernel(const T* __restri
         const unsigned mid = lo + ((hi - lo) >> 1);
         int c = 0;
 #pragma unroll
-        for (int u = 0; u < KSEL_TILES; ++u) c += key[u][e] <= mid ? 1 : 0;
+        for (int u = 0; u < TILES; ++u) c += key[u][e] <= mid ? 1 : 0;
         c = row16_sum(c);
         const bool down = act && c >= kd, up = act && c < kd;
         hi = down ? mid : hi;
@@ -807,12 +809,12 @@ __global__ __launch_bounds__(KNN2_THREADS) void knn_sel_kernel(const T* __restri
       KSEL_MARK(2);
       int n = 0;
 #pragma unroll
-      for (int u = 0; u < KSEL_TILES; ++u) n += key[u][e] <= hi ? 1 : 0;
+      for (int u = 0; u < TILES; ++u) n += key[u][e] <= hi ? 1 : 0;
       int pos = row16_scan(n) - n;
 #pragma unroll
-      for (int u = 0; u < KSEL_TILES; ++u) {
+      for (int u = 0; u < TILES; ++u) {
         const bool cand = key[u][e] <= hi;
-        slot[cand ? pos : 256 + KSEL_CH] = ((unsigned long long)key[u][e] << 32) | (unsigned)(16 * u + lr);
+        slot[cand ? pos : 16 * TILES + KSEL_CH] = ((unsigned long long)key[u][e] << 32) | (unsigned)(16 * u + lr);
         pos += cand ? 1 : 0;
       }
       if (lr < KSEL_CH) slot[chi + lr] = ~0ull;                // pad to whole trips: the largest word precedes nothing
@@ -842,20 +844,20 @@ __global__ __launch_bounds__(KNN2_THREADS) void knn_sel_kernel(const T* __restri
 #endif
 }
 
-template <typename T>
+template <typename T, int TILES>
 int launch_knn_sel(const void* r, int ldr, const float* scale, const float* shift, int B, int N, int C, int k,
                    int dilation, int32_t* idx, hipStream_t s) {
   const size_t bytes = (size_t)2 * N * C * 2 + (size_t)N * sizeof(float) +
-                       (size_t)KNN2_WAVES * 4 * (256 + 2 * KSEL_CH) * sizeof(unsigned long long);
-  if (bytes > 160 * 1024) return 1;
+                       (size_t)KNN2_WAVES * 4 * (16 * TILES + 2 * KSEL_CH) * sizeof(unsigned long long);
+  if (bytes > 160 * 1024 || N != 16 * TILES) return 1;
   static bool configured = false;
   if (!configured) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(knn_sel_kernel<T>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(knn_sel_kernel<T, TILES>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
       return NSID_ELAUNCH;
     configured = true;
   }
-  NSID_LAUNCH((knn_sel_kernel<T>), dim3(B), dim3(KNN2_THREADS), bytes, s, static_cast<const T*>(r), (long)ldr, scale,
+  NSID_LAUNCH((knn_sel_kernel<T, TILES>), dim3(B), dim3(KNN2_THREADS), bytes, s, static_cast<const T*>(r), (long)ldr, scale,
               shift, N, C, k, dilation, idx);
   return nsid_launch_status();
 }
@@ -936,17 +938,25 @@ extern "C" int nsid_knn_graph(const void* r, int ldr, const float* scale, const 
   const int kd = k * dilation;
   const bool use_fast = nsid_tune(NSID_T_knn_strips) == 0;
   const bool pow2 = C >= 64 && C <= 512 && (C & (C - 1)) == 0 && N >= 32 && (N & (N - 1)) == 0;
-  if (use_fast && pow2 && kd > 8 && N <= 128) {              // deep configuration, small graphs: rank counting
+  // deep configuration: threshold select in registers where a row is much longer than the wanted list (256- and 128-node graphs),
+  // rank counting where k*d is most of the row (64 and 32 nodes)
+  if (use_fast && pow2 && kd > 8 && kd <= 64 && N >= nsid_tune(NSID_T_knn_sel_min_n)) {
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    int rc = 1;
+#define NSID_KSEL_CASE(TL)                                                                                            \
+    case 16 * TL:                                                                                                    \
+      rc = dtype == NSID_BF16 ? launch_knn_sel<__bf16, TL>(r, ldr, scale, shift, B, N, C, k, dilation, idx, s)       \
+                              : launch_knn_sel<float, TL>(r, ldr, scale, shift, B, N, C, k, dilation, idx, s);       \
+      break;
+    switch (N) { NSID_KSEL_CASE(16) NSID_KSEL_CASE(8) NSID_KSEL_CASE(4) NSID_KSEL_CASE(2) default: break; }
+#undef NSID_KSEL_CASE
+    if (rc != 1) { nsid_count(NSID_C_knn_sel); return rc; }
+  }
+  if (use_fast && pow2 && kd > 8 && N <= 128) {              // small graphs: rank counting
     nsid_count(NSID_C_knn_rank);
     hipStream_t s = static_cast<hipStream_t>(stream);
     return dtype == NSID_BF16 ? launch_knn_rank<__bf16>(r, ldr, scale, shift, B, N, C, k, dilation, idx, s)
                               : launch_knn_rank<float>(r, ldr, scale, shift, B, N, C, k, dilation, idx, s);
-  }
-  if (use_fast && pow2 && kd > 8 && kd <= 64 && N == 256) {   // deep configuration, stage 0: threshold select
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    const int rc = dtype == NSID_BF16 ? launch_knn_sel<__bf16>(r, ldr, scale, shift, B, N, C, k, dilation, idx, s)
-                                      : launch_knn_sel<float>(r, ldr, scale, shift, B, N, C, k, dilation, idx, s);
-    if (rc != 1) { nsid_count(NSID_C_knn_sel); return rc; }
   }
   if (use_fast && kd <= 8 && pow2) {
     nsid_count(NSID_C_knn2);

@@ -157,6 +157,7 @@ static inline bool nsid_aligned16(const void* p) { return (reinterpret_cast<uint
   X(w3_min_tiles, 64)                                                                                                         \
   X(knn_strips, 0)             /* 1: always the general strip kernel (tests of the fallback) */                               \
   X(knn_pair_min, 512)         /* clips per launch from which knn2 runs as two 128-VGPR workgroups per CU; 0 = never */        \
+  X(knn_sel_min_n, 128)        /* graphs of at least this many nodes take the in-register threshold select for k*d > 8 */       \
   X(mr_grid_stride, 0)         /* 1: grid-stride aggregation instead of the LDS-staged per-clip kernel */                     \
   X(mr_split, 0)               /* channel split of the LDS-staged aggregation (0 = heuristic) */                              \
   X(ffn_waves, 8)              /* waves per workgroup of the fused eval-mode FFN (4 or 8) */                                  \

@@ -663,7 +663,8 @@ def knn_graph(r, B, N, C, k, dilation=1, aff: Optional[BNAffine] = None) -> torc
         aff = None
     idx = torch.empty((B, N, k), device=r.device, dtype=torch.int32)
     kd = k * dilation
-    name = "knn2_kernel" if kd <= 8 else ("knn_rank_kernel" if N <= 128 else ("knn_sel_kernel" if kd <= 64 else "knn_kernel"))
+    sel = 8 < kd <= 64 and N >= get_tuning("knn_sel_min_n")      # csrc/knn.hip nsid_knn_graph
+    name = "knn2_kernel" if kd <= 8 else ("knn_sel_kernel" if sel else ("knn_rank_kernel" if N <= 128 else "knn_kernel"))
     # read the features once, write int32 ids; 2*N^2*C flop on the fp32 matrix pipe
     _timed(name, 2.0 * B * N * N * C, float(B) * (N * C * r.element_size() + N * k * 4), lambda: call(
         "nsid_knn_graph", _p(r), r.shape[-1], _p(aff.scale) if aff else None, _p(aff.shift) if aff else None,

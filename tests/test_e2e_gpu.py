@@ -294,7 +294,7 @@ def test_simclr_e2e(golden, k):
 
 def test_deep_config4_e2e(golden):
     """BASELINE config 4 — GraphEncoder(blocks=[4,4,12,4], k=18, use_dilation=True): dilation 1/2/3/1 by stage, i.e. kNN
-    through knn_sel_kernel (N = 256, k*d = 18) and knn_rank_kernel (k*d = 36 / 54 / 18) — against the reference's own
+    through knn_sel_kernel (N = 256 / 128, k*d = 18 / 36) and knn_rank_kernel (N = 64 / 32, k*d = 54 / 18) — against the reference's own
     classes assembled with that schedule (make_golden.py::deep_reference_encoder): eval forward, then step 0 of training."""
     from neuralsampleid_amd import functional as F_
     from neuralsampleid_amd.encoder.graph_encoder import GraphEncoder

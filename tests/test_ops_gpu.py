@@ -209,7 +209,7 @@ def test_batchnorm_eval_affine_is_cached_until_a_tensor_changes(ops):
     assert torch.allclose(a3.scale, ref()[0], rtol=1e-6, atol=1e-7) and torch.allclose(a3.shift, ref()[1], rtol=1e-6, atol=1e-6)
 
 
-# k = 18 entries: BASELINE config 4's four shapes — (C64,N256,d1) -> knn_sel_kernel, (C128,N128,d2) / (C256,N64,d3) / (C512,N32,d1)
+# k = 18 entries: BASELINE config 4's four shapes — (C64,N256,d1) / (C128,N128,d2) -> knn_sel_kernel, (C256,N64,d3) / (C512,N32,d1)
 # -> knn_rank_kernel; c80n256 (size 's' channel count, not a power of two) -> the general strip kernel knn_kernel
 @pytest.mark.parametrize("tag,kds", [("c64n256", [(3, 1), (5, 1), (4, 2), (18, 3), (18, 1)]),
                                      ("c128n128", [(3, 1), (18, 2)]),
@@ -294,6 +294,29 @@ def test_knn2_pair_variant_equals_the_default(ops, N, C, dt):
             got = ops.knn_graph(r, B, N, C, k, d, aff)
             assert ops.launch_counters()["knn2_pair"] == c0 + 1
             assert (got == want).all(), (k, d)
+    finally:
+        ops.reset_tuning()
+
+
+@pytest.mark.parametrize("N,C,k,d", [(128, 128, 18, 2), (64, 256, 18, 3), (32, 512, 18, 1), (128, 128, 16, 4)])
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_knn_threshold_select_equals_rank_counting(ops, N, C, k, d, dt):
+    """the two large-k*d kernels compute the same distances in the same order and break ties the same way (lower index): on low-rank
+    features with duplicated nodes (many exact ties) knn_sel_kernel<T, N/16> and knn_rank_kernel must return identical ids"""
+    B = 12
+    g = torch.Generator().manual_seed(N + k)
+    r = (torch.randn(B * N, 6, generator=g) @ torch.randn(6, C, generator=g)).to(DEV).to(dt)
+    r[:N * 2:7] = r[1:N * 2 + 1:7].clone()
+    aff = ops.BNAffine(torch.rand(C, generator=g).to(DEV) + 0.5, torch.randn(C, generator=g).to(DEV) * 0.1)
+    try:
+        ops.set_tuning("knn_sel_min_n", 512)
+        c0 = ops.launch_counters()
+        want = ops.knn_graph(r, B, N, C, k, d, aff)
+        ops.set_tuning("knn_sel_min_n", 32)
+        got = ops.knn_graph(r, B, N, C, k, d, aff)
+        c1 = ops.launch_counters()
+        assert c1["knn_rank"] == c0["knn_rank"] + 1 and c1["knn_sel"] == c0["knn_sel"] + 1
+        assert (got == want).all()
     finally:
         ops.reset_tuning()
 
