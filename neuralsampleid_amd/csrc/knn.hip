@@ -691,11 +691,30 @@ __device__ __forceinline__ unsigned knn_key(float x) {
   const unsigned key = b ^ ((unsigned)((int)b >> 31) | 0x80000000u);
   return x != x ? 0xffffffffu : key;
 }
+__device__ __forceinline__ float knn_unkey(unsigned key) {          // the value a key stands for (inverse of knn_key on non-NaN keys)
+  return __uint_as_float((key & 0x80000000u) ? key ^ 0x80000000u : ~key);
+}
 __device__ __forceinline__ int row16_sum(int v) {                    // every lane of a 16-lane row gets the row's total
   v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true);      // quad_perm [1,0,3,2]
   v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true);      // quad_perm [2,3,0,1]
   v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, true);     // row_half_mirror
   v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, true);     // row_mirror
+  return v;
+}
+__device__ __forceinline__ unsigned row16_min(unsigned v) {          // minimum / maximum over a 16-lane row, in every lane
+  unsigned o;
+  o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true); v = o < v ? o : v;
+  o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true); v = o < v ? o : v;
+  o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, true); v = o < v ? o : v;
+  o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, true); v = o < v ? o : v;
+  return v;
+}
+__device__ __forceinline__ unsigned row16_max(unsigned v) {
+  unsigned o;
+  o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true); v = o > v ? o : v;
+  o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true); v = o > v ? o : v;
+  o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, true); v = o > v ? o : v;
+  o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, true); v = o > v ? o : v;
   return v;
 }
 __device__ __forceinline__ int row16_scan(int v) {                   // inclusive prefix sum within a 16-lane row
@@ -782,9 +801,21 @@ __global__ __launch_bounds__(KNN2_THREADS) void knn_sel_kernel(const T* __restri
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       int32_t* out = idx + ((long)b * N + 16 * s + 4 * rq + e) * k;
-      // bisection: #{key <= lo} < kd <= #{key <= hi} = chi throughout (key 0 belongs to no value: it would be a negative NaN)
-      unsigned lo = 0u, hi = 0xff800000u;                      // +inf: everything but NaN
-      int chi;
+      // threshold search: clo = #{key <= lo} < kd <= #{key <= hi} = chi throughout. The bracket starts at the row's own smallest and
+      // largest comparable key; steps alternate between INTERPOLATION (the key at which a locally uniform density would put rank
+      // k*d + 1.5) and plain bisection (keeps the worst case at twice the bisection count whatever the density): 7-8 steps where
+      // bisection of the whole key space took 13-14. Any threshold in the slack gives the same ids: the ranks below are exact.
+      unsigned kmin = 0xffffffffu, kmax = 0u;
+#pragma unroll
+      for (int u = 0; u < TILES; ++u) {
+        kmin = key[u][e] < kmin ? key[u][e] : kmin;
+        const unsigned kk = key[u][e] == 0xffffffffu ? 0u : key[u][e];        // NaN is not a threshold
+        kmax = kk > kmax ? kk : kmax;
+      }
+      kmin = row16_min(kmin);
+      kmax = row16_max(kmax);
+      unsigned lo = kmin - 1u, hi = kmax;                      // kmin >= key(-inf) = 0x007fffff: no wrap
+      int clo = 0, chi;
       {
         int c = 0;
 #pragma unroll
@@ -793,9 +824,18 @@ __global__ __launch_bounds__(KNN2_THREADS) void knn_sel_kernel(const T* __restri
       }
       if (chi < kd)                                            // NaN-poisoned row: fewer comparable entries than wanted
         for (int j = lr; j < k; j += 16) out[j] = j;
-      bool act = chi > kd + KSEL_SLACK;
-      while (__any(act)) {
-        const unsigned mid = lo + ((hi - lo) >> 1);
+      bool act = chi > kd + KSEL_SLACK && hi > lo + 1u;
+      for (int it = 0; __any(act); ++it) {
+        const unsigned span = hi - lo;
+        unsigned mid = lo + (span >> 1);
+        if ((it & 1) == 0) {                                   // interpolate between the DISTANCES the two keys stand for
+          const float want = ((float)(kd - clo) + 1.5f) * __builtin_amdgcn_rcpf((float)(chi - clo));
+          const float vlo = knn_unkey(lo), vhi = knn_unkey(hi);
+          unsigned guess = knn_key(vlo + (vhi - vlo) * want);
+          guess = guess <= lo ? lo + 1u : guess;
+          guess = guess >= hi ? hi - 1u : guess;
+          mid = act ? guess : mid;                             // (span >= 2 while act)
+        }
         int c = 0;
 #pragma unroll
         for (int u = 0; u < TILES; ++u) c += key[u][e] <= mid ? 1 : 0;
@@ -804,6 +844,7 @@ __global__ __launch_bounds__(KNN2_THREADS) void knn_sel_kernel(const T* __restri
         hi = down ? mid : hi;
         chi = down ? c : chi;
         lo = up ? mid : lo;
+        clo = up ? c : clo;
         act = act && chi > kd + KSEL_SLACK && hi - lo > 1u;
       }
       KSEL_MARK(2);
