@@ -510,8 +510,9 @@ void knn2_pair_kernel(const T* __restrict__ r, long ldr, const float* __restrict
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// Large k*dilation on small graphs (N <= 128; the deep configuration: k = 18 with dilation 2-3 asks for the 36 or 54
-// nearest of 128 or 64 nodes, nearly a full sort): selection by RANK COUNTING. A wave computes a 16-row distance strip
+// Large k*dilation on small graphs (N <= 128; by default the 64- and 32-node graphs, where k*d is most of the row — the deep
+// configuration asks for the 54 nearest of 64 nodes — while 128 nodes take knn_sel_kernel, tuning key knn_sel_min_n): selection by
+// RANK COUNTING. A wave computes a 16-row distance strip
 // into LDS (4 MFMA accumulator chains), then every lane takes (row, j) pairs and counts the entries of that row that
 // precede D[row][j] in (distance, index) order — N compares on LDS broadcasts, no dependent reductions, no rounds. The
 // element of rank p*dilation is neighbour p. The strip kernel's k*d rounds of wave-wide arg-min took 330 us per call here.
