@@ -247,7 +247,7 @@ def test_simclr_e2e(golden, k):
     for got, name in ((h_i, "h_i_eval"), (h_j, "h_j_eval")):
         assert maxerr(got, g.t(name)) < 1e-4 * max(1.0, float(g.t(name).abs().max())), name
     assert maxerr(z_i, g.t("z_i_eval")) < 1e-5 and maxerr(z_j, g.t("z_j_eval")) < 1e-5
-    assert abs(float(loss) - float(g["loss_eval"][0])) < 1e-5
+    assert abs(float(loss.detach()) - float(g["loss_eval"][0])) < 1e-5
 
     # ---- three training steps exactly as train.py:53-75 writes them (zero_grad / forward / loss / backward /
     #      clip_grad_norm_ / Adam.step) with stock torch.optim.Adam driving our modules
@@ -323,7 +323,7 @@ def test_deep_config4_e2e(golden):
     assert hard == 0 and soft <= rows * 5e-3, (hard, soft, rows)
     assert maxerr(h_i, g.t("h_i_eval")) < 1e-4 * max(1.0, float(g.t("h_i_eval").abs().max()))
     assert maxerr(z_i, g.t("z_i_eval")) < 2e-5 and maxerr(z_j, g.t("z_j_eval")) < 2e-5
-    assert abs(float(loss) - float(g["loss_eval"][0])) < 1e-5
+    assert abs(float(loss.detach()) - float(g["loss_eval"][0])) < 1e-5
     model.train()
     gold_idx, gaps = tape_of(g, "s0")
     F_.TAPE = F_.KnnTape(replay=gold_idx)
@@ -380,7 +380,7 @@ def test_fused_optimizer_matches_torch_adam(golden):
             if kind == "torch":
                 torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=1.0)
             opt.step()
-            ls.append(float(loss))
+            ls.append(float(loss.detach()))
         losses[kind] = ls
         finals[kind] = {n: p.detach().clone() for n, p in model.named_parameters() if p.requires_grad}
     assert abs(losses["torch"][0] - losses["fused"][0]) < 1e-5
@@ -482,7 +482,7 @@ def test_two_stream_views_equal_sequential(golden):
         loss = ntxent_loss(z_i, z_j, GRAFP_CFG)
         loss.backward()
         opt.step()                                   # joins the side stream before reading the gradients
-        res[overlap] = (float(loss), opt.flat_g.clone(), {k: v.clone() for k, v in model.state_dict().items()
+        res[overlap] = (float(loss.detach()), opt.flat_g.clone(), {k: v.clone() for k, v in model.state_dict().items()
                                                           if k.endswith(("running_mean", "running_var",
                                                                          "num_batches_tracked"))})
     assert abs(res[True][0] - res[False][0]) < 1e-5

@@ -466,7 +466,7 @@ def test_ntxent_golden(ops, golden, B):
     g = golden(f"ntxent_b{B}")
     zi, zj = g.t("z_i").to(DEV), g.t("z_j").to(DEV)
     loss, dzi, dzj = ops.ntxent_fwd_bwd(zi, zj, float(g["tau"]))
-    assert abs(float(loss) - float(g["loss"][0])) < 2e-6 * max(1.0, abs(float(g["loss"][0])))
+    assert abs(float(loss.detach()) - float(g["loss"][0])) < 2e-6 * max(1.0, abs(float(g["loss"][0])))
     close(dzi, g.t("dz_i"), tol=2e-6, what="dz_i")
     close(dzj, g.t("dz_j"), tol=2e-6, what="dz_j")
 
@@ -486,7 +486,7 @@ def test_ntxent_sharded(ops, golden):
     lref = R.ntxent(zi2, zj2, 0.1)
     lref.backward()
     loss, dzi, dzj = ops.ntxent_fwd_bwd(zi2.detach().to(DEV), zj2.detach().to(DEV), 0.1)
-    assert abs(float(loss) - float(lref)) < 2e-6
+    assert abs(float(loss.detach()) - float(lref)) < 2e-6
     close(dzi, zi2.grad, tol=2e-6, what="ragged dz_i")
     close(dzj, zj2.grad, tol=2e-6, what="ragged dz_j")
 
@@ -509,14 +509,14 @@ def test_ntxent_global_batch_2048_row_slices(ops):
     for r in range(world):
         loss, gi, gj = ops.ntxent_fwd_bwd(zi_d, zj_d, tau, r * per, per)
         want = float(R.ntxent_rows(z_all, 2 * r * per, 2 * per, tau)) / (2 * Bg)
-        assert abs(float(loss) - want) < 2e-6 * max(1.0, abs(want)), (r, float(loss), want)
-        losses.append(float(loss)); dzi.append(gi); dzj.append(gj)
+        assert abs(float(loss.detach()) - want) < 2e-6 * max(1.0, abs(want)), (r, float(loss.detach()), want)
+        losses.append(float(loss.detach())); dzi.append(gi); dzj.append(gj)
     assert abs(sum(losses) - float(full)) < 5e-6
     close(torch.cat(dzi), zi_r.grad, tol=2e-6, what="dz_i of the 8 slices")
     close(torch.cat(dzj), zj_r.grad, tol=2e-6, what="dz_j of the 8 slices")
     # one launch over the whole global batch (what a single-GPU step at B = 2048 would run) agrees as well
     loss, gi, gj = ops.ntxent_fwd_bwd(zi_d, zj_d, tau)
-    assert abs(float(loss) - float(full)) < 5e-6
+    assert abs(float(loss.detach()) - float(full)) < 5e-6
     close(gi, zi_r.grad, tol=2e-6, what="dz_i global")
 
 

@@ -216,7 +216,7 @@ def test_e2e(golden, k):
     for got, name in ((h_i, "h_i_eval"), (h_j, "h_j_eval")):
         assert (got - g.t(name)).abs().max() < 1e-4 * max(1.0, float(g.t(name).abs().max())), name
     assert (z_i - g.t("z_i_eval")).abs().max() < 1e-5 and (z_j - g.t("z_j_eval")).abs().max() < 1e-5
-    assert abs(float(loss) - float(g["loss_eval"][0])) < 1e-5
+    assert abs(float(loss.detach()) - float(g["loss_eval"][0])) < 1e-5
 
     # --- three training steps (train.py:53-75), indices forced per step
     opt = R.AdamState({k_: P[k_] for k_ in R.trainable_keys(P)}, lr=GRAFP_CFG["lr"])
@@ -322,7 +322,7 @@ def test_deep_config4(golden):
     assert hard == 0 and soft <= rows * 5e-3, (hard, soft, rows)
     assert (h_i - g.t("h_i_eval")).abs().max() < 1e-4 * max(1.0, float(g.t("h_i_eval").abs().max()))
     assert (z_j - g.t("z_j_eval")).abs().max() < 2e-5
-    assert abs(float(loss) - float(g["loss_eval"][0])) < 1e-5
+    assert abs(float(loss.detach()) - float(g["loss_eval"][0])) < 1e-5
     keys = R.trainable_keys(P)
     for k_ in keys:
         P[k_].requires_grad_(True)
@@ -336,7 +336,7 @@ def test_deep_config4(golden):
     finally:
         R.TAPE = None
     assert (h_i - g.t("h_i_train")).abs().max() < 5e-4 and (z_i - g.t("z_i_train")).abs().max() < 5e-5
-    assert abs(float(loss) - float(g["loss_train"][0])) < 5e-5
+    assert abs(float(loss.detach()) - float(g["loss_train"][0])) < 5e-5
     for name in [n for n in g if n.startswith("grad.")]:
         ref, got = g.t(name), P[name[5:]].grad
         if float(ref.norm()) < 1e-5:

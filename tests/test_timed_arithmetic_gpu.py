@@ -305,7 +305,7 @@ def test_bench_configuration_one_replay_vs_eager_steps(bf16_mode):
     dp = opt.flat_p - p0
 
     def compare(ref):
-        return {"dloss": abs(float(loss) - ref["loss"]), "rel_flat_g": relerr(opt.flat_g, ref["g"]),
+        return {"dloss": abs(float(loss.detach()) - ref["loss"]), "rel_flat_g": relerr(opt.flat_g, ref["g"]),
                 "gn_rel": abs(float(opt.grad_norm) - ref["gn"]) / ref["gn"],
                 "update_mean_abs_diff_over_lr": float((dp - ref["dp"]).abs().mean()) / lr,
                 "bn_worst": max(maxerr(b.double(), ref["bn"][n].double()) / max(1.0, float(ref["bn"][n].double().abs().max()))
