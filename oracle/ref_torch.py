@@ -330,4 +330,4 @@ def train_step(P: Dict[str, Tensor], x_i: Tensor, x_j: Tensor, cfg: dict, plan, 
         P[k] = v
     for k in keys:
         P[k].grad = None
-    return float(loss.detach()), gn
+    return float(loss), gn

@@ -81,3 +81,17 @@ def test_oracle_b256_eval_and_train_step0(golden):
         assert abs(float(P[name].grad.double().norm()) - nrm) <= 5e-3 * nrm, name
     for name, (s_, nrm) in chk["bn_after_step1"].items():
         assert abs(float(st.updates[name].double().norm()) - nrm) <= 1e-4 * max(nrm, 1.0), name
+
+
+def test_bf16_emulation_fixture_matches_the_oracle_source():
+    """tests/golden/b256_seed42_k3_bf16emu.* were computed by oracle/ref_torch.py with STORAGE = "bf16" (3 minutes of CPU) and record the
+    digest of that source; the GPU test refuses a stale fixture — this is the same check where there is no GPU, so that an edit of the
+    oracle is caught here first (regenerate with tests/golden/make_b256_emulation.py)"""
+    import json
+    import os
+    import sys
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    sys.path.insert(0, gold)
+    from make_b256_emulation import oracle_digest
+    with open(os.path.join(gold, "b256_seed42_k3_bf16emu_checksums.json")) as f:
+        assert json.load(f)["oracle_digest"] == oracle_digest()

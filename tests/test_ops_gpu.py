@@ -486,7 +486,7 @@ def test_ntxent_sharded(ops, golden):
     lref = R.ntxent(zi2, zj2, 0.1)
     lref.backward()
     loss, dzi, dzj = ops.ntxent_fwd_bwd(zi2.detach().to(DEV), zj2.detach().to(DEV), 0.1)
-    assert abs(float(loss.detach()) - float(lref)) < 2e-6
+    assert abs(float(loss.detach()) - float(lref.detach())) < 2e-6
     close(dzi, zi2.grad, tol=2e-6, what="ragged dz_i")
     close(dzj, zj2.grad, tol=2e-6, what="ragged dz_j")
 
