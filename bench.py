@@ -544,9 +544,9 @@ def main():
     ap.add_argument("--micro-batch", type=int, default=2048,
                     help="--mode infer: clips per forward call (config 5: >= 1024; measured on MI355X: 3.5 ms per 1 024 clips at "
                          "2 048 and 4 096 against 4.1 ms at 1 024 — the 1 024-clip launches leave partial rounds of tiles)")
-    ap.add_argument("--infer-streams", type=int, default=3,
-                    help="--mode infer: concurrent hipGraph replays (one HIP stream each, micro-batches dealt round-robin); measured "
-                         "306 k / 333 k / 350 k clips/s with 1 / 2 / 3")
+    ap.add_argument("--infer-streams", type=int, default=2,
+                    help="--mode infer: concurrent hipGraph replays (one HIP stream each, the caller's stream among them, micro-batches "
+                         "dealt round-robin); measured 386 k / 413 k / 403 k / 408 k clips/s with 1 / 2 / 3 / 4")
     ap.add_argument("--no-graph", action="store_true", help="do not capture the step in a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -591,7 +591,8 @@ def main():
     for kv in args.flag:
         target, _, val = kv.partition("=")
         mod, _, name = target.partition(".")
-        module = {"ops": ops, "functional": F_}[mod]
+        from neuralsampleid_amd import fingerprint as FP_
+        module = {"ops": ops, "functional": F_, "fingerprint": FP_}[mod]
         if not hasattr(module, name):
             raise SystemExit(f"--flag: {mod} has no switch {name}")
         setattr(module, name, int(val))

@@ -592,11 +592,17 @@ def test_graphed_fingerprinter_equals_eager_extraction(golden):
     assert maxerr(z, ref) < 2e-6                                             # same kernels; split-K atomics in the projector
     # three concurrent replays on three HIP streams (micro-batches dealt round-robin): the same numbers, twice in a row (the static
     # buffers of a stream are reused by its next micro-batch)
+    from neuralsampleid_amd import fingerprint as FP_
     fp3 = GraphedFingerprinter(model, micro_batch=4, streams=3)
-    for _ in range(2):
-        z3 = fp3(x)
-        torch.cuda.synchronize()
-        assert maxerr(z3, ref) < 2e-6
+    try:
+        for caller_lane in (True, False):                                    # the caller's stream as one of the lanes, or idle
+            FP_.USE_CALLER_STREAM = caller_lane
+            for _ in range(2):
+                z3 = fp3(x)
+                torch.cuda.synchronize()
+                assert maxerr(z3, ref) < 2e-6
+    finally:
+        FP_.USE_CALLER_STREAM = True
     del fp3
     assert maxerr(z[:8], g.t("z_i_eval")) < 1e-2                             # and the reference's eval goldens (own kNN)
     # torch-side weight changes move only `_version`: load_state_dict after the capture must be refused as well,
