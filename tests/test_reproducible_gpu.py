@@ -163,3 +163,27 @@ def test_gemm_family_repeats_bitwise_at_the_timed_shapes(M, Nout, K, groups):
     dgamma, dbeta = torch.zeros(groups * K, device=DEV), torch.zeros(groups * K, device=DEV)
     dx = torch.randn(M, groups * K, device=DEV, generator=g).bfloat16()
     assert _repeat_bitwise(lambda: (ops.bn_backward(dx, x, aff, ops.ACT_RELU, dgamma, dbeta),)) == 0
+
+
+@pytest.mark.parametrize("M,Nout,K,groups", [(32768, 512, 128, 1), (32768, 128, 128, 1), (16384, 128, 128, 4), (8192, 2048, 512, 1)])
+def test_weight_gradients_repeat_to_atomics_noise(M, Nout, K, groups):
+    """the weight-gradient kernels (rectangular / square gemm_kernel tiles, wgrad3_kernel) reduce their row splits with fp32 atomics:
+    100 launches on the same operands agree to summation-order noise (1e-5 of the largest entry); a stale or dropped tile would be
+    orders of magnitude above that"""
+    from neuralsampleid_amd import functional as F_, ops
+    F_.set_activation_dtype("bf16")
+    g = torch.Generator(device=DEV).manual_seed(M + Nout)
+    x = torch.randn(M, groups * K, device=DEV, generator=g).bfloat16()
+    dy = torch.randn(M, groups * Nout, device=DEV, generator=g).bfloat16()
+    sc = 1 + 0.1 * torch.randn(groups * K, device=DEV, generator=g)
+    sh = 0.1 * torch.randn(groups * K, device=DEV, generator=g)
+
+    def run():
+        dw = torch.zeros(groups * Nout, K, device=DEV)
+        ops.linear_bwd_weight(dy, x, dw, M, Nout, K, groups, sc, sh, ops.ACT_RELU)
+        return dw
+    first = run()
+    worst = torch.zeros((), device=DEV)
+    for _ in range(100):
+        worst = torch.maximum(worst, (run() - first).abs().max())
+    assert float(worst) <= 1e-5 * float(first.abs().max())
