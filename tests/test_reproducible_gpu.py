@@ -187,3 +187,40 @@ def test_weight_gradients_repeat_to_atomics_noise(M, Nout, K, groups):
     for _ in range(100):
         worst = torch.maximum(worst, (run() - first).abs().max())
     assert float(worst) <= 1e-5 * float(first.abs().max())
+
+
+@pytest.mark.parametrize("N,C,k", [(256, 64, 3), (128, 128, 3), (64, 256, 18), (32, 512, 18)])
+def test_aggregation_kernels_repeat(N, C, k):
+    """max-relative aggregation at B = 256, bf16: the forward (values and arg-max bytes) bit for bit; the backward is a gather over a
+    reversed graph whose per-node edge order depends on an integer-atomics race (mr.hip), i.e. fp32 sums of k terms on average in a
+    varying order — results within one bf16 ulp of each other (order-dependent rounding of an fp32 sum), never a wrong edge"""
+    from neuralsampleid_amd import functional as F_, ops
+    F_.set_activation_dtype("bf16")
+    B = 256
+    g = torch.Generator(device=DEV).manual_seed(N + k)
+    r = torch.randn(B * N, C, device=DEV, generator=g).bfloat16()
+    idx = torch.randint(0, N, (B, N, k), device=DEV, generator=g, dtype=torch.int32)
+    aff = ops.BNAffine(torch.rand(C, device=DEV, generator=g) + 0.5, torch.randn(C, device=DEV, generator=g) * 0.1)
+    assert _repeat_bitwise(lambda: ops.mr_aggregate_fwd(r, idx, B, N, C, aff, True), n=50) == 0
+    u, am = ops.mr_aggregate_fwd(r, idx, B, N, C, aff, True)
+    du = torch.randn(B * N, 2 * C, device=DEV, generator=g).bfloat16()
+    first = ops.mr_aggregate_bwd(du, idx, am, B, N, C).float()
+    worst = torch.zeros((), device=DEV)
+    for _ in range(50):
+        worst = torch.maximum(worst, ((ops.mr_aggregate_bwd(du, idx, am, B, N, C).float() - first).abs() / first.abs().clamp_min(1.0)).max())
+    assert float(worst) <= 2 ** -7          # one bf16 ulp of the result (order-dependent rounding of the fp32 sum), never a wrong edge
+
+
+def test_ntxent_repeats_to_atomics_noise():
+    """NT-Xent at the global batch of config 3 (2 048 pairs, this rank's 256): loss and dz to 1e-6 over 50 launches (split column ranges:
+    partial (max, sum) merges and atomics into dz)"""
+    from neuralsampleid_amd import ops
+    g = torch.Generator(device=DEV).manual_seed(3)
+    zi = torch.nn.functional.normalize(torch.randn(2048, 128, device=DEV, generator=g), dim=1)
+    zj = torch.nn.functional.normalize(zi + 0.3 * torch.randn(2048, 128, device=DEV, generator=g), dim=1)
+    l0, a0, b0 = [t.clone() for t in ops.ntxent_fwd_bwd(zi, zj, 0.05, 256, 256)]
+    worst = torch.zeros((), device=DEV)
+    for _ in range(50):
+        l, a, b = ops.ntxent_fwd_bwd(zi, zj, 0.05, 256, 256)
+        worst = torch.maximum(worst, torch.maximum((l - l0).abs().max(), torch.maximum((a - a0).abs().max(), (b - b0).abs().max())))
+    assert float(worst) <= 1e-6 * max(1.0, float(a0.abs().max()))
