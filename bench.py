@@ -462,7 +462,7 @@ def run_config(args, ctx, side=False):
         dt = (time.perf_counter() - t1) / n_alt
         other = {"precision": alt, "ms_per_step": round(1e3 * dt, 3), "value": round(args.batch / dt, 1),
                  "unit": "clips/s", "hipgraph": alt_graph is not None,
-                 "note": "same model continued; fp32 = strict-parity arithmetic (exact fp32 MFMA, fp32 storage)"}
+                 "note": "same model continued; fp32 = strict-parity arithmetic (exact fp32 MFMA GEMMs, fp32 storage; kNN distance products from a two-part fp16 split, 3e-7 from fp64 like the reference's own fp32 GEMM)"}
         del alt_graph
         ops.set_gemm_precision(args.precision)
         F_.set_activation_dtype(args.storage)
@@ -528,7 +528,7 @@ def main():
     ap.add_argument("--k", type=int, default=3, help="kNN neighbours (GraphEncoder default 3; train.py --k default 5)")
     ap.add_argument("--precision", choices=["fp32", "bf16"], default="bf16",
                     help="GEMM operand arithmetic: bf16 operands / fp32 storage+accumulate (BASELINE config 2, default) "
-                         "or fp32 (exact fp32 MFMA, the strict-parity path); the other mode is timed as a side number")
+                         "or fp32 (exact fp32 MFMA GEMMs and fp32 storage: the strict-parity path; its kNN distances use the split-fp16 product too); the other mode is timed as a side number")
     ap.add_argument("--storage", choices=["fp32", "bf16"], default=None,
                     help="activation storage in HBM (default: bf16 with --precision bf16 = BASELINE config 2's "
                          "'bf16 storage / fp32 accumulate'; fp32 with --precision fp32)")

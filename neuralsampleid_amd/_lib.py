@@ -61,11 +61,33 @@ SIGNATURES = {
     "nsid_batched_index_select_fwd": "ppiiiiips",
     "nsid_batched_index_select_bwd": "ppiiiiips",
     "nsid_fill_zero": "pzs",
+    # fixed-point BatchNorm sums (include/nsid.h, "lazy" forms): q = pointer to a nsid_bn_lazy_t / nsid_bn_bwd_lazy_t in HOST memory
+    "nsid_linear_fwd_lazy": "pipippiiiiiqipiis",
+    "nsid_downsample3_fwd_lazy": "piiipippipiis",
+    "nsid_knn_graph_lazy": "piqiiiiipis",
+    "nsid_bn_apply_lazy": "pqippiiis",
+    "nsid_bn_materialize": "qs",
+    "nsid_linear_bwd_data_bn_lazy": "pipipipiiiiiipppppipis",
+    "nsid_bn_bwd_reduce_lazy": "ppiippppipiis",
+    "nsid_bn_bwd_apply_lazy": "ppiippppiqpis",
+    "nsid_bn_bwd_materialize": "qs",
     "nsid_scale_f32": "pplps",
 }
 
 _CT = {"p": ctypes.c_void_p, "i": ctypes.c_int, "l": ctypes.c_long, "f": ctypes.c_float, "s": ctypes.c_void_p,
-       "z": ctypes.c_size_t}
+       "z": ctypes.c_size_t, "q": ctypes.c_void_p}
+
+
+class BnLazyC(ctypes.Structure):
+    """nsid_bn_lazy_t (include/nsid.h)"""
+    _fields_ = [("acc", ctypes.c_void_p), ("replicas", ctypes.c_int), ("channels", ctypes.c_int), ("rows", ctypes.c_long),
+                ("gamma", ctypes.c_void_p), ("beta", ctypes.c_void_p), ("eps", ctypes.c_float), ("out", ctypes.c_void_p)]
+
+
+class BnBwdLazyC(ctypes.Structure):
+    """nsid_bn_bwd_lazy_t (include/nsid.h)"""
+    _fields_ = [("acc", ctypes.c_void_p), ("replicas", ctypes.c_int), ("channels", ctypes.c_int), ("rows", ctypes.c_long),
+                ("dgamma", ctypes.c_void_p), ("dbeta", ctypes.c_void_p), ("coef", ctypes.c_void_p)]
 
 
 def _load():

@@ -20,19 +20,37 @@ def strip_data_parallel_prefix(state_dict: Mapping[str, torch.Tensor]) -> Dict[s
     return dict(state_dict)
 
 
-def load_reference_checkpoint(model: torch.nn.Module, path_or_dict, strict: bool = True, map_location="cpu") -> dict:
+def _numpy_log_globals():
+    """what numpy scalars / arrays pickle to: the reference logs `loss` and `hit_rate_log` entries as numpy values (train.py:150-158)"""
+    import numpy as np
+    out = [np.ndarray, np.dtype, np.float32, np.float64, np.int64, np.int32, np.bool_]
+    core = getattr(np, "_core", None) or getattr(np, "core")
+    out += [core.multiarray._reconstruct, core.multiarray.scalar]
+    out += [type(np.dtype(t)) for t in ("float32", "float64", "int64", "int32", "bool")]
+    return out
+
+
+def load_reference_checkpoint(model: torch.nn.Module, path_or_dict, strict: bool = True, map_location="cpu",
+                              trusted: bool = False) -> dict:
     """Load a checkpoint written by the reference's save_ckp (or a bare state_dict) into `model`; returns the checkpoint
-    dict (epoch / loss / optimizer / scheduler entries untouched) so a caller can resume as train.py:131-137 does."""
+    dict (epoch / loss / optimizer / scheduler entries untouched) so a caller can resume as train.py:131-137 does.
+
+    A file is read with torch's restricted unpickler (`weights_only=True`) plus the numpy scalar / array reconstructors the
+    reference's loss and hit-rate logs contain. `trusted=True` is the caller's statement that the file is local and theirs: only
+    then does a file the restricted unpickler rejects get the unrestricted `torch.load` the reference itself uses
+    (util.py:149-158, generate.py:88-97) — which executes whatever the pickle says. Never set it for a downloaded file."""
     ckpt = path_or_dict
     if not isinstance(ckpt, Mapping):
+        import pickle
         try:
-            ckpt = torch.load(path_or_dict, map_location=map_location)
-        except Exception as strict_err:      # torch >= 2.6 defaults to weights_only=True
-            import pickle
-            if not isinstance(strict_err, (pickle.UnpicklingError, RuntimeError)):
-                raise
-            # the reference's own checkpoints carry loss / hit-rate logs with numpy scalars and are loaded there with an
-            # unrestricted torch.load (util.py:149-158, generate.py:88-97): a LOCAL, TRUSTED file gets the same treatment
+            with torch.serialization.safe_globals(_numpy_log_globals()):
+                ckpt = torch.load(path_or_dict, map_location=map_location, weights_only=True)
+        except (pickle.UnpicklingError, RuntimeError) as safe_err:
+            if not trusted:
+                raise pickle.UnpicklingError(
+                    f"{path_or_dict}: rejected by the restricted unpickler ({safe_err}). If this is a local file you trust "
+                    "(e.g. a checkpoint the reference's train.py wrote on this machine), pass trusted=True to "
+                    "load_reference_checkpoint; that runs an unrestricted pickle load, which can execute arbitrary code.") from safe_err
             ckpt = torch.load(path_or_dict, map_location=map_location, weights_only=False)
     sd = ckpt["state_dict"] if "state_dict" in ckpt and isinstance(ckpt["state_dict"], Mapping) else ckpt
     model.load_state_dict(strip_data_parallel_prefix(sd), strict=strict)

@@ -54,6 +54,12 @@ struct GemmArgs {
   // (nsid_bn_bwd_finalize_fused). The workgroups of column tile 0 also write dr (abn_dr, row stride abn_lddr) for the weight
   // gradient: the separate bn_bwd_apply pass (read dy, read r, write dr) disappears.
   const void* abn_r; const float* abn_coef; long abn_plane; float abn_slope; void* abn_dr; long abn_lddr;
+  // Fixed-point BatchNorm sums (nsid_common.h, "lazy" training-mode BatchNorm): stat_acc / bn_acc replace the per-tile float partials
+  // `stat` / `bn_partial` (integer atomics, one replica per row tile modulo *_rep); a_lazy: the A operand's BatchNorm is still a
+  // pair of sums — every workgroup evaluates it in its prologue (a_scale / a_shift then point into a_lazy.out).
+  long long* stat_acc; int stat_rep;
+  long long* bn_acc; int bn_rep;
+  NsidBnLazy a_lazy;
 };
 
 // Precision H = false: fp32 operands, v_mfma_f32_16x16x4_f32, BK = 16 (exact fp32 — the parity path).
@@ -393,6 +399,9 @@ void gemm_kernel(const GemmArgs p) {
   }
   const int ti = bid / tiles_j, tj = bid % tiles_j;
   if (ti >= tiles_i) return;
+  if constexpr (AAFF) {
+    if (p.a_lazy.acc != nullptr) nsid_bn_lazy_finalize_wg(p.a_lazy);      // uniform: the producer's BatchNorm from its fixed-point sums
+  }
   const int g = blockIdx.z;
   const int i0 = ti * BM, j0 = tj * BN;
   const int rbeg = split * p.rchunk;
@@ -678,7 +687,7 @@ void gemm_kernel(const GemmArgs p) {
     const bool jqok = FULL || jq < p.J;          // J % OE == 0: a chunk is all-in or all-out
     char* Cb = reinterpret_cast<char*>(p.C) + g * p.c_goff * OSZ;
     const char* Ab = reinterpret_cast<const char*>(p.addend) + g * p.c_goff * OSZ;
-    if (p.stat != nullptr) {
+    if (p.stat != nullptr || p.stat_acc != nullptr) {
       // BatchNorm partial statistics of (acc + bias) from the accumulator registers, parked in LDS behind the transpose
       // buffers BEFORE the store loop: its barrier publishes them and the stores hide the LDS latency
       float* red = lds + NW * RB * OLD;      // [2 sums][wave-rows][4 row groups][BN]
@@ -840,15 +849,21 @@ void gemm_kernel(const GemmArgs p) {
                   a0 += red2[((0 * NW + (2 * wr + half)) * ROWS_PER_PASS + o) * WN + cw];
                   a1 += red2[((1 * NW + (2 * wr + half)) * ROWS_PER_PASS + o) * WN + cw];
                 }
-              p.bn_partial[((long)ti * STILES + t2) * p.bn_ld + col] = a0;
-              p.bn_partial[p.bn_plane + ((long)ti * STILES + t2) * p.bn_ld + col] = a1;
+              if (p.bn_acc != nullptr) {        // uniform
+                const int rep = (int)(((long)ti * STILES + t2) & (p.bn_rep - 1));
+                nsid_acc_add(p.bn_acc, (int)p.bn_ld, rep, 0, (int)col, nsid_fix_bwd(a0));
+                nsid_acc_add(p.bn_acc, (int)p.bn_ld, rep, 1, (int)col, nsid_fix_bwd(a1));
+              } else {
+                p.bn_partial[((long)ti * STILES + t2) * p.bn_ld + col] = a0;
+                p.bn_partial[p.bn_plane + ((long)ti * STILES + t2) * p.bn_ld + col] = a1;
+              }
             }
           }
         }
       }
     }
   }
-  if (p.stat != nullptr) {   // uniform branch: the column sums were parked in LDS before the store loop (see above)
+  if (p.stat != nullptr || p.stat_acc != nullptr) {   // uniform branch: the column sums were parked in LDS before the store loop (see above)
     const float* red = lds + NW * RB * ((BN / 2) + 4);
     if (threadIdx.x < BN) {
       const int j = j0 + threadIdx.x;
@@ -862,8 +877,14 @@ void gemm_kernel(const GemmArgs p) {
             s += red[(0 * WROWS * 4 + k) * BN + threadIdx.x];
             q += red[(1 * WROWS * 4 + k) * BN + threadIdx.x];
           }
-          p.stat[((long)ti * STILES + t2) * p.stat_ld + col] = s;
-          p.stat[p.stat_plane + ((long)ti * STILES + t2) * p.stat_ld + col] = q;
+          if (p.stat_acc != nullptr) {          // uniform
+            const int rep = (int)(((long)ti * STILES + t2) & (p.stat_rep - 1));
+            nsid_acc_add(p.stat_acc, (int)p.stat_ld, rep, 0, (int)col, nsid_fix_fwd(s));
+            nsid_acc_add(p.stat_acc, (int)p.stat_ld, rep, 1, (int)col, nsid_fix_fwd(q));
+          } else {
+            p.stat[((long)ti * STILES + t2) * p.stat_ld + col] = s;
+            p.stat[p.stat_plane + ((long)ti * STILES + t2) * p.stat_ld + col] = q;
+          }
         }
       }
     }
@@ -1070,8 +1091,8 @@ extern "C" int nsid_version(void) { return 3; }
 //   col[m][kk] = xflat[(2m - 1)*C + kk],  kk in [0, 3C): row stride 2C, overlapping rows, base x - C,
 // except that the first C columns of the rows m with m % No == 0 are the left padding (zero; they would alias the previous
 // clip's last row). The three GEMMs below read that view through the padded-operand loads of gemm_kernel.
-extern "C" int nsid_downsample3_fwd(const void* x, int B, int N, int C, const void* wp, int w_dtype, const float* bias,
-                                    void* out, int Cout, float* stat, int act_dtype, void* stream) {
+static int downsample3_fwd_impl(const void* x, int B, int N, int C, const void* wp, int w_dtype, const float* bias,
+                                void* out, int Cout, float* stat, long long* stat_acc, int stat_rep, int act_dtype, void* stream) {
   NSID_REQUIRE(x && wp && out && B > 0 && N > 0 && N % 2 == 0 && C > 0 && Cout > 0 && NSID_DTYPE_OK(act_dtype));
   const int ch = act_dtype == NSID_BF16 ? 8 : 4;
   NSID_REQUIRE(C % ch == 0 && C % 4 == 0 && Cout % ch == 0 && Cout % 4 == 0 && nsid_aligned16(x) && nsid_aligned16(wp) &&
@@ -1086,12 +1107,25 @@ extern "C" int nsid_downsample3_fwd(const void* x, int B, int N, int C, const vo
   p.a_slope = 1.f;
   p.bias = bias; p.bias_goff = Cout;
   p.stat = stat; p.stat_ld = Cout; p.stat_plane = (long)nsid_row_tiles(M) * Cout;
+  p.stat_acc = stat_acc; p.stat_rep = stat_rep;
+  if (stat_acc != nullptr) nsid_count(NSID_C_bn_stat_acc);
   p.rsplit = 1; p.rchunk = 3 * C;
   p.pad_period = No; p.pad_phase = 0; p.pad_c0 = 0; p.pad_c1 = C; p.pad_safe = C;
   hipStream_t s = static_cast<hipStream_t>(stream);
   const bool wb = w_dtype == NSID_BF16;
   if (Cout <= 64) return launch_pad<128, 64, true, true, 1>(p, 1, s, act_dtype, wb);
   return launch_pad<128, 128, true, true, 1>(p, 1, s, act_dtype, wb);
+}
+
+extern "C" int nsid_downsample3_fwd(const void* x, int B, int N, int C, const void* wp, int w_dtype, const float* bias,
+                                    void* out, int Cout, float* stat, int act_dtype, void* stream) {
+  return downsample3_fwd_impl(x, B, N, C, wp, w_dtype, bias, out, Cout, stat, nullptr, 0, act_dtype, stream);
+}
+extern "C" int nsid_downsample3_fwd_lazy(const void* x, int B, int N, int C, const void* wp, int w_dtype, const float* bias, void* out,
+                                         int Cout, int64_t* stat_acc, int stat_replicas, int act_dtype, void* stream) {
+  NSID_REQUIRE(nsid_acc_ok(stat_acc, stat_replicas));
+  return downsample3_fwd_impl(x, B, N, C, wp, w_dtype, bias, out, Cout, nullptr, reinterpret_cast<long long*>(stat_acc), stat_replicas,
+                              act_dtype, stream);
 }
 
 // dwp[o][kk] += sum_m dout[m][o] * col[m][kk]   (fp32 atomics over row splits, like every weight gradient)
@@ -1168,10 +1202,27 @@ extern "C" int nsid_get_gemm_precision(void) { return g_gemm_precision; }
 extern "C" long nsid_gemm_g256_launches(void) { return g_g256_launches; }
 extern "C" int nsid_row_tiles(int M) { return (M + NSID_ROW_TILE - 1) / NSID_ROW_TILE; }
 
+struct LazyFwd {          // fixed-point statistics / a BatchNorm still held as sums on the operand side (nsid_linear_fwd_lazy)
+  long long* stat_acc = nullptr; int stat_rep = 0; const nsid_bn_lazy_t* in_bn = nullptr;
+};
 static int linear_fwd_impl(const void* x, int ldx, const void* w, int w_dtype, const float* bias, void* out, int ldo,
                            int M, int Nout, int K, int groups, const float* in_scale, const float* in_shift, int act_in,
                            int act_out, float* stat, int ksplit, int act_dtype, const void* addend, int ldadd,
-                           void* stream);
+                           void* stream, const LazyFwd& lz = LazyFwd());
+
+// nsid_linear_fwd with fixed-point statistics and / or a BatchNorm on the operand side that is still a pair of sums
+extern "C" int nsid_linear_fwd_lazy(const void* x, int ldx, const void* w, int w_dtype, const float* bias, void* out, int ldo, int M,
+                                    int Nout, int K, int groups, const nsid_bn_lazy_t* in_bn, int act_in, int64_t* stat_acc,
+                                    int stat_replicas, int act_dtype, void* stream) {
+  NSID_REQUIRE(in_bn == nullptr || nsid_lazy_ok(in_bn, groups * K));
+  NSID_REQUIRE(stat_acc == nullptr || (nsid_acc_ok(stat_acc, stat_replicas) && nsid_aligned16(stat_acc)));
+  LazyFwd lz;
+  lz.stat_acc = reinterpret_cast<long long*>(stat_acc); lz.stat_rep = stat_replicas; lz.in_bn = in_bn;
+  const float* sc = in_bn ? in_bn->out : nullptr;
+  const float* sh = in_bn ? in_bn->out + (long)groups * K : nullptr;
+  return linear_fwd_impl(x, ldx, w, w_dtype, bias, out, ldo, M, Nout, K, groups, sc, sh, act_in, NSID_ACT_NONE, nullptr, 1, act_dtype,
+                         nullptr, 0, stream, lz);
+}
 
 extern "C" int nsid_linear_fwd(const void* x, int ldx, const void* w, int w_dtype, const float* bias, void* out, int ldo,
                                int M, int Nout, int K, int groups, const float* in_scale, const float* in_shift,
@@ -1195,7 +1246,7 @@ extern "C" int nsid_linear_fwd_res(const void* x, int ldx, const void* w, int w_
 static int linear_fwd_impl(const void* x, int ldx, const void* w, int w_dtype, const float* bias, void* out, int ldo,
                            int M, int Nout, int K, int groups, const float* in_scale, const float* in_shift, int act_in,
                            int act_out, float* stat, int ksplit, int act_dtype, const void* addend, int ldadd,
-                           void* stream) {
+                           void* stream, const LazyFwd& lz) {
   NSID_REQUIRE(x && w && out && M > 0 && Nout > 0 && K > 0 && groups > 0 && ksplit >= 1 && NSID_DTYPE_OK(act_dtype));
   NSID_REQUIRE(NSID_DTYPE_OK(w_dtype) && (w_dtype == NSID_F32 || (act_dtype == NSID_BF16 && K % 8 == 0)));
   const int ch = act_dtype == NSID_BF16 ? 8 : 4;     // elements per 16-byte chunk of the activation tensors
@@ -1220,6 +1271,10 @@ static int linear_fwd_impl(const void* x, int ldx, const void* w, int w_dtype, c
   p.bias = bias; p.bias_goff = Nout;
   p.addend = addend; p.ldadd = ldadd;
   p.stat = stat; p.stat_ld = (long)groups * Nout; p.stat_plane = (long)nsid_row_tiles(M) * groups * Nout;
+  p.stat_acc = lz.stat_acc; p.stat_rep = lz.stat_rep;
+  if (lz.stat_acc != nullptr) nsid_count(NSID_C_bn_stat_acc);
+  if (lz.in_bn != nullptr && lz.in_bn->acc != nullptr) { p.a_lazy = nsid_lazy_view(lz.in_bn); nsid_count(NSID_C_bn_lazy_finalize); }
+  const bool any_stat = stat != nullptr || lz.stat_acc != nullptr;
   p.rsplit = ksplit;
   p.rchunk = (K + ksplit - 1) / ksplit;
   p.atomic_out = ksplit > 1;
@@ -1242,7 +1297,7 @@ static int linear_fwd_impl(const void* x, int ldx, const void* w, int w_dtype, c
   // training step never takes it (it needs the statistics epilogue; 256x128 measured neutral there), fingerprinting at micro-batch
   // 1 024 has 1 024 - 4 096 tiles per GEMM: +4 % clips/s.
   const long tall_min = nsid_tune(NSID_T_tall_min);
-  const bool tall = stat == nullptr && act_dtype == NSID_BF16 && wb && !narrow && t128 >= tall_min && M % 256 == 0 &&
+  const bool tall = !any_stat && act_dtype == NSID_BF16 && wb && !narrow && t128 >= tall_min && M % 256 == 0 &&
                     Nout % 128 == 0 && K % 64 == 0 && ksplit == 1;
   // 8 waves on 256x128 tiles (round 2): same per-wave work as the 128x128 kernel, a quarter fewer operand bytes per flop,
   // statistics epilogue included (two 128-row statistics tiles per workgroup). Tuning key w8_min = smallest number of 128x128
@@ -1255,7 +1310,7 @@ static int linear_fwd_impl(const void* x, int ldx, const void* w, int w_dtype, c
   // (<= 256 such tiles per launch) is neutral to slightly worse with it (8.30 vs 8.34 ms: a workgroup that owns 150 KB of a CU's LDS
   // keeps the other view's kernels off that CU), so it stays on gemm.hip.
   const long g256_min = nsid_tune(NSID_T_g256_min);
-  if (g256_min > 0 && (stat == nullptr || nsid_tune(NSID_T_g256_train) != 0) && act_dtype == NSID_BF16 && wb && groups == 1 && in_scale == nullptr && ksplit == 1 &&
+  if (g256_min > 0 && lz.stat_acc == nullptr && (stat == nullptr || nsid_tune(NSID_T_g256_train) != 0) && act_dtype == NSID_BF16 && wb && groups == 1 && in_scale == nullptr && ksplit == 1 &&
       (act_out == NSID_ACT_NONE || act_out == NSID_ACT_RELU) && act_in == NSID_ACT_NONE && ldx >= K &&
       (long)(M / 256) * (Nout / 256) >= g256_min) {
     const int rc256 = nsid_gemm256_fwd_launch(x, ldx, w, bias, addend, ldadd, out, ldo, M, Nout, K, act_out == NSID_ACT_RELU, stat,
@@ -1279,7 +1334,8 @@ struct AbnArgs {          // BatchNorm backward of the layer in front, applied o
 static int linear_bwd_data_impl(const void* dout, int ldd, const void* w, int w_dtype, const void* addend, int ldadd,
                                 void* din, int ldi, int M, int Nout, int K, int groups, int act_dtype, void* stream,
                                 const void* bn_r, const float* bn_scale, const float* bn_shift, const float* bn_mean,
-                                const float* bn_invstd, int bn_act, float* bn_partial, const AbnArgs* abn = nullptr);
+                                const float* bn_invstd, int bn_act, float* bn_partial, const AbnArgs* abn = nullptr,
+                                long long* bn_acc = nullptr, int bn_rep = 0);
 
 extern "C" int nsid_linear_bwd_data(const void* dout, int ldd, const void* w, int w_dtype, const void* addend, int ldadd,
                                     void* din, int ldi, int M, int Nout, int K, int groups, int act_dtype,
@@ -1300,6 +1356,18 @@ extern "C" int nsid_linear_bwd_data_bn(const void* dout, int ldd, const void* w,
                               bn_r, bn_scale, bn_shift, bn_mean, bn_invstd, bn_act, bn_partial);
 }
 
+// nsid_linear_bwd_data_bn with the column sums ADDED into fixed-point accumulators (no per-tile partial buffer, no finalize launch)
+extern "C" int nsid_linear_bwd_data_bn_lazy(const void* dout, int ldd, const void* w, int w_dtype, const void* addend, int ldadd,
+                                            void* din, int ldi, int M, int Nout, int K, int groups, int act_dtype, const void* bn_r,
+                                            const float* bn_scale, const float* bn_shift, const float* bn_mean,
+                                            const float* bn_invstd, int bn_act, int64_t* bn_acc, int bn_replicas, void* stream) {
+  NSID_REQUIRE(bn_r && bn_scale && bn_shift && bn_mean && bn_invstd && nsid_acc_ok(bn_acc, bn_replicas) && act_dtype == NSID_BF16);
+  NSID_REQUIRE(ldi == groups * K && (groups * K) % 8 == 0 && nsid_aligned16(bn_r));
+  NSID_REQUIRE(bn_act == NSID_ACT_NONE || bn_act == NSID_ACT_RELU || bn_act == NSID_ACT_LEAKY);
+  return linear_bwd_data_impl(dout, ldd, w, w_dtype, addend, ldadd, din, ldi, M, Nout, K, groups, act_dtype, stream, bn_r, bn_scale,
+                              bn_shift, bn_mean, bn_invstd, bn_act, nullptr, nullptr, reinterpret_cast<long long*>(bn_acc), bn_replicas);
+}
+
 // Backward-data of a conv whose OUTPUT gradient still has to go through the BatchNorm(+activation) backward of that conv's own
 // BatchNorm: din = addend + dr w with dr = BN-backward(dy, r) evaluated on the operand load (no bn_bwd_apply pass), dr written once as
 // a side output for the weight gradient. coef4[4][groups*Nout] = {sc, sh, P, Q} from nsid_bn_bwd_finalize_fused. The optional bn_*
@@ -1311,6 +1379,8 @@ extern "C" int nsid_linear_bwd_data_bnapply(const void* dy, const void* r, const
                                             const float* bn_shift, const float* bn_mean, const float* bn_invstd, int bn_act,
                                             float* bn_partial, void* stream) {
   NSID_REQUIRE(dy && r && coef4 && dr && nsid_aligned16(r) && nsid_aligned16(dr) && nsid_aligned16(coef4));
+  // only column tile 0 writes dr while every column tile of the row panel reads dy and r, unordered: an aliased call would race
+  NSID_REQUIRE(dr != dy && dr != r);
   NSID_REQUIRE(act == NSID_ACT_NONE || act == NSID_ACT_RELU || act == NSID_ACT_LEAKY);
   if (act_dtype != NSID_BF16 || w_dtype != NSID_BF16 || (groups * Nout) % 8 != 0) return 1;
   if (bn_r != nullptr) {
@@ -1326,7 +1396,8 @@ extern "C" int nsid_linear_bwd_data_bnapply(const void* dy, const void* r, const
 static int linear_bwd_data_impl(const void* dout, int ldd, const void* w, int w_dtype, const void* addend, int ldadd,
                                 void* din, int ldi, int M, int Nout, int K, int groups, int act_dtype, void* stream,
                                 const void* bn_r, const float* bn_scale, const float* bn_shift, const float* bn_mean,
-                                const float* bn_invstd, int bn_act, float* bn_partial, const AbnArgs* abn) {
+                                const float* bn_invstd, int bn_act, float* bn_partial, const AbnArgs* abn, long long* bn_acc,
+                                int bn_rep) {
   NSID_REQUIRE(dout && w && din && M > 0 && Nout > 0 && K > 0 && groups > 0 && NSID_DTYPE_OK(act_dtype));
   NSID_REQUIRE(NSID_DTYPE_OK(w_dtype) && (w_dtype == NSID_F32 || (act_dtype == NSID_BF16 && K % 8 == 0)));
   const bool wb = w_dtype == NSID_BF16;
@@ -1346,6 +1417,8 @@ static int linear_bwd_data_impl(const void* dout, int ldd, const void* w, int w_
   p.bn_scale = bn_scale; p.bn_shift = bn_shift; p.bn_mean = bn_mean; p.bn_invstd = bn_invstd;
   p.bn_slope = act_slope(bn_act);
   p.bn_partial = bn_partial; p.bn_ld = (long)groups * K; p.bn_plane = (long)nsid_row_tiles(M) * groups * K;
+  p.bn_acc = bn_acc; p.bn_rep = bn_rep;
+  if (bn_acc != nullptr) nsid_count(NSID_C_bn_stat_acc);
   hipStream_t s = static_cast<hipStream_t>(stream);
   const long t128 = (long)nsid_row_tiles(M) * ((K + 127) / 128) * groups;
   const bool half = g_gemm_precision == NSID_GEMM_BF16 || act_dtype == NSID_BF16;
@@ -1363,7 +1436,7 @@ static int linear_bwd_data_impl(const void* dout, int ldd, const void* w, int w_
   // the 8-wave 256x128 form loses here (16384x256x1024: 21.8 -> 41.4 us cold): 169 registers = one workgroup per CU, and the
   // transposed weight reads + addend / BatchNorm-sum epilogue do not shrink with the tile. Kept for experiments only.
   const long w8_min = nsid_tune(NSID_T_w8_bwd_min);
-  if (w8_min > 0 && !narrow && act_dtype == NSID_BF16 && wb && t128 >= w8_min && M % 256 == 0 && K % 128 == 0 && Nout % 64 == 0)
+  if (abn == nullptr && w8_min > 0 && !narrow && act_dtype == NSID_BF16 && wb && t128 >= w8_min && M % 256 == 0 && K % 128 == 0 && Nout % 64 == 0)
     return launch<256, 128, true, false, 8>(p, groups, s, act_dtype, wb);
   if (narrow) return launch<128, 64, true, false>(p, groups, s, act_dtype, wb);
   return launch<128, 128, true, false>(p, groups, s, act_dtype, wb);

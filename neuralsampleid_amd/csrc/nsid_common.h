@@ -127,6 +127,83 @@ static inline bool nsid_aligned16(const void* p) { return (reinterpret_cast<uint
     if (!(cond)) return NSID_EINVAL; \
   } while (0)
 
+// ---- training-mode BatchNorm statistics as FIXED-POINT column sums (round 4) ---------------------------------------------------
+// The per-row-tile float partials + one finalize launch per BatchNorm layer (256 launches of ~5 us per step, 0.57 ms of the
+// two-stream step by a skip-the-launch diagnosis) are replaced by: the producing kernel ADDS its column sums, converted to 64-bit
+// fixed point, into acc[replica][2][C] with integer atomics — integer addition is associative, so the totals do not depend on
+// the order the workgroups arrive in (the float-atomic form would) — and the FIRST kernel that consumes the layer evaluates
+// mean / variance / scale / shift from the totals itself, every workgroup for itself (same integers, same arithmetic: same
+// bits), and writes them where the later consumers (backward, the deferred running-statistics update) expect them.
+// Forward sums use 2^-28 as the unit (|sum of squares| < 3.4e10 over the batch), backward sums 2^-44 (|sum| < 5.2e5).
+struct NsidBnLazy {                 // device view of nsid_bn_lazy_t; acc == nullptr: `out` already holds the five vectors
+  const long long* acc; int R; int C; long rows;
+  const float* gamma; const float* beta; float eps;
+  float* out;                       // [5][C]: scale, shift, mean, invstd, unbiased variance
+};
+struct NsidBnBwdLazy {              // device view of nsid_bn_bwd_lazy_t
+  const long long* acc; int R; int C; long rows;
+  float* dgamma; float* dbeta;      // += (atomic: the two views of a step may add concurrently); either may be null
+  float* coef;                      // optional [2][C]: c0 = sum(g) / rows, c1 = sum(g * xhat) / rows
+};
+__device__ __forceinline__ long long nsid_fix_fwd(float v) { return __double2ll_rn((double)v * (double)(1LL << NSID_STAT_FWD_SHIFT)); }
+__device__ __forceinline__ long long nsid_fix_bwd(float v) { return __double2ll_rn((double)v * (double)(1LL << NSID_STAT_BWD_SHIFT)); }
+// acc[replica][which][C] += v (no-return 64-bit integer atomic: executes at the memory side, any order gives the same total)
+__device__ __forceinline__ void nsid_acc_add(long long* acc, int C, int replica, int which, int c, long long v) {
+  atomicAdd(reinterpret_cast<unsigned long long*>(acc) + ((long)(2 * replica + which) * C + c), (unsigned long long)v);
+}
+__device__ __forceinline__ void nsid_acc_total(const long long* acc, int R, int C, int c, long long& s, long long& q) {
+  s = 0; q = 0;
+  for (int r = 0; r < R; ++r) { s += acc[(long)(2 * r) * C + c]; q += acc[(long)(2 * r + 1) * C + c]; }
+}
+// the arithmetic of bn_finalize_kernel (bn.hip) on the totals of one channel
+__device__ __forceinline__ void nsid_bn_lazy_channel(const NsidBnLazy& z, int c, float& sc, float& sh, float& mu, float& is, float& uv) {
+  long long s, q;
+  nsid_acc_total(z.acc, z.R, z.C, c, s, q);
+  const double unit = 1.0 / (double)(1LL << NSID_STAT_FWD_SHIFT), M = (double)z.rows;
+  const double mean = (double)s * unit / M;
+  double var = (double)q * unit / M - mean * mean;
+  if (var < 0.0) var = 0.0;
+  is = (float)(1.0 / sqrt(var + (double)z.eps));
+  sc = z.gamma[c] * is;
+  sh = z.beta[c] - (float)mean * sc;
+  mu = (float)mean;
+  uv = (float)(var * (M / (z.rows > 1 ? M - 1.0 : 1.0)));
+}
+// Whole workgroup: evaluate every channel, write the five vectors, and make them readable by this workgroup's own later loads.
+// Every workgroup of the consuming launch does this; they all write the same bits, so the writes need no ordering between
+// workgroups, and a workgroup reads only what it has written itself (drained + barrier).
+__device__ __forceinline__ void nsid_bn_lazy_finalize_wg(const NsidBnLazy& z) {
+  for (int c = threadIdx.x; c < z.C; c += blockDim.x) {
+    float sc, sh, mu, is, uv;
+    nsid_bn_lazy_channel(z, c, sc, sh, mu, is, uv);
+    z.out[c] = sc; z.out[z.C + c] = sh; z.out[2 * z.C + c] = mu; z.out[3 * z.C + c] = is; z.out[4 * z.C + c] = uv;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+}
+__device__ __forceinline__ void nsid_bn_bwd_lazy_channel(const NsidBnBwdLazy& z, int c, float& c0, float& c1, float& sg, float& sgx) {
+  long long s, q;
+  nsid_acc_total(z.acc, z.R, z.C, c, s, q);
+  const double unit = 1.0 / (double)(1LL << NSID_STAT_BWD_SHIFT), M = (double)z.rows;
+  const double dsg = (double)s * unit, dsgx = (double)q * unit;
+  sg = (float)dsg; sgx = (float)dsgx;
+  c0 = (float)(dsg / M); c1 = (float)(dsgx / M);
+}
+static inline NsidBnLazy nsid_lazy_view(const nsid_bn_lazy_t* z) {
+  return NsidBnLazy{reinterpret_cast<const long long*>(z->acc), z->replicas, z->channels, z->rows, z->gamma, z->beta, z->eps, z->out};
+}
+static inline NsidBnBwdLazy nsid_bwd_lazy_view(const nsid_bn_bwd_lazy_t* z) {
+  return NsidBnBwdLazy{reinterpret_cast<const long long*>(z->acc), z->replicas, z->channels, z->rows, z->dgamma, z->dbeta, z->coef};
+}
+static inline bool nsid_lazy_ok(const nsid_bn_lazy_t* z, int C) {
+  return z && z->out && z->channels == C && nsid_aligned16(z->out) && C % 4 == 0 &&
+         (z->acc == nullptr || (z->gamma && z->beta && z->rows > 0 && z->replicas >= 1 && z->replicas <= NSID_STAT_MAX_REPLICAS &&
+                                (z->replicas & (z->replicas - 1)) == 0));
+}
+static inline bool nsid_acc_ok(const int64_t* acc, int replicas) {
+  return acc && replicas >= 1 && replicas <= NSID_STAT_MAX_REPLICAS && (replicas & (replicas - 1)) == 0;
+}
+
 // ---- tuning table (include/nsid.h: nsid_set_tuning / nsid_get_tuning / nsid_reset_tuning; defined in tuning.hip) -----------
 // Every launch heuristic that has a number in it reads that number from here. The defaults are the values that won their one-box
 // A/B of the whole two-stream step (docs/experiments.md); the library never reads the environment, so the arithmetic and the kernel
@@ -191,7 +268,10 @@ static inline long nsid_tune(NsidTuneKey k) { return g_nsid_tune[k]; }
   X(knn2) X(knn2_pair) X(knn_rank) X(knn_sel) X(knn_strips)                                                  \
   X(mr_fwd_lds) X(mr_fwd_grid)                                                                  \
   X(ffn_fused)            /* eval-mode FFN in one launch (ffn_fused.hip) */                     \
-  X(mrconv_fused)         /* eval-mode max-relative aggregation + grouped conv in one launch (mrconv_fused.hip) */
+  X(mrconv_fused)         /* eval-mode max-relative aggregation + grouped conv in one launch (mrconv_fused.hip) */ \
+  X(bn_stat_acc)          /* producers that ADD BatchNorm column sums in fixed point (no partial-sum buffer) */ \
+  X(bn_lazy_finalize)     /* consumers that evaluate a BatchNorm from those sums in their own prologue (no finalize launch) */ \
+  X(bn_materialize)       /* stand-alone finalize launches from fixed-point sums (a consumer without the prologue) */
 
 enum NsidCounterKey {
 #define NSID_CNT_ENUM(name) NSID_C_##name,

@@ -192,10 +192,31 @@ def conv_bn(x: Tensor, M: int, K: int, Nout: int, w: Tensor, bias: Optional[Tens
         r, _ = ops.linear_fwd(x, wf, bf, M, Nout, K, groups, sc, sh, act_in, folded_act, addend=residual)
         return r, (None if folded_act != ACT_NONE else ops.identity_affine(groups * Nout, x.device))
     assert residual is None
+    if lazy_stats(training, rm):
+        # statistics as fixed-point sums added by the GEMM; the BatchNorm in front (in_aff), if still unevaluated, is evaluated in this
+        # launch's prologue: no finalize launch on either side (ops.LAZY_BN)
+        acc = (ops.STAT_ARENA.take(ops.stat_replicas(M) * 2 * groups * Nout, x.device), ops.stat_replicas(M))
+        if in_aff is not None and in_aff.lazy is None:
+            in_aff = None if in_aff.identity and act_in == ACT_NONE else in_aff
+        if in_aff is None or in_aff.lazy is not None:
+            r, _ = ops.linear_fwd(x, ops.w2d(w), bias, M, Nout, K, groups, act_in=act_in, in_aff=in_aff, stat_acc=acc)
+            return r, lazy_affine_from(acc, M, gamma, beta, rm, rv, nbt)
     r, stat = ops.linear_fwd(x, ops.w2d(w), bias, M, Nout, K, groups,
                              in_aff.scale if in_aff else None, in_aff.shift if in_aff else None, act_in,
                              ACT_NONE, want_stat=training)
     return r, bn_affine_from(stat, M, gamma, beta, rm, rv, nbt, training)
+
+
+def lazy_stats(training: bool, rm) -> bool:
+    """training-mode BatchNorm statistics as fixed-point sums, evaluated by the consuming kernel (ops.LAZY_BN): bf16 storage, the two
+    views on two streams (deferred running-statistics update), a zeroed accumulator arena"""
+    return training and VIEW_ORDER.mode is not None and rm is not None and ops.lazy_bn_enabled(ACT_DTYPE == torch.bfloat16)
+
+
+def lazy_affine_from(acc, M, gamma, beta, rm, rv, nbt) -> BNAffine:
+    aff, uvar = ops.lazy_affine(acc[0], acc[1], M, gamma, beta)
+    VIEW_ORDER.pending[VIEW_ORDER.mode].append((rm, rv, nbt, aff._mean, uvar))     # filled by the layer's first consumer
+    return aff
 
 
 def bn_affine_from(stat, M, gamma, beta, rm, rv, nbt, training: bool) -> BNAffine:
@@ -363,8 +384,13 @@ def downsample_forward(x: Tensor, P, S: Optional[dict], B: int, N: int, training
         ops.SHADOWS.register(wp, ops.f32_to_bf16(wp), owner=wp, fresh=True)
     if view:
         gamma, beta, rm, rv, nbt, _ = _bn(P, S, "conv.1.")
-        r, stat = ops.downsample3_fwd(x, B, N, C, wp, P["conv.0.bias"], Co, want_stat=training)
-        aff = bn_affine_from(stat, B * No, gamma, beta, rm, rv, nbt, training)
+        if lazy_stats(training, rm):
+            acc = (ops.STAT_ARENA.take(ops.stat_replicas(B * No) * 2 * Co, x.device), ops.stat_replicas(B * No))
+            r, _ = ops.downsample3_fwd(x, B, N, C, wp, P["conv.0.bias"], Co, stat_acc=acc)
+            aff = lazy_affine_from(acc, B * No, gamma, beta, rm, rv, nbt)
+        else:
+            r, stat = ops.downsample3_fwd(x, B, N, C, wp, P["conv.0.bias"], Co, want_stat=training)
+            aff = bn_affine_from(stat, B * No, gamma, beta, rm, rv, nbt, training)
     else:
         r, aff = conv_bn(col, B * No, 3 * C, Co, wp, P["conv.0.bias"], _bn(P, S, "conv.1."), training)
     out = ops.bn_apply(r, aff, ACT_NONE)

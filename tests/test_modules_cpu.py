@@ -104,3 +104,36 @@ def test_batched_index_select_symbol_exists_with_the_reference_signature():
     import inspect
     from neuralsampleid_amd.encoder.gcn_lib.torch_nn import batched_index_select
     assert list(inspect.signature(batched_index_select).parameters) == ["x", "idx"]      # torch_nn.py:79
+
+
+def test_checkpoint_loading_is_restricted_unless_the_caller_says_trusted(tmp_path):
+    """ADVICE r3: a checkpoint is read with torch's restricted unpickler (+ the numpy scalars the reference's logs hold, train.py:150-158);
+    anything it rejects is loaded with an unrestricted pickle only when the caller passes trusted=True."""
+    import pickle
+    import numpy as np
+    import pytest
+    from neuralsampleid_amd.checkpoint import load_reference_checkpoint
+    torch.manual_seed(6)
+    src = build()
+    sd = src.state_dict()
+    # (a) numpy values in the logs, as the reference writes them: accepted by the restricted load
+    ck = {"epoch": 2, "loss": np.float64(0.75), "hit_rate_log": [np.float32(0.5), np.array([1.0, 2.0])], "state_dict": sd,
+          "optimizer": None, "scheduler": None}
+    p1 = tmp_path / "np_logs.pth"
+    torch.save(ck, p1)
+    dst = build()
+    out = load_reference_checkpoint(dst, str(p1))
+    assert float(out["loss"]) == 0.75 and all(torch.equal(dst.state_dict()[k], sd[k]) for k in sd)
+
+    # (b) a pickle that names an arbitrary global: refused with a hint, loaded only with trusted=True
+    class Marker:
+        pass
+    globals()["Marker"] = Marker                      # picklable by reference
+    Marker.__module__, Marker.__qualname__ = __name__, "Marker"
+    p2 = tmp_path / "arbitrary.pth"
+    torch.save({"state_dict": sd, "extra": Marker()}, p2)
+    with pytest.raises(pickle.UnpicklingError, match="trusted=True"):
+        load_reference_checkpoint(build(), str(p2))
+    dst3 = build()
+    load_reference_checkpoint(dst3, str(p2), trusted=True)
+    assert all(torch.equal(dst3.state_dict()[k], sd[k]) for k in sd)

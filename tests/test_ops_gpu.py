@@ -298,6 +298,28 @@ def test_knn2_pair_variant_equals_the_default(ops, N, C, dt):
         ops.reset_tuning()
 
 
+@pytest.mark.parametrize("N,C,k", [(256, 64, 3), (256, 64, 8), (128, 128, 3), (64, 256, 3), (32, 512, 3), (128, 128, 18), (64, 256, 18)])
+def test_knn_split_fp16_distance_error_bound(ops, N, C, k):
+    """every fast kNN path computes the distance products from a two-part fp16 split (csrc/knn.hip); its error against an
+    fp64 evaluation is ~3e-7 on unit-norm rows, PROVIDED the matrix core keeps fp16 subnormal inputs (the low parts of features around
+    0.04 are subnormal: flushed, the error grows to ~1e-5). The kernels do not export distances, so the bound is stated on what they
+    decide: on every row whose first k+1 fp64 distances are separated by more than 2e-6, the neighbour ids must be the fp64 ranking."""
+    B = 48
+    r = rnd(f"knnsplit{N}{C}", B * N, C).to(DEV)
+    idx = ops.knn_graph(r, B, N, C, k, 1, None).long().cpu()
+    y = r.double().reshape(B, N, C).cpu()
+    y = y / y.norm(dim=2, keepdim=True).clamp_min(1e-12)
+    sq = (y * y).sum(2)
+    D = sq[:, :, None] - 2.0 * torch.bmm(y, y.transpose(1, 2)) + sq[:, None, :]
+    Ds, order = torch.sort(D, dim=2, stable=True)
+    gaps = (Ds[:, :, 1:k + 1] - Ds[:, :, :k]).min(dim=2).values           # separation inside the first k+1 (incl. the k / k+1 boundary)
+    clear = gaps > 2e-6
+    assert float(clear.float().mean()) > 0.5, "the input has too many near-ties for this test to say anything"
+    same = (idx == order[:, :, :k]).all(dim=2)
+    bad = int((clear & ~same).sum())
+    assert bad == 0, f"{bad} rows with fp64 gaps > 2e-6 got other neighbours: the split-fp16 distances are off by more than 1e-6"
+
+
 @pytest.mark.parametrize("N,C,k,d", [(128, 128, 18, 2), (64, 256, 18, 3), (32, 512, 18, 1), (128, 128, 16, 4)])
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
 def test_knn_threshold_select_equals_rank_counting(ops, N, C, k, d, dt):
