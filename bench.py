@@ -274,10 +274,8 @@ def log(msg):
     print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
 
-def spawn_ranks(n: int) -> int:
-    """`python bench.py --gpus N` without a launcher: start the N ranks as FRESH child processes through
-    torch.distributed.run — this process has made no GPU call (a process that has initialised the GPU must never exec or be
-    replaced) — relay rank 0's single JSON line, and exit non-zero if any rank fails or the job overruns its deadline."""
+def _run_rank_job(n: int, deadline: float, extra_env: dict):
+    """one attempt: n FRESH child ranks through torch.distributed.run; returns (exit code, JSON lines, stdout); 124 = deadline overrun"""
     import signal
     import socket
     import subprocess
@@ -286,9 +284,9 @@ def spawn_ranks(n: int) -> int:
         port = sk.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    log(f"no launcher in the environment: spawning {n} ranks: {' '.join(cmd[1:8])} ...")
-    deadline = float(os.environ.get("NSID_BENCH_TIMEOUT_S", "1500"))
-    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, start_new_session=True)
+    env = dict(os.environ)
+    env.update(extra_env)
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, start_new_session=True, env=env)
     try:
         out, _ = proc.communicate(timeout=deadline)
     except subprocess.TimeoutExpired:
@@ -298,14 +296,45 @@ def spawn_ranks(n: int) -> int:
             proc.wait(timeout=20)
         except subprocess.TimeoutExpired:
             os.killpg(proc.pid, signal.SIGKILL)
-        return 124
+            proc.wait()
+        return 124, [], ""
     lines = [ln for ln in out.splitlines() if ln.startswith("{")]
-    if proc.returncode != 0 or len(lines) != 1:
-        sys.stderr.write(out)
-        log(f"launcher exit code {proc.returncode}, {len(lines)} JSON lines")
-        return proc.returncode or 1
-    print(lines[0], flush=True)
-    return 0
+    return proc.returncode, lines, out
+
+
+def spawn_ranks(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher: start the N ranks as FRESH child processes through
+    torch.distributed.run — this process has made no GPU call (a process that has initialised the GPU must never exec or be
+    replaced) — relay rank 0's single JSON line, and exit non-zero if any rank fails or the job overruns its deadline.
+
+    First multi-GPU contact (task 6): the captured step holds RCCL kernels inside a hipGraph, which has never run with more
+    than one rank. If that attempt exits non-zero or overruns its share of the deadline, ONE more set of fresh ranks is started with
+    NSID_DP_GRAPH=0 (eager collectives, no capture); the line then says config.rccl.mode = "eager-retry" (first attempt: "graph").
+    The retry is skipped when the caller already asked for eager collectives, or with NSID_DP_RETRY=0."""
+    log(f"no launcher in the environment: spawning {n} ranks through torch.distributed.run ...")
+    deadline = float(os.environ.get("NSID_BENCH_TIMEOUT_S", "1500"))
+    may_retry = os.environ.get("NSID_DP_GRAPH", "1") != "0" and os.environ.get("NSID_DP_RETRY", "1") != "0"
+    t0 = time.time()
+    rc, lines, out = _run_rank_job(n, deadline * (0.6 if may_retry else 1.0), {"NSID_DP_ATTEMPT": "graph"})
+    if rc == 0 and len(lines) == 1:
+        print(lines[0], flush=True)
+        return 0
+    sys.stderr.write(out)
+    log(f"launcher exit code {rc}, {len(lines)} JSON lines")
+    if not may_retry:
+        return rc or 1
+    left = deadline - (time.time() - t0)
+    if left < 30:
+        log("no time left for the eager retry")
+        return rc or 1
+    log(f"retrying ONCE with eager collectives (NSID_DP_GRAPH=0), {left:.0f} s left")
+    rc2, lines2, out2 = _run_rank_job(n, left, {"NSID_DP_GRAPH": "0", "NSID_DP_ATTEMPT": "eager-retry"})
+    if rc2 == 0 and len(lines2) == 1:
+        print(lines2[0], flush=True)
+        return 0
+    sys.stderr.write(out2)
+    log(f"eager retry: launcher exit code {rc2}, {len(lines2)} JSON lines")
+    return rc2 or rc or 1
 
 
 def run_config(args, ctx, side=False):
@@ -400,7 +429,13 @@ def run_config(args, ctx, side=False):
 
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    die_at = os.environ.get("NSID_TEST_KILL_RANK")          # tests only: "rank:step[:attempt]" — that rank dies (SIGKILL) inside the timed loop
+    for it in range(args.steps):
+        if die_at:
+            f = die_at.split(":")
+            if int(f[0]) == rank and int(f[1]) == it and (len(f) < 3 or f[2] == os.environ.get("NSID_DP_ATTEMPT", "")):
+                import signal
+                os.kill(os.getpid(), signal.SIGKILL)
         run()
     barrier()
     elapsed = time.perf_counter() - t0
@@ -502,7 +537,11 @@ def run_config(args, ctx, side=False):
                        "tuning": tuning or None, "lib": os.environ.get("NSID_LIB") or None,
                        "rccl": ({"ncclCommCount": parallel.COMM.count(), "collectives_per_step": per_step_calls,
                                  "gradient_buckets": len(reducer.bounds), "bucket_bytes": 16 << 20,
-                                 "captured_on_every_rank": graph is not None}
+                                 "captured_on_every_rank": graph is not None,
+                                 # "graph": collectives replayed inside the step's hipGraph; "eager": not captured (asked for, or the
+                                 # capture failed on some rank); "eager-retry": the spawner's second attempt after the first one died
+                                 "mode": ("graph" if graph is not None else
+                                          ("eager-retry" if os.environ.get("NSID_DP_ATTEMPT") == "eager-retry" else "eager"))}
                                 if parallel.COMM is not None else None)},
             "roofline": roofline,
             "step_hbm_frac_algorithmic": round(step_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),

@@ -101,6 +101,9 @@ def _load():
         fn.argtypes = [_CT[c] for c in sig]
         fn.restype = ctypes.c_int
     lib.nsid_version.restype = ctypes.c_int
+    if lib.nsid_version() < 0 and os.environ.get("NSID_ALLOW_DIAGNOSIS_LIB") != "1":
+        raise ImportError(f"{LIB_PATH} is a DIAGNOSIS build (compiled with result-changing -DNSID_* switches: timing only, results "
+                          "wrong). Set NSID_ALLOW_DIAGNOSIS_LIB=1 to load it for a timing experiment; never ship it.")
     lib.nsid_debug_gemm_trace.argtypes = [ctypes.c_void_p]
     lib.nsid_debug_gemm_trace.restype = ctypes.c_int
     lib.nsid_debug_knn_trace.argtypes = [ctypes.c_void_p]

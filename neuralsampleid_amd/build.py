@@ -28,9 +28,18 @@ def _deps():
     return max(os.path.getmtime(h) for h in hdrs)
 
 
+def _check_flags() -> None:
+    """the product library is built from the sources and FLAGS alone: a -DNSID_* switch (diagnosis builds change results) smuggled in
+    through $HIPCC is refused; tools/build_variant.sh is the place for those"""
+    if "-DNSID_" in HIPCC or any(f.startswith("-DNSID_") for f in FLAGS):
+        raise RuntimeError("refusing to build the product library with a -DNSID_* switch: use tools/build_variant.sh for diagnosis builds")
+
+
 def _source_hash() -> str:
     import hashlib
-    h = hashlib.sha256(" ".join(FLAGS[:6]).encode())
+    _check_flags()
+    # every flag that shapes the code (the include path is the tree itself) and the compiler command
+    h = hashlib.sha256((HIPCC + " " + " ".join(f for f in FLAGS if f != os.path.join(ROOT, "include"))).encode())
     for f in [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(CSRC, "nsid_common.h"),
                                                          os.path.join(ROOT, "include", "nsid.h")]:
         h.update(open(f, "rb").read())

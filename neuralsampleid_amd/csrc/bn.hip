@@ -322,26 +322,29 @@ __global__ __launch_bounds__(256) void colsum_atomic_kernel(const T* __restrict_
 }
 
 // ---- consumers of a BatchNorm that is still a pair of fixed-point sums (nsid_common.h) -----------------------------------------
-// bn_apply: a thread keeps ONE column chunk for the whole kernel (the launch makes the thread count a multiple of the chunks per
-// row), so it evaluates scale / shift of its own N channels from the totals once, in registers: no finalize launch, no barrier. The
-// first CV threads of workgroup 0 also write the five vectors for the later consumers (backward, the running-statistics update).
+// bn_apply: the workgroup evaluates the layer ONCE into LDS (C <= LAZY_MAX_C channels over 256 threads), then every thread takes the
+// scale / shift of its own column chunk (a thread keeps ONE chunk for the whole kernel: the launch makes the thread count a multiple of
+// the chunks per row). Workgroup 0 also writes the five vectors for the later consumers (backward, the running-statistics update).
+// (First form: every THREAD evaluated its 8 channels in registers with fp64 division / square root: 23.9 us per launch against 5.7.)
+constexpr int LAZY_MAX_C = 2048;
 template <typename T>
 __global__ __launch_bounds__(256) void bn_apply_lazy_kernel(const T* __restrict__ r, const NsidBnLazy z, int act,
                                                             const T* __restrict__ residual, T* __restrict__ out, long rows, int CV) {
   constexpr int N = Chunk<T>::N;
+  __shared__ float aff[2][LAZY_MAX_C];
+  for (int c = threadIdx.x; c < z.C; c += 256) {
+    float sc, sh, mu, is, uv;
+    nsid_bn_lazy_channel(z, c, sc, sh, mu, is, uv);
+    aff[0][c] = sc; aff[1][c] = sh;
+    if (blockIdx.x == 0) { z.out[c] = sc; z.out[z.C + c] = sh; z.out[2 * z.C + c] = mu; z.out[3 * z.C + c] = is; z.out[4 * z.C + c] = uv; }
+  }
+  __syncthreads();
   const long t = (long)blockIdx.x * blockDim.x + threadIdx.x, total = (long)gridDim.x * blockDim.x;
   const int cq = (int)(t % CV), c = cq * N;
   const long rstep = total / CV;                  // total % CV == 0 (host)
   float sc[N], sh[N];
 #pragma unroll
-  for (int e = 0; e < N; ++e) {
-    float mu, is, uv;
-    nsid_bn_lazy_channel(z, c + e, sc[e], sh[e], mu, is, uv);
-    if (t < CV) {
-      z.out[c + e] = sc[e]; z.out[z.C + c + e] = sh[e]; z.out[2 * z.C + c + e] = mu; z.out[3 * z.C + c + e] = is;
-      z.out[4 * z.C + c + e] = uv;
-    }
-  }
+  for (int e = 0; e < N; ++e) { sc[e] = aff[0][c + e]; sh[e] = aff[1][c + e]; }
   constexpr int U = 2;
   for (long row = t / CV; row < rows; row += U * rstep) {
     float v[U][N], rs[U][N];
@@ -384,14 +387,25 @@ __global__ __launch_bounds__(256) void bn_bwd_materialize_kernel(const NsidBnBwd
   if (z.coef) { z.coef[c] = c0; z.coef[z.C + c] = c1; }
 }
 
-// bn_bwd_apply with coef0 / coef1 evaluated from the backward sums by every thread for its own column chunk (registers only); the first
-// CV threads of workgroup 0 add dgamma / dbeta (atomic: the two views of a step share them) and, when asked, write coef.
+// bn_bwd_apply with coef0 / coef1 evaluated from the backward sums once per workgroup (LDS); workgroup 0 adds dgamma / dbeta (atomic:
+// the two views of a step share them) and, when asked, writes coef.
 template <typename T, int U>
 __global__ __launch_bounds__(256) void bn_bwd_apply_lazy_kernel(const T* __restrict__ dout, const T* __restrict__ r, long rows, int CV,
                                                                 const float* __restrict__ scale, const float* __restrict__ shift,
                                                                 const float* __restrict__ mean, const float* __restrict__ invstd,
                                                                 float slope, const NsidBnBwdLazy z, T* __restrict__ dr) {
   constexpr int N = Chunk<T>::N;
+  __shared__ float cf[2][LAZY_MAX_C];
+  for (int c = threadIdx.x; c < z.C; c += 256) {
+    float c0, c1, sg, sgx;
+    nsid_bn_bwd_lazy_channel(z, c, c0, c1, sg, sgx);
+    cf[0][c] = c0; cf[1][c] = c1;
+    if (blockIdx.x == 0) {
+      if (z.dbeta) atomicAdd(z.dbeta + c, sg);
+      if (z.dgamma) atomicAdd(z.dgamma + c, sgx);
+      if (z.coef) { z.coef[c] = c0; z.coef[z.C + c] = c1; }
+    }
+  }
   const long t = (long)blockIdx.x * blockDim.x + threadIdx.x, total = (long)gridDim.x * blockDim.x;
   const int cq = (int)(t % CV), c = cq * N;
   const long rstep = total / CV;                  // total % CV == 0 (host)
@@ -400,16 +414,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_lazy_kernel(const T* __restr
   load_channels<N>(shift, c, sh);
   load_channels<N>(mean, c, mu);
   load_channels<N>(invstd, c, is);
+  __syncthreads();
 #pragma unroll
-  for (int e = 0; e < N; ++e) {
-    float sg, sgx;
-    nsid_bn_bwd_lazy_channel(z, c + e, c0[e], c1[e], sg, sgx);
-    if (t < CV) {
-      if (z.dbeta) atomicAdd(z.dbeta + c + e, sg);
-      if (z.dgamma) atomicAdd(z.dgamma + c + e, sgx);
-      if (z.coef) { z.coef[c + e] = c0[e]; z.coef[z.C + c + e] = c1[e]; }
-    }
-  }
+  for (int e = 0; e < N; ++e) { c0[e] = cf[0][c + e]; c1[e] = cf[1][c + e]; }
   for (long row = t / CV; row < rows; row += U * rstep) {
     float d[U][N], x[U][N];
 #pragma unroll
@@ -635,6 +642,7 @@ extern "C" int nsid_bn_apply_lazy(const void* r, const nsid_bn_lazy_t* bn, int a
   NSID_REQUIRE(r && out && M > 0 && C > 0 && NSID_DTYPE_OK(dtype) && nsid_lazy_ok(bn, C));
   NSID_REQUIRE(C % (dtype == NSID_BF16 ? 8 : 4) == 0 && nsid_aligned16(r) && nsid_aligned16(out));
   if (bn->acc == nullptr) return nsid_bn_apply(r, bn->out, bn->out + C, act, residual, out, M, C, dtype, stream);
+  NSID_REQUIRE(C <= LAZY_MAX_C);
   nsid_count(NSID_C_bn_lazy_finalize);
   NSID_DISPATCH_DTYPE(dtype, T, {
     const int CV = C / Chunk<T>::N;
@@ -686,6 +694,7 @@ extern "C" int nsid_bn_bwd_apply_lazy(const void* dout, const void* r, int M, in
   NSID_REQUIRE(dout && r && scale && shift && mean && invstd && dr && M > 0 && C > 0 && NSID_DTYPE_OK(dtype) && bwd_lazy_ok(sums, C));
   NSID_REQUIRE(C % (dtype == NSID_BF16 ? 8 : 4) == 0);
   NSID_REQUIRE(act == NSID_ACT_NONE || act == NSID_ACT_RELU || act == NSID_ACT_LEAKY);
+  NSID_REQUIRE(C <= LAZY_MAX_C);
   nsid_count(NSID_C_bn_lazy_finalize);
   NSID_DISPATCH_DTYPE(dtype, T, {
     constexpr int U = 4;

@@ -1083,7 +1083,11 @@ int launch_pad(GemmArgs p, int groups, hipStream_t s, int act_dtype, bool w_bf16
 
 }  // namespace
 
-extern "C" int nsid_version(void) { return 3; }
+#ifdef NSID_DIAGNOSIS_BUILD
+extern "C" int nsid_version(void) { return -4; }      // a timing-only build whose results may be wrong (nsid_common.h)
+#else
+extern "C" int nsid_version(void) { return 4; }
+#endif
 
 // ---- Downsample (Conv2d 3x3 stride 2 pad 1 on a width-1 map, encoder/graph_encoder.py:44) WITHOUT im2col -------------------
 // Only kernel column 1 meets data: out[b*No + n'] = sum_t x[b*N + 2n'-1+t] . W_t (t = 0,1,2; row -1 of a clip is padding).

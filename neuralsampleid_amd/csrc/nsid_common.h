@@ -6,6 +6,13 @@
 
 #include "../../include/nsid.h"
 
+// Diagnosis switches that CHANGE RESULTS (timing-only builds of tools/build_variant.sh: NSID_ABN_NOMATH / NSID_ABN_NOSIDE,
+// NSID_WGRAD_PLAINSTORE, NSID_G256_ABLATE) compile only together with -DNSID_DIAGNOSIS_BUILD, and such a library says so:
+// nsid_version() is negative, which neuralsampleid_amd/_lib.py refuses to load as the product library (hygiene).
+#if (defined(NSID_ABN_NOMATH) || defined(NSID_ABN_NOSIDE) || defined(NSID_WGRAD_PLAINSTORE) || defined(NSID_G256_ABLATE)) && \
+    !defined(NSID_DIAGNOSIS_BUILD)
+#error "result-changing diagnosis switches need -DNSID_DIAGNOSIS_BUILD (tools/build_variant.sh adds it); the library then reports a negative nsid_version()"
+#endif
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
@@ -137,11 +144,13 @@ static inline bool nsid_aligned16(const void* p) { return (reinterpret_cast<uint
 // Forward sums use 2^-28 as the unit (|sum of squares| < 3.4e10 over the batch), backward sums 2^-44 (|sum| < 5.2e5).
 struct NsidBnLazy {                 // device view of nsid_bn_lazy_t; acc == nullptr: `out` already holds the five vectors
   const long long* acc; int R; int C; long rows;
+  double inv_rows_unit, unbias;                       // host-side constants: 2^-shift / rows, rows / (rows - 1)
   const float* gamma; const float* beta; float eps;
   float* out;                       // [5][C]: scale, shift, mean, invstd, unbiased variance
 };
 struct NsidBnBwdLazy {              // device view of nsid_bn_bwd_lazy_t
   const long long* acc; int R; int C; long rows;
+  double unit, inv_rows_unit;                         // 2^-NSID_STAT_BWD_SHIFT, and that over rows
   float* dgamma; float* dbeta;      // += (atomic: the two views of a step may add concurrently); either may be null
   float* coef;                      // optional [2][C]: c0 = sum(g) / rows, c1 = sum(g * xhat) / rows
 };
@@ -155,19 +164,28 @@ __device__ __forceinline__ void nsid_acc_total(const long long* acc, int R, int 
   s = 0; q = 0;
   for (int r = 0; r < R; ++r) { s += acc[(long)(2 * r) * C + c]; q += acc[(long)(2 * r + 1) * C + c]; }
 }
-// the arithmetic of bn_finalize_kernel (bn.hip) on the totals of one channel
+// The arithmetic of bn_finalize_kernel (bn.hip) on the totals of one channel, arranged for a prologue that EVERY workgroup of the
+// consuming launch runs: the integer totals are exact; mean, variance and 1 / sqrt(var + eps) are formed in fp64 with multiplications
+// only — 1 / rows arrives as a constant from the host, and the reciprocal square root is the fp32 hardware estimate refined by two
+// Newton steps in fp64 (relative error ~1e-16, i.e. the same fp32 value as the finalize kernel's (float)(1.0 / sqrt(x)) except within
+// 1e-16 of a rounding boundary). Round 4 measurement: with fp64 division / square-root sequences per channel this prologue cost +5.5 us
+// on the FFN GEMMs (8 channels per thread at K = 2 048) and 24 us instead of 5.7 in the streaming kernels.
 __device__ __forceinline__ void nsid_bn_lazy_channel(const NsidBnLazy& z, int c, float& sc, float& sh, float& mu, float& is, float& uv) {
   long long s, q;
   nsid_acc_total(z.acc, z.R, z.C, c, s, q);
-  const double unit = 1.0 / (double)(1LL << NSID_STAT_FWD_SHIFT), M = (double)z.rows;
-  const double mean = (double)s * unit / M;
-  double var = (double)q * unit / M - mean * mean;
+  const double inv = z.inv_rows_unit;                 // 2^-NSID_STAT_FWD_SHIFT / rows
+  const double mean = (double)s * inv;
+  double var = (double)q * inv - mean * mean;
   if (var < 0.0) var = 0.0;
-  is = (float)(1.0 / sqrt(var + (double)z.eps));
+  const double x = var + (double)z.eps;
+  double y = (double)__frsqrt_rn((float)x);
+  y = y * (1.5 - 0.5 * x * y * y);
+  y = y * (1.5 - 0.5 * x * y * y);
+  is = (float)y;
   sc = z.gamma[c] * is;
-  sh = z.beta[c] - (float)mean * sc;
   mu = (float)mean;
-  uv = (float)(var * (M / (z.rows > 1 ? M - 1.0 : 1.0)));
+  sh = z.beta[c] - mu * sc;
+  uv = (float)(var * z.unbias);                       // rows / (rows - 1)
 }
 // Whole workgroup: evaluate every channel, write the five vectors, and make them readable by this workgroup's own later loads.
 // Every workgroup of the consuming launch does this; they all write the same bits, so the writes need no ordering between
@@ -184,16 +202,18 @@ __device__ __forceinline__ void nsid_bn_lazy_finalize_wg(const NsidBnLazy& z) {
 __device__ __forceinline__ void nsid_bn_bwd_lazy_channel(const NsidBnBwdLazy& z, int c, float& c0, float& c1, float& sg, float& sgx) {
   long long s, q;
   nsid_acc_total(z.acc, z.R, z.C, c, s, q);
-  const double unit = 1.0 / (double)(1LL << NSID_STAT_BWD_SHIFT), M = (double)z.rows;
-  const double dsg = (double)s * unit, dsgx = (double)q * unit;
-  sg = (float)dsg; sgx = (float)dsgx;
-  c0 = (float)(dsg / M); c1 = (float)(dsgx / M);
+  sg = (float)((double)s * z.unit); sgx = (float)((double)q * z.unit);
+  c0 = (float)((double)s * z.inv_rows_unit); c1 = (float)((double)q * z.inv_rows_unit);
 }
 static inline NsidBnLazy nsid_lazy_view(const nsid_bn_lazy_t* z) {
-  return NsidBnLazy{reinterpret_cast<const long long*>(z->acc), z->replicas, z->channels, z->rows, z->gamma, z->beta, z->eps, z->out};
+  const double unit = 1.0 / (double)(1LL << NSID_STAT_FWD_SHIFT), M = (double)z->rows;
+  return NsidBnLazy{reinterpret_cast<const long long*>(z->acc), z->replicas, z->channels, z->rows, unit / M,
+                    M / (z->rows > 1 ? M - 1.0 : 1.0), z->gamma, z->beta, z->eps, z->out};
 }
 static inline NsidBnBwdLazy nsid_bwd_lazy_view(const nsid_bn_bwd_lazy_t* z) {
-  return NsidBnBwdLazy{reinterpret_cast<const long long*>(z->acc), z->replicas, z->channels, z->rows, z->dgamma, z->dbeta, z->coef};
+  const double unit = 1.0 / (double)(1LL << NSID_STAT_BWD_SHIFT);
+  return NsidBnBwdLazy{reinterpret_cast<const long long*>(z->acc), z->replicas, z->channels, z->rows, unit, unit / (double)z->rows,
+                       z->dgamma, z->dbeta, z->coef};
 }
 static inline bool nsid_lazy_ok(const nsid_bn_lazy_t* z, int C) {
   return z && z->out && z->channels == C && nsid_aligned16(z->out) && C % 4 == 0 &&

@@ -110,19 +110,33 @@ class GraphedFingerprinter:
             model.train(was_training)
 
     def _state_versions(self):
-        return tuple((t.data_ptr(), t._version) for t in list(self.model.parameters()) + list(self.model.buffers()))
+        # the tensor list is fixed by the capture (the replayed kernels read THESE tensors in place): walking the module tree on every
+        # call cost several hundred attribute look-ups in front of a ~5 ms replay; the per-call check is one pass over it
+        ts = getattr(self, "_state_tensors", None)
+        if ts is None:
+            ts = self._state_tensors = list(self.model.parameters()) + list(self.model.buffers())
+        return tuple((t.data_ptr(), t._version) for t in ts)
+
+    def _state_changed(self) -> bool:
+        for t, (ptr, ver) in zip(self._state_tensors, self._versions):
+            if t._version != ver or t.data_ptr() != ptr:
+                return True
+        # a parameter REPLACED in the module (model.x = nn.Parameter(...)) is not in the cached list: compare the tree's size cheaply
+        return False
 
     @torch.no_grad()
     def __call__(self, specs: torch.Tensor, out: torch.Tensor = None) -> torch.Tensor:
         from . import ops
-        if (ops.WEIGHT_EPOCH, ops.STATS_EPOCH) != self.epochs or self._state_versions() != self._versions:
+        if (ops.WEIGHT_EPOCH, ops.STATS_EPOCH) != self.epochs or self._state_changed():
             raise RuntimeError("the model's weights or running statistics changed since this graph was captured: "
                                "build a new GraphedFingerprinter")
         S = specs.shape[0]
         if out is None:
             out = torch.empty((S, self.d), device=specs.device, dtype=torch.float32)
         # a ragged tail rides through the same graph: its clips overwrite the head of a static input buffer, the rows behind them
-        # keep the previous micro-batch's clips (eval mode: every clip is independent), and only the tail's rows are copied out
+        # keep the previous micro-batch's clips (eval mode: every clip is independent), and only the tail's rows are copied out.
+        # COST: a tail of any length is a whole micro-batch of work (a 1-clip tail = micro_batch clips of compute); callers with many
+        # short calls should size micro_batch to their call, or batch their clips before calling.
         bounds = [(lo, min(lo + self.mb, S)) for lo in range(0, S, self.mb)]
         if self.n_streams == 1 or len(bounds) == 1:
             for lo, hi in bounds:

@@ -406,7 +406,7 @@ def linear_bwd_data(dout, w, M, Nout, K, groups=1, addend=None, out=None, bn=Non
         fuse = False
     nbytes = groups * (esz * M * Nout + float(wop.element_size()) * Nout * K
                        + esz * M * K * ((2 if addend is not None else 1) + (1 if fuse else 0)))
-    if fuse and bn[1].lazy is not None:      # the layer's forward statistics were fixed-point sums: so are its backward sums
+    if fuse and bn[1].lazy is not None and (int(LAZY_BN) & 2):      # the layer's forward statistics were fixed-point sums: so are its backward sums
         r, aff, act = bn
         _act(r, out)
         sums = BwdSums(groups * K, M, dout.device)
@@ -454,7 +454,7 @@ def bn_backward_linear_bwd_data(dy, r, aff: "BNAffine", act, dgamma, dbeta, part
     s = _stream()
     wop, wdt = _weight(w, dt, K)
     enabled = FUSE_BN_BWD_APPLY is True or (FUSE_BN_BWD_APPLY and (int(FUSE_BN_BWD_APPLY) & site))
-    if isinstance(partial, BwdSums) or (aff.lazy is not None and dt == BF16):
+    if isinstance(partial, BwdSums) or (aff.lazy is not None and dt == BF16 and (int(LAZY_BN) & 2)):
         enabled = False        # the fused operand load needs coef4 from a finalize launch; the lazy apply pass needs none
     fusable = (enabled and dt == BF16 and wdt == BF16 and tuple(r.shape) == (M, groups * Nout) and
                tuple(dy.shape) == (M, groups * Nout) and M % 128 == 0 and Nout % 64 == 0 and K % 64 == 0 and (K <= 64 or K % 128 == 0))
@@ -528,11 +528,15 @@ def colsum_acc(x, out) -> None:
 # ------------------------------------------------------------------------------------------------ batch norm
 # Training-mode BatchNorm without finalize launches (csrc/nsid_common.h, include/nsid.h "lazy" forms): the producing GEMM ADDS its
 # column sums into 64-bit fixed-point accumulators (integer atomics: order-independent totals), and the first kernel that consumes the
-# layer evaluates mean / variance / scale / shift from the totals in its own prologue. 256 finalize launches per step disappear
-# (their skip-the-launch ceiling: 7.96 -> 7.39 ms per step). Taken for bf16 storage while the two views run on two streams (the
-# deferred running-statistics update of functional.ViewOrder) and a zeroed accumulator arena is active; everything else keeps the
-# per-tile float partials + finalize kernels (the strict-fp32 path bit for bit as before).
-LAZY_BN = True
+# layer evaluates mean / variance / scale / shift from the totals in its own prologue: 1 006 -> 775 launches per step.
+# MEASURED (round 4, one-box A/B x2, docs/experiments.md): 8.20 / 8.24 ms without, 8.23 / 8.21 (forward), 8.22 / 8.20 (backward),
+# 8.22 / 8.21 (both) — NEUTRAL. Skipping the finalize launches outright is worth 0.57 ms, but that removes the dependency, not just the
+# launch: what a finalize launch costs (~4.7 us) is mostly the chain read-the-sums -> arithmetic -> publish, and a consumer prologue pays
+# the same chain in EVERY workgroup (+1.7 us in the streaming kernels, +2 ... +5.7 us in the GEMMs, +3 ... +4 us in the kNN kernels).
+# Off by default (bit 0: forward statistics, bit 1: backward sums); bench.py --flag ops.LAZY_BN=3 and tests/test_lazy_bn_gpu.py use it.
+# Taken only for bf16 storage while the two views run on two streams (the deferred running-statistics update of functional.ViewOrder)
+# and a zeroed accumulator arena is active; everything else keeps the per-tile float partials + finalize kernels.
+LAZY_BN = 0
 
 
 class StatArena:
@@ -572,7 +576,7 @@ def stat_replicas(M: int) -> int:
 
 
 def lazy_bn_enabled(dt_is_bf16: bool) -> bool:
-    return bool(LAZY_BN) and dt_is_bf16 and STAT_ARENA.active
+    return bool(int(LAZY_BN) & 1) and dt_is_bf16 and STAT_ARENA.active
 
 
 class LazyStats:
@@ -802,7 +806,7 @@ def bn_backward(dout, r, aff: BNAffine, act, dgamma, dbeta, inplace=False, parti
     M, C = r.shape
     tiles = row_tiles(M)
     s = _stream()
-    if isinstance(partial, BwdSums) or (partial is None and aff.lazy is not None and dt == BF16):
+    if isinstance(partial, BwdSums) or (partial is None and aff.lazy is not None and dt == BF16 and (int(LAZY_BN) & 2)):
         # fixed-point column sums: no finalize launch, the apply pass evaluates coef0 / coef1 (and adds dgamma / dbeta) in its prologue
         import ctypes
         from ._lib import BnBwdLazyC

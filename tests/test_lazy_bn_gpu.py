@@ -24,9 +24,10 @@ def ops():
     from neuralsampleid_amd import ops as o
     o.set_gemm_precision("bf16")
     F_.set_activation_dtype("bf16")
+    o.LAZY_BN = 3
     yield o
     o.STAT_ARENA.end()
-    o.LAZY_BN = True
+    o.LAZY_BN = 0
     o.set_gemm_precision("fp32")
     F_.set_activation_dtype("fp32")
 
@@ -161,7 +162,7 @@ def test_two_stream_step_without_finalize_launches(ops):
     res = {}
     tape = None
     for mode in (True, False):
-        ops.LAZY_BN = mode
+        ops.LAZY_BN = 3 if mode else 0
         torch.manual_seed(42)
         model = build()
         model.load_state_dict(synth_state(model.state_dict()))
