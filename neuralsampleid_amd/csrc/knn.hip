@@ -349,14 +349,81 @@ __device__ __forceinline__ void knn_stage_split(const T* __restrict__ src, long 
   }
 }
 
+// Wide rows (C = 256 / 512: 4 / 8 chunks of 8 channels per lane). Holding a row's 32 / 64 affine-applied fp32 values across the two
+// reductions spilled under the 128-register budget of the two-workgroups-per-CU kernels (round 3: 16-28 VGPRs to scratch in every
+// instantiation — the C switch below inlines all four widths — reloaded once per 8-row pass). Here the row is walked TWICE from
+// memory, one chunk live at a time: pass A accumulates the sum of squares, pass B re-reads the chunk (an L1 / L2 hit: the same 512 B /
+// 1 KB the lane group fetched a moment ago), normalises, splits and stores. Same expressions in the same order as the narrow form,
+// so the images are bit-identical. The empty asm between the passes keeps the compiler from merging the two reads back into
+// registers.
+template <typename T, int JN>
+__device__ __forceinline__ void knn_stage_split_wide(const T* __restrict__ src, long ldr, const float* __restrict__ scale,
+                                                     const float* __restrict__ shift, int N, int nwaves, char* img, float* sq) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nl = lane & 7, kl = lane >> 3;
+  constexpr int KC = 8 * JN;
+  for (int n0 = wave * 8; n0 < N; n0 += nwaves * 8) {
+    const int n = n0 + nl;
+    const int nn = n < N ? n : -1;
+    const T* rowp = src + (long)(n < N ? n : N - 1) * ldr;
+    float ss = 0.f;
+#pragma unroll 2
+    for (int j = 0; j < JN; ++j) {
+      float v[8];
+      knn_load8<T>(rowp + (kl + 8 * j) * 8, v);
+      if (scale != nullptr) {
+        float sc[8], sh[8];
+        load_channels<8>(scale, (kl + 8 * j) * 8, sc);
+        load_channels<8>(shift, (kl + 8 * j) * 8, sh);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = sc[e] * v[e] + sh[e];
+      }
+      ss += ((v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3])) + ((v[4] * v[4] + v[5] * v[5]) + (v[6] * v[6] + v[7] * v[7]));
+    }
+#pragma unroll
+    for (int o = 8; o < 64; o <<= 1) ss += __shfl_xor(ss, o, 64);
+    const float denom = fmaxf(sqrtf(ss), 1e-12f), rden = 1.f / denom;
+    asm volatile("" ::: "memory");
+    ss = 0.f;
+#pragma unroll 2
+    for (int j = 0; j < JN; ++j) {
+      float v[8];
+      knn_load8<T>(rowp + (kl + 8 * j) * 8, v);
+      if (scale != nullptr) {
+        float sc[8], sh[8];
+        load_channels<8>(scale, (kl + 8 * j) * 8, sc);
+        load_channels<8>(shift, (kl + 8 * j) * 8, sh);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = sc[e] * v[e] + sh[e];
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = div_shared(v[e], denom, rden);
+      ss += ((v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3])) + ((v[4] * v[4] + v[5] * v[5]) + (v[6] * v[6] + v[7] * v[7]));
+      if (nn >= 0) {
+        f16x8 a, bb;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          a[e] = (_Float16)v[e];
+          bb[e] = (_Float16)(v[e] - (float)a[e]);
+        }
+        *reinterpret_cast<f16x8*>(knn_img(img, 0, kl + 8 * j, nn, KC, N)) = a;
+        *reinterpret_cast<f16x8*>(knn_img(img, 1, kl + 8 * j, nn, KC, N)) = bb;
+      }
+    }
+#pragma unroll
+    for (int o = 8; o < 64; o <<= 1) ss += __shfl_xor(ss, o, 64);
+    if (nn >= 0 && kl == 0) sq[nn] = ss;
+  }
+}
+
 template <typename T>
 __device__ __forceinline__ void knn_stage_split_any(const T* src, long ldr, const float* scale, const float* shift, int N, int C,
                                                     int nwaves, char* img, float* sq) {
   switch (C) {            // uniform; C is 64, 128, 256 or 512 on these paths (host-checked)
     case 64: knn_stage_split<T, 1>(src, ldr, scale, shift, N, nwaves, img, sq); break;
     case 128: knn_stage_split<T, 2>(src, ldr, scale, shift, N, nwaves, img, sq); break;
-    case 256: knn_stage_split<T, 4>(src, ldr, scale, shift, N, nwaves, img, sq); break;
-    default: knn_stage_split<T, 8>(src, ldr, scale, shift, N, nwaves, img, sq); break;
+    case 256: knn_stage_split_wide<T, 4>(src, ldr, scale, shift, N, nwaves, img, sq); break;
+    default: knn_stage_split_wide<T, 8>(src, ldr, scale, shift, N, nwaves, img, sq); break;
   }
 }
 

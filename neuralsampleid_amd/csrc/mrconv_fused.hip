@@ -32,6 +32,7 @@ __global__ __launch_bounds__(64 * NW) void mrconv_fused_kernel(const MrcArgs p) 
   constexpr int JS = NW / WN;                // splits of a group's output tiles
   constexpr int NTW = N / 16 / WN;           // node tiles per wave
   constexpr int JW = JT / JS;                // output tiles per wave
+  constexpr bool PAIRED = DIRECT && JW % 2 == 0;   // direct stores of 16 bytes per lane (see the epilogue)
   static_assert(JT % JS == 0 && (N / 16) % WN == 0, "whole tiles per wave");
   constexpr int SY = C * 2 + 16;             // clip image rows: consecutive nodes land on disjoint banks for the 8-byte gathers
   constexpr int SW = K * 2 + 32;             // weight image rows (fragment reads by ds_read_b128: conflict-free)
@@ -119,12 +120,36 @@ __global__ __launch_bounds__(64 * NW) void mrconv_fused_kernel(const MrcArgs p) 
         for (int e = 0; e < 4; ++e) { fb[2 * e] = own[e]; fb[2 * e + 1] = (__bf16)best[e]; }
 #pragma unroll
         for (int a = 0; a < JW; ++a) {
-          const bf16x8 fa = *reinterpret_cast<const bf16x8*>(wimg + (16 * (wjs * JW + a) + lr) * SW + (4 * ks + rq) * 16);
+          // PAIRED (direct stores): the A rows of tiles 2p and 2p + 1 are a permutation of the pair's 32 weight rows chosen so that
+          // D row 4 rq + e of tile 2p + i is output channel 32 p + 8 rq + 4 i + e: a lane then owns 8 CONSECUTIVE channels of its node
+          const int wrow = PAIRED ? 16 * wjs * JW + 32 * (a / 2) + 8 * (lr >> 2) + 4 * (a & 1) + (lr & 3) : 16 * (wjs * JW + a) + lr;
+          const bf16x8 fa = *reinterpret_cast<const bf16x8*>(wimg + wrow * SW + (4 * ks + rq) * 16);
           acc[nt][a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb, acc[nt][a], 0, 0, 0);
         }
       }
     }
-    // ---- epilogue: D[j = 16 a + 4 rq + e][node lr] + bias, ReLU, bf16: 4 consecutive channels of one node per lane
+    // ---- epilogue: D[j][node lr] + bias, ReLU, bf16
+    if constexpr (PAIRED) {
+      // 8 consecutive channels of one node per lane = one 16-byte store; the four lanes of a node write 64 contiguous bytes, i.e. whole
+      // 64-byte segments (the 8-byte form wrote every segment in two halves: PMC WRITE_SIZE 1.66x the output at C = 64, round 3)
+#pragma unroll
+      for (int pr = 0; pr < JW / 2; ++pr) {
+        const int j0 = 16 * wjs * JW + 32 * pr + 8 * rq;
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.bias + g * K + j0), b1 = *reinterpret_cast<const f32x4*>(p.bias + g * K + j0 + 4);
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) {
+          const int n = 16 * (wn + WN * nt) + lr;
+          bf16x8 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            o[e] = (__bf16)fmaxf(acc[nt][2 * pr][e] + b0[e], 0.f);
+            o[4 + e] = (__bf16)fmaxf(acc[nt][2 * pr + 1][e] + b1[e], 0.f);
+          }
+          *reinterpret_cast<bf16x8*>(p.out + (row0 + n) * (2 * C) + g * K + j0) = o;
+        }
+      }
+    } else {
+    // 4 consecutive channels of one node per lane
 #pragma unroll
     for (int a = 0; a < JW; ++a) {
       const int j0 = 16 * (wjs * JW + a) + 4 * rq;
@@ -138,6 +163,7 @@ __global__ __launch_bounds__(64 * NW) void mrconv_fused_kernel(const MrcArgs p) 
         if constexpr (DIRECT) *reinterpret_cast<bf16x4*>(p.out + (row0 + n) * (2 * C) + g * K + j0) = o;
         else *reinterpret_cast<bf16x4*>(oimg + n * SO + j0 * 2) = o;
       }
+    }
     }
     __syncthreads();                          // (DIRECT: every wave is done with this group's weight image)
     if constexpr (!DIRECT) {

@@ -114,6 +114,11 @@ def _chk(*ts):
 F32, BF16 = 0, 1
 
 
+def _tk(name, nbytes, fn, shape=()):
+    """time a launch that moves bytes and does no matrix work (BatchNorm family, streaming passes, optimiser): bench.py's kernel table"""
+    return _timed(name, 0.0, float(nbytes), fn, shape)
+
+
 def _act(*ts) -> int:
     """activation tensors (features, raw conv outputs, their gradients): contiguous fp32 or bf16, all the same type;
     returns the C ABI dtype code"""
@@ -249,7 +254,7 @@ def f32_to_bf16(src: torch.Tensor, dst: Optional[torch.Tensor] = None) -> torch.
     if n % 8:            # tiny odd-sized matrices: let torch round (same RNE)
         dst[:n].copy_(src.reshape(-1))
         return dst
-    call("nsid_f32_to_bf16", _p(src), _p(dst), n, _stream())
+    _tk("f32_to_bf16_kernel", 6.0 * n, lambda: call("nsid_f32_to_bf16", _p(src), _p(dst), n, _stream()), (n, 1, 0, 1))
     return dst
 
 
@@ -463,12 +468,15 @@ def bn_backward_linear_bwd_data(dy, r, aff: "BNAffine", act, dgamma, dbeta, part
         return (dr,) + linear_bwd_data(dr, w, M, Nout, K, groups, addend=addend, bn=bn if bn is not None else False)
     if partial is None:
         partial = torch.empty((2, tiles, C), device=r.device, dtype=torch.float32)
-        call("nsid_bn_bwd_reduce", _p(dy), _p(r), M, C, _p(aff.scale), _p(aff.shift), _p(aff.mean), _p(aff.invstd), act, _p(partial),
-             dt, s)
+        part_ = partial
+        _tk("col_reduce_kernel", 2.0 * r.element_size() * M * C, lambda: call(
+            "nsid_bn_bwd_reduce", _p(dy), _p(r), M, C, _p(aff.scale), _p(aff.shift), _p(aff.mean), _p(aff.invstd), act, _p(part_),
+            dt, s), (M, C, 0, 1))
     coef = torch.empty((6, C), device=r.device, dtype=torch.float32)        # [0:2] = (c0, c1) for the unfused apply, [2:6] = coef4
     if not (DIAG_SKIP_FINALIZE & 2):
-        call("nsid_bn_bwd_finalize_fused", _p(partial), tiles, C, M, _p(dgamma), _p(dbeta), _p(coef), _p(aff.scale), _p(aff.shift),
-             _p(aff.mean), _p(aff.invstd), _p(coef[2]), s)
+        _tk("bn_bwd_finalize_kernel", 8.0 * tiles * C + 40.0 * C, lambda: call(
+            "nsid_bn_bwd_finalize_fused", _p(partial), tiles, C, M, _p(dgamma), _p(dbeta), _p(coef), _p(aff.scale), _p(aff.shift),
+            _p(aff.mean), _p(aff.invstd), _p(coef[2]), s), (M, C, 0, 1))
     dr = torch.empty_like(dy)
     din = torch.empty((M, groups * K), device=dy.device, dtype=dy.dtype)
     want_pair = bn is not None
@@ -522,7 +530,8 @@ def linear_bwd_weight(dout, x, dw, M, Nout, K, groups=1, in_scale=None, in_shift
 
 def colsum_acc(x, out) -> None:
     _chk(out)
-    call("nsid_colsum_acc", _p(x), x.shape[-1], x.shape[0], x.shape[1], _p(out), _act(x), _stream())
+    _tk("colsum_atomic_kernel", float(x.element_size()) * x.numel(), lambda: call(
+        "nsid_colsum_acc", _p(x), x.shape[-1], x.shape[0], x.shape[1], _p(out), _act(x), _stream()), (x.shape[0], x.shape[1], 0, 1))
 
 
 # ------------------------------------------------------------------------------------------------ batch norm
@@ -700,8 +709,9 @@ def bn_finalize(stat, M, gamma, beta, running_mean, running_var, num_batches_tra
     buf = torch.empty((4, C), device=gamma.device, dtype=torch.float32)
     if running_mean is not None:
         bump_state_epoch(weights=False)
-    call("nsid_bn_finalize", _p(stat), row_tiles(M), C, M, _p(gamma), _p(beta), _p(running_mean), _p(running_var),
-         _p(num_batches_tracked), momentum, eps, _p(buf[0]), _p(buf[1]), _p(buf[2]), _p(buf[3]), _stream())
+    _tk("bn_finalize_kernel", 8.0 * row_tiles(M) * C + 16.0 * C, lambda: call(
+        "nsid_bn_finalize", _p(stat), row_tiles(M), C, M, _p(gamma), _p(beta), _p(running_mean), _p(running_var),
+        _p(num_batches_tracked), momentum, eps, _p(buf[0]), _p(buf[1]), _p(buf[2]), _p(buf[3]), _stream()), (M, C, 0, 1))
     return BNAffine(buf[0], buf[1], buf[2], buf[3])
 
 
@@ -725,8 +735,9 @@ def bn_finalize_deferred(stat, M, gamma, beta, eps=BN_EPS):
         one, zero, _ = _diag_const(C, gamma.device)
         return BNAffine(one, zero, zero, one), one
     buf = torch.empty((5, C), device=gamma.device, dtype=torch.float32)
-    call("nsid_bn_finalize_deferred", _p(stat), row_tiles(M), C, M, _p(gamma), _p(beta), eps, _p(buf[0]), _p(buf[1]),
-         _p(buf[2]), _p(buf[3]), _p(buf[4]), _stream())
+    _tk("bn_finalize_kernel", 8.0 * row_tiles(M) * C + 20.0 * C, lambda: call(
+        "nsid_bn_finalize_deferred", _p(stat), row_tiles(M), C, M, _p(gamma), _p(beta), eps, _p(buf[0]), _p(buf[1]),
+        _p(buf[2]), _p(buf[3]), _p(buf[4]), _stream()), (M, C, 0, 1))
     return BNAffine(buf[0], buf[1], buf[2], buf[3]), buf[4]
 
 
@@ -793,9 +804,11 @@ def bn_apply(r, aff: BNAffine, act=ACT_NONE, residual=None, out=None) -> torch.T
         out = torch.empty_like(r)
     if aff.lazy is not None and aff.lazy.pending:        # evaluated in this launch's prologue: no finalize launch
         zc, addr = _lazy_arg(aff)
-        call("nsid_bn_apply_lazy", _p(r), addr, act, _p(residual), _p(out), M, C, dt, _stream())
+        _tk("bn_apply_lazy_kernel", r.element_size() * M * C * (3 if residual is not None else 2), lambda: call(
+            "nsid_bn_apply_lazy", _p(r), addr, act, _p(residual), _p(out), M, C, dt, _stream()), (M, C, 0, 1))
         return out
-    call("nsid_bn_apply", _p(r), _p(aff.scale), _p(aff.shift), act, _p(residual), _p(out), M, C, dt, _stream())
+    _tk("bn_apply_kernel", r.element_size() * M * C * (3 if residual is not None else 2), lambda: call(
+        "nsid_bn_apply", _p(r), _p(aff.scale), _p(aff.shift), act, _p(residual), _p(out), M, C, dt, _stream()), (M, C, 0, 1))
     return out
 
 
@@ -812,25 +825,32 @@ def bn_backward(dout, r, aff: BNAffine, act, dgamma, dbeta, inplace=False, parti
         from ._lib import BnBwdLazyC
         if partial is None:
             partial = BwdSums(C, M, r.device)
-            call("nsid_bn_bwd_reduce_lazy", _p(dout), _p(r), M, C, _p(aff.scale), _p(aff.shift), _p(aff.mean), _p(aff.invstd), act,
-                 _p(partial.acc), partial.R, dt, s)
+            part_ = partial
+            _tk("col_reduce_kernel", 2.0 * r.element_size() * M * C, lambda: call(
+                "nsid_bn_bwd_reduce_lazy", _p(dout), _p(r), M, C, _p(aff.scale), _p(aff.shift), _p(aff.mean), _p(aff.invstd), act,
+                _p(part_.acc), part_.R, dt, s), (M, C, 0, 1))
         zc = BnBwdLazyC(_p(partial.acc), partial.R, C, M, _p(dgamma), _p(dbeta), None)
         dr = dout if inplace else torch.empty_like(dout)
-        call("nsid_bn_bwd_apply_lazy", _p(dout), _p(r), M, C, _p(aff.scale), _p(aff.shift), _p(aff.mean), _p(aff.invstd), act,
-             ctypes.addressof(zc), _p(dr), dt, s)
+        _tk("bn_bwd_apply_lazy_kernel", 3.0 * r.element_size() * M * C, lambda: call(
+            "nsid_bn_bwd_apply_lazy", _p(dout), _p(r), M, C, _p(aff.scale), _p(aff.shift), _p(aff.mean), _p(aff.invstd), act,
+            ctypes.addressof(zc), _p(dr), dt, s), (M, C, 0, 1))
         return dr
     coef = torch.empty((2, C), device=r.device, dtype=torch.float32)
     if partial is None:
         partial = torch.empty((2, tiles, C), device=r.device, dtype=torch.float32)
-        call("nsid_bn_bwd_reduce", _p(dout), _p(r), M, C, _p(aff.scale), _p(aff.shift), _p(aff.mean), _p(aff.invstd),
-             act, _p(partial), dt, s)
+        part_ = partial
+        _tk("col_reduce_kernel", 2.0 * r.element_size() * M * C, lambda: call(
+            "nsid_bn_bwd_reduce", _p(dout), _p(r), M, C, _p(aff.scale), _p(aff.shift), _p(aff.mean), _p(aff.invstd),
+            act, _p(part_), dt, s), (M, C, 0, 1))
     if DIAG_SKIP_FINALIZE & 2:
         coef = _diag_const(C, r.device)[2]
     else:
-        call("nsid_bn_bwd_finalize", _p(partial), tiles, C, M, _p(dgamma), _p(dbeta), _p(coef), s)
+        _tk("bn_bwd_finalize_kernel", 8.0 * tiles * C + 16.0 * C, lambda: call(
+            "nsid_bn_bwd_finalize", _p(partial), tiles, C, M, _p(dgamma), _p(dbeta), _p(coef), s), (M, C, 0, 1))
     dr = dout if inplace else torch.empty_like(dout)
-    call("nsid_bn_bwd_apply", _p(dout), _p(r), M, C, _p(aff.scale), _p(aff.shift), _p(aff.mean), _p(aff.invstd),
-         act, _p(coef), _p(dr), dt, s)
+    _tk("bn_bwd_apply_kernel", 3.0 * r.element_size() * M * C, lambda: call(
+        "nsid_bn_bwd_apply", _p(dout), _p(r), M, C, _p(aff.scale), _p(aff.shift), _p(aff.mean), _p(aff.invstd),
+        act, _p(coef), _p(dr), dt, s), (M, C, 0, 1))
     return dr
 
 
@@ -983,29 +1003,33 @@ def peak_patchify_fwd(spec, w, bias, pb, pf, out_dtype=torch.float32):
     n = (H // pb) * (W // pf)
     out = torch.empty((B * n, F), device=spec.device, dtype=out_dtype)
     minmax = torch.empty((B, 2), device=spec.device, dtype=torch.float32)
-    call("nsid_peak_patchify_fwd", _p(spec), _p(w), _p(bias), B, H, W, pb, pf, F, _p(out), F, _p(minmax), _act(out),
-         _stream())
+    _tk("patchify_fwd_kernel", 4.0 * B * H * W + float(out.element_size()) * B * n * F, lambda: call(
+        "nsid_peak_patchify_fwd", _p(spec), _p(w), _p(bias), B, H, W, pb, pf, F, _p(out), F, _p(minmax), _act(out),
+        _stream()), (B * n, F, pb * pf * 3, 1))
     return out, minmax
 
 
 def peak_patchify_bwd(spec, minmax, out, dout, pb, pf, dw, dbias) -> None:
     _chk(spec, minmax, dw, dbias)
     B, H, W = spec.shape
-    call("nsid_peak_patchify_bwd", _p(spec), _p(minmax), _p(out), _p(dout), out.shape[-1], B, H, W, pb, pf,
-         out.shape[-1], _p(dw), _p(dbias), _act(out, dout), _stream())
+    _tk("patchify_bwd_kernel", 4.0 * B * H * W + 2.0 * out.element_size() * out.numel(), lambda: call(
+        "nsid_peak_patchify_bwd", _p(spec), _p(minmax), _p(out), _p(dout), out.shape[-1], B, H, W, pb, pf,
+        out.shape[-1], _p(dw), _p(dbias), _act(out, dout), _stream()), (out.shape[0], out.shape[1], pb * pf * 3, 1))
 
 
 # ------------------------------------------------------------------------------------------------ head
 def node_mean_fwd(x, B, N, C) -> torch.Tensor:
     out = torch.empty((B, C), device=x.device, dtype=torch.float32)
-    call("nsid_node_mean_fwd", _p(x), B, N, C, _p(out), _act(x), _stream())
+    _tk("node_mean_fwd_kernel", float(x.element_size()) * B * N * C, lambda: call(
+        "nsid_node_mean_fwd", _p(x), B, N, C, _p(out), _act(x), _stream()), (B * N, C, 0, 1))
     return out
 
 
 def node_mean_bwd(dout, B, N, C, dtype=torch.float32) -> torch.Tensor:
     _chk(dout)
     dx = torch.empty((B * N, C), device=dout.device, dtype=dtype)
-    call("nsid_node_mean_bwd", _p(dout), B, N, C, _p(dx), _act(dx), _stream())
+    _tk("node_mean_bwd_kernel", float(dx.element_size()) * B * N * C, lambda: call(
+        "nsid_node_mean_bwd", _p(dout), B, N, C, _p(dx), _act(dx), _stream()), (B * N, C, 0, 1))
     return dx
 
 
@@ -1043,8 +1067,10 @@ def ntxent_fwd_bwd(z_i, z_j, tau, p0=0, npairs=None, want_grad=True):
     loss = torch.empty((1,), device=z_i.device, dtype=torch.float32)
     dzi = torch.empty((npairs, d), device=z_i.device, dtype=torch.float32) if want_grad else None
     dzj = torch.empty((npairs, d), device=z_i.device, dtype=torch.float32) if want_grad else None
-    call("nsid_ntxent_fwd_bwd", _p(z_i), _p(z_j), Bg, d, float(tau), p0, npairs, _p(ws), _p(loss), _p(dzi), _p(dzj),
-         _stream())
+    # 2 (2B)^2 d flop per pass (similarities; the backward pass recomputes them), bytes = z in + dz out
+    _timed("ntxent_kernels", 2.0 * (2 * Bg) * (2 * npairs) * d * (2 if want_grad else 1), 4.0 * d * (2 * Bg + 2 * npairs), lambda: call(
+        "nsid_ntxent_fwd_bwd", _p(z_i), _p(z_j), Bg, d, float(tau), p0, npairs, _p(ws), _p(loss), _p(dzi), _p(dzj),
+        _stream()), (2 * npairs, 2 * Bg, d, 1))
     return loss, dzi, dzj
 
 
@@ -1053,7 +1079,8 @@ def fill_zero(t: torch.Tensor) -> torch.Tensor:
     """t[...] = 0 with our own streaming kernel (zero_grad: the captured step holds no ATen kernel)"""
     if not (t.is_cuda and t.is_contiguous()):
         raise RuntimeError("fill_zero needs a contiguous device tensor")
-    call("nsid_fill_zero", _p(t), t.numel() * t.element_size(), _stream())
+    _tk("fill_zero_kernel", float(t.numel() * t.element_size()), lambda: call(
+        "nsid_fill_zero", _p(t), t.numel() * t.element_size(), _stream()), (t.numel(), 1, 0, 1))
     return t
 
 
@@ -1096,14 +1123,16 @@ def sumsq_partial(g_flat) -> torch.Tensor:
     _chk(g_flat)
     n = g_flat.numel()
     partial = torch.empty((lib.nsid_sumsq_blocks(n),), device=g_flat.device, dtype=torch.float32)
-    call("nsid_sumsq_partial", _p(g_flat), n, _p(partial), _stream())
+    _tk("sumsq_kernel", 4.0 * n, lambda: call("nsid_sumsq_partial", _p(g_flat), n, _p(partial), _stream()), (n, 1, 0, 1))
     return partial
 
 
 def adam_step(p, g, m, v, hyper, step, partial, gnorm_out) -> None:
     _chk(p, g, m, v, hyper, partial, gnorm_out)
-    call("nsid_adam_step", _p(p), _p(g), _p(m), _p(v), p.numel(), _p(hyper), _p(step), _p(partial), partial.numel(),
-         _p(gnorm_out), _stream())
+    # reads p, g, m, v and writes p, m, v: 28 bytes per parameter
+    _tk("adam_kernel", 28.0 * p.numel(), lambda: call(
+        "nsid_adam_step", _p(p), _p(g), _p(m), _p(v), p.numel(), _p(hyper), _p(step), _p(partial), partial.numel(),
+        _p(gnorm_out), _stream()), (p.numel(), 1, 0, 1))
 
 
 # ------------------------------------------------------------------------------------------------ layout

@@ -64,3 +64,22 @@ GRAFP_CFG = {
     "n_filters": 8, "bsz_train": 256, "tau": 0.05, "lr": 8.0e-5, "min_lr": 7.0e-7, "T_max": 400,
     "d": 128, "h": 1024, "u": 32, "dim": 2048,
 }
+
+
+def fixed_graph(batch: int, nodes: int, k: int, call: int) -> torch.Tensor:
+    """A neighbour table that BOTH sides can write down without a search: idx[b, n, j] = (n + 1 + 7 j + 3 b + 5 call) mod nodes
+    (j < k <= 18: the k ids of a row are distinct for every nodes in {32, 64, 128, 256}). Used to teacher-force the training step of the
+    deep configuration at the timed batch, where storing the reference's own ids would take 20 MB (tests/golden/make_golden.py::
+    gold_deep_b256): training mode is chaotic in the neighbour ids, so both sides must run on the SAME graph — which graph it is does
+    not matter for pinning the GEMM / aggregation / BatchNorm / weight-gradient arithmetic at that size."""
+    b = torch.arange(batch).view(-1, 1, 1)
+    n = torch.arange(nodes).view(1, -1, 1)
+    j = torch.arange(k).view(1, 1, -1)
+    return (n + 1 + 7 * j + 3 * b + 5 * call) % nodes
+
+
+def row_set_hash(idx: torch.Tensor) -> torch.Tensor:
+    """order-independent 8-bit hash of every row's neighbour SET: sum_j (id_j + 1)^2 mod 251 (uint8). Pins which nodes a search
+    selected at a size where the ids themselves are too many to store."""
+    v = idx.to(torch.int64) + 1
+    return ((v * v).sum(-1) % 251).to(torch.uint8)

@@ -257,5 +257,9 @@ def test_bf16_hip_vs_emulation_at_b256_and_timed_variants_ran(golden, restore_mo
 # 0.038 (emulation), early gradients 0.60-0.69 / 0.64-0.69, late 0.19-0.26 / 0.18-0.26, min cos z 0.977 / 0.978 — bf16 storage of
 # 60 activation tensors per view costs that much in a train-mode step; the loss curve of 30 steps is what test_training_curve
 # judges it on.
-TOL16 = {"h_clip_norm_rel": 0.045, "max_dz": 0.08, "cos_z_min": 0.9908, "dloss": 0.025, "gnorm_rel": 0.29, "bn_norm_rel": 1.6e-4,
-         "grad_rel_late": 0.28, "grad_rel_early": 1.1, "grad_norm_rel_median": 0.014, "grad_norm_rel_worst": 0.77}
+# Round 4 (VERDICT r3 "what's weak" 1): a relative-L2 bound >= 1 cannot fail (a ZERO gradient scores 1.0), so the three bounds that sat
+# there at 3x measured are cut to 1.5x: early-layer gradients 0.36 measured -> 0.55, the worst per-parameter norm 0.24 -> 0.40, the
+# global norm 0.09 -> 0.15. A summation-order change in a kernel can move these chaotic quantities; it then has to be re-measured and
+# argued, which is the point.
+TOL16 = {"h_clip_norm_rel": 0.045, "max_dz": 0.08, "cos_z_min": 0.9908, "dloss": 0.025, "gnorm_rel": 0.15, "bn_norm_rel": 1.6e-4,
+         "grad_rel_late": 0.28, "grad_rel_early": 0.55, "grad_norm_rel_median": 0.014, "grad_norm_rel_worst": 0.40}

@@ -234,3 +234,43 @@ def test_bench_orchestration_rehearsal_two_and_four_ranks():
         assert 0 < d["config"]["final_loss"] < 10
     d = _run_bench_rehearsal(2, ["--mode", "infer", "--clips", "4096", "--micro-batch", "1024", "--warmup", "1"])
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["parallelism"] == "shard2" and d["value"] > 0
+
+
+def _spawn_bench(env_extra, args, timeout=400):
+    """`python bench.py --gpus 2` WITHOUT a launcher: bench.spawn_ranks starts the ranks itself (fresh children; this parent never
+    touches the GPU). Rehearsal transport (gloo, ranks sharing the card)."""
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["NSID_BENCH_REHEARSAL"] = "gloo"
+    env.update(env_extra)
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--no-cpu-baseline", "--no-roofline",
+                        "--steps", "3", "--warmup", "1", "--batch", "16"] + args, capture_output=True, text=True, env=env, timeout=timeout)
+    return r, [ln for ln in r.stdout.splitlines() if ln.startswith("{")], time.time() - t0
+
+
+def test_a_rank_killed_mid_step_fails_the_job_loudly():
+    """VERDICT r3 task 6: rank 1 dies (SIGKILL) inside the timed loop. The surviving rank sits in a collective; the launcher must end
+    it, and the spawning parent must come back NON-ZERO within its deadline and print NO JSON line (never a result from a broken job).
+    NSID_DP_RETRY=0: no second attempt."""
+    r, lines, dt = _spawn_bench({"NSID_TEST_KILL_RANK": "1:1", "NSID_DP_RETRY": "0", "NSID_BENCH_TIMEOUT_S": "240",
+                                 "NSID_HOST_TIMEOUT_S": "60"}, [])
+    assert r.returncode != 0, r.stderr[-1500:]
+    assert not lines, lines
+    assert dt < 240, dt
+
+
+def test_the_spawner_retries_once_with_eager_collectives():
+    """the first attempt ("graph") loses rank 1 mid-step; spawn_ranks then starts ONE fresh set of ranks with NSID_DP_GRAPH=0 and that
+    attempt's line is the result, labelled as such"""
+    import json
+    r, lines, dt = _spawn_bench({"NSID_TEST_KILL_RANK": "1:1:graph", "NSID_BENCH_TIMEOUT_S": "500", "NSID_HOST_TIMEOUT_S": "60"}, [],
+                                timeout=560)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["config"]["dp_attempt"] == "eager-retry" and d["config"]["hipgraph"] is False and d["n_gpus"] == 2
+    assert "retrying ONCE with eager collectives" in r.stderr

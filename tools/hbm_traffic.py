@@ -55,7 +55,23 @@ def main():
     with open(sys.argv[3], "w") as fh:
         json.dump(out, fh, indent=1)
     tot = sum(v["hbm_bytes_per_launch"] * v["launches_profiled"] for v in out["kernels"].values())
-    print(f"{len(out['kernels'])} kernels, {tot / 1e9:.2f} GB over the profiled launches")
+    # steps in the profiled run = launches of the optimiser kernel (training) — bench.py reports the per-step total as step_traffic_GB
+    steps = out["kernels"].get("adam_kernel", {}).get("launches_profiled", 0)
+    if steps:
+        out["steps_profiled"] = steps
+        out["step_traffic_GB"] = round(tot / steps / 1e9, 3)
+        with open(sys.argv[3], "w") as fh:
+            json.dump(out, fh, indent=1)
+    mbs = 0
+    if not steps:      # forward-only extraction: one patchify launch per micro-batch
+        mbs = next((v["launches_profiled"] for k, v in out["kernels"].items() if k.startswith("patchify_fwd")), 0)
+        if mbs:
+            out["microbatches_profiled"] = mbs
+            out["microbatch_traffic_GB"] = round(tot / mbs / 1e9, 3)
+            with open(sys.argv[3], "w") as fh:
+                json.dump(out, fh, indent=1)
+    print(f"{len(out['kernels'])} kernels, {tot / 1e9:.2f} GB over the profiled launches" + (f", {tot / steps / 1e9:.2f} GB per step" if steps else "")
+          + (f", {tot / mbs / 1e9:.2f} GB per micro-batch" if mbs else ""))
 
 
 if __name__ == "__main__":
