@@ -42,6 +42,8 @@ SIGNATURES = {
     "nsid_downsample3_bwd_weight": "pppiiiiis",
     "nsid_downsample3_bwd_data": "pppipiiiiis",
     "nsid_unpack_ds_wgrad": "piips",
+    "nsid_ds_prepack": "ipppppps",
+    "nsid_ds_unpack_all": "ipppps",
     "nsid_peak_patchify_fwd": "pppiiiiiipipis",
     "nsid_peak_patchify_bwd": "ppppiiiiiiippis",
     "nsid_node_mean_fwd": "piiipis",

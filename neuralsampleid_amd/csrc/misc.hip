@@ -1,5 +1,6 @@
 // Small HBM-bound kernels of the path: downsample row gather, peak-extractor patchify, node mean, ELU', L2
 // normalise, clip+Adam, and the (B,C,N) <-> node-major layout change at the module boundary.
+#include <algorithm>
 #include "nsid_common.h"
 
 namespace {
@@ -83,6 +84,50 @@ __global__ void unpack_ds_wgrad_kernel(const float* __restrict__ dwp, int Cout, 
     const int c = (int)(q % Cin), t = (int)((q / Cin) % 3);
     const long o = q / (3L * Cin);
     atomicAdd(dw + ((o * Cin + c) * 3 + t) * 3 + 1, dwp[q]);     // both views may accumulate concurrently
+  }
+}
+
+// Step-scoped preparation of ALL Downsample conv weights in one launch (round 4): a training step used to spend 36 small launches on
+// the three Downsample layers — pack (forward) + pack (backward) + two bf16 conversions + a zero fill and an unpack of the packed
+// gradient, per layer AND per view. Here one launch at the start of the step writes, for every layer, the packed forward weight
+// wp[o][t*Cin + c] = w[o][c][t][1] and the packed backward weight wb = [W_2 ; W_0] straight to bf16 and zeroes the layer's two packed
+// gradient buffers (one per view; each view still unpacks its own right after its weight-gradient GEMM, so a parameter's .grad is
+// complete when backward returns). ds_unpack_all_kernel serves callers that prefer one unpack per step.
+constexpr int DSP_LAYERS = 8;
+#define NSID_DS_SLOTS 2
+struct DsPrepArgs {
+  const float* w[DSP_LAYERS]; __bf16* wp16[DSP_LAYERS]; __bf16* wb16[DSP_LAYERS]; float* dwp[DSP_LAYERS];
+  int Cout[DSP_LAYERS], Cin[DSP_LAYERS];
+};
+__global__ __launch_bounds__(256) void ds_prepack_kernel(const DsPrepArgs a) {
+  const int l = blockIdx.y;
+  const float* w = a.w[l];
+  const int Cout = a.Cout[l], Cin = a.Cin[l];
+  const long total = (long)Cout * 3 * Cin;
+  for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(q % Cin), t = (int)((q / Cin) % 3);
+    const long o = q / (3L * Cin);
+    a.wp16[l][q] = (__bf16)w[((o * Cin + c) * 3 + t) * 3 + 1];
+    if (a.dwp[l] != nullptr) {                       // NSID_DS_SLOTS packed gradient buffers per layer (one per view), contiguous
+#pragma unroll
+      for (int v = 0; v < NSID_DS_SLOTS; ++v) a.dwp[l][v * total + q] = 0.f;
+    }
+    if (q < 2L * Cout * Cin) {                       // wb[r][c] = w[o][c][2][1] for r = o < Cout, w[o][c][0][1] for r = Cout + o
+      const long r = q / Cin, ob = r % Cout;
+      const int tb = r < Cout ? 2 : 0;
+      a.wb16[l][q] = (__bf16)w[((ob * Cin + c) * 3 + tb) * 3 + 1];
+    }
+  }
+}
+struct DsUnpackArgs { const float* dwp[DSP_LAYERS]; float* dw[DSP_LAYERS]; int Cout[DSP_LAYERS], Cin[DSP_LAYERS]; };
+__global__ __launch_bounds__(256) void ds_unpack_all_kernel(const DsUnpackArgs a) {
+  const int l = blockIdx.y;
+  const int Cout = a.Cout[l], Cin = a.Cin[l];
+  const long total = (long)Cout * 3 * Cin;
+  for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(q % Cin), t = (int)((q / Cin) % 3);
+    const long o = q / (3L * Cin);
+    a.dw[l][((o * Cin + c) * 3 + t) * 3 + 1] += a.dwp[l][q];      // one launch, after both views' backward: no other writer
   }
 }
 
@@ -500,6 +545,33 @@ extern "C" int nsid_unpack_ds_wgrad(const float* dwp, int Cout, int Cin, float* 
   NSID_REQUIRE(dwp && dw && Cout > 0 && Cin > 0);
   NSID_LAUNCH(unpack_ds_wgrad_kernel, dim3(grid_for((long)Cout * 3 * Cin)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), dwp, Cout, Cin, dw);
+  return nsid_launch_status();
+}
+
+extern "C" int nsid_ds_prepack(int n, const float* const* w, void* const* wp16, void* const* wb16, float* const* dwp, const int* Cout,
+                               const int* Cin, void* stream) {
+  NSID_REQUIRE(n > 0 && n <= DSP_LAYERS && w && wp16 && wb16 && Cout && Cin);
+  DsPrepArgs a{};
+  long most = 0;
+  for (int i = 0; i < n; ++i) {
+    NSID_REQUIRE(w[i] && wp16[i] && wb16[i] && Cout[i] > 0 && Cin[i] > 0);
+    a.w[i] = w[i]; a.wp16[i] = static_cast<__bf16*>(wp16[i]); a.wb16[i] = static_cast<__bf16*>(wb16[i]);
+    a.dwp[i] = dwp ? dwp[i] : nullptr; a.Cout[i] = Cout[i]; a.Cin[i] = Cin[i];
+    most = std::max(most, (long)Cout[i] * 3 * Cin[i]);
+  }
+  NSID_LAUNCH(ds_prepack_kernel, dim3(grid_for(most, 256), n), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+  return nsid_launch_status();
+}
+extern "C" int nsid_ds_unpack_all(int n, const float* const* dwp, float* const* dw, const int* Cout, const int* Cin, void* stream) {
+  NSID_REQUIRE(n > 0 && n <= DSP_LAYERS && dwp && dw && Cout && Cin);
+  DsUnpackArgs a{};
+  long most = 0;
+  for (int i = 0; i < n; ++i) {
+    NSID_REQUIRE(dwp[i] && dw[i] && Cout[i] > 0 && Cin[i] > 0);
+    a.dwp[i] = dwp[i]; a.dw[i] = dw[i]; a.Cout[i] = Cout[i]; a.Cin[i] = Cin[i];
+    most = std::max(most, (long)Cout[i] * 3 * Cin[i]);
+  }
+  NSID_LAUNCH(ds_unpack_all_kernel, dim3(grid_for(most, 256), n), dim3(256), 0, static_cast<hipStream_t>(stream), a);
   return nsid_launch_status();
 }
 

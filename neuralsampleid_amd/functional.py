@@ -377,6 +377,22 @@ def downsample_forward(x: Tensor, P, S: Optional[dict], B: int, N: int, training
         if view:
             return ops.downsample3_fwd(x, B, N, C, wf, bf, Co)[0]
         return ops.linear_fwd(col, wf, bf, B * No, Co, 3 * C)[0]
+    prep = ops.DS_PREP.get(P["conv.0.weight"]) if (view and S is not None and ACT_DTYPE == torch.bfloat16) else None
+    if prep is not None:
+        # prepared once per step for both views (ops.DsPrep): packed weights already in bf16, one shared packed gradient buffer
+        gamma, beta, rm, rv, nbt, _ = _bn(P, S, "conv.1.")
+        if lazy_stats(training, rm):
+            acc = (ops.STAT_ARENA.take(ops.stat_replicas(B * No) * 2 * Co, x.device), ops.stat_replicas(B * No))
+            r, _ = ops.downsample3_fwd(x, B, N, C, None, P["conv.0.bias"], Co, stat_acc=acc, w16=prep["wp16"])
+            aff = lazy_affine_from(acc, B * No, gamma, beta, rm, rv, nbt)
+        else:
+            r, stat = ops.downsample3_fwd(x, B, N, C, None, P["conv.0.bias"], Co, want_stat=training, w16=prep["wp16"])
+            aff = bn_affine_from(stat, B * No, gamma, beta, rm, rv, nbt, training)
+        out = ops.bn_apply(r, aff, ACT_NONE)
+        S.update(col=None, x=x, wp=None, prep=prep, dwp_slot=ops.DS_PREP.take_slot(prep), r=r, aff=aff, B=B, N=N, C=C)
+        if CHAIN is not None:
+            CHAIN.produce(S, r, aff, ACT_NONE)
+        return out
     wp = ops.pack_ds_weight(P["conv.0.weight"])
     if ACT_DTYPE == torch.bfloat16 and S is not None:
         # the packed weight lives until this block's backward: one bf16 conversion serves the forward and the backward-data
@@ -406,6 +422,14 @@ def downsample_backward(dout: Tensor, P, S, G) -> Tensor:
     Mo, Co = r.shape
     dr = ops.bn_backward(dout, r, aff, ACT_NONE, G["conv.1.weight"], G["conv.1.bias"], partial=_link_partial(S))
     _bias_grad_before_bn(dr, G["conv.0.bias"])
+    prep = S.get("prep")
+    if prep is not None:
+        dwp = S.get("dwp_slot")                       # zeroed by the step's prepack launch; None: both slots were taken
+        if dwp is None:
+            dwp = ops.zeros(prep["dwp"].shape[1:], prep["dwp"].device)
+        ops.downsample3_bwd_weight(dr, x, dwp, B, N, C, Co)
+        ops.unpack_ds_wgrad(dwp, G["conv.0.weight"])
+        return ops.downsample3_bwd_data(dr, None, None, B, N, C, Co, w16=(prep["wp16"], prep["wb16"]))
     dwp = ops.zeros(wp.shape, wp.device)
     if col is None:                                  # strided-view form: x is the operand
         ops.downsample3_bwd_weight(dr, x, dwp, B, N, C, Co)

@@ -920,16 +920,94 @@ def im2col3_bwd(dcol, B, N, C) -> torch.Tensor:
     return dx
 
 
-def downsample3_fwd(x, B, N, C, wp, bias, Cout, want_stat=False, stat_acc=None):
+class DsPrep:
+    """Step-scoped prepared Downsample weights (csrc/misc.hip ds_prepack_kernel): for every registered conv weight (Cout, Cin, 3, 3) the
+    packed forward / backward weights in bf16 and two zeroed packed-gradient buffers (one per view), refreshed by ONE launch at the start
+    of a step. A training step spent 36 launches on this (pack, pack_bwd, 2 conversions, zero fill, unpack — per layer and per view);
+    7 remain (this one + the unpack of each layer and view, which keeps p.grad complete when backward returns)."""
+
+    def __init__(self):
+        self.entries = {}           # weight data_ptr -> dict(w, wp16, wb16, dwp, key)
+
+    def register(self, w) -> None:
+        if w.data_ptr() in self.entries or len(self.entries) >= 8:
+            return
+        Cout, Cin = w.shape[0], w.shape[1]
+        dev = w.device
+        self.entries[w.data_ptr()] = dict(w=w, Cout=Cout, Cin=Cin, key=None, used=False,
+                                          wp16=torch.empty((Cout, 3 * Cin), device=dev, dtype=torch.bfloat16),
+                                          wb16=torch.empty((2 * Cout, Cin), device=dev, dtype=torch.bfloat16),
+                                          dwp=torch.empty((2, Cout, 3 * Cin), device=dev, dtype=torch.float32), slots=0)
+
+    def clear(self) -> None:
+        self.entries.clear()
+
+    def _arrays(self, es, *names):
+        import ctypes
+        n = len(es)
+        out = []
+        for name in names:
+            if name in ("Cout", "Cin"):
+                out.append((ctypes.c_int * n)(*[e[name] for e in es]))
+            else:
+                out.append((ctypes.c_void_p * n)(*[e[name].data_ptr() for e in es]))
+        return out
+
+    def refresh(self) -> None:
+        """pack every registered weight (current values) and zero the shared packed gradients: one launch on the current stream"""
+        es = [e for e in self.entries.values() if e["w"].is_cuda] if DS_PREP_ENABLED else []
+        if not es:
+            return
+        w, wp16, wb16, dwp, Cout, Cin = self._arrays(es, "w", "wp16", "wb16", "dwp", "Cout", "Cin")
+        _tk("ds_prepack_kernel", sum(4.0 * e["w"].numel() / 3 + 2.0 * 5 * e["Cout"] * e["Cin"] + 12.0 * e["Cout"] * e["Cin"] for e in es),
+            lambda: call("nsid_ds_prepack", len(es), w, wp16, wb16, dwp, Cout, Cin, _stream()))
+        for e in es:
+            e["key"], e["used"], e["slots"] = (e["w"]._version, WEIGHT_EPOCH), False, 0
+
+    def take_slot(self, e):
+        """a zeroed packed-gradient buffer of this step (two per layer: one per view), or None when both are taken"""
+        if e["slots"] >= e["dwp"].shape[0]:
+            return None
+        e["slots"] += 1
+        return e["dwp"][e["slots"] - 1]
+
+    def get(self, w):
+        """the prepared entry of `w` if it was refreshed for the weight's current contents, else None (callers pack per call)"""
+        e = self.entries.get(w.data_ptr())
+        if not DS_PREP_ENABLED or e is None or e["key"] != (w._version, WEIGHT_EPOCH):
+            return None
+        return e
+
+    def unpack_all(self) -> None:
+        """grad(w) += packed gradient for every layer whose shared buffer was accumulated into this step: one launch"""
+        es = [e for e in self.entries.values() if e["used"] and e["w"].grad is not None]
+        if not es:
+            return
+        import ctypes
+        n = len(es)
+        dwp, Cout, Cin = self._arrays(es, "dwp", "Cout", "Cin")
+        dw = (ctypes.c_void_p * n)(*[e["w"].grad.data_ptr() for e in es])
+        _tk("ds_unpack_all_kernel", sum(24.0 * e["Cout"] * e["Cin"] for e in es),
+            lambda: call("nsid_ds_unpack_all", n, dwp, dw, Cout, Cin, _stream()))
+        for e in es:
+            e["used"] = False
+
+
+DS_PREP = DsPrep()
+DS_PREP_ENABLED = 1        # bench.py --flag ops.DS_PREP_ENABLED=0: the per-call pack / convert / zero launches instead (one-box A/B)
+
+
+def downsample3_fwd(x, B, N, C, wp, bias, Cout, want_stat=False, stat_acc=None, w16=None):
     """Conv2d 3x3 s2 p1 on a width-1 map as ONE GEMM over a zero-padded strided view of x (no im2col): (B*N, C) ->
-    (B*N/2, Cout) raw conv output (+ BatchNorm partial statistics). wp: packed weight (Cout, 3C) fp32 (pack_ds_weight)."""
+    (B*N/2, Cout) raw conv output (+ BatchNorm partial statistics). wp: packed weight (Cout, 3C) fp32 (pack_ds_weight); w16: the same
+    already in bf16 (DsPrep; wp may then be None)."""
     _chk(wp, bias)
     dt = _act(x)
     No = N // 2
     M = B * No
     out = torch.empty((M, Cout), device=x.device, dtype=x.dtype)
     stat = torch.empty((2, row_tiles(M), Cout), device=x.device, dtype=torch.float32) if (want_stat and stat_acc is None) else None
-    wop, wdt = _weight(wp, dt, 3 * C)
+    wop, wdt = (w16, BF16) if (w16 is not None and dt == BF16) else _weight(wp, dt, 3 * C)      # w16: prepared bf16 packed weight (DsPrep)
     esz = x.element_size()
     if stat_acc is not None:       # statistics added into fixed-point accumulators (stat_acc = (int64 tensor, replicas))
         _timed("gemm_kernel<128,%d,true,true>" % (64 if Cout <= 64 else 128), 2.0 * M * Cout * 3 * C,
@@ -955,13 +1033,17 @@ def downsample3_bwd_weight(dout, x, dwp, B, N, C, Cout) -> None:
            (M, Cout, 3 * C, 1))
 
 
-def downsample3_bwd_data(dout, wp, w_odd, B, N, C, Cout) -> torch.Tensor:
-    """dx (B*N, C) from dout (B*N/2, Cout): even rows one GEMM, odd rows one GEMM over overlapping rows of dout (no col2im)"""
-    _chk(wp, w_odd)
+def downsample3_bwd_data(dout, wp, w_odd, B, N, C, Cout, w16=None) -> torch.Tensor:
+    """dx (B*N, C) from dout (B*N/2, Cout): even rows one GEMM, odd rows one GEMM over overlapping rows of dout (no col2im).
+    w16 = (packed forward weight, packed odd-row weight) already in bf16 (DsPrep): wp / w_odd may then be None"""
     dt = _act(dout)
     dx = torch.empty((B * N, C), device=dout.device, dtype=dout.dtype)
-    wop, wdt = _weight(wp, dt, 3 * C)
-    oop, odt = _weight(w_odd, dt, C)
+    if w16 is not None and dt == BF16:
+        wop, oop, wdt, odt = w16[0], w16[1], BF16, BF16
+    else:
+        _chk(wp, w_odd)
+        wop, wdt = _weight(wp, dt, 3 * C)
+        oop, odt = _weight(w_odd, dt, C)
     if odt != wdt:                       # both from the same arithmetic mode
         wop, wdt, oop, odt = wp, F32, w_odd, F32
     M = B * (N // 2)

@@ -40,6 +40,11 @@ class FusedClipAdam:
         for p, off in zip(self.params, self.offsets):
             if p.numel() % 8 == 0:
                 ops.SHADOWS.register(p.data, self.flat_p16[off:off + p.numel()], owner=self.flat_p)
+        # Downsample conv weights (Cout, Cin, 3, 3): packed forms + shared packed gradient prepared once per step (ops.DsPrep)
+        ops.DS_PREP.clear()
+        for p in self.params:
+            if p.dim() == 4 and tuple(p.shape[2:]) == (3, 3):
+                ops.DS_PREP.register(p)
         self.hyper = torch.tensor([lr, betas[0], betas[1], eps, max_norm if max_norm else 0.0], device=dev)
         self.step_count = torch.zeros((), dtype=torch.int64, device=dev)
         self.grad_norm = torch.zeros(1, device=dev)       # pre-clip global norm of the last step
@@ -53,6 +58,7 @@ class FusedClipAdam:
         ops.fill_zero(self.flat_g)
         if functional.ACT_DTYPE == torch.bfloat16:
             self.sync_shadow()
+            ops.DS_PREP.refresh()        # (the step's two views run behind this point on both streams)
 
     def sync_shadow(self):
         """refresh the bf16 weight shadows from the fp32 master parameters"""
