@@ -30,12 +30,36 @@ class Golden(dict):
         return torch.from_numpy(np.asarray(self[key]))
 
 
+def _by_rule(rule, args):
+    """inputs a fixture does not store because a rule reproduces them bit for bit (tests/golden/make_golden.py::save)"""
+    from synth import GRAFP_CFG, synth_clips, synth_randn
+    if rule == "randn":
+        return synth_randn(args[0], *args[1])
+    if rule in ("clips_i", "clips_j"):
+        return synth_clips(args[0])[0 if rule == "clips_i" else 1]
+    if rule in ("bench_i", "bench_j"):          # bench.py's synth_clips
+        gi, gj = torch.Generator().manual_seed(args[1]), torch.Generator().manual_seed(args[1] + 1)
+        x_i = torch.randn(args[0], GRAFP_CFG["n_mels"], GRAFP_CFG["n_frames"], generator=gi) * 20.0 - 40.0
+        x_j = x_i + 3.0 * torch.randn(args[0], GRAFP_CFG["n_mels"], GRAFP_CFG["n_frames"], generator=gj)
+        return x_i if rule == "bench_i" else x_j
+    raise KeyError(rule)
+
+
+def load_golden(name):
+    """a fixture of tests/golden as a Golden dict, rule-made inputs regenerated"""
+    import json
+    with np.load(os.path.join(GOLDEN, name + ".npz")) as z:
+        data = {k: z[k] for k in z.files}
+    rules = data.pop("__synth__", None)
+    if rules is not None:
+        for key, (rule, args) in json.loads(bytes(rules).decode()).items():
+            data[key] = _by_rule(rule, args).numpy()
+    return Golden(data)
+
+
 @pytest.fixture(scope="session")
 def golden():
-    def load(name):
-        with np.load(os.path.join(GOLDEN, name + ".npz")) as z:
-            return Golden({k: z[k] for k in z.files})
-    return load
+    return load_golden
 
 
 def to_rows(x4):

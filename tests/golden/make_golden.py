@@ -69,15 +69,42 @@ torch.set_num_threads(8)
 CFG = dict(GRAFP_CFG)
 
 
+# Inputs that a RULE reproduces (synth.synth_randn / synth_clips, bench_clips) are not stored: the fixture records which rule made them
+# ("__synth__": key -> [rule, args]) and tests/conftest.py regenerates them on load — random fp32 inputs do not compress, and they were a
+# third of the bytes under tests/golden ("small fixtures").
+_RULE_MADE = []          # (rule name, args, tensor) of every rule call of this run
+_synth_randn, _synth_clips = synth_randn, synth_clips
+
+
+def synth_randn(tag, *shape):      # noqa: F811  (shadows the import on purpose)
+    t = _synth_randn(tag, *shape)
+    _RULE_MADE.append(("randn", [tag, list(shape)], t.clone()))
+    return t
+
+
+def synth_clips(batch):            # noqa: F811
+    x_i, x_j = _synth_clips(batch)
+    _RULE_MADE.extend([("clips_i", [batch], x_i.clone()), ("clips_j", [batch], x_j.clone())])
+    return x_i, x_j
+
+
 def save(name, **arrays):
-    out = {}
+    out, synth = {}, {}
     for k, v in arrays.items():
         if isinstance(v, torch.Tensor):
             v = v.detach().cpu().numpy()
+        v = np.asarray(v)
+        rule = next(((r, a) for r, a, t in _RULE_MADE if tuple(t.shape) == v.shape and v.dtype == np.float32
+                     and np.array_equal(t.numpy(), v)), None)
+        if rule is not None:
+            synth[k] = [rule[0], rule[1]]
+            continue
         out[k] = v
+    if synth:
+        out["__synth__"] = np.frombuffer(json.dumps(synth, sort_keys=True).encode(), dtype=np.uint8)
     path = os.path.join(HERE, name + ".npz")
     np.savez_compressed(path, **out)
-    print(f"  {name}.npz  {os.path.getsize(path) / 1024:.0f} KB")
+    print(f"  {name}.npz  {os.path.getsize(path) / 1024:.0f} KB" + (f"  (by rule: {sorted(synth)})" if synth else ""))
 
 
 def load_synth(module, prefix=""):
@@ -314,6 +341,7 @@ def bench_clips(batch, seed):
     gj = torch.Generator().manual_seed(seed + 1)
     x_i = torch.randn(batch, CFG["n_mels"], CFG["n_frames"], generator=gi) * 20.0 - 40.0
     x_j = x_i + 3.0 * torch.randn(batch, CFG["n_mels"], CFG["n_frames"], generator=gj)
+    _RULE_MADE.extend([("bench_i", [batch, seed], x_i.clone()), ("bench_j", [batch, seed], x_j.clone())])
     return x_i, x_j
 
 
@@ -674,6 +702,6 @@ def gold_relpos():
 if __name__ == "__main__":
     torch.manual_seed(0)
     only = sys.argv[1:] or ["shapes", "init", "relpos", "knn", "mrconv", "block", "downsample", "peak", "ntxent", "e2e",
-                            "deep", "fpdb", "b256"]
+                            "deep", "fpdb", "b256", "deep_b256"]
     for name in only:
         globals()["gold_" + name]()

@@ -5,7 +5,8 @@ from neuralsampleid_amd import ops, functional as F_
 from neuralsampleid_amd.encoder.graph_encoder import GraphEncoder
 from neuralsampleid_amd.simclr.simclr import SimCLR
 from neuralsampleid_amd.simclr.ntxent import ntxent_loss
-g=np.load('tests/golden/e2e_b8_k3.npz')
+import conftest
+g=conftest.load_golden('e2e_b8_k3')
 def rel(a,b):
     a=a.detach().cpu().double(); b=torch.from_numpy(b).double(); return float((a-b).norm()/b.norm())
 def cosmin(a,b):

@@ -10,8 +10,7 @@ import conftest, test_e2e_gpu as T
 from neuralsampleid_amd import functional as F_, ops
 from neuralsampleid_amd.encoder.graph_encoder import GraphEncoder
 from neuralsampleid_amd.simclr.simclr import SimCLR
-with np.load(os.path.join(T.GOLDEN, "deep_b4_k18.npz")) as z:
-    g = conftest.Golden({k: z[k] for k in z.files})
+g = conftest.load_golden("deep_b4_k18")
 model = SimCLR(T.GRAFP_CFG, GraphEncoder(T.GRAFP_CFG, in_channels=T.GRAFP_CFG["n_filters"], k=18, size="t",
                                          blocks=[4, 4, 12, 4], use_dilation=True))
 T.load_synth(model)

@@ -9,16 +9,14 @@ import conftest, test_e2e_gpu as T
 from neuralsampleid_amd import functional as F_
 from neuralsampleid_amd.encoder.graph_encoder import GraphEncoder
 from neuralsampleid_amd.simclr.simclr import SimCLR
-with np.load(os.path.join(T.GOLDEN, "deep_b4_k18.npz")) as z:
-    g = conftest.Golden({k: z[k] for k in z.files})
+g = conftest.load_golden("deep_b4_k18")
 model = SimCLR(T.GRAFP_CFG, GraphEncoder(T.GRAFP_CFG, in_channels=T.GRAFP_CFG["n_filters"], k=18, size="t",
                                          blocks=[4, 4, 12, 4], use_dilation=True))
 T.load_synth(model)
 x_i, x_j = g.t("x_i").to(T.DEV), g.t("x_j").to(T.DEV)
 if len(sys.argv) > 1:       # the call of test_knn_module_layout first (the failure depends on what ran before)
     from neuralsampleid_amd.encoder.gcn_lib.torch_edge import DenseDilatedKnnGraph
-    with np.load(os.path.join(T.GOLDEN, "knn_c64n256.npz")) as z:
-        xx = torch.from_numpy(z["x"]).to(T.DEV)
+    xx = conftest.load_golden("knn_c64n256").t("x").to(T.DEV)
     ei = DenseDilatedKnnGraph(4, 2)(xx)
     print("pre-call done", ei.shape)
 for tag, train in (("eval", False), ("s0", True)):

@@ -12,8 +12,7 @@ from neuralsampleid_amd._lib import lib
 from neuralsampleid_amd.encoder.graph_encoder import GraphEncoder
 from neuralsampleid_amd.simclr.simclr import SimCLR
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 500
-with np.load(os.path.join(T.GOLDEN, "deep_b4_k18.npz")) as z:
-    g = conftest.Golden({k: z[k] for k in z.files})
+g = conftest.load_golden("deep_b4_k18")
 model = SimCLR(T.GRAFP_CFG, GraphEncoder(T.GRAFP_CFG, in_channels=T.GRAFP_CFG["n_filters"], k=18, size="t",
                                          blocks=[4, 4, 12, 4], use_dilation=True))
 T.load_synth(model)
