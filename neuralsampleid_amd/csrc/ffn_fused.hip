@@ -188,6 +188,13 @@ int ffn_launch(const FfnArgs& p, hipStream_t s) {
 extern "C" int nsid_ffn_fused_fwd(const void* x, const void* w1, const float* b1, const void* w2, const float* b2, void* out, int M,
                                   int C, int H, void* stream) {
   NSID_REQUIRE(x && w1 && b1 && w2 && b2 && out && M > 0);
+  if (C == 256 && H == 1024 && M % 256 == 0 && nsid_tune(NSID_T_ffn256) != 0) {      // the x tile in registers: ffn256_fused.hip
+    NSID_REQUIRE(nsid_aligned16(x) && nsid_aligned16(w1) && nsid_aligned16(w2) && nsid_aligned16(out) && nsid_aligned16(b1) &&
+                 nsid_aligned16(b2));
+    const int rc = nsid_ffn256_fused_launch(x, w1, b1, w2, b2, out, M, C, H, static_cast<hipStream_t>(stream));
+    if (rc == NSID_OK) nsid_count(NSID_C_ffn_fused);
+    return rc;
+  }
   if (!(C == 64 || C == 128) || H != 4 * C || M % FF_TM != 0) return 1;
   NSID_REQUIRE(nsid_aligned16(x) && nsid_aligned16(w1) && nsid_aligned16(w2) && nsid_aligned16(out) && nsid_aligned16(b1) &&
                nsid_aligned16(b2));

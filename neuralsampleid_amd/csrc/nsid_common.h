@@ -7,9 +7,10 @@
 #include "../../include/nsid.h"
 
 // Diagnosis switches that CHANGE RESULTS (timing-only builds of tools/build_variant.sh: NSID_ABN_NOMATH / NSID_ABN_NOSIDE,
-// NSID_WGRAD_PLAINSTORE, NSID_G256_ABLATE) compile only together with -DNSID_DIAGNOSIS_BUILD, and such a library says so:
+// NSID_WGRAD_PLAINSTORE, NSID_G256_ABLATE, NSID_F256_NCH, NSID_F256_NOBARRIER) compile only together with -DNSID_DIAGNOSIS_BUILD, and such a library says so:
 // nsid_version() is negative, which neuralsampleid_amd/_lib.py refuses to load as the product library (hygiene).
-#if (defined(NSID_ABN_NOMATH) || defined(NSID_ABN_NOSIDE) || defined(NSID_WGRAD_PLAINSTORE) || defined(NSID_G256_ABLATE)) && \
+#if (defined(NSID_ABN_NOMATH) || defined(NSID_ABN_NOSIDE) || defined(NSID_WGRAD_PLAINSTORE) || defined(NSID_G256_ABLATE) || defined(NSID_F256_NCH) || \
+     defined(NSID_F256_NOBARRIER)) && \
     !defined(NSID_DIAGNOSIS_BUILD)
 #error "result-changing diagnosis switches need -DNSID_DIAGNOSIS_BUILD (tools/build_variant.sh adds it); the library then reports a negative nsid_version()"
 #endif
@@ -258,6 +259,7 @@ static inline bool nsid_acc_ok(const int64_t* acc, int replicas) {
   X(mr_grid_stride, 0)         /* 1: grid-stride aggregation instead of the LDS-staged per-clip kernel */                     \
   X(mr_split, 0)               /* channel split of the LDS-staged aggregation (0 = heuristic) */                              \
   X(ffn_waves, 8)              /* waves per workgroup of the fused eval-mode FFN (4 or 8) */                                  \
+  X(ffn256, 1)                 /* 1: the C = 256 stage's eval-mode FFN as one launch (ffn256_fused.hip); 0: two GEMM launches */ \
   X(mrconv_variant, 3)         /* fused eval-mode aggregation + grouped conv: bit 0 = 8 waves, bit 1 = direct 8-byte stores */
 
 enum NsidTuneKey {
@@ -311,4 +313,7 @@ int nsid_wgrad2_launch(const void* dout, int ldd, const void* x, int ldx, float*
 int nsid_gemm256_fwd_launch(const void* x, int ldx, const void* w, const float* bias, const void* addend, int ldadd, void* out,
                             int ldo, int M, int Nout, int K, bool relu_out, float* stat, long stat_plane, long stat_ld,
                             hipStream_t stream);
+// ffn256_fused.hip: eval-mode FFN of the C = 256 stage in one launch; returns 1 outside C = 256, H = 1024, M % 256 == 0
+int nsid_ffn256_fused_launch(const void* x, const void* w1, const float* b1, const void* w2, const float* b2, void* out, int M, int C,
+                             int H, hipStream_t stream);
 extern void* g_gemm_trace_host;        // gemm.hip: the buffer installed by nsid_debug_gemm_trace (nullptr = none)

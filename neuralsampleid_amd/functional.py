@@ -323,7 +323,7 @@ def grapher_backward(dx1: Tensor, P, S, G) -> Tensor:
 def ffn_forward(x1: Tensor, P, S: Optional[dict], training: bool) -> Tensor:
     M, C = x1.shape
     H = P["fc1.0.weight"].shape[0]
-    if fold_eval(training, S) and C in (64, 128) and H == 4 * C and M % 128 == 0:
+    if fold_eval(training, S) and C in (64, 128, 256) and H == 4 * C and M % (256 if C == 256 else 128) == 0:
         # forward-only, both BatchNorms folded into their convs: one launch, the hidden tensor never leaves the CU (csrc/ffn_fused.hip)
         g1, be1, rm1, rv1, _, _ = _bn(P, S, "fc1.1.")
         g2, be2, rm2, rv2, _, _ = _bn(P, S, "fc2.1.")

@@ -349,9 +349,11 @@ def test_eval_mrconv_in_one_launch(ops, B, C, k):
     assert ops.mrconv_fused_fwd(y[:, :32].contiguous(), idx, B, N, 32, w[:64, :16].contiguous(), b[:64]) is None
 
 
-@pytest.mark.parametrize("M,C", [(2048, 64), (128, 64), (4096, 128), (65536, 64)])
+@pytest.mark.parametrize("M,C", [(2048, 64), (128, 64), (4096, 128), (65536, 64), (256, 256), (16384, 256), (76800, 256),
+                                 (131072, 256)])
 def test_eval_ffn_in_one_launch(ops, M, C):
-    """csrc/ffn_fused.hip: out = x + W2 relu(W1 x + b1) + b2 (FFN.forward in eval mode with both BatchNorms folded) in one launch,
+    """csrc/ffn_fused.hip (C = 64 / 128: x tile in LDS) and csrc/ffn256_fused.hip (C = 256: x tile in registers, weights by LDS-DMA):
+    out = x + W2 relu(W1 x + b1) + b2 (FFN.forward in eval mode with both BatchNorms folded) in one launch,
     the M x 4C hidden tensor never written: against an fp64 evaluation with the same two bf16 rounding points (hidden, output) and
     against the two-launch form (nsid_linear_fwd with the ReLU epilogue + nsid_linear_fwd_res)"""
     from neuralsampleid_amd._lib import launch_counters
@@ -376,6 +378,29 @@ def test_eval_ffn_in_one_launch(ops, M, C):
     assert relerr(out, two) < 1e-3 and float((out != two).float().mean()) < 0.02      # same rounding points, another summation order
     assert ops.ffn_fused_fwd(x[:, :32].contiguous(), w1[:128, :32].contiguous(), b1[:128], w2[:32, :128].contiguous(), b2[:32],
                              M, 32, 128) is None                            # outside the fused form: the caller falls back
+
+
+def test_eval_ffn256_variants_agree(ops):
+    """csrc/ffn256_fused.hip under its tuning key: persistent over the row tiles (300 tiles on one workgroup per CU: some take two, the
+    next tile's x fetched by the epilogue of the one before), one workgroup per tile, and the 4-wave form with the output accumulators
+    in AGPRs all evaluate the same sums in the same order -- bit-identical outputs"""
+    M, C, H = 76800, 256, 1024
+    x = synth_randn(f"ffx{M}{C}", M, C).to(BF).to(DEV)
+    w1 = (synth_randn(f"ffw1{C}", H, C) * C ** -0.5).to(DEV)
+    w2 = (synth_randn(f"ffw2{C}", C, H) * H ** -0.5).to(DEV)
+    b1, b2 = (0.3 * synth_randn(f"ffb1{C}", H)).to(DEV), (0.3 * synth_randn(f"ffb2{C}", C)).to(DEV)
+    for w in (w1, w2):
+        ops.SHADOWS.register(w, ops.f32_to_bf16(w), owner=w)
+    outs = {}
+    try:
+        for key in (1, 2, 4):
+            ops.set_tuning("ffn256", key)
+            outs[key] = ops.ffn_fused_fwd(x, w1, b1, w2, b2, M, C, H)
+            torch.cuda.synchronize()
+    finally:
+        ops.set_tuning("ffn256", 1)
+    assert all(o is not None for o in outs.values())
+    assert torch.equal(outs[1], outs[2]) and torch.equal(outs[1], outs[4])
 
 
 @pytest.mark.parametrize("M,Nout,K,groups,affine", [(512, 256, 512, 1, True), (200, 64, 64, 1, False), (384, 128, 128, 4, True)])
