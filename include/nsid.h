@@ -54,7 +54,7 @@ int nsid_get_gemm_precision(void);
 /* ---- tuning: named launch-heuristic constants (tile-width thresholds, workgroup caps, split targets, kernel-family switches).
    The library never reads the environment: defaults are compiled in (csrc/nsid_common.h NSID_TUNING_TABLE lists every key with
    its default and meaning), and a run changes them only through these calls, so kernel selection and arithmetic depend on explicit
-   caller state alone. Keys used by the tests: "g256_min", "g256_train", "w8_min", "knn_strips". Unknown key -> NSID_EINVAL. */
+   caller state alone. Keys used by the tests: "g256_min", "g256_train", "ffn256", "knn_strips". Unknown key -> NSID_EINVAL. */
 int nsid_set_tuning(const char* key, long value);
 int nsid_get_tuning(const char* key, long* value);
 int nsid_reset_tuning(void);                 /* every key back to its compiled-in default */

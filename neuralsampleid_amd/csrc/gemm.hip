@@ -913,9 +913,6 @@ __global__ void elu_inplace_kernel(float* __restrict__ x, long rows, int cols, l
 }
 
 int g_gemm_precision = NSID_GEMM_FP32;     // process-wide (nsid_set_gemm_precision)
-// Tuning key w8_min: smallest number of 128x128 tiles for which the forward GEMM takes the 8-wave 256x128 form (0 = never).
-// Cold-operand microbenchmark: -12 ... -20 % on every >= 1024-tile forward GEMM (24.6 -> 20.1 us at 16384x1024x256); whole
-// training step 8.31 / 8.33 ms without against 8.35 / 8.38 ms with it, inference 286 k against 282 k clips/s: off by default.
 // Tuning keys g256_min / g256_train: smallest number of 256x256 tiles for which the forward GEMM takes gemm256.hip (LDS-DMA
 // staging); launches WITH a statistics epilogue (training) take it only when g256_train = 1 — the default serves forward-only work,
 // so that the arithmetic of a training step does not depend on the batch size.
@@ -982,8 +979,6 @@ int launch(GemmArgs p, int groups, hipStream_t s, int act_dtype, bool w_bf16 = f
   nsid_count(AR ? (BR ? NSID_C_gemm_fwd : NSID_C_gemm_bwd_data) : NSID_C_gemm_bwd_weight);
   if (p.split_major) nsid_count(NSID_C_gemm_split_major);
   if (aff) nsid_count(NSID_C_gemm_affine_load);
-  if (NW == 8) nsid_count(NSID_C_gemm_w8);
-  if (BM == 256 && NW == 4) nsid_count(NSID_C_gemm_tall);
   if (AR && !BR && p.bn_r != nullptr) nsid_count(NSID_C_gemm_bn_sums);
   if (!AR) nsid_count(BM == BN ? NSID_C_wgrad_square : NSID_C_wgrad_rect);
   {
@@ -1296,19 +1291,9 @@ static int linear_fwd_impl(const void* x, int ldx, const void* w, int w_dtype, c
   if (half && t128 < 128) narrow = true;        // few row tiles (the projector head, M = batch): more, narrower workgroups
   if (force_narrow >= 0 && Nout > 64) narrow = force_narrow != 0;
   const bool wb = w_dtype == NSID_BF16;
-  // Forward-only work (no BatchNorm statistics: eval mode) with more 128x128 tiles than four rounds of the chip: 256x128
-  // tiles move a quarter fewer operand bytes L2 -> LDS, which is what bounds the main loop. The
-  // training step never takes it (it needs the statistics epilogue; 256x128 measured neutral there), fingerprinting at micro-batch
-  // 1 024 has 1 024 - 4 096 tiles per GEMM: +4 % clips/s.
-  const long tall_min = nsid_tune(NSID_T_tall_min);
-  const bool tall = !any_stat && act_dtype == NSID_BF16 && wb && !narrow && t128 >= tall_min && M % 256 == 0 &&
-                    Nout % 128 == 0 && K % 64 == 0 && ksplit == 1;
-  // 8 waves on 256x128 tiles (round 2): same per-wave work as the 128x128 kernel, a quarter fewer operand bytes per flop,
-  // statistics epilogue included (two 128-row statistics tiles per workgroup). Tuning key w8_min = smallest number of 128x128
-  // tiles that takes it (0 = never).
-  const long w8_min = nsid_tune(NSID_T_w8_min);
-  const bool w8 = w8_min > 0 && act_dtype == NSID_BF16 && wb && !narrow && t128 >= w8_min && M % 256 == 0 && Nout % 128 == 0 &&
-                  K % 64 == 0 && ksplit == 1;
+  // (256x128-tile forms of this kernel -- 4 waves "tall", 8 waves "w8" -- existed through round 3: every instantiation spilled 13-81
+  // registers to scratch, and the extraction bench measured them within 0.3 % of the 128x128 tiles (4.540 against 4.555 ms per
+  // micro-batch, docs/experiments.md round 4): removed. Large forward-only shapes go to gemm256.hip below.)
   // 256x256 tiles with LDS-DMA staging (gemm256.hip): tuning key g256_min = smallest number of 256x256 tiles that takes it (0 = never)
   // default 512 (two tiles per CU and more: fingerprinting at micro-batch 2 048): 7.09 -> 6.56 ms per micro-batch. The training step
   // (<= 256 such tiles per launch) is neutral to slightly worse with it (8.30 vs 8.34 ms: a workgroup that owns 150 KB of a CU's LDS
@@ -1321,10 +1306,7 @@ static int linear_fwd_impl(const void* x, int ldx, const void* w, int w_dtype, c
                                               p.stat_plane, p.stat_ld, s);
     if (rc256 != 1) { ++g_g256_launches; nsid_count(NSID_C_gemm256); return rc256; }
   }
-  const int rc = w8 ? launch<256, 128, true, true, 8>(p, groups, s, act_dtype, wb)
-                    : tall ? launch<256, 128, true, true>(p, groups, s, act_dtype, wb)
-                           : narrow ? launch<128, 64, true, true>(p, groups, s, act_dtype, wb)
-                                    : launch<128, 128, true, true>(p, groups, s, act_dtype, wb);
+  const int rc = narrow ? launch<128, 64, true, true>(p, groups, s, act_dtype, wb) : launch<128, 128, true, true>(p, groups, s, act_dtype, wb);
   if (rc != NSID_OK || act_out != NSID_ACT_ELU) return rc;
   const long n = (long)M * groups * Nout;
   NSID_LAUNCH(elu_inplace_kernel, dim3((int)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256)), dim3(256), 0, s,
@@ -1437,11 +1419,6 @@ static int linear_bwd_data_impl(const void* dout, int ldd, const void* w, int w_
     p.abn_dr = abn->dr; p.abn_lddr = (long)groups * Nout;
     if (K % (narrow ? 64 : 128) != 0 || M % 128 != 0 || Nout % 64 != 0) return 1;
   }
-  // the 8-wave 256x128 form loses here (16384x256x1024: 21.8 -> 41.4 us cold): 169 registers = one workgroup per CU, and the
-  // transposed weight reads + addend / BatchNorm-sum epilogue do not shrink with the tile. Kept for experiments only.
-  const long w8_min = nsid_tune(NSID_T_w8_bwd_min);
-  if (abn == nullptr && w8_min > 0 && !narrow && act_dtype == NSID_BF16 && wb && t128 >= w8_min && M % 256 == 0 && K % 128 == 0 && Nout % 64 == 0)
-    return launch<256, 128, true, false, 8>(p, groups, s, act_dtype, wb);
   if (narrow) return launch<128, 64, true, false>(p, groups, s, act_dtype, wb);
   return launch<128, 128, true, false>(p, groups, s, act_dtype, wb);
 }

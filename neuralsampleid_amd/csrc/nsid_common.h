@@ -239,9 +239,6 @@ static inline bool nsid_acc_ok(const int64_t* acc, int replicas) {
   X(gemm_deep_kinds, 5)        /* which GEMM kinds take the deep form: bit 0 forward, bit 1 backward-data, bit 2 weight gradient */ \
   X(fwd_narrow, -1)            /* -1: shape heuristic; 0 / 1 force 128- / 64-wide forward tiles */                             \
   X(bwd_narrow, -1)                                                                                                           \
-  X(tall_min, 1024)            /* forward-only GEMMs with >= this many 128x128 tiles take 256x128 tiles */                    \
-  X(w8_min, 0)                 /* >= this many 128x128 tiles: 8-wave 256x128 forward kernel (0 = never) */                    \
-  X(w8_bwd_min, 0)                                                                                                            \
   X(g256_min, 512)             /* >= this many 256x256 tiles: gemm256.hip (LDS-DMA staging); 0 = never */                     \
   X(g256_train, 0)             /* 1: launches WITH a statistics epilogue (training) may take gemm256.hip too */               \
   X(g256_grid, 0)              /* workgroups of the persistent gemm256 launch (0 = one per CU) */                             \
@@ -278,7 +275,7 @@ static inline long nsid_tune(NsidTuneKey k) { return g_nsid_tune[k]; }
   X(gemm_fwd) X(gemm_bwd_data) X(gemm_bwd_weight)        /* launches of gemm.hip by kind */      \
   X(gemm_full)            /* predication-free full-tile instantiation */                        \
   X(gemm_ks2)             /* 64-deep LDS stages */                                              \
-  X(gemm_pd4) X(gemm_ec) X(gemm_w8) X(gemm_tall)                                                \
+  X(gemm_pd4) X(gemm_ec)                                                \
   X(gemm_split_major)     /* split index fastest in the grid (a split stays on one XCD) */      \
   X(gemm_affine_load)     /* producer BatchNorm + activation applied on the operand load */     \
   X(gemm_relu_load)                                                                             \

@@ -292,18 +292,14 @@ def linear_fwd(x, w, bias, M, Nout, K, groups=1, in_scale=None, in_shift=None, a
         narrow = True
     esz = x.element_size()
     wop, wdt = _weight(w, dt, K)
-    # csrc/gemm.hip linear_fwd_impl: forward-only work with >= NSID_TALL_MIN (1024) tiles of 128x128 takes 256x128 tiles
-    tall = (not want_stat and dt == BF16 and wdt == BF16 and not narrow and ksplit == 1 and M % 256 == 0 and Nout % 128 == 0
-            and K % 64 == 0 and row_tiles(M) * ((Nout + 127) // 128) * groups >= get_tuning("tall_min"))
-    name_ = "gemm_kernel<%d,%d,true,true>" % (256 if tall else 128, 64 if narrow else 128)
+    name_ = "gemm_kernel<128,%d,true,true>" % (64 if narrow else 128)
     n256 = lib.nsid_gemm_g256_launches() if PROFILE is not None else 0
     # csrc/gemm.hip decides between the tile families; the launch counter of the 256x256-tile LDS-DMA kernel says which one ran
     name = lambda: "gemm256_fwd_kernel" if lib.nsid_gemm_g256_launches() > n256 else name_
     if in_scale is None and act_in != ACT_NONE:
         # activation on load without an affine: only ReLU on bf16 operands, bf16 weights and whole tiles (csrc/gemm.hip ARELU)
         bn_ = 64 if narrow else 128
-        bm_ = 256 if (not want_stat and not narrow and row_tiles(M) * ((Nout + 127) // 128) * groups >= 1024
-                      and M % 256 == 0 and Nout % 128 == 0) else 128
+        bm_ = 128
         if not (act_in == ACT_RELU and dt == BF16 and wdt == BF16 and M % bm_ == 0 and Nout % bn_ == 0 and K % 64 == 0
                 and ksplit == 1):
             raise ValueError("activation-on-load without an affine needs ReLU, bf16 storage, bf16 weights and whole tiles")

@@ -42,7 +42,7 @@ def test_tuning_table_roundtrip(libpath):
     import subprocess
     from neuralsampleid_amd import _lib
     keys = _lib.tuning_keys()
-    assert len(keys) == len(set(keys)) >= 20 and {"g256_min", "g256_train", "w8_min", "knn_strips", "bn_bwd_apply_max_wg"} <= set(keys)
+    assert len(keys) == len(set(keys)) >= 20 and {"g256_min", "g256_train", "ffn256", "knn_strips", "bn_bwd_apply_max_wg"} <= set(keys)
     defaults = {k: _lib.get_tuning(k) for k in keys}
     assert defaults["g256_min"] == 512 and defaults["bn_bwd_apply_max_wg"] == 384
     _lib.set_tuning("g256_min", 7)

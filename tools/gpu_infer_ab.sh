@@ -6,7 +6,7 @@ timeout -k 10 900 python -m pytest tests/test_ops_gpu.py tests/test_bf16_storage
 tail -4 $out/tests.log
 [ $rc -ne 0 ] && exit $rc
 for rep in 1 2; do
-  for cfg in "base:" "w8:--tune w8_min=1024" "$@"; do
+  for cfg in "base:" "$@"; do
     tag=${cfg%%:*}; flags=${cfg#*:}
     timeout -k 10 300 python3 bench.py --mode infer --no-cpu-baseline --no-roofline $flags > $out/$tag.$rep.json 2> $out/$tag.$rep.err || { tail -5 $out/$tag.$rep.err; exit 1; }
     python3 -c "import json;d=json.load(open('$out/$tag.$rep.json'));print('$tag', d['value'], d['ms_per_step'])"
