@@ -40,7 +40,8 @@ constexpr int F_SLOT = 32768;                 // W1 chunk image (16 sub-blocks) 
 constexpr int F_NS = 4;                       // ring slots: chunk ch (GEMM 1), chunk ch - 1 (GEMM 2), chunks ch + 1 and ch + 2 in flight
 constexpr int F_HB = 16 * 1024;               // 16 row tiles x 1 KB: every wave its own hidden sub-blocks
 constexpr int F_B1 = F_H * 4;                 // b1 in LDS
-constexpr int F_LDS = F_NS * F_SLOT + F_HB + F_B1;
+constexpr int F_B2 = F_C * 4;                 // b2 in LDS
+constexpr int F_LDS = F_NS * F_SLOT + F_HB + F_B1 + F_B2;
 #ifndef NSID_F256_PF
 #define NSID_F256_PF 1
 #endif
@@ -78,6 +79,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64 * NW, 64 * NW), amdgpu_
 void ffn256_fused_kernel(const F256Args p) {
   constexpr int RT = 16 / NW;                 // 16-row tiles per wave
   constexpr int PW = 32 / NW;                 // LDS-DMA pieces per wave and chunk
+  constexpr int EP = 2 * 8 * RT;              // global loads + stores a wave issues in a tile's epilogue (when another tile follows)
   __shared__ __attribute__((aligned(1024))) char lds[F_LDS];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -85,6 +87,7 @@ void ffn256_fused_kernel(const F256Args p) {
   const int ntiles = p.M / 256;
   char* const hb = lds + F_NS * F_SLOT + wave * (RT * 1024);
   float* const b1s = reinterpret_cast<float*>(lds + F_NS * F_SLOT + F_HB);
+  float* const b2s = b1s + F_H;
   const unsigned lds0 = (unsigned)(size_t)(lds_vptr)lds;
 
   // ---- x fragments: lane (lr, rq) of row tile b holds x[row0 + 16 b + lr][32 ks + 8 rq .. + 7]
@@ -100,6 +103,7 @@ void ffn256_fused_kernel(const F256Args p) {
       for (int ks = 0; ks < 8; ++ks) xf[ks][b] = *reinterpret_cast<const bf16x8*>(xt + xo + b * (16 * F_C * 2) + ks * 64);
   }
   for (int i = tid; i < F_H / 4; i += 64 * NW) reinterpret_cast<f32x4*>(b1s)[i] = reinterpret_cast<const f32x4*>(p.b1)[i];
+  if (tid < F_C / 4) reinterpret_cast<f32x4*>(b2s)[tid] = reinterpret_cast<const f32x4*>(p.b2)[tid];
 
   // ---- LDS-DMA addressing (gemm256.hip): lane l supplies row l >> 2 of a 16-row sub-block and the logical 16-byte chunk that lives at
   // physical chunk l & 3
@@ -135,6 +139,7 @@ void ffn256_fused_kernel(const F256Args p) {
     char* const ot = reinterpret_cast<char*>(p.out + (long)tile * 256 * F_C);
     const char* const xn = reinterpret_cast<const char*>(p.x + ((long)tile + gridDim.x) * 256 * F_C);    // the next tile's x (if any)
     const bool more = tile + (int)gridDim.x < ntiles;                   // uniform
+    const bool first = tile == (int)blockIdx.x;
     f32x4 acc2[16][RT];
 #pragma unroll
     for (int c = 0; c < 16; ++c)
@@ -159,7 +164,12 @@ void ffn256_fused_kernel(const F256Args p) {
       // chunk ch has landed for THIS wave when at most the PW pieces of chunk ch + 1 are still in flight; the barrier then says so
       // for every wave, and that every wave is done with the slot chunk ch + 2 is about to overwrite (chunk ch - 2: its W2 image was
       // read in iteration ch - 1)
-      if (ch + 1 < F_NCH) f_wait_vm<PW>();
+      // (vmcnt counts loads, stores and LDS-DMA together, in issue order. On a later tile of a persistent workgroup the epilogue of the
+      // tile before issued EP operations -- the next x fragments and the output stores -- AFTER chunks 0 and 1: they are younger than
+      // what iterations 0 and 1 wait for and stay in flight; waiting them out here would put every tile's store tail on the critical
+      // path)
+      if (ch < 2 && !first) f_wait_vm<(PW + EP < 63 ? PW + EP : 63)>();
+      else if (ch + 1 < F_NCH) f_wait_vm<PW>();
       else f_wait_vm<0>();
 #ifndef NSID_F256_NOBARRIER                  // diagnosis build: what the per-chunk barrier costs (wrong results)
       __builtin_amdgcn_s_barrier();
@@ -235,8 +245,8 @@ void ffn256_fused_kernel(const F256Args p) {
     // so the residual needs no second read of x, no LDS staging and no barrier, and a lane stores 8 consecutive channels (16 bytes).
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) {
-      const f32x4 bc0 = *reinterpret_cast<const f32x4*>(p.b2 + 32 * ks + 8 * rq);
-      const f32x4 bc1 = *reinterpret_cast<const f32x4*>(p.b2 + 32 * ks + 8 * rq + 4);
+      const f32x4 bc0 = *reinterpret_cast<const f32x4*>(b2s + 32 * ks + 8 * rq);
+      const f32x4 bc1 = *reinterpret_cast<const f32x4*>(b2s + 32 * ks + 8 * rq + 4);
 #pragma unroll
       for (int b = 0; b < RT; ++b) {
         const f32x4 y0 = acc2[2 * ks][b] + bc0, y1 = acc2[2 * ks + 1][b] + bc1;
