@@ -106,10 +106,20 @@ int nsid_linear_fwd_res(const void* x, int ldx, const void* w, int w_dtype, cons
                         const float* in_shift, int act_in, int act_dtype, void* stream);
 /* eval-mode FFN in ONE launch: out = x + W2 relu(W1 x + b1) + b2 with both BatchNorms folded into (W1, b1) (H x C) and (W2, b2)
    (C x H) — FFN.forward, encoder/graph_encoder.py:82-89, in eval mode. x, out: M x C bf16 contiguous; W1, W2: bf16 row-major;
-   b1, b2 fp32. The M x H hidden tensor never reaches HBM. Returns 1 (nothing launched) outside C in {64, 128}, H = 4C, M % 128 == 0:
-   the caller then runs nsid_linear_fwd + nsid_linear_fwd_res. */
+   b1, b2 fp32. The M x H hidden tensor never reaches HBM. Returns 1 (nothing launched) outside C in {64, 128} with M % 128 == 0 or
+   C = 256 with M % 256 == 0 (csrc/ffn256_fused.hip; tuning key "ffn256"), H = 4C: the caller then runs nsid_linear_fwd +
+   nsid_linear_fwd_res. */
 int nsid_ffn_fused_fwd(const void* x, const void* w1, const float* b1, const void* w2, const float* b2, void* out, int M, int C,
                        int H, void* stream);
+/* Grapher tail + FFN of one eval-mode block in ONE launch:
+       x1  = x + Wp r2 + bp                   (Grapher.forward: fc2 + BatchNorm folded into (Wp, bp) + shortcut, gcn_lib/torch_vertex.py:183-195)
+       out = x1 + W2 relu(W1 x1 + b1) + b2    (FFN.forward, encoder/graph_encoder.py:82-89)
+   x: M x C bf16 (the block's input), r2: M x 2C bf16 (the graph conv's output, nsid_mrconv_fused_fwd), Wp: C x 2C bf16 row-major,
+   bp fp32[C]; the rest as nsid_ffn_fused_fwd. x1 is rounded to bf16 once (as nsid_linear_fwd_res would store it) and never written.
+   out must not alias x or r2. Returns 1 (nothing launched) outside C = 256, H = 1024, M % 256 == 0: the caller then runs
+   nsid_linear_fwd_res + nsid_ffn_fused_fwd. */
+int nsid_block_tail_fused_fwd(const void* x, const void* r2, const void* wp, const float* bp, const void* w1, const float* b1,
+                              const void* w2, const float* b2, void* out, int M, int C, int H, void* stream);
 /* eval-mode MRConv2d in ONE launch, one workgroup per clip: v = relu(W (*)_4 [y, max_j(y[idx_j] - y)] + b) with the BatchNorm folded
    into (W, b) — MRConv2d.forward (gcn_lib/torch_vertex.py:19-34) + BasicConv (torch_nn.py:52-76) in eval mode. y: (B*N, C) bf16 plain
    values (the producer's BatchNorm folded too), idx: (B, N, k) clip-local, w: (2C, C/2) bf16, bias: (2C) fp32, out: (B*N, 2C) bf16.

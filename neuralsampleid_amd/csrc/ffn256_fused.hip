@@ -31,6 +31,8 @@ namespace {
 struct F256Args {
   const __bf16* x; const __bf16* w1; const float* b1; const __bf16* w2; const float* b2; __bf16* out;
   int M;
+  // PRE form (Grapher tail + FFN): the FFN's input is x1 = x + Wp r2 + bp, evaluated by the same launch
+  const __bf16* r2; const __bf16* wp; const float* bp;
 };
 
 typedef __attribute__((address_space(3))) void* lds_vptr;
@@ -41,7 +43,10 @@ constexpr int F_NS = 4;                       // ring slots: chunk ch (GEMM 1), 
 constexpr int F_HB = 16 * 1024;               // 16 row tiles x 1 KB: every wave its own hidden sub-blocks
 constexpr int F_B1 = F_H * 4;                 // b1 in LDS
 constexpr int F_B2 = F_C * 4;                 // b2 in LDS
-constexpr int F_LDS = F_NS * F_SLOT + F_HB + F_B1 + F_B2;
+constexpr int F_BP = F_C * 4;                 // bp in LDS (PRE form)
+constexpr int F_LDS = F_NS * F_SLOT + F_HB + F_B1 + F_B2 + F_BP;
+constexpr int F_KP = 2 * F_C;                 // PRE form: width of r2 (the Grapher's 2C-channel graph-conv output)
+constexpr int F_NP = F_KP / 32;               // its k-steps = prologue iterations
 #ifndef NSID_F256_PF
 #define NSID_F256_PF 1
 #endif
@@ -74,9 +79,18 @@ __device__ __forceinline__ void f_mfma_acc(f32x4& acc, const bf16x8& a, const bf
 //   NW = 8: 32 rows per wave, two waves per SIMD at <= 256 registers;
 //   NW = 4: 64 rows per wave, ONE wave per SIMD with the whole 512-register budget (128 of x fragments, 256 of output accumulators):
 //           every weight fragment read from LDS feeds four MFMAs instead of two, which halves the LDS reads per matrix cycle.
-template <int NW>
+//
+// PRE = true (nsid_block_tail_fused_fwd): the Grapher's last conv + shortcut in front of the FFN (torch_vertex.py:183-195),
+//     x1 = bf16((Wp r2 + bp) + x)      (gemm256.hip's residual epilogue: one rounding),     out = x1 + W2 relu(W1 x1 + b1) + b2,
+// as F_NP = 16 more iterations of the same ring in front of the 32 FFN chunks: iteration u brings the k-step image of Wp (256 x 32,
+// rows permuted like W2's: 16 KB) and the r2 slice of the workgroup's 256 rows (16 sub-blocks of [16 rows][32 k]: 16 KB) by LDS-DMA
+// into slot u % 4 -- the same 32 pieces, so the vmcnt / barrier protocol does not change -- and runs 16 x RT MFMAs per wave into the
+// output accumulators. Their channel order is that of the lane's own x fragments, so x1 replaces x in registers without leaving
+// the lane. x1 itself is never written: per block that removes a launch, a write of M x 256 and two reads (55.6 us stand-alone).
+template <int NW, bool PRE>
 __global__ __attribute__((amdgpu_flat_work_group_size(64 * NW, 64 * NW), amdgpu_waves_per_eu(NW / 4, NW / 4)))
 void ffn256_fused_kernel(const F256Args p) {
+  constexpr int NP = PRE ? F_NP : 0;          // prologue iterations; chunk index u = 0 .. NP + F_NCH - 1, slot u % 4
   constexpr int RT = 16 / NW;                 // 16-row tiles per wave
   constexpr int PW = 32 / NW;                 // LDS-DMA pieces per wave and chunk
   constexpr int EP = 2 * 8 * RT;              // global loads + stores a wave issues in a tile's epilogue (when another tile follows)
@@ -88,6 +102,7 @@ void ffn256_fused_kernel(const F256Args p) {
   char* const hb = lds + F_NS * F_SLOT + wave * (RT * 1024);
   float* const b1s = reinterpret_cast<float*>(lds + F_NS * F_SLOT + F_HB);
   float* const b2s = b1s + F_H;
+  float* const bps = b2s + F_C;
   const unsigned lds0 = (unsigned)(size_t)(lds_vptr)lds;
 
   // ---- x fragments: lane (lr, rq) of row tile b holds x[row0 + 16 b + lr][32 ks + 8 rq .. + 7]
@@ -104,6 +119,7 @@ void ffn256_fused_kernel(const F256Args p) {
   }
   for (int i = tid; i < F_H / 4; i += 64 * NW) reinterpret_cast<f32x4*>(b1s)[i] = reinterpret_cast<const f32x4*>(p.b1)[i];
   if (tid < F_C / 4) reinterpret_cast<f32x4*>(b2s)[tid] = reinterpret_cast<const f32x4*>(p.b2)[tid];
+  if (PRE && tid < F_C / 4) reinterpret_cast<f32x4*>(bps)[tid] = reinterpret_cast<const f32x4*>(p.bp)[tid];
 
   // ---- LDS-DMA addressing (gemm256.hip): lane l supplies row l >> 2 of a 16-row sub-block and the logical 16-byte chunk that lives at
   // physical chunk l & 3
@@ -112,22 +128,36 @@ void ffn256_fused_kernel(const F256Args p) {
   // W2: row stride 1024 elements; sub-block c = 2 ks + half takes its row 4 q + e from output channel 32 ks + 8 q + 4 half + e, so
   // that a lane's accumulators are the channels of its own x fragments (epilogue)
   const unsigned voff2 = (unsigned)((8 * (grow >> 2) + (grow & 3)) * F_H + lc * 8) * 2u;
-  auto issue = [&](int ch) {                                            // this wave's PW pieces of chunk ch
-    const unsigned dst = lds0 + (ch % F_NS) * F_SLOT;
-    const int h0 = ch * F_HC;
+  // Wp: row stride 512 elements, rows permuted like W2's; r2: sub-block sb = rows 16 sb .. 16 sb + 15 of the tile, row stride 512
+  const unsigned voffp = (unsigned)((8 * (grow >> 2) + (grow & 3)) * F_KP + lc * 8) * 2u;
+  const unsigned voffr = (unsigned)(grow * F_KP + lc * 8) * 2u;
+  auto issue = [&](int u, int tile) {                                   // this wave's PW pieces of chunk u (of row tile `tile`)
+    const unsigned dst = lds0 + (u % F_NS) * F_SLOT;
+    if (PRE && u < NP) {
 #pragma unroll
-    for (int u = 0; u < PW / 2; ++u) {
-      const int q = (PW / 2) * wave + u, a = q >> 3, ks = q & 7;        // W1 sub-block (hidden tile a, k-step ks)
+      for (int i = 0; i < PW; ++i) {
+        const int q = PW * wave + i;                                    // 0-15: Wp sub-block (channel tile q); 16-31: r2 sub-block q - 16
+        if (q < 16)
+          f_glds16(reinterpret_cast<const char*>(p.wp + (long)(32 * (q >> 1) + 4 * (q & 1)) * F_KP + 32 * u), voffp, dst + q * 1024);
+        else
+          f_glds16(reinterpret_cast<const char*>(p.r2 + ((long)tile * 256 + 16 * (q - 16)) * F_KP + 32 * u), voffr, dst + q * 1024);
+      }
+      return;
+    }
+    const int h0 = (u - NP) * F_HC;
+#pragma unroll
+    for (int i = 0; i < PW / 2; ++i) {
+      const int q = (PW / 2) * wave + i, a = q >> 3, ks = q & 7;        // W1 sub-block (hidden tile a, k-step ks)
       f_glds16(reinterpret_cast<const char*>(p.w1 + (long)(h0 + 16 * a) * F_C + 32 * ks), voff1, dst + q * 1024);
     }
 #pragma unroll
-    for (int u = 0; u < PW / 2; ++u) {
-      const int c = (PW / 2) * wave + u;                                // W2 sub-block (channel tile c)
+    for (int i = 0; i < PW / 2; ++i) {
+      const int c = (PW / 2) * wave + i;                                // W2 sub-block (channel tile c)
       f_glds16(reinterpret_cast<const char*>(p.w2 + (long)(32 * (c >> 1) + 4 * (c & 1)) * F_H + h0), voff2, dst + 16384 + c * 1024);
     }
   };
-  issue(0);
-  issue(1);
+  issue(0, blockIdx.x);
+  issue(1, blockIdx.x);
   const int lo = (lr * 64 + rq * 16) ^ (((lr >> 3) & 1) << 5);          // fragment read offset inside a weight sub-block
   // the wave-private hidden sub-blocks use their own swizzle, chunk ^ (row >> 1 & 3): the 8-byte stores of a 16-lane group (one column
   // of 16 rows) then fall on 8 different 16-byte slots (2-way; 4-way with the weight images' swizzle, measured as 23 % of the
@@ -149,6 +179,50 @@ void ffn256_fused_kernel(const F256Args p) {
 #pragma unroll
     for (int b = 0; b < RT; ++b) hf[b] = bf16x8{};
 
+    if constexpr (PRE) {
+      // ---- x1 = bf16((Wp r2 + bp) + x): 16 k-steps, each one slot = [Wp k-step image | r2 slice], into the output accumulators
+      for (int u = 0; u < NP; ++u) {
+        if (u < 2 && !first) f_wait_vm<(PW + EP < 63 ? PW + EP : 63)>();     // (see the chunk loop below)
+        else f_wait_vm<PW>();
+        __builtin_amdgcn_s_barrier();
+        issue(u + 2, tile);
+        const char* sp = lds + (u % F_NS) * F_SLOT;
+        bf16x8 rb[RT];
+#pragma unroll
+        for (int b = 0; b < RT; ++b) rb[b] = *reinterpret_cast<const bf16x8*>(sp + 16384 + (RT * wave + b) * 1024 + lo);
+        bf16x8 fa = *reinterpret_cast<const bf16x8*>(sp + lo);
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+          const bf16x8 f = fa;
+          if (c + 1 < 16) fa = *reinterpret_cast<const bf16x8*>(sp + (c + 1) * 1024 + lo);
+#pragma unroll
+          for (int b = 0; b < RT; ++b) {
+            if constexpr (NW == 4) f_mfma_acc(acc2[c][b], f, rb[b]);
+            else acc2[c][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f, rb[b], acc2[c][b], 0, 0, 0);
+          }
+        }
+      }
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        const f32x4 bc0 = *reinterpret_cast<const f32x4*>(bps + 32 * ks + 8 * rq);
+        const f32x4 bc1 = *reinterpret_cast<const f32x4*>(bps + 32 * ks + 8 * rq + 4);
+#pragma unroll
+        for (int b = 0; b < RT; ++b) {
+          const f32x4 y0 = acc2[2 * ks][b] + bc0, y1 = acc2[2 * ks + 1][b] + bc1;
+          const bf16x8 xr = xf[ks][b];
+          bf16x8 x1;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            x1[e] = (__bf16)(y0[e] + (float)xr[e]);
+            x1[4 + e] = (__bf16)(y1[e] + (float)xr[4 + e]);
+          }
+          xf[ks][b] = x1;
+          acc2[2 * ks][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+          acc2[2 * ks + 1][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+      }
+    }
+
     // Software pipeline over the chunks: iteration ch runs GEMM 1 of chunk ch (W1 image of slot ch % 4) interleaved with GEMM 2 of
     // chunk ch - 1 (W2 image of slot (ch - 1) % 4, hidden fragments in registers): the two are independent, so the matrix pipe never
     // waits for the bias / ReLU / pack / LDS round trip of the hidden chunk, and 16 steps of {2 fragment reads, 4 RT/2 MFMAs} hide the
@@ -168,16 +242,16 @@ void ffn256_fused_kernel(const F256Args p) {
       // tile before issued EP operations -- the next x fragments and the output stores -- AFTER chunks 0 and 1: they are younger than
       // what iterations 0 and 1 wait for and stay in flight; waiting them out here would put every tile's store tail on the critical
       // path)
-      if (ch < 2 && !first) f_wait_vm<(PW + EP < 63 ? PW + EP : 63)>();
+      if (!PRE && ch < 2 && !first) f_wait_vm<(PW + EP < 63 ? PW + EP : 63)>();
       else if (ch + 1 < F_NCH) f_wait_vm<PW>();
       else f_wait_vm<0>();
 #ifndef NSID_F256_NOBARRIER                  // diagnosis build: what the per-chunk barrier costs (wrong results)
       __builtin_amdgcn_s_barrier();
 #endif
-      if (ch + 2 < F_NCH) issue(ch + 2);
-      else if (!g1 && more) { issue(0); issue(1); }
-      const char* s1 = lds + (ch % F_NS) * F_SLOT;                       // W1 image of chunk ch
-      const char* s2 = lds + ((ch + F_NS - 1) % F_NS) * F_SLOT + 16384;  // W2 image of chunk ch - 1
+      if (ch + 2 < F_NCH) issue(NP + ch + 2, tile);
+      else if (!g1 && more) { issue(0, tile + gridDim.x); issue(1, tile + gridDim.x); }
+      const char* s1 = lds + ((NP + ch) % F_NS) * F_SLOT;                       // W1 image of chunk ch
+      const char* s2 = lds + ((NP + ch + F_NS - 1) % F_NS) * F_SLOT + 16384;    // W2 image of chunk ch - 1
       f32x4 acc1[2][RT];
 #pragma unroll
       for (int a = 0; a < 2; ++a)
@@ -266,13 +340,14 @@ void ffn256_fused_kernel(const F256Args p) {
 
 }  // namespace
 
-// returns NSID_OK / NSID_ELAUNCH, or 1 (nothing launched) outside C = 256, H = 1024, M % 256 == 0
+// returns NSID_OK / NSID_ELAUNCH, or 1 (nothing launched) outside C = 256, H = 1024, M % 256 == 0.
+// r2 != nullptr: the PRE form (x1 = x + wp r2 + bp in front of the FFN; r2: M x 512 bf16, wp: 256 x 512 bf16, bp: fp32[256])
 __attribute__((visibility("hidden")))
 int nsid_ffn256_fused_launch(const void* x, const void* w1, const float* b1, const void* w2, const float* b2, void* out, int M, int C,
-                             int H, hipStream_t stream) {
+                             int H, hipStream_t stream, const void* r2, const void* wp, const float* bp) {
   if (C != F_C || H != F_H || M % 256 != 0 || M <= 0) return 1;
   F256Args p{static_cast<const __bf16*>(x), static_cast<const __bf16*>(w1), b1, static_cast<const __bf16*>(w2), b2,
-             static_cast<__bf16*>(out), M};
+             static_cast<__bf16*>(out), M, static_cast<const __bf16*>(r2), static_cast<const __bf16*>(wp), bp};
   static int n_cu = 0;
   if (n_cu == 0) {
     int dev = 0, n = 0;               // an attribute query: legal whatever the stream is doing (capture)
@@ -284,7 +359,13 @@ int nsid_ffn256_fused_launch(const void* x, const void* w1, const float* b1, con
   // tuning key ffn256: 1 = persistent, one workgroup of 8 waves per CU; 2 = 8 waves, one workgroup per tile; 4 = persistent, 4 waves of
   // 64 rows with the output accumulators in AGPRs (measured 154 us against 146 us: docs/experiments.md)
   const int wgs = (nsid_tune(NSID_T_ffn256) == 2 || ntiles < n_cu) ? ntiles : n_cu;
-  if (nsid_tune(NSID_T_ffn256) == 4) NSID_LAUNCH(ffn256_fused_kernel<4>, dim3(wgs), dim3(256), 0, stream, p);
-  else NSID_LAUNCH(ffn256_fused_kernel<8>, dim3(wgs), dim3(512), 0, stream, p);
+  const bool w4 = nsid_tune(NSID_T_ffn256) == 4;
+  if (r2 != nullptr) {
+    if (w4) NSID_LAUNCH((ffn256_fused_kernel<4, true>), dim3(wgs), dim3(256), 0, stream, p);
+    else NSID_LAUNCH((ffn256_fused_kernel<8, true>), dim3(wgs), dim3(512), 0, stream, p);
+  } else {
+    if (w4) NSID_LAUNCH((ffn256_fused_kernel<4, false>), dim3(wgs), dim3(256), 0, stream, p);
+    else NSID_LAUNCH((ffn256_fused_kernel<8, false>), dim3(wgs), dim3(512), 0, stream, p);
+  }
   return nsid_launch_status();
 }

@@ -255,7 +255,11 @@ def stem_backward(dx0: Tensor, P, S, G, need_input_grad: bool = True) -> Optiona
 
 
 # ------------------------------------------------------------------------------------------------ Grapher
-def grapher_forward(x0: Tensor, P, S: Optional[dict], B: int, N: int, k: int, dilation: int, training: bool) -> Tensor:
+def grapher_forward(x0: Tensor, P, S: Optional[dict], B: int, N: int, k: int, dilation: int, training: bool,
+                    defer_tail: Optional[list] = None) -> Tensor:
+    """defer_tail (a list, eval mode without a backward only): when the folded path produced r2 = relu(BN(graph conv)), the last
+    conv + shortcut is NOT evaluated here -- r2 is appended to the list and x0 returned; the caller evaluates it inside the FFN
+    launch (block_eval_fused)."""
     M, C = x0.shape
     r1, a1 = conv_bn(x0, M, C, C, P["fc1.0.weight"], P["fc1.0.bias"], _bn(P, S, "fc1.1."), training)
     idx = ops.knn_graph(r1, B, N, C, k, dilation, a1)
@@ -276,6 +280,9 @@ def grapher_forward(x0: Tensor, P, S: Optional[dict], B: int, N: int, k: int, di
         r2, a2 = conv_bn(u, M, C // 2, C // 2, P[pre + "0.weight"], P[pre + "0.bias"], _bn(P, S, pre + "1."), training,
                          groups=4, folded_act=ACT_RELU)
     if fold_eval(training, S):   # conv + BatchNorm + shortcut in one launch; r2 already is relu(BN(conv)) (a2 is None)
+        if defer_tail is not None and a2 is None:
+            defer_tail.append(r2)
+            return x0
         return conv_bn(r2, M, 2 * C, C, P["fc2.0.weight"], P["fc2.0.bias"], _bn(P, S, "fc2.1."), training,
                        in_aff=a2, act_in=ACT_RELU, residual=x0)[0]
     r3, a3 = conv_bn(r2, M, 2 * C, C, P["fc2.0.weight"], P["fc2.0.bias"], _bn(P, S, "fc2.1."), training,
@@ -344,6 +351,33 @@ def ffn_forward(x1: Tensor, P, S: Optional[dict], training: bool) -> Tensor:
             CHAIN.consume(S)
             CHAIN.produce(S, r5, a5, ACT_NONE)
     return x2
+
+
+def block_eval_fused(x0: Tensor, PG, PF, B: int, N: int, k: int, dilation: int) -> Optional[Tensor]:
+    """One eval-mode block (Grapher + FFN, no backward) with the Grapher's fc2 + BatchNorm + shortcut evaluated inside the FFN launch
+    (csrc/ffn256_fused.hip PRE form; reference: torch_vertex.py:183-195 + graph_encoder.py:82-89). PG / PF: the two modules'
+    parameters and buffers. None when the block is outside the fused form (C = 256, M % 256 == 0, bf16 storage, folded BatchNorms):
+    the caller then runs the two modules as usual."""
+    M, C = x0.shape
+    H = PF["fc1.0.weight"].shape[0]
+    if not (ops.FUSE_BLOCK_TAIL and fold_eval(False, None) and C == 256 and H == 4 * C and M % 256 == 0
+            and ops.get_tuning("ffn256") != 0):
+        return None
+    tail: list = []
+    x = grapher_forward(x0, PG, None, B, N, k, dilation, False, defer_tail=tail)
+    if tail:
+        g, be, rm, rv, _, _ = _bn(PG, None, "fc2.1.")
+        wpf, bpf = ops.folded_conv_bn(ops.w2d(PG["fc2.0.weight"]), PG["fc2.0.bias"], g, be, rm, rv)
+        g1, be1, rm1, rv1, _, _ = _bn(PF, None, "fc1.1.")
+        g2, be2, rm2, rv2, _, _ = _bn(PF, None, "fc2.1.")
+        w1f, b1f = ops.folded_conv_bn(ops.w2d(PF["fc1.0.weight"]), None, g1, be1, rm1, rv1)
+        w2f, b2f = ops.folded_conv_bn(ops.w2d(PF["fc2.0.weight"]), None, g2, be2, rm2, rv2)
+        out = ops.block_tail_fused_fwd(x0, tail[0], wpf, bpf, w1f, b1f, w2f, b2f, M, C, H)
+        if out is not None:
+            return out
+        x = conv_bn(tail[0], M, 2 * C, C, PG["fc2.0.weight"], PG["fc2.0.bias"], _bn(PG, None, "fc2.1."), False, in_aff=None,
+                    act_in=ACT_RELU, residual=x0)[0]
+    return ffn_forward(x, PF, None, False)
 
 
 def ffn_backward(dx2: Tensor, P, S, G) -> Tensor:

@@ -354,6 +354,39 @@ def ffn_fused_fwd(x, w1f, b1f, w2f, b2f, M, C, H):
     return out
 
 
+FUSE_BLOCK_TAIL = True        # eval mode, C = 256: the Grapher's fc2 + shortcut evaluated inside the FFN launch (csrc/ffn256_fused.hip PRE form)
+
+
+def block_tail_fused_fwd(x0, r2, wpf, bpf, w1f, b1f, w2f, b2f, M, C, H):
+    """out = x1 + w2f relu(w1f x1 + b1f) + b2f with x1 = x0 + wpf r2 + bpf (one rounding to bf16, never written) in one launch: the tail
+    of an eval-mode Grapher and the FFN behind it. None when the shape is outside the fused form."""
+    _chk(wpf, bpf, w1f, b1f, w2f, b2f)
+    if not (FUSE_BLOCK_TAIL and FUSE_EVAL_FFN) or _act(x0) != BF16 or _act(r2) != BF16 or x0.shape != (M, C) or r2.shape != (M, 2 * C):
+        return None
+    if not (x0.is_contiguous() and r2.is_contiguous()):
+        return None
+    wp, dp = _weight(wpf, BF16, 2 * C)
+    w1, d1 = _weight(w1f, BF16, C)
+    w2, d2 = _weight(w2f, BF16, H)
+    if dp != BF16 or d1 != BF16 or d2 != BF16:
+        return None
+    out = torch.empty_like(x0)
+    rc = [0]
+
+    def launch():
+        rc[0] = lib.nsid_block_tail_fused_fwd(_p(x0), _p(r2), _p(wp), _p(bpf), _p(w1), _p(b1f), _p(w2), _p(b2f), _p(out), M, C, H, _stream())
+    esz = x0.element_size()
+    _timed("ffn256_fused_kernel<pre>", 4.0 * M * C * H + 4.0 * M * C * C, esz * M * (C + 2 * C + C) + 2.0 * (2 * C * H + 2 * C * C), launch,
+           (M, C, H, 2))
+    if rc[0] == 1:
+        if PROFILE is not None:
+            PROFILE.records.pop()
+        return None
+    if rc[0] != 0:
+        raise RuntimeError(f"nsid_block_tail_fused_fwd failed: {rc[0]}")
+    return out
+
+
 FUSE_EVAL_MRCONV = True       # eval-mode max-relative aggregation + grouped conv as one launch (csrc/mrconv_fused.hip)
 
 
