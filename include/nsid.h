@@ -120,6 +120,15 @@ int nsid_ffn_fused_fwd(const void* x, const void* w1, const float* b1, const voi
    nsid_linear_fwd_res + nsid_ffn_fused_fwd. */
 int nsid_block_tail_fused_fwd(const void* x, const void* r2, const void* wp, const float* bp, const void* w1, const float* b1,
                               const void* w2, const float* b2, void* out, int M, int C, int H, void* stream);
+/* ... and the max-relative graph conv in front of that: r2 = relu(Wg (*)_4 [y, max_j(y[idx_j] - y)] + bg) (what nsid_mrconv_fused_fwd
+   writes; MRConv2d.forward + BasicConv, gcn_lib/torch_vertex.py:19-34, torch_nn.py:52-76) is evaluated by the same launch, slice by
+   slice, rounded to bf16 and never written. y: M x C bf16 (the Grapher's fc1 output, BatchNorm folded), idx: M x k clip-local ids
+   (nsid_knn_graph), N nodes per clip, Wg: 2C x C/2 bf16, bg fp32[2C]; the rest as nsid_block_tail_fused_fwd. Returns 1 (nothing
+   launched) outside C = 256, H = 1024, M % 256 == 0, 256 % N == 0: the caller then runs nsid_mrconv_fused_fwd +
+   nsid_block_tail_fused_fwd. */
+int nsid_block_gr_fused_fwd(const void* x, const void* y, const int32_t* idx, int k, int N, const void* wg, const float* bg,
+                            const void* wp, const float* bp, const void* w1, const float* b1, const void* w2, const float* b2,
+                            void* out, int M, int C, int H, void* stream);
 /* eval-mode MRConv2d in ONE launch, one workgroup per clip: v = relu(W (*)_4 [y, max_j(y[idx_j] - y)] + b) with the BatchNorm folded
    into (W, b) — MRConv2d.forward (gcn_lib/torch_vertex.py:19-34) + BasicConv (torch_nn.py:52-76) in eval mode. y: (B*N, C) bf16 plain
    values (the producer's BatchNorm folded too), idx: (B, N, k) clip-local, w: (2C, C/2) bf16, bias: (2C) fp32, out: (B*N, 2C) bf16.

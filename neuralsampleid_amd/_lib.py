@@ -140,6 +140,8 @@ def _load():
     lib.nsid_ffn_fused_fwd.restype = ctypes.c_int
     lib.nsid_block_tail_fused_fwd.argtypes = [_CT[c] for c in "pppppppppiiis"]
     lib.nsid_block_tail_fused_fwd.restype = ctypes.c_int
+    lib.nsid_block_gr_fused_fwd.argtypes = [_CT[c] for c in "pppiipppppppppiiis"]
+    lib.nsid_block_gr_fused_fwd.restype = ctypes.c_int
     lib.nsid_mrconv_fused_fwd.argtypes = [_CT[c] for c in "ppiiiippps"]
     lib.nsid_mrconv_fused_fwd.restype = ctypes.c_int
     lib.nsid_row_tiles.argtypes = [ctypes.c_int]
@@ -152,7 +154,7 @@ def _load():
 
 
 lib = _load()
-EXPORTS = list(SIGNATURES) + ["nsid_version", "nsid_debug_gemm_trace", "nsid_debug_knn_trace", "nsid_get_gemm_precision", "nsid_gemm_g256_launches", "nsid_linear_bwd_data_bnapply", "nsid_ffn_fused_fwd", "nsid_block_tail_fused_fwd", "nsid_mrconv_fused_fwd", "nsid_debug_counter", "nsid_debug_counters_reset", "nsid_debug_counter_count", "nsid_debug_counter_key", "nsid_set_tuning", "nsid_get_tuning", "nsid_reset_tuning", "nsid_tuning_count", "nsid_tuning_key", "nsid_row_tiles", "nsid_sumsq_blocks", "nsid_ntxent_ws_floats", "nsid_workspace_bytes"]
+EXPORTS = list(SIGNATURES) + ["nsid_version", "nsid_debug_gemm_trace", "nsid_debug_knn_trace", "nsid_get_gemm_precision", "nsid_gemm_g256_launches", "nsid_linear_bwd_data_bnapply", "nsid_ffn_fused_fwd", "nsid_block_tail_fused_fwd", "nsid_block_gr_fused_fwd", "nsid_mrconv_fused_fwd", "nsid_debug_counter", "nsid_debug_counters_reset", "nsid_debug_counter_count", "nsid_debug_counter_key", "nsid_set_tuning", "nsid_get_tuning", "nsid_reset_tuning", "nsid_tuning_count", "nsid_tuning_key", "nsid_row_tiles", "nsid_sumsq_blocks", "nsid_ntxent_ws_floats", "nsid_workspace_bytes"]
 
 _ERR = {-1: "NSID_EINVAL (unsupported shape, misaligned pointer or bad argument)",
         -2: "NSID_ELAUNCH (HIP runtime refused the launch)"}

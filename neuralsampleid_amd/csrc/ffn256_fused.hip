@@ -33,6 +33,8 @@ struct F256Args {
   int M;
   // PRE form (Grapher tail + FFN): the FFN's input is x1 = x + Wp r2 + bp, evaluated by the same launch
   const __bf16* r2; const __bf16* wp; const float* bp;
+  // GR form (graph conv + Grapher tail + FFN): r2 itself is evaluated by the launch from the fc1 features y and the neighbour lists
+  const __bf16* y; const int32_t* idx; const __bf16* wg; const float* bg; int k; int N;
 };
 
 typedef __attribute__((address_space(3))) void* lds_vptr;
@@ -44,7 +46,8 @@ constexpr int F_HB = 16 * 1024;               // 16 row tiles x 1 KB: every wave
 constexpr int F_B1 = F_H * 4;                 // b1 in LDS
 constexpr int F_B2 = F_C * 4;                 // b2 in LDS
 constexpr int F_BP = F_C * 4;                 // bp in LDS (PRE form)
-constexpr int F_LDS = F_NS * F_SLOT + F_HB + F_B1 + F_B2 + F_BP;
+constexpr int F_BG = 2 * F_C * 4;             // bg in LDS (GR form)
+constexpr int F_LDS = F_NS * F_SLOT + F_HB + F_B1 + F_B2 + F_BP + F_BG;
 constexpr int F_KP = 2 * F_C;                 // PRE form: width of r2 (the Grapher's 2C-channel graph-conv output)
 constexpr int F_NP = F_KP / 32;               // its k-steps = prologue iterations
 #ifndef NSID_F256_PF
@@ -87,13 +90,24 @@ __device__ __forceinline__ void f_mfma_acc(f32x4& acc, const bf16x8& a, const bf
 // into slot u % 4 -- the same 32 pieces, so the vmcnt / barrier protocol does not change -- and runs 16 x RT MFMAs per wave into the
 // output accumulators. Their channel order is that of the lane's own x fragments, so x1 replaces x in registers without leaving
 // the lane. x1 itself is never written: per block that removes a launch, a write of M x 256 and two reads (55.6 us stand-alone).
-template <int NW, bool PRE>
+//
+// MODE 2 = GR (nsid_block_gr_fused_fwd): r2 is not read but EVALUATED, slice by slice, where PRE consumes it -- the eval-mode MRConv2d
+// (gcn_lib/torch_vertex.py:19-34 + BasicConv, torch_nn.py:52-76; csrc/mrconv_fused.hip is the stand-alone form):
+//     r2[n, 128 g + j] = relu( sum_k Wg[128 g + j][k] u[n, 128 g + k] + bg ),   u[n, 2c] = y[n, c],  u[n, 2c + 1] = max_j (y[idx[n, j], c] - y[n, c])
+// Every fourth prologue iteration a lane gathers its rows' and their neighbours' 4-channel pieces of y straight from global memory (a
+// clip is 32 KB: L2 hits after the first touch), forms the max-relative in fp32 and keeps the group's eight B fragments (32 VGPRs).
+// The slot's second half then carries the 32-row slice of Wg (8 sub-blocks, rows permuted so that the two accumulator tiles of a lane
+// are 8 CONSECUTIVE r2 channels of its row): 4 x 2 x RT MFMAs give the slice, bias + ReLU + bf16 pack turn it into the B fragment of
+// the Wp MFMAs in the lane's own registers. r2 (M x 512: 134 MB written and read back per block at a 2 048-clip micro-batch) and the
+// mrconv launch are gone; x is read late (its registers hold the gathered fragments until the last slice).
+template <int NW, int MODE>
 __global__ __attribute__((amdgpu_flat_work_group_size(64 * NW, 64 * NW), amdgpu_waves_per_eu(NW / 4, NW / 4)))
 void ffn256_fused_kernel(const F256Args p) {
+  constexpr bool PRE = MODE >= 1, GR = MODE == 2;
   constexpr int NP = PRE ? F_NP : 0;          // prologue iterations; chunk index u = 0 .. NP + F_NCH - 1, slot u % 4
   constexpr int RT = 16 / NW;                 // 16-row tiles per wave
   constexpr int PW = 32 / NW;                 // LDS-DMA pieces per wave and chunk
-  constexpr int EP = 2 * 8 * RT;              // global loads + stores a wave issues in a tile's epilogue (when another tile follows)
+  constexpr int EP = (GR ? 1 : 2) * 8 * RT;   // global loads + stores a wave issues in a tile's epilogue (when another tile follows)
   __shared__ __attribute__((aligned(1024))) char lds[F_LDS];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -103,6 +117,7 @@ void ffn256_fused_kernel(const F256Args p) {
   float* const b1s = reinterpret_cast<float*>(lds + F_NS * F_SLOT + F_HB);
   float* const b2s = b1s + F_H;
   float* const bps = b2s + F_C;
+  float* const bgs = bps + F_C;
   const unsigned lds0 = (unsigned)(size_t)(lds_vptr)lds;
 
   // ---- x fragments: lane (lr, rq) of row tile b holds x[row0 + 16 b + lr][32 ks + 8 rq .. + 7]
@@ -110,7 +125,7 @@ void ffn256_fused_kernel(const F256Args p) {
   bf16x8 xf[8][RT];
   // a lane's byte offset inside a tile's x / out rows (uniform 64-bit tile base + 32-bit lane offset + immediate)
   const unsigned xo = (unsigned)((wave * (16 * RT) + lr) * F_C + 8 * rq) * 2u;
-  {
+  if constexpr (!GR) {
     const char* xt = reinterpret_cast<const char*>(p.x + (long)blockIdx.x * 256 * F_C);
 #pragma unroll
     for (int b = 0; b < RT; ++b)
@@ -120,6 +135,7 @@ void ffn256_fused_kernel(const F256Args p) {
   for (int i = tid; i < F_H / 4; i += 64 * NW) reinterpret_cast<f32x4*>(b1s)[i] = reinterpret_cast<const f32x4*>(p.b1)[i];
   if (tid < F_C / 4) reinterpret_cast<f32x4*>(b2s)[tid] = reinterpret_cast<const f32x4*>(p.b2)[tid];
   if (PRE && tid < F_C / 4) reinterpret_cast<f32x4*>(bps)[tid] = reinterpret_cast<const f32x4*>(p.bp)[tid];
+  if (GR && tid < 2 * F_C / 4) reinterpret_cast<f32x4*>(bgs)[tid] = reinterpret_cast<const f32x4*>(p.bg)[tid];
 
   // ---- LDS-DMA addressing (gemm256.hip): lane l supplies row l >> 2 of a 16-row sub-block and the logical 16-byte chunk that lives at
   // physical chunk l & 3
@@ -131,6 +147,9 @@ void ffn256_fused_kernel(const F256Args p) {
   // Wp: row stride 512 elements, rows permuted like W2's; r2: sub-block sb = rows 16 sb .. 16 sb + 15 of the tile, row stride 512
   const unsigned voffp = (unsigned)((8 * (grow >> 2) + (grow & 3)) * F_KP + lc * 8) * 2u;
   const unsigned voffr = (unsigned)(grow * F_KP + lc * 8) * 2u;
+  // Wg (GR): row stride 128 elements; sub-block (a, ks) of slice sl of group g takes its row 4 q + e from output channel
+  // 128 g + 32 sl + 8 q + 4 a + e
+  const unsigned voffg = (unsigned)((8 * (grow >> 2) + (grow & 3)) * (F_C / 2) + lc * 8) * 2u;
   auto issue = [&](int u, int tile) {                                   // this wave's PW pieces of chunk u (of row tile `tile`)
     const unsigned dst = lds0 + (u % F_NS) * F_SLOT;
     if (PRE && u < NP) {
@@ -139,8 +158,11 @@ void ffn256_fused_kernel(const F256Args p) {
         const int q = PW * wave + i;                                    // 0-15: Wp sub-block (channel tile q); 16-31: r2 sub-block q - 16
         if (q < 16)
           f_glds16(reinterpret_cast<const char*>(p.wp + (long)(32 * (q >> 1) + 4 * (q & 1)) * F_KP + 32 * u), voffp, dst + q * 1024);
-        else
+        else if (!GR)
           f_glds16(reinterpret_cast<const char*>(p.r2 + ((long)tile * 256 + 16 * (q - 16)) * F_KP + 32 * u), voffr, dst + q * 1024);
+        else if (q < 24)      // (GR: waves 6 and 7 have no piece of a prologue chunk)
+          f_glds16(reinterpret_cast<const char*>(p.wg + (long)(32 * u + 4 * ((q - 16) >> 2)) * (F_C / 2) + 32 * ((q - 16) & 3)), voffg,
+                   dst + q * 1024);
       }
       return;
     }
@@ -181,15 +203,85 @@ void ffn256_fused_kernel(const F256Args p) {
 
     if constexpr (PRE) {
       // ---- x1 = bf16((Wp r2 + bp) + x): 16 k-steps, each one slot = [Wp k-step image | r2 slice], into the output accumulators
-      for (int u = 0; u < NP; ++u) {
+      bf16x8 ug[4][RT];                       // GR: the current group's max-relative B fragments (k-step, row tile)
+      auto pre_iter = [&](const int u, auto LAST) {
+        constexpr bool last = decltype(LAST)::value;      // peeled: only there are the x registers written (GR)
         if (u < 2 && !first) f_wait_vm<(PW + EP < 63 ? PW + EP : 63)>();     // (see the chunk loop below)
         else f_wait_vm<PW>();
         __builtin_amdgcn_s_barrier();
-        issue(u + 2, tile);
         const char* sp = lds + (u % F_NS) * F_SLOT;
         bf16x8 rb[RT];
+        if constexpr (GR) {
+          if ((u & 3) == 0) {
+            // this lane's fragments of group g: interleaved channels 32 ks + 8 rq .. + 7 = y channels c0 .. c0 + 3 of its row and of the
+            // row's neighbours (clip-local ids, clamped as in mrconv_fused.hip); max-relative in fp32, strict > from -inf (the first
+            // maximum wins, NaN never enters), ONE rounding to bf16 -- where the two-launch form rounds u
+            const int g = u >> 2, k = p.k, N = p.N;
 #pragma unroll
-        for (int b = 0; b < RT; ++b) rb[b] = *reinterpret_cast<const bf16x8*>(sp + 16384 + (RT * wave + b) * 1024 + lo);
+            for (int b = 0; b < RT; ++b) {
+              const int nl = wave * (16 * RT) + 16 * b + lr;            // row inside the tile; its clip starts at row nl - nl % N
+              const long nrow = (long)tile * 256 + nl, crow = nrow - nl % N;
+#pragma unroll
+              for (int ks = 0; ks < 4; ++ks) {
+                const int c0 = 64 * g + 16 * ks + 4 * rq;
+                const bf16x4 own = *reinterpret_cast<const bf16x4*>(p.y + nrow * F_C + c0);
+                float ys[4], best[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { ys[e] = (float)own[e]; best[e] = -__builtin_inff(); }
+                for (int j = 0; j < k; ++j) {
+                  int m = p.idx[nrow * k + j];
+                  m = m < 0 ? 0 : (m >= N ? N - 1 : m);
+                  const bf16x4 v = *reinterpret_cast<const bf16x4*>(p.y + (crow + m) * F_C + c0);
+#pragma unroll
+                  for (int e = 0; e < 4; ++e) {
+                    const float d = (float)v[e] - ys[e];
+                    best[e] = d > best[e] ? d : best[e];
+                  }
+                }
+                bf16x8 fb;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { fb[2 * e] = own[e]; fb[2 * e + 1] = (__bf16)best[e]; }
+                ug[ks][b] = fb;
+              }
+            }
+          }
+          issue(u + 2, tile);                 // behind the gathers: the waits for their data do not cover these pieces
+          // the slice: D[8 q + 4 a + e][row] per accumulator tile a
+          f32x4 gacc[2][RT];
+#pragma unroll
+          for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < RT; ++b) gacc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+              const bf16x8 fg = *reinterpret_cast<const bf16x8*>(sp + 16384 + (4 * a + ks) * 1024 + lo);
+#pragma unroll
+              for (int b = 0; b < RT; ++b) gacc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fg, ug[ks][b], gacc[a][b], 0, 0, 0);
+            }
+          const f32x4 bb0 = *reinterpret_cast<const f32x4*>(bgs + 32 * u + 8 * rq);
+          const f32x4 bb1 = *reinterpret_cast<const f32x4*>(bgs + 32 * u + 8 * rq + 4);
+#pragma unroll
+          for (int b = 0; b < RT; ++b) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              rb[b][e] = (__bf16)fmaxf(gacc[0][b][e] + bb0[e], 0.f);
+              rb[b][4 + e] = (__bf16)fmaxf(gacc[1][b][e] + bb1[e], 0.f);
+            }
+          }
+          if constexpr (last) {               // the gathered fragments are dead: x arrives behind the last Wp MFMAs
+            const char* xt = reinterpret_cast<const char*>(p.x + (long)tile * 256 * F_C);
+#pragma unroll
+            for (int b = 0; b < RT; ++b)
+#pragma unroll
+              for (int ks = 0; ks < 8; ++ks) xf[ks][b] = *reinterpret_cast<const bf16x8*>(xt + xo + b * (16 * F_C * 2) + ks * 64);
+          }
+        } else {
+          issue(u + 2, tile);
+#pragma unroll
+          for (int b = 0; b < RT; ++b) rb[b] = *reinterpret_cast<const bf16x8*>(sp + 16384 + (RT * wave + b) * 1024 + lo);
+        }
         bf16x8 fa = *reinterpret_cast<const bf16x8*>(sp + lo);
 #pragma unroll
         for (int c = 0; c < 16; ++c) {
@@ -201,7 +293,9 @@ void ffn256_fused_kernel(const F256Args p) {
             else acc2[c][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f, rb[b], acc2[c][b], 0, 0, 0);
           }
         }
-      }
+      };
+      for (int u = 0; u < NP - 1; ++u) pre_iter(u, std::false_type{});
+      pre_iter(NP - 1, std::true_type{});
 #pragma unroll
       for (int ks = 0; ks < 8; ++ks) {
         const f32x4 bc0 = *reinterpret_cast<const f32x4*>(bps + 32 * ks + 8 * rq);
@@ -332,7 +426,7 @@ void ffn256_fused_kernel(const F256Args p) {
           o[4 + e] = (__bf16)(y1[e] + (float)xr[4 + e]);
         }
         *reinterpret_cast<bf16x8*>(ot + xo + b * (16 * F_C * 2) + ks * 64) = o;
-        if (more) xf[ks][b] = *reinterpret_cast<const bf16x8*>(xn + xo + b * (16 * F_C * 2) + ks * 64);
+        if (!GR && more) xf[ks][b] = *reinterpret_cast<const bf16x8*>(xn + xo + b * (16 * F_C * 2) + ks * 64);
       }
     }
   }  // tile
@@ -341,13 +435,18 @@ void ffn256_fused_kernel(const F256Args p) {
 }  // namespace
 
 // returns NSID_OK / NSID_ELAUNCH, or 1 (nothing launched) outside C = 256, H = 1024, M % 256 == 0.
-// r2 != nullptr: the PRE form (x1 = x + wp r2 + bp in front of the FFN; r2: M x 512 bf16, wp: 256 x 512 bf16, bp: fp32[256])
+// r2 != nullptr: the PRE form (x1 = x + wp r2 + bp in front of the FFN; r2: M x 512 bf16, wp: 256 x 512 bf16, bp: fp32[256]);
+// y != nullptr: the GR form (r2 evaluated from y (M x 256 bf16), idx (M x k, clip-local), wg (512 x 128 bf16), bg (fp32[512]); N nodes
+// per clip, 256 % N == 0)
 __attribute__((visibility("hidden")))
 int nsid_ffn256_fused_launch(const void* x, const void* w1, const float* b1, const void* w2, const float* b2, void* out, int M, int C,
-                             int H, hipStream_t stream, const void* r2, const void* wp, const float* bp) {
+                             int H, hipStream_t stream, const void* r2, const void* wp, const float* bp, const void* y,
+                             const int32_t* idx, int k, int N, const void* wg, const float* bg) {
   if (C != F_C || H != F_H || M % 256 != 0 || M <= 0) return 1;
+  if (y != nullptr && (N <= 0 || 256 % N != 0 || k <= 0)) return 1;
   F256Args p{static_cast<const __bf16*>(x), static_cast<const __bf16*>(w1), b1, static_cast<const __bf16*>(w2), b2,
-             static_cast<__bf16*>(out), M, static_cast<const __bf16*>(r2), static_cast<const __bf16*>(wp), bp};
+             static_cast<__bf16*>(out), M, static_cast<const __bf16*>(r2), static_cast<const __bf16*>(wp), bp,
+             static_cast<const __bf16*>(y), idx, static_cast<const __bf16*>(wg), bg, k, N};
   static int n_cu = 0;
   if (n_cu == 0) {
     int dev = 0, n = 0;               // an attribute query: legal whatever the stream is doing (capture)
@@ -360,12 +459,15 @@ int nsid_ffn256_fused_launch(const void* x, const void* w1, const float* b1, con
   // 64 rows with the output accumulators in AGPRs (measured 154 us against 146 us: docs/experiments.md)
   const int wgs = (nsid_tune(NSID_T_ffn256) == 2 || ntiles < n_cu) ? ntiles : n_cu;
   const bool w4 = nsid_tune(NSID_T_ffn256) == 4;
-  if (r2 != nullptr) {
-    if (w4) NSID_LAUNCH((ffn256_fused_kernel<4, true>), dim3(wgs), dim3(256), 0, stream, p);
-    else NSID_LAUNCH((ffn256_fused_kernel<8, true>), dim3(wgs), dim3(512), 0, stream, p);
+  if (y != nullptr) {
+    if (w4) NSID_LAUNCH((ffn256_fused_kernel<4, 2>), dim3(wgs), dim3(256), 0, stream, p);
+    else NSID_LAUNCH((ffn256_fused_kernel<8, 2>), dim3(wgs), dim3(512), 0, stream, p);
+  } else if (r2 != nullptr) {
+    if (w4) NSID_LAUNCH((ffn256_fused_kernel<4, 1>), dim3(wgs), dim3(256), 0, stream, p);
+    else NSID_LAUNCH((ffn256_fused_kernel<8, 1>), dim3(wgs), dim3(512), 0, stream, p);
   } else {
-    if (w4) NSID_LAUNCH((ffn256_fused_kernel<4, false>), dim3(wgs), dim3(256), 0, stream, p);
-    else NSID_LAUNCH((ffn256_fused_kernel<8, false>), dim3(wgs), dim3(512), 0, stream, p);
+    if (w4) NSID_LAUNCH((ffn256_fused_kernel<4, 0>), dim3(wgs), dim3(256), 0, stream, p);
+    else NSID_LAUNCH((ffn256_fused_kernel<8, 0>), dim3(wgs), dim3(512), 0, stream, p);
   }
   return nsid_launch_status();
 }

@@ -288,6 +288,7 @@ static inline long nsid_tune(NsidTuneKey k) { return g_nsid_tune[k]; }
   X(mr_fwd_lds) X(mr_fwd_grid)                                                                  \
   X(ffn_fused)            /* eval-mode FFN in one launch (ffn_fused.hip) */                     \
   X(block_tail_fused)     /* ... with the Grapher's fc2 + shortcut in front of it (ffn256_fused.hip PRE form) */ \
+  X(block_gr_fused)       /* ... and the max-relative graph conv in front of that (GR form) */          \
   X(mrconv_fused)         /* eval-mode max-relative aggregation + grouped conv in one launch (mrconv_fused.hip) */ \
   X(bn_stat_acc)          /* producers that ADD BatchNorm column sums in fixed point (no partial-sum buffer) */ \
   X(bn_lazy_finalize)     /* consumers that evaluate a BatchNorm from those sums in their own prologue (no finalize launch) */ \
@@ -313,5 +314,7 @@ int nsid_gemm256_fwd_launch(const void* x, int ldx, const void* w, const float* 
                             hipStream_t stream);
 // ffn256_fused.hip: eval-mode FFN of the C = 256 stage in one launch; returns 1 outside C = 256, H = 1024, M % 256 == 0
 int nsid_ffn256_fused_launch(const void* x, const void* w1, const float* b1, const void* w2, const float* b2, void* out, int M, int C,
-                             int H, hipStream_t stream, const void* r2 = nullptr, const void* wp = nullptr, const float* bp = nullptr);
+                             int H, hipStream_t stream, const void* r2 = nullptr, const void* wp = nullptr, const float* bp = nullptr,
+                             const void* y = nullptr, const int32_t* idx = nullptr, int k = 0, int N = 0, const void* wg = nullptr,
+                             const float* bg = nullptr);
 extern void* g_gemm_trace_host;        // gemm.hip: the buffer installed by nsid_debug_gemm_trace (nullptr = none)

@@ -274,6 +274,9 @@ def grapher_forward(x0: Tensor, P, S: Optional[dict], B: int, N: int, k: int, di
         # forward-only, BatchNorms folded: aggregation + grouped conv in one launch per clip, the interleaved tensor u never formed
         gg, gb, grm, grv, _, _ = _bn(P, S, pre + "1.")
         wgf, bgf = ops.folded_conv_bn(ops.w2d(P[pre + "0.weight"]), P[pre + "0.bias"], gg, gb, grm, grv)
+        if defer_tail is not None and ops.FUSE_BLOCK_GR and C == 256 and 256 % N == 0 and idx.dtype == torch.int32:
+            defer_tail.append(("gr", r1, idx, wgf, bgf))       # evaluated inside the FFN launch too (block_eval_fused)
+            return x0
         r2, a2 = ops.mrconv_fused_fwd(r1, idx, B, N, C, wgf, bgf), None
     if r2 is None:
         u, amax = ops.mr_aggregate_fwd(r1, idx, B, N, C, a1, want_argmax=S is not None)
@@ -281,7 +284,7 @@ def grapher_forward(x0: Tensor, P, S: Optional[dict], B: int, N: int, k: int, di
                          groups=4, folded_act=ACT_RELU)
     if fold_eval(training, S):   # conv + BatchNorm + shortcut in one launch; r2 already is relu(BN(conv)) (a2 is None)
         if defer_tail is not None and a2 is None:
-            defer_tail.append(r2)
+            defer_tail.append(("pre", r2))
             return x0
         return conv_bn(r2, M, 2 * C, C, P["fc2.0.weight"], P["fc2.0.bias"], _bn(P, S, "fc2.1."), training,
                        in_aff=a2, act_in=ACT_RELU, residual=x0)[0]
@@ -372,10 +375,21 @@ def block_eval_fused(x0: Tensor, PG, PF, B: int, N: int, k: int, dilation: int) 
         g2, be2, rm2, rv2, _, _ = _bn(PF, None, "fc2.1.")
         w1f, b1f = ops.folded_conv_bn(ops.w2d(PF["fc1.0.weight"]), None, g1, be1, rm1, rv1)
         w2f, b2f = ops.folded_conv_bn(ops.w2d(PF["fc2.0.weight"]), None, g2, be2, rm2, rv2)
-        out = ops.block_tail_fused_fwd(x0, tail[0], wpf, bpf, w1f, b1f, w2f, b2f, M, C, H)
+        r2 = None
+        if tail[0][0] == "gr":
+            _, r1, idx, wgf, bgf = tail[0]
+            out = ops.block_gr_fused_fwd(x0, r1, idx, B, N, wgf, bgf, wpf, bpf, w1f, b1f, w2f, b2f, M, C, H)
+            if out is not None:
+                return out
+            r2 = ops.mrconv_fused_fwd(r1, idx, B, N, C, wgf, bgf)
+            if r2 is None:
+                raise RuntimeError("block_eval_fused: the graph conv of a C = 256 block fell outside nsid_mrconv_fused_fwd")
+        else:
+            r2 = tail[0][1]
+        out = ops.block_tail_fused_fwd(x0, r2, wpf, bpf, w1f, b1f, w2f, b2f, M, C, H)
         if out is not None:
             return out
-        x = conv_bn(tail[0], M, 2 * C, C, PG["fc2.0.weight"], PG["fc2.0.bias"], _bn(PG, None, "fc2.1."), False, in_aff=None,
+        x = conv_bn(r2, M, 2 * C, C, PG["fc2.0.weight"], PG["fc2.0.bias"], _bn(PG, None, "fc2.1."), False, in_aff=None,
                     act_in=ACT_RELU, residual=x0)[0]
     return ffn_forward(x, PF, None, False)
 

@@ -354,14 +354,17 @@ def ffn_fused_fwd(x, w1f, b1f, w2f, b2f, M, C, H):
     return out
 
 
-FUSE_BLOCK_TAIL = True        # eval mode, C = 256: the Grapher's fc2 + shortcut evaluated inside the FFN launch (csrc/ffn256_fused.hip PRE form)
+# eval mode, C = 256: the Grapher's fc2 + shortcut evaluated inside the FFN launch (csrc/ffn256_fused.hip PRE form). Opt-in: one launch
+# and 0.5 GB of traffic less per micro-batch, but 199 us against 54 + 132 us stand-alone (the 16 extra ring iterations carry half the MFMAs
+# of an FFN chunk behind the same barrier and LDS-DMA issue), and 451 k against 454 k clips/s in the two-stream extraction
+FUSE_BLOCK_TAIL = False       # (the planner's switch, functional.block_eval_fused; the op itself is always available)
 
 
 def block_tail_fused_fwd(x0, r2, wpf, bpf, w1f, b1f, w2f, b2f, M, C, H):
     """out = x1 + w2f relu(w1f x1 + b1f) + b2f with x1 = x0 + wpf r2 + bpf (one rounding to bf16, never written) in one launch: the tail
     of an eval-mode Grapher and the FFN behind it. None when the shape is outside the fused form."""
     _chk(wpf, bpf, w1f, b1f, w2f, b2f)
-    if not (FUSE_BLOCK_TAIL and FUSE_EVAL_FFN) or _act(x0) != BF16 or _act(r2) != BF16 or x0.shape != (M, C) or r2.shape != (M, 2 * C):
+    if not FUSE_EVAL_FFN or _act(x0) != BF16 or _act(r2) != BF16 or x0.shape != (M, C) or r2.shape != (M, 2 * C):
         return None
     if not (x0.is_contiguous() and r2.is_contiguous()):
         return None
@@ -384,6 +387,46 @@ def block_tail_fused_fwd(x0, r2, wpf, bpf, w1f, b1f, w2f, b2f, M, C, H):
         return None
     if rc[0] != 0:
         raise RuntimeError(f"nsid_block_tail_fused_fwd failed: {rc[0]}")
+    return out
+
+
+# ... and the max-relative graph conv in front of that (GR form): no mrconv launch, r2 never written (needs FUSE_BLOCK_TAIL). Opt-in:
+# 290 us against 80 + 199 us stand-alone, 433 k clips/s (docs/experiments.md, round 4 part 2)
+FUSE_BLOCK_GR = False
+
+
+def block_gr_fused_fwd(x0, y, idx, B, N, wgf, bgf, wpf, bpf, w1f, b1f, w2f, b2f, M, C, H):
+    """graph conv + Grapher tail + FFN of one eval-mode block in one launch (csrc/ffn256_fused.hip GR form): r2 = relu(wgf (*)_4 [y,
+    max-relative(y)] + bgf) evaluated slice by slice where block_tail_fused_fwd reads it. None outside the fused form."""
+    _chk(wgf, bgf, wpf, bpf, w1f, b1f, w2f, b2f)
+    if not (FUSE_EVAL_FFN and FUSE_EVAL_MRCONV) or _act(x0) != BF16 or _act(y) != BF16:
+        return None
+    if x0.shape != (M, C) or y.shape != (M, C) or M != B * N or 256 % N != 0 or idx.dtype != torch.int32 or not idx.is_contiguous():
+        return None
+    if not (x0.is_contiguous() and y.is_contiguous()):
+        return None
+    wg, dg = _weight(wgf, BF16, C // 2)
+    wp, dp = _weight(wpf, BF16, 2 * C)
+    w1, d1 = _weight(w1f, BF16, C)
+    w2, d2 = _weight(w2f, BF16, H)
+    if dg != BF16 or dp != BF16 or d1 != BF16 or d2 != BF16:
+        return None
+    k = idx.shape[-1]
+    out = torch.empty_like(x0)
+    rc = [0]
+
+    def launch():
+        rc[0] = lib.nsid_block_gr_fused_fwd(_p(x0), _p(y), _p(idx), k, N, _p(wg), _p(bgf), _p(wp), _p(bpf), _p(w1), _p(b1f), _p(w2),
+                                            _p(b2f), _p(out), M, C, H, _stream())
+    esz = x0.element_size()
+    _timed("ffn256_fused_kernel<gr>", 4.0 * M * C * H + 4.0 * M * C * C + 2.0 * M * C * C, esz * M * 3 * C + 4.0 * M * k +
+           2.0 * (2 * C * H + 2 * C * C + C * C), launch, (M, C, H, 3))
+    if rc[0] == 1:
+        if PROFILE is not None:
+            PROFILE.records.pop()
+        return None
+    if rc[0] != 0:
+        raise RuntimeError(f"nsid_block_gr_fused_fwd failed: {rc[0]}")
     return out
 
 

@@ -26,4 +26,14 @@ def timeit(fn, n=30):
 t1 = timeit(lambda: ops.linear_fwd(x0, wfc1, bfc1, M, C, C))
 t2 = timeit(lambda: ops.linear_fwd(r2, wfc2, bfc2, M, C, 2 * C, addend=x0))
 t3 = timeit(lambda: ops.ffn_fused_fwd(x0, w1, b1, w2, b2, M, C, 4 * C))
+N, k = 64, 3
+B = M // N
+y = rnd(M, C).to(torch.bfloat16).cuda()
+idx = torch.randint(0, N, (B, N, k), generator=g).to(torch.int32).cuda()
+wg, bg = rnd(2 * C, C // 2, scale=(C // 2) ** -0.5).cuda(), rnd(2 * C).cuda()
+ops.SHADOWS.register(wg, ops.f32_to_bf16(wg), owner=wg)
+t4 = timeit(lambda: ops.mrconv_fused_fwd(y, idx, B, N, C, wg, bg))
+t5 = timeit(lambda: ops.block_tail_fused_fwd(x0, r2, wfc2, bfc2, w1, b1, w2, b2, M, C, 4 * C))
+t6 = timeit(lambda: ops.block_gr_fused_fwd(x0, y, idx, B, N, wg, bg, wfc2, bfc2, w1, b1, w2, b2, M, C, 4 * C))
+print(f"mrconv {t4:.1f} us | tail+FFN (PRE) {t5:.1f} us | graph conv+tail+FFN (GR) {t6:.1f} us")
 print(f"fc1 256->256 {t1:.1f} us | fc2 512->256 + shortcut {t2:.1f} us | fused FFN {t3:.1f} us")
