@@ -137,6 +137,125 @@ __global__ __launch_bounds__(MRF_THREADS) void mr_fwd_lds_kernel(const T* __rest
   }
 }
 
+// The same aggregation for MANY neighbours (the deep configuration: k = 18), bf16 storage. mr_fwd_lds_kernel spends six VALU operations
+// per neighbour and element (convert, affine, subtract, compare, two selects): 13 us of an 18.8 us launch at k = 18. Here the search is
+// done on INTEGERS:
+//   * The clip is staged as order-preserving 16-bit keys (sign-magnitude -> unsigned; NaN -> 0, below everything), flipped per channel
+//     where the BatchNorm scale is negative. d_j = (sc v_j + sh) - y is a monotone non-decreasing function of the key (every rounding
+//     involved is monotone), so the neighbour with the largest key has the largest d.
+//   * Key and position travel together: (key << 16) | (255 - j). ONE v_lshl_or / v_and_or and ONE v_max_u32 per neighbour and element;
+//     among equal keys the smallest j wins (torch.max: the first maximum).
+//   * d is evaluated ONCE per element from the winning key, with the expressions of mr_fwd_lds_kernel -- the same value bit for bit.
+//   * What integers cannot see: two DIFFERENT keys whose d rounds to the same fp32 (tiny values beside a large shift; a zero scale;
+//     +-inf) -- torch.max then takes the first of them. Those sit directly below the winner, so one extra evaluation of d at key - 1 says
+//     whether that can have happened; if any lane of the wave says so, the wave redoes its chunk with the scalar search (rare: the data
+//     must put a neighbour within 2^-16 of the maximum relative to the shift).
+//   * d that is not above -inf (NaN, -inf): best = -inf, arg-max 0, as the strict '>' from -inf leaves them.
+__device__ __forceinline__ uint32_t mrk_sortable2(uint32_t x) {           // two bf16 -> two keys
+  const uint32_t neg = ((x >> 15) & 0x00010001u) * 0xFFFFu;
+  uint32_t key = x ^ (neg | 0x80008000u);
+  const uint32_t nan = ((((x & 0x7FFF7FFFu) + 0x007F007Fu) >> 15) & 0x00010001u) * 0xFFFFu;
+  return key & ~nan;
+}
+__device__ __forceinline__ float mrk_value(uint32_t key16) {                // key -> the bf16 value as fp32 (key 0 -> NaN)
+  const uint32_t raw = (key16 & 0x8000u) ? (key16 ^ 0x8000u) : (~key16 & 0xFFFFu);
+  return __builtin_bit_cast(float, raw << 16);
+}
+
+__global__ __launch_bounds__(MRF_THREADS) void mr_fwd_key_kernel(const __bf16* __restrict__ r, long ldr,
+                                                                 const float* __restrict__ scale, const float* __restrict__ shift,
+                                                                 const int32_t* __restrict__ idx, int N, int C, int k,
+                                                                 __bf16* __restrict__ u, uint8_t* __restrict__ argmax, int split) {
+  extern __shared__ __attribute__((aligned(16))) char mrf_smem[];
+  constexpr int NV = 8;
+  uint16_t* keys = reinterpret_cast<uint16_t*>(mrf_smem);           // [N][Cp]
+  const int b = blockIdx.x / split, part = blockIdx.x % split, t = threadIdx.x;
+  const long row0 = (long)b * N;
+  const int CV = C / NV, CVp = CV / split, Cp = CVp * NV, c_lo = part * Cp, total = N * CVp;
+  int* nbl = reinterpret_cast<int*>(mrf_smem + (size_t)N * Cp * 2);
+  for (int q = t; q < N * k; q += MRF_THREADS) nbl[q] = min(max(idx[row0 * k + q], 0), N - 1);
+  for (int q = t; q < total; q += MRF_THREADS) {
+    const int n = q / CVp, cl = (q % CVp) * NV;
+    const u32x4 x = *reinterpret_cast<const u32x4*>(r + (row0 + n) * ldr + c_lo + cl);
+    float sc[NV];
+#pragma unroll
+    for (int e = 0; e < NV; ++e) sc[e] = 1.f;
+    if (scale != nullptr) load_channels<NV>(scale, c_lo + cl, sc);
+    u32x4 y;
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+      y[p] = mrk_sortable2(x[p]) ^ ((sc[2 * p] < 0.f ? 0x0000FFFFu : 0u) | (sc[2 * p + 1] < 0.f ? 0xFFFF0000u : 0u));
+    *reinterpret_cast<u32x4*>(keys + (long)n * Cp + cl) = y;
+  }
+  __syncthreads();
+  for (int q = t; q < total; q += MRF_THREADS) {
+    const int n = q / CVp, cl = (q % CVp) * NV, c = c_lo + cl;
+    float sc[NV], sh[NV], y[NV];
+#pragma unroll
+    for (int e = 0; e < NV; ++e) { sc[e] = 1.f; sh[e] = 0.f; }
+    if (scale != nullptr) {
+      load_channels<NV>(scale, c, sc);
+      load_channels<NV>(shift, c, sh);
+    }
+    Chunk<__bf16>::load(r + (row0 + n) * ldr + c, y);             // the node's own values: raw, from memory (a NaN stays a NaN)
+#pragma unroll
+    for (int e = 0; e < NV; ++e) y[e] = sc[e] * y[e] + sh[e];
+    const int* nb = nbl + n * k;
+    uint32_t win[NV];
+#pragma unroll
+    for (int e = 0; e < NV; ++e) win[e] = 0u;
+    for (int j = 0; j < k; ++j) {
+      const u32x4 w = *reinterpret_cast<const u32x4*>(keys + (long)nb[j] * Cp + cl);
+      const uint32_t cj = 255u - (uint32_t)j;
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        win[2 * p] = max(win[2 * p], (w[p] << 16) | cj);
+        win[2 * p + 1] = max(win[2 * p + 1], (w[p] & 0xFFFF0000u) | (cj & 0x0000FFFFu));      // one v_bfi_b32
+      }
+    }
+    float best[NV];
+    int arg[NV];
+    bool redo = false;
+#pragma unroll
+    for (int e = 0; e < NV; ++e) {
+      const uint32_t flip = sc[e] < 0.f ? 0xFFFFu : 0u;
+      const uint32_t key = win[e] >> 16;
+      const float d = (sc[e] * mrk_value(key ^ flip) + sh[e]) - y[e];
+      const float dn = (sc[e] * mrk_value((key - 1u) ^ flip) + sh[e]) - y[e];       // (key 0: NaN either way)
+      redo |= dn == d;
+      const bool up = d > -__builtin_inff();
+      best[e] = up ? d : -__builtin_inff();
+      arg[e] = up ? 255 - (int)(win[e] & 255u) : 0;
+    }
+    if (__builtin_amdgcn_ballot_w64(redo) != 0) {             // the scalar search of mr_fwd_lds_kernel, on the decoded keys
+#pragma unroll
+      for (int e = 0; e < NV; ++e) { best[e] = -__builtin_inff(); arg[e] = 0; }
+      for (int j = 0; j < k; ++j) {
+        const u32x4 w = *reinterpret_cast<const u32x4*>(keys + (long)nb[j] * Cp + cl);
+#pragma unroll
+        for (int e = 0; e < NV; ++e) {
+          const uint32_t flip = sc[e] < 0.f ? 0xFFFFu : 0u;
+          const uint32_t key = (e & 1) ? (w[e / 2] >> 16) : (w[e / 2] & 0xFFFFu);
+          const float d = (sc[e] * mrk_value(key ^ flip) + sh[e]) - y[e];
+          if (d > best[e]) { best[e] = d; arg[e] = j; }
+        }
+      }
+    }
+    float o[2 * NV];
+#pragma unroll
+    for (int e = 0; e < NV; ++e) { o[2 * e] = y[e]; o[2 * e + 1] = best[e]; }
+    __bf16* dst = u + (row0 + n) * (2L * C) + 2 * c;
+    Chunk<__bf16>::store(dst, o);
+    Chunk<__bf16>::store(dst + NV, o + NV);
+    if (argmax != nullptr) {
+#pragma unroll
+      for (int e = 0; e < NV; e += 4)
+        *reinterpret_cast<uchar4*>(argmax + (row0 + n) * C + c + e) =
+            make_uchar4((unsigned char)arg[e], (unsigned char)arg[e + 1], (unsigned char)arg[e + 2], (unsigned char)arg[e + 3]);
+    }
+  }
+}
+
 // backward as a GATHER over the reversed graph (LDS float atomics cost ~3 cycles per lane: the scatter form spent 2/3 of
 // its time in 16 K ds_add_f32 per clip). Per clip:
 //   A. stage the odd half of du (the max-relative gradient, in its storage type) and the arg-max bytes in LDS;
@@ -145,6 +264,9 @@ __global__ __launch_bounds__(MRF_THREADS) void mr_fwd_lds_kernel(const T* __rest
 //      point at n of du_odd[m, c] where argmax[m, c] == j.
 // The order of a node's incoming edges depends on the fill race, so the fp32 sum order is not fixed (neither was the
 // atomic scatter's); a node's incoming values are few (k on average).
+// (Round 4 re-tried the scatter with ONE element per lane -- 64 consecutive channels per ds_add_f32, two lanes per bank, no conflicts,
+// work independent of k: 31 us per launch at k = 3 and at k = 18 alike, against 10-12 / 22-29 us for this gather. The LDS float-add
+// unit retires about one lane per 2.7 cycles whatever the banks: 16 384 adds per clip are 20 us. docs/experiments.md.)
 constexpr int MRB_THREADS = 1024;
 
 template <typename T>
@@ -320,7 +442,9 @@ extern "C" int nsid_mr_aggregate_fwd(const void* r, int ldr, const float* scale,
   if (use_lds && clip_bytes <= 64 * 1024 && (size_t)N * k * 4 <= 64 * 1024) {
     static bool configured = false;
     if (!configured) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(mr_fwd_lds_kernel<float>),
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(mr_fwd_key_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess ||
+          hipFuncSetAttribute(reinterpret_cast<const void*>(mr_fwd_lds_kernel<float>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess ||
           hipFuncSetAttribute(reinterpret_cast<const void*>(mr_fwd_lds_kernel<__bf16>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess)
@@ -331,6 +455,14 @@ extern "C" int nsid_mr_aggregate_fwd(const void* r, int ldr, const float* scale,
     nsid_count(NSID_C_mr_fwd_lds);
     int split = force_split > 0 ? force_split : (B <= 256 ? 2 : 1);
     while (split > 1 && (C / nv) % split != 0) split >>= 1;
+    // many neighbours, bf16 storage: the integer-key search (tuning key mr_key_min_k: smallest k that takes it, 0 = never)
+    const long key_min = nsid_tune(NSID_T_mr_key_min_k);
+    if (dtype == NSID_BF16 && key_min > 0 && k >= key_min) {
+      nsid_count(NSID_C_mr_fwd_key);
+      NSID_LAUNCH(mr_fwd_key_kernel, dim3(B * split), dim3(MRF_THREADS), clip_bytes / split + (size_t)N * k * 4, static_cast<hipStream_t>(stream),
+                  static_cast<const __bf16*>(r), (long)ldr, scale, shift, idx, N, C, k, static_cast<__bf16*>(u), argmax, split);
+      return nsid_launch_status();
+    }
     NSID_DISPATCH_DTYPE(dtype, T, {
       NSID_LAUNCH((mr_fwd_lds_kernel<T>), dim3(B * split), dim3(MRF_THREADS), clip_bytes / split + (size_t)N * k * 4, static_cast<hipStream_t>(stream),
                   static_cast<const T*>(r), (long)ldr, scale, shift, idx, N, C, k, static_cast<T*>(u), argmax, split);

@@ -16,6 +16,7 @@
 #endif
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
@@ -255,6 +256,7 @@ static inline bool nsid_acc_ok(const int64_t* acc, int replicas) {
   X(knn_sel_min_n, 128)        /* graphs of at least this many nodes take the in-register threshold select for k*d > 8 */       \
   X(mr_grid_stride, 0)         /* 1: grid-stride aggregation instead of the LDS-staged per-clip kernel */                     \
   X(mr_split, 0)               /* channel split of the LDS-staged aggregation (0 = heuristic) */                              \
+  X(mr_key_min_k, 8)           /* bf16 aggregation with >= this many neighbours: integer-key search (mr_fwd_key_kernel); 0 = never */ \
   X(ffn_waves, 8)              /* waves per workgroup of the fused eval-mode FFN (4 or 8) */                                  \
   X(ffn256, 1)                 /* 1: the C = 256 stage's eval-mode FFN as one launch (ffn256_fused.hip); 0: two GEMM launches */ \
   X(mrconv_variant, 3)         /* fused eval-mode aggregation + grouped conv: bit 0 = 8 waves, bit 1 = direct 8-byte stores */
@@ -285,7 +287,7 @@ static inline long nsid_tune(NsidTuneKey k) { return g_nsid_tune[k]; }
   X(wgrad_rect) X(wgrad_square) X(wgrad3)                                                       \
   X(bn_bwd_apply) X(bn_bwd_apply_capped)                                                        \
   X(knn2) X(knn2_pair) X(knn_rank) X(knn_sel) X(knn_strips)                                                  \
-  X(mr_fwd_lds) X(mr_fwd_grid)                                                                  \
+  X(mr_fwd_lds) X(mr_fwd_grid) X(mr_fwd_key)                                                                  \
   X(ffn_fused)            /* eval-mode FFN in one launch (ffn_fused.hip) */                     \
   X(block_tail_fused)     /* ... with the Grapher's fc2 + shortcut in front of it (ffn256_fused.hip PRE form) */ \
   X(block_gr_fused)       /* ... and the max-relative graph conv in front of that (GR form) */          \

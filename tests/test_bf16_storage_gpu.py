@@ -460,6 +460,70 @@ def test_graph_conv_and_block_tail_in_the_ffn_launch(ops, M, k):
     assert torch.equal(out, out4)
 
 
+@pytest.mark.parametrize("N,C,k,case", [(256, 64, 18, "random"), (128, 128, 18, "random"), (64, 256, 18, "ties"), (32, 512, 18, "ties"),
+                                         (256, 64, 18, "collapse"), (128, 128, 9, "special"), (64, 256, 18, "noaffine")])
+def test_integer_key_max_relative_equals_the_scalar_search(ops, N, C, k, case):
+    """csrc/mr.hip mr_fwd_key_kernel (bf16 storage, k >= tuning key mr_key_min_k: the deep configuration's k = 18): the neighbour search
+    on order-preserving integer keys with the position in the low bits must give mr_fwd_lds_kernel's output and arg-max BYTE FOR BYTE --
+    torch.max's first maximum of d = (sc v + sh) - y (gcn_lib/torch_vertex.py:21-32) -- on random data with negative BatchNorm
+    scales, on a tie-heavy input (values from a set of five), where different values collapse to the same d (tiny values beside a
+    large shift, a zero scale: the wave falls back to the scalar search), and with NaN / +-inf / -0 entries"""
+    from neuralsampleid_amd._lib import launch_counters
+    B = 64
+    g = torch.Generator().manual_seed(N * 7 + k)
+    r = torch.randn(B * N, C, generator=g)
+    sc = 1 + 0.8 * torch.randn(C, generator=g)            # a fifth of the channels negative
+    sh = 0.5 * torch.randn(C, generator=g)
+    if case == "ties":
+        r = torch.tensor([-1.5, -0.25, 0.0, 0.25, 2.0])[torch.randint(0, 5, (B * N, C), generator=g)]
+    elif case == "collapse":
+        r = r * 1e-6                                       # 2^-8 steps of 1e-6 vanish beside shifts of 0.5: many neighbours share the maximal d
+        sc[::7] = 0.0                                      # a zero scale: every neighbour ties
+    elif case == "special":
+        pick = torch.rand(B * N, C, generator=g)
+        r = torch.where(pick < 0.02, torch.tensor(float("nan")), r)
+        r = torch.where((pick >= 0.02) & (pick < 0.04), torch.tensor(float("inf")), r)
+        r = torch.where((pick >= 0.04) & (pick < 0.06), torch.tensor(float("-inf")), r)
+        r = torch.where((pick >= 0.06) & (pick < 0.10), torch.tensor(-0.0), r)
+    r = r.to(BF).to(DEV)
+    idx = torch.randint(0, N, (B, N, k), generator=g).to(torch.int32).to(DEV)
+    aff = None if case == "noaffine" else ops.BNAffine(sc.to(DEV), sh.to(DEV))
+    launch_counters(reset=True)
+    u_key, a_key = ops.mr_aggregate_fwd(r, idx, B, N, C, aff)
+    assert launch_counters()["mr_fwd_key"] == 1
+    try:
+        ops.set_tuning("mr_key_min_k", 0)
+        launch_counters(reset=True)
+        u_ref, a_ref = ops.mr_aggregate_fwd(r, idx, B, N, C, aff)
+        assert launch_counters()["mr_fwd_key"] == 0 and launch_counters()["mr_fwd_lds"] == 1
+    finally:
+        ops.reset_tuning()
+    assert torch.equal(a_key, a_ref), float((a_key != a_ref).float().mean())
+    assert torch.equal(u_key.view(torch.int16), u_ref.view(torch.int16))          # bit patterns: NaN == NaN, -0 != +0
+
+
+@pytest.mark.parametrize("N,C,k,dt", [(256, 64, 18, "bf16"), (128, 128, 18, "bf16"), (64, 256, 3, "bf16"), (32, 512, 5, "bf16"),
+                                       (128, 128, 18, "fp32"), (256, 64, 3, "fp32")])
+def test_max_relative_backward_with_hub_nodes(ops, N, C, k, dt):
+    """csrc/mr.hip mr_bwd_kernel (CSR gather over the reversed graph) against a dense fp64 evaluation of torch_vertex.py:21-32's backward
+    on graphs with hub nodes (a third of the ids point at node 0: in-degrees of hundreds) and repeated ids inside a list, arg-max
+    bytes from the forward kernel"""
+    B = 32
+    tdt = BF if dt == "bf16" else torch.float32
+    g = torch.Generator().manual_seed(N + C + k)
+    r = torch.randn(B * N, C, generator=g).to(tdt).to(DEV)
+    idx = torch.randint(0, N, (B, N, k), generator=g)
+    idx = torch.where(torch.rand(B, N, k, generator=g) < 0.33, torch.zeros_like(idx), idx).to(torch.int32).to(DEV)
+    du = torch.randn(B * N, 2 * C, generator=g).to(tdt).to(DEV)
+    _, amax = ops.mr_aggregate_fwd(r, idx, B, N, C)
+    dy = ops.mr_aggregate_bwd(du, idx, amax, B, N, C)
+    d = du.double().reshape(B, N, C, 2)
+    ref = d[..., 0] - d[..., 1]
+    tgt = torch.gather(idx.long(), 2, amax.reshape(B, N, C).long())                       # (B, N, C): the row each element's gradient goes to
+    ref = ref.scatter_add(1, tgt, d[..., 1].contiguous()).reshape(B * N, C)
+    assert relerr(dy, ref) < (4e-3 if dt == "bf16" else 1e-6), relerr(dy, ref)      # the output is rounded to the storage type once
+
+
 def test_eval_ffn256_variants_agree(ops):
     """csrc/ffn256_fused.hip under its tuning key: persistent over the row tiles (300 tiles on one workgroup per CU: some take two, the
     next tile's x fetched by the epilogue of the one before), one workgroup per tile, and the 4-wave form with the output accumulators
