@@ -39,17 +39,10 @@ struct F256Args {
 
 typedef __attribute__((address_space(3))) void* lds_vptr;
 
-constexpr int F_C = 256, F_H = 1024, F_HC = 32, F_NCH = F_H / F_HC;
-constexpr int F_SLOT = 32768;                 // W1 chunk image (16 sub-blocks) + W2 chunk image (16 sub-blocks)
+constexpr int F_HC = 32;                      // hidden units per chunk
 constexpr int F_NS = 4;                       // ring slots: chunk ch (GEMM 1), chunk ch - 1 (GEMM 2), chunks ch + 1 and ch + 2 in flight
-constexpr int F_HB = 16 * 1024;               // 16 row tiles x 1 KB: every wave its own hidden sub-blocks
-constexpr int F_B1 = F_H * 4;                 // b1 in LDS
-constexpr int F_B2 = F_C * 4;                 // b2 in LDS
-constexpr int F_BP = F_C * 4;                 // bp in LDS (PRE form)
-constexpr int F_BG = 2 * F_C * 4;             // bg in LDS (GR form)
-constexpr int F_LDS = F_NS * F_SLOT + F_HB + F_B1 + F_B2 + F_BP + F_BG;
-constexpr int F_KP = 2 * F_C;                 // PRE form: width of r2 (the Grapher's 2C-channel graph-conv output)
-constexpr int F_NP = F_KP / 32;               // its k-steps = prologue iterations
+// per channel count C (H = 4 C): a chunk's W1 image is 32 hidden rows x C = C / 16 sub-blocks of [16 rows][32 k] (1 KB each), its W2
+// image C rows x 32 hidden = C / 16 sub-blocks: a ring slot is C / 8 KB (32 KB at C = 256)
 #ifndef NSID_F256_PF
 #define NSID_F256_PF 1
 #endif
@@ -100,19 +93,34 @@ __device__ __forceinline__ void f_mfma_acc(f32x4& acc, const bf16x8& a, const bf
 // are 8 CONSECUTIVE r2 channels of its row): 4 x 2 x RT MFMAs give the slice, bias + ReLU + bf16 pack turn it into the B fragment of
 // the Wp MFMAs in the lane's own registers. r2 (M x 512: 134 MB written and read back per block at a 2 048-clip micro-batch) and the
 // mrconv launch are gone; x is read late (its registers hold the gathered fragments until the last slice).
-template <int NW, int MODE>
+//
+// C = 128 / 64 (round 4): the same kernel with RT = 2 / 4 row tiles per wave (256- / 512-row workgroup tiles; C = 128 with RT = 4 needs
+// 55 registers more than a wave has at two per SIMD); a chunk is 16 / 8 LDS-DMA pieces. They replace ffn_fused.hip's
+// x-tile-in-LDS form for these widths (tuning key ffn_regs).
+template <int F_C, int NW, int RT, int MODE>
 __global__ __attribute__((amdgpu_flat_work_group_size(64 * NW, 64 * NW), amdgpu_waves_per_eu(NW / 4, NW / 4)))
 void ffn256_fused_kernel(const F256Args p) {
   constexpr bool PRE = MODE >= 1, GR = MODE == 2;
+  static_assert(MODE == 0 || (F_C == 256 && NW * RT == 16), "the Grapher-tail forms are written for C = 256, 256-row tiles");
+  constexpr int F_H = 4 * F_C, F_NCH = F_H / F_HC;
+  constexpr int KS1 = F_C / 32;               // k-steps of GEMM 1 = x fragments per row tile
+  constexpr int CT = F_C / 16;                // output-channel tiles of GEMM 2 (= GEMM 1 fragments per chunk: 2 hidden tiles x KS1)
+  constexpr int W2OFF = CT * 1024;            // a slot: [W1 chunk image | W2 chunk image]
+  constexpr int F_SLOT = 2 * CT * 1024;
+  constexpr int TR = NW * RT * 16;            // rows per workgroup tile
+  constexpr int F_HB = NW * RT * 1024;        // every wave its own hidden sub-blocks (one per row tile)
+  constexpr int F_KP = 2 * F_C;               // PRE form: width of r2 (the Grapher's 2C-channel graph-conv output)
+  constexpr int F_NP = F_KP / 32;             // its k-steps = prologue iterations
+  constexpr int F_LDS = F_NS * F_SLOT + F_HB + F_H * 4 + F_C * 4 + (PRE ? F_C * 4 : 0) + (GR ? 2 * F_C * 4 : 0);
   constexpr int NP = PRE ? F_NP : 0;          // prologue iterations; chunk index u = 0 .. NP + F_NCH - 1, slot u % 4
-  constexpr int RT = 16 / NW;                 // 16-row tiles per wave
-  constexpr int PW = 32 / NW;                 // LDS-DMA pieces per wave and chunk
+  constexpr int PW = 2 * CT / NW;             // LDS-DMA pieces per wave and chunk
+  static_assert(2 * CT % NW == 0 && F_NCH % F_NS == 0 && NP % F_NS == 0, "whole pieces per wave; a tile's chunks start on slot 0");
   constexpr int EP = (GR ? 1 : 2) * 8 * RT;   // global loads + stores a wave issues in a tile's epilogue (when another tile follows)
   __shared__ __attribute__((aligned(1024))) char lds[F_LDS];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lr = lane & 15, rq = lane >> 4;
-  const int ntiles = p.M / 256;
+  const int ntiles = p.M / TR;
   char* const hb = lds + F_NS * F_SLOT + wave * (RT * 1024);
   float* const b1s = reinterpret_cast<float*>(lds + F_NS * F_SLOT + F_HB);
   float* const b2s = b1s + F_H;
@@ -122,15 +130,15 @@ void ffn256_fused_kernel(const F256Args p) {
 
   // ---- x fragments: lane (lr, rq) of row tile b holds x[row0 + 16 b + lr][32 ks + 8 rq .. + 7]
   // (the first tile's here; every later tile's are fetched by the epilogue of the tile before, register by register as it lets go of them)
-  bf16x8 xf[8][RT];
+  bf16x8 xf[KS1][RT];
   // a lane's byte offset inside a tile's x / out rows (uniform 64-bit tile base + 32-bit lane offset + immediate)
   const unsigned xo = (unsigned)((wave * (16 * RT) + lr) * F_C + 8 * rq) * 2u;
   if constexpr (!GR) {
-    const char* xt = reinterpret_cast<const char*>(p.x + (long)blockIdx.x * 256 * F_C);
+    const char* xt = reinterpret_cast<const char*>(p.x + (long)blockIdx.x * TR * F_C);
 #pragma unroll
     for (int b = 0; b < RT; ++b)
 #pragma unroll
-      for (int ks = 0; ks < 8; ++ks) xf[ks][b] = *reinterpret_cast<const bf16x8*>(xt + xo + b * (16 * F_C * 2) + ks * 64);
+      for (int ks = 0; ks < KS1; ++ks) xf[ks][b] = *reinterpret_cast<const bf16x8*>(xt + xo + b * (16 * F_C * 2) + ks * 64);
   }
   for (int i = tid; i < F_H / 4; i += 64 * NW) reinterpret_cast<f32x4*>(b1s)[i] = reinterpret_cast<const f32x4*>(p.b1)[i];
   if (tid < F_C / 4) reinterpret_cast<f32x4*>(b2s)[tid] = reinterpret_cast<const f32x4*>(p.b2)[tid];
@@ -168,14 +176,15 @@ void ffn256_fused_kernel(const F256Args p) {
     }
     const int h0 = (u - NP) * F_HC;
 #pragma unroll
-    for (int i = 0; i < PW / 2; ++i) {
-      const int q = (PW / 2) * wave + i, a = q >> 3, ks = q & 7;        // W1 sub-block (hidden tile a, k-step ks)
-      f_glds16(reinterpret_cast<const char*>(p.w1 + (long)(h0 + 16 * a) * F_C + 32 * ks), voff1, dst + q * 1024);
-    }
-#pragma unroll
-    for (int i = 0; i < PW / 2; ++i) {
-      const int c = (PW / 2) * wave + i;                                // W2 sub-block (channel tile c)
-      f_glds16(reinterpret_cast<const char*>(p.w2 + (long)(32 * (c >> 1) + 4 * (c & 1)) * F_H + h0), voff2, dst + 16384 + c * 1024);
+    for (int i = 0; i < PW; ++i) {
+      const int q = PW * wave + i;            // 0 .. CT - 1: W1 sub-block (hidden tile a, k-step ks); CT .. 2 CT - 1: W2 sub-block (channel tile c)
+      if (q < CT) {
+        const int a = q / KS1, ks = q % KS1;
+        f_glds16(reinterpret_cast<const char*>(p.w1 + (long)(h0 + 16 * a) * F_C + 32 * ks), voff1, dst + q * 1024);
+      } else {
+        const int c = q - CT;
+        f_glds16(reinterpret_cast<const char*>(p.w2 + (long)(32 * (c >> 1) + 4 * (c & 1)) * F_H + h0), voff2, dst + W2OFF + c * 1024);
+      }
     }
   };
   issue(0, blockIdx.x);
@@ -188,13 +197,13 @@ void ffn256_fused_kernel(const F256Args p) {
   const int loh = lr * 64 + ((rq ^ hsw) << 4);
   // ---- persistent over the row tiles: workgroup g takes tiles g, g + grid, ... (one workgroup per CU: 148 KB of LDS)
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    char* const ot = reinterpret_cast<char*>(p.out + (long)tile * 256 * F_C);
-    const char* const xn = reinterpret_cast<const char*>(p.x + ((long)tile + gridDim.x) * 256 * F_C);    // the next tile's x (if any)
+    char* const ot = reinterpret_cast<char*>(p.out + (long)tile * TR * F_C);
+    const char* const xn = reinterpret_cast<const char*>(p.x + ((long)tile + gridDim.x) * TR * F_C);    // the next tile's x (if any)
     const bool more = tile + (int)gridDim.x < ntiles;                   // uniform
     const bool first = tile == (int)blockIdx.x;
-    f32x4 acc2[16][RT];
+    f32x4 acc2[CT][RT];
 #pragma unroll
-    for (int c = 0; c < 16; ++c)
+    for (int c = 0; c < CT; ++c)
 #pragma unroll
       for (int b = 0; b < RT; ++b) acc2[c][b] = f32x4{0.f, 0.f, 0.f, 0.f};
     bf16x8 hf[RT];                            // the hidden chunk of the PREVIOUS iteration as GEMM 2's B fragments
@@ -275,7 +284,7 @@ void ffn256_fused_kernel(const F256Args p) {
 #pragma unroll
             for (int b = 0; b < RT; ++b)
 #pragma unroll
-              for (int ks = 0; ks < 8; ++ks) xf[ks][b] = *reinterpret_cast<const bf16x8*>(xt + xo + b * (16 * F_C * 2) + ks * 64);
+              for (int ks = 0; ks < KS1; ++ks) xf[ks][b] = *reinterpret_cast<const bf16x8*>(xt + xo + b * (16 * F_C * 2) + ks * 64);
           }
         } else {
           issue(u + 2, tile);
@@ -345,14 +354,14 @@ void ffn256_fused_kernel(const F256Args p) {
       if (ch + 2 < F_NCH) issue(NP + ch + 2, tile);
       else if (!g1 && more) { issue(0, tile + gridDim.x); issue(1, tile + gridDim.x); }
       const char* s1 = lds + ((NP + ch) % F_NS) * F_SLOT;                       // W1 image of chunk ch
-      const char* s2 = lds + ((NP + ch + F_NS - 1) % F_NS) * F_SLOT + 16384;    // W2 image of chunk ch - 1
+      const char* s2 = lds + ((NP + ch + F_NS - 1) % F_NS) * F_SLOT + W2OFF;    // W2 image of chunk ch - 1
       f32x4 acc1[2][RT];
 #pragma unroll
       for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int b = 0; b < RT; ++b) acc1[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
       // fragment reads run F_PF steps ahead of their MFMAs
-      auto rd1 = [&](int st) { return *reinterpret_cast<const bf16x8*>(s1 + (((st & 1) * 8) + (st >> 1)) * 1024 + lo); };
+      auto rd1 = [&](int st) { return *reinterpret_cast<const bf16x8*>(s1 + (((st & 1) * KS1) + (st >> 1)) * 1024 + lo); };
       auto rd2 = [&](int st) { return *reinterpret_cast<const bf16x8*>(s2 + st * 1024 + lo); };
       bf16x8 q1[F_PF], q2[F_PF];
 #pragma unroll
@@ -363,9 +372,9 @@ void ffn256_fused_kernel(const F256Args p) {
         if constexpr (g2) q2[i] = rd2(i);
       }
 #pragma unroll
-      for (int st = 0; st < 16; ++st) {       // GEMM 1 step (ks = st >> 1, a = st & 1) beside GEMM 2 step (channel tile st)
+      for (int st = 0; st < CT; ++st) {       // GEMM 1 step (ks = st >> 1, a = st & 1) beside GEMM 2 step (channel tile st)
         const bf16x8 f1 = q1[st % F_PF], f2 = q2[st % F_PF];
-        if (st + F_PF < 16) {
+        if (st + F_PF < CT) {
           if constexpr (g1) q1[st % F_PF] = rd1(st + F_PF);
           if constexpr (g2) q2[st % F_PF] = rd2(st + F_PF);
         }
@@ -412,7 +421,7 @@ void ffn256_fused_kernel(const F256Args p) {
     // lane (lr, rq) is channel 32 ks + 8 rq + 4 half + e of row 16 b + lr -- the very channels whose x the lane holds in xf[ks][b] --
     // so the residual needs no second read of x, no LDS staging and no barrier, and a lane stores 8 consecutive channels (16 bytes).
 #pragma unroll
-    for (int ks = 0; ks < 8; ++ks) {
+    for (int ks = 0; ks < KS1; ++ks) {
       const f32x4 bc0 = *reinterpret_cast<const f32x4*>(b2s + 32 * ks + 8 * rq);
       const f32x4 bc1 = *reinterpret_cast<const f32x4*>(b2s + 32 * ks + 8 * rq + 4);
 #pragma unroll
@@ -434,15 +443,18 @@ void ffn256_fused_kernel(const F256Args p) {
 
 }  // namespace
 
-// returns NSID_OK / NSID_ELAUNCH, or 1 (nothing launched) outside C = 256, H = 1024, M % 256 == 0.
+// returns NSID_OK / NSID_ELAUNCH, or 1 (nothing launched) outside {C = 256 or 128, M % 256 == 0} / {C = 64, M % 512 == 0} with H = 4 C.
 // r2 != nullptr: the PRE form (x1 = x + wp r2 + bp in front of the FFN; r2: M x 512 bf16, wp: 256 x 512 bf16, bp: fp32[256]);
 // y != nullptr: the GR form (r2 evaluated from y (M x 256 bf16), idx (M x k, clip-local), wg (512 x 128 bf16), bg (fp32[512]); N nodes
-// per clip, 256 % N == 0)
+// per clip, 256 % N == 0) -- both C = 256 only
 __attribute__((visibility("hidden")))
 int nsid_ffn256_fused_launch(const void* x, const void* w1, const float* b1, const void* w2, const float* b2, void* out, int M, int C,
                              int H, hipStream_t stream, const void* r2, const void* wp, const float* bp, const void* y,
                              const int32_t* idx, int k, int N, const void* wg, const float* bg) {
-  if (C != F_C || H != F_H || M % 256 != 0 || M <= 0) return 1;
+  if (!(C == 256 || C == 128 || C == 64) || H != 4 * C || M <= 0) return 1;
+  const int tr = C == 64 ? 512 : 256;         // rows per workgroup tile
+  if (M % tr != 0) return 1;
+  if ((r2 != nullptr || y != nullptr) && C != 256) return 1;
   if (y != nullptr && (N <= 0 || 256 % N != 0 || k <= 0)) return 1;
   F256Args p{static_cast<const __bf16*>(x), static_cast<const __bf16*>(w1), b1, static_cast<const __bf16*>(w2), b2,
              static_cast<__bf16*>(out), M, static_cast<const __bf16*>(r2), static_cast<const __bf16*>(wp), bp,
@@ -454,20 +466,24 @@ int nsid_ffn256_fused_launch(const void* x, const void* w1, const float* b1, con
             hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess) ? n : 256;
     if (n_cu <= 0) n_cu = 256;
   }
-  const int ntiles = M / 256;
+  const int ntiles = M / tr;
   // tuning key ffn256: 1 = persistent, one workgroup of 8 waves per CU; 2 = 8 waves, one workgroup per tile; 4 = persistent, 4 waves of
-  // 64 rows with the output accumulators in AGPRs (measured 154 us against 146 us: docs/experiments.md)
+  // 64 rows with the output accumulators in AGPRs (C = 256 only; measured 154 us against 146 us: docs/experiments.md)
   const int wgs = (nsid_tune(NSID_T_ffn256) == 2 || ntiles < n_cu) ? ntiles : n_cu;
   const bool w4 = nsid_tune(NSID_T_ffn256) == 4;
-  if (y != nullptr) {
-    if (w4) NSID_LAUNCH((ffn256_fused_kernel<4, 2>), dim3(wgs), dim3(256), 0, stream, p);
-    else NSID_LAUNCH((ffn256_fused_kernel<8, 2>), dim3(wgs), dim3(512), 0, stream, p);
+  if (C == 128) {
+    NSID_LAUNCH((ffn256_fused_kernel<128, 8, 2, 0>), dim3(wgs), dim3(512), 0, stream, p);
+  } else if (C == 64) {
+    NSID_LAUNCH((ffn256_fused_kernel<64, 8, 4, 0>), dim3(wgs), dim3(512), 0, stream, p);
+  } else if (y != nullptr) {
+    if (w4) NSID_LAUNCH((ffn256_fused_kernel<256, 4, 4, 2>), dim3(wgs), dim3(256), 0, stream, p);
+    else NSID_LAUNCH((ffn256_fused_kernel<256, 8, 2, 2>), dim3(wgs), dim3(512), 0, stream, p);
   } else if (r2 != nullptr) {
-    if (w4) NSID_LAUNCH((ffn256_fused_kernel<4, 1>), dim3(wgs), dim3(256), 0, stream, p);
-    else NSID_LAUNCH((ffn256_fused_kernel<8, 1>), dim3(wgs), dim3(512), 0, stream, p);
+    if (w4) NSID_LAUNCH((ffn256_fused_kernel<256, 4, 4, 1>), dim3(wgs), dim3(256), 0, stream, p);
+    else NSID_LAUNCH((ffn256_fused_kernel<256, 8, 2, 1>), dim3(wgs), dim3(512), 0, stream, p);
   } else {
-    if (w4) NSID_LAUNCH((ffn256_fused_kernel<4, 0>), dim3(wgs), dim3(256), 0, stream, p);
-    else NSID_LAUNCH((ffn256_fused_kernel<8, 0>), dim3(wgs), dim3(512), 0, stream, p);
+    if (w4) NSID_LAUNCH((ffn256_fused_kernel<256, 4, 4, 0>), dim3(wgs), dim3(256), 0, stream, p);
+    else NSID_LAUNCH((ffn256_fused_kernel<256, 8, 2, 0>), dim3(wgs), dim3(512), 0, stream, p);
   }
   return nsid_launch_status();
 }

@@ -188,7 +188,12 @@ int ffn_launch(const FfnArgs& p, hipStream_t s) {
 extern "C" int nsid_ffn_fused_fwd(const void* x, const void* w1, const float* b1, const void* w2, const float* b2, void* out, int M,
                                   int C, int H, void* stream) {
   NSID_REQUIRE(x && w1 && b1 && w2 && b2 && out && M > 0);
-  if (C == 256 && H == 1024 && M % 256 == 0 && nsid_tune(NSID_T_ffn256) != 0) {      // the x tile in registers: ffn256_fused.hip
+  // the x tile in registers (ffn256_fused.hip): C = 256 always (tuning key ffn256), C = 128 / 64 where tuning key ffn_regs has bit 1 / bit 0
+  // set and the rows make whole 256- / 512-row tiles
+  const long regs = nsid_tune(NSID_T_ffn_regs);
+  const bool rx = nsid_tune(NSID_T_ffn256) != 0 && H == 4 * C &&
+                  ((C == 256 && M % 256 == 0) || (C == 128 && (regs & 2) != 0 && M % 256 == 0) || (C == 64 && (regs & 1) != 0 && M % 512 == 0));
+  if (rx) {
     NSID_REQUIRE(nsid_aligned16(x) && nsid_aligned16(w1) && nsid_aligned16(w2) && nsid_aligned16(out) && nsid_aligned16(b1) &&
                  nsid_aligned16(b2));
     const int rc = nsid_ffn256_fused_launch(x, w1, b1, w2, b2, out, M, C, H, static_cast<hipStream_t>(stream));

@@ -256,6 +256,7 @@ static inline bool nsid_acc_ok(const int64_t* acc, int replicas) {
   X(knn_sel_min_n, 128)        /* graphs of at least this many nodes take the in-register threshold select for k*d > 8 */       \
   X(mr_grid_stride, 0)         /* 1: grid-stride aggregation instead of the LDS-staged per-clip kernel */                     \
   X(mr_split, 0)               /* channel split of the LDS-staged aggregation (0 = heuristic) */                              \
+  X(ffn_regs, 3)               /* eval FFN with the x tile in registers (ffn256_fused.hip) also at C = 64 (bit 0) / C = 128 (bit 1) */ \
   X(mr_key_min_k, 8)           /* bf16 aggregation with >= this many neighbours: integer-key search (mr_fwd_key_kernel); 0 = never */ \
   X(ffn_waves, 8)              /* waves per workgroup of the fused eval-mode FFN (4 or 8) */                                  \
   X(ffn256, 1)                 /* 1: the C = 256 stage's eval-mode FFN as one launch (ffn256_fused.hip); 0: two GEMM launches */ \

@@ -4,7 +4,8 @@ import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from neuralsampleid_amd import ops
 ops.set_gemm_precision("bf16")
-M, C, H = 131072, 256, 1024
+C = int(os.environ.get("FFN_C", "256"))
+M, H = 131072 * 256 // C, 4 * C
 g = torch.Generator().manual_seed(0)
 x = torch.randn(M, C, generator=g).to(torch.bfloat16).cuda()
 w1 = (torch.randn(H, C, generator=g) * C ** -0.5).cuda(); w2 = (torch.randn(C, H, generator=g) * H ** -0.5).cuda()
@@ -23,7 +24,7 @@ def two():
     h, _ = ops.linear_fwd(x, w1, b1, M, H, C, act_out=ops.ACT_RELU)
     ops.linear_fwd(h, w2, b2, M, C, H, addend=x)
 for a in sys.argv[1:]:
-    if a.startswith("ffn256="): ops.set_tuning("ffn256", int(a.split("=")[1]))
+    if "=" in a: ops.set_tuning(a.split("=")[0], int(a.split("=")[1]))
 t_f = timeit(lambda: ops.ffn_fused_fwd(x, w1, b1, w2, b2, M, C, H))
 t_2 = float("nan") if "--fused-only" in sys.argv else timeit(two)
 fl = 4.0 * M * C * H
