@@ -1,6 +1,7 @@
-// Eval-mode FFN of the C = 256 stage in ONE launch (forward-only fingerprint extraction, BASELINE config 5):
-//     out = x + W2 relu(W1 x + b1) + b2      (encoder/graph_encoder.py:82-89 with both BatchNorms folded into the convs), H = 4C = 1024.
-// Six of the twelve blocks sit at this stage, and their un-fused FFN pair is a quarter of a micro-batch: gemm256 writes the hidden
+// Eval-mode FFN in ONE launch with the x tile in registers (forward-only fingerprint extraction, BASELINE config 5):
+//     out = x + W2 relu(W1 x + b1) + b2      (encoder/graph_encoder.py:82-89 with both BatchNorms folded into the convs), H = 4C.
+// Written for the C = 256 stage (described below with its numbers), since templated on C and serving C = 128 / 64 too (see the kernel).
+// Six of the twelve blocks sit at C = 256, and their un-fused FFN pair is a quarter of a micro-batch: gemm256 writes the hidden
 // tensor (M x 1024 bf16: 268 MB at a 2 048-clip micro-batch) in 116 us and reads it back in 87 us — both launches are bound by those
 // bytes, not by the matrix pipe (0.7 PFLOP/s). ffn_fused.hip keeps the hidden chunk on the CU for C = 64 / 128 with the x tile in
 // LDS; at C = 256 that form needs 161 KB. Here the x tile lives in REGISTERS instead:
