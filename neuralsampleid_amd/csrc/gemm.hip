@@ -79,7 +79,10 @@ struct TileGeom {
   // (32-deep stages) fold 2-way onto the 32 write banks: SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.22-0.31 on the KS = 1 kernels,
   // 0.04-0.08 with 160-byte rows (KS = 2) (profiles/r02d_final/pmc_sq_summary.txt). Those replays stay under the 13 cycles the write
   // instruction spends moving its operands to the LDS anyway (guide: a store conflict costs time only once the array cycles exceed
-  // the instruction's own), so the row pitch is chosen for the reads:
+  // the instruction's own) -- measured in round 4 (tools/lds_stage_write_bench.hip, profiles/r04d/lds_stage_write_bench.jsonl): this
+  // stage's two ds_write_b128 per thread + barrier cost 241.8 cycles per stage at pitch 96 (2-way), at pitch 80 (conflict-free writes)
+  // and at pitch 128 alike (256.0 each with three workgroups per CU), while the fragment reads + MFMAs cost 343 cycles at pitch 96
+  // against 424 at pitch 80 (404 / 516 with three workgroups) -- so the row pitch is chosen for the reads:
   //  RMAJOR: lds[row][BK elements + 32 B pad] (row = i or j, R contiguous): 96-byte rows in both precisions (160-byte rows
   //          with KS = 2: 16-byte block (10*lr + rq) mod 16 is a bijection for the same lane split). A fragment
   //          read is one ds_read_b128 per lane at (row lr, 16-byte chunk rq); the hardware serves lanes {0-3,12-15,20-27}
