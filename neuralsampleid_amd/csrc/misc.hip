@@ -142,12 +142,24 @@ __device__ __forceinline__ float linspace01(int i, int steps) {
 // normalisation applied once): the per-patch loops then read LDS instead of issuing dependent strided global loads (the
 // first versions were pure load-latency chains: 85 us forward, 214 us backward for a 2 MFLOP op).
 constexpr int PATCH_PAD = 8;     // row stride W+8 floats: the pb rows of a patch fall on different banks
+// v / d for the 8 192 values of a clip that share the divisor d = max - min, 0 <= v <= d: q = v r, q += (v - q d) r with r the correctly
+// rounded 1 / d is the correctly rounded quotient (Markstein; the lone exception, a divisor whose significand is all ones, is off by at
+// most one ulp) -- three operations instead of the ~10 of an IEEE division (32 divisions per thread were a third of the kernel's VALU).
+// d = 0 (a constant clip): r = inf, 0 * inf = NaN, as the reference's 0 / 0.
+__device__ __forceinline__ float patch_div(float v, float d, float r) {
+  const float q = v * r;
+  return fmaf(fmaf(-q, d, v), r, q);
+}
 
-template <typename T, int MAXPATCH>
+// PB, PF > 0: the patch shape at compile time (GraFP: 4 x 8). The time / frequency ramps of a patch are then PF + PB values instead of
+// two more per-element planes (64 registers less: 216 -> under 128 VGPRs, four workgroups per CU instead of two), same accumulation order.
+template <typename T, int MAXPATCH, int PB = 0, int PF = 0>
 __global__ __launch_bounds__(256) void patchify_fwd_kernel(const float* __restrict__ spec, const float* __restrict__ w,
-                                                           const float* __restrict__ bias, int H, int W, int pb,
-                                                           int pf, int F, T* __restrict__ out, int ldo,
+                                                           const float* __restrict__ bias, int H, int W, int pb_,
+                                                           int pf_, int F, T* __restrict__ out, int ldo,
                                                            float* __restrict__ minmax) {
+  constexpr bool FIX = PB > 0;
+  const int pb = FIX ? PB : pb_, pf = FIX ? PF : pf_;
   extern __shared__ __attribute__((aligned(16))) float sm[];   // weights [F][3][pb][pf], scratch [8], clip [H][W+pad]
   const int b = blockIdx.x, t = threadIdx.x;
   const float* x = spec + (long)b * H * W;
@@ -182,35 +194,62 @@ __global__ __launch_bounds__(256) void patchify_fwd_kernel(const float* __restri
   lo = fminf(fminf(red[0], red[1]), fminf(red[2], red[3]));
   hi = fmaxf(fmaxf(red[4], red[5]), fmaxf(red[6], red[7]));
   if (t == 0 && minmax != nullptr) { minmax[2 * b] = lo; minmax[2 * b + 1] = hi; }
-  const float range = hi - lo;
+  const float range = hi - lo, rrange = 1.f / range;             // one IEEE reciprocal per clip
   const int Hp = H / pb, Wp = W / pf, NP = Hp * Wp;
   // MAXPATCH >= pb*pf (host-checked; the instantiation with MAXPATCH == pb*pf has no predicates): the patch's three
   // input planes sit in registers, one division per spectrogram value
   for (int p = t; p < NP; p += blockDim.x) {
     const int ph = p / Wp, pw = p % Wp;
     T* dst = out + ((long)b * NP + p) * ldo;
-    float sv[MAXPATCH], lw[MAXPATCH], lh[MAXPATCH];
+    constexpr int NLW = FIX ? PF : MAXPATCH, NLH = FIX ? PB : MAXPATCH;
+    float sv[MAXPATCH], lw[NLW], lh[NLH];
 #pragma unroll
     for (int q = 0; q < MAXPATCH; ++q) {
       if (q < pb * pf) {
         const int i = q / pf, j = q % pf;
-        sv[q] = (xs[(ph * pb + i) * LDW + pw * pf + j] - lo) / range;
-        lw[q] = linspace01(pw * pf + j, W);
-        lh[q] = linspace01(ph * pb + i, H);
-      }
-    }
-    for (int f = 0; f < F; ++f) {
-      float acc = bias[f];
-      const float* wf = wl + f * 3 * pb * pf;
-#pragma unroll
-      for (int q = 0; q < MAXPATCH; ++q) {
-        if (q < pb * pf) {                       // accumulation order: (i, j) row-major, planes time/freq/spec
-          acc += wf[q] * lw[q];
-          acc += wf[pb * pf + q] * lh[q];
-          acc += wf[2 * pb * pf + q] * sv[q];
+        sv[q] = patch_div(xs[(ph * pb + i) * LDW + pw * pf + j] - lo, range, rrange);
+        if constexpr (!FIX) {
+          lw[q] = linspace01(pw * pf + j, W);
+          lh[q] = linspace01(ph * pb + i, H);
         }
       }
-      dst[f] = (T)(acc < 0.f ? 0.f : acc);     // NaN (constant clip: 0/0) propagates, as in the reference
+    }
+    if constexpr (FIX) {
+#pragma unroll
+      for (int j = 0; j < PF; ++j) lw[j] = linspace01(pw * PF + j, W);
+#pragma unroll
+      for (int i = 0; i < PB; ++i) lh[i] = linspace01(ph * PB + i, H);
+    }
+    constexpr int NV = Chunk<T>::N;                          // filters per 16-byte store (the encoder's stem: F = 8 bf16 = one store)
+    for (int f0 = 0; f0 < F; f0 += NV) {
+      float res[NV];
+#pragma unroll
+      for (int ff = 0; ff < NV; ++ff) {
+        const int f = f0 + ff;
+        res[ff] = 0.f;
+        if (f < F) {
+          float acc = bias[f];
+          // the filter's weights straight from (read-only) global memory: the index is uniform, so they arrive by scalar loads and feed
+          // the FMAs as SGPR operands -- from the LDS copy they were 96 broadcast ds_read_b32 per filter and thread
+          const float* wf = (MAXPATCH == 32 ? w : wl) + f * 3 * pb * pf;
+#pragma unroll
+          for (int q = 0; q < MAXPATCH; ++q) {
+            if (q < pb * pf) {                   // accumulation order: (i, j) row-major, planes time/freq/spec
+              acc += wf[q] * lw[FIX ? q % (FIX ? PF : 1) : q];
+              acc += wf[pb * pf + q] * lh[FIX ? q / (FIX ? PF : 1) : q];
+              acc += wf[2 * pb * pf + q] * sv[q];
+            }
+          }
+          res[ff] = acc < 0.f ? 0.f : acc;       // NaN (constant clip: 0/0) propagates, as in the reference
+        }
+      }
+      if (f0 + NV <= F && ldo % NV == 0 && (reinterpret_cast<size_t>(out) & 15) == 0) {
+        Chunk<T>::store(dst + f0, res);          // (the eight 2-byte stores of a patch were the kernel's store traffic: 16 B rows)
+      } else {
+#pragma unroll
+        for (int ff = 0; ff < NV; ++ff)
+          if (f0 + ff < F) dst[f0 + ff] = (T)res[ff];
+      }
     }
   }
 }
@@ -582,7 +621,10 @@ extern "C" int nsid_peak_patchify_fwd(const float* spec, const float* w, const f
   const size_t bytes = ((size_t)F * 3 * pb * pf + 8 + (size_t)H * (W + 8)) * sizeof(float);
   NSID_REQUIRE(bytes <= 64 * 1024 && W % 4 == 0 && (F * 3 * pb * pf) % 4 == 0 && nsid_aligned16(spec) && pb * pf <= 64);
   NSID_DISPATCH_DTYPE(out_dtype, T, {
-    if (pb * pf == 32)
+    if (pb == 4 && pf == 8)
+      NSID_LAUNCH((patchify_fwd_kernel<T, 32, 4, 8>), dim3(B), dim3(256), bytes, static_cast<hipStream_t>(stream), spec, w,
+                  bias, H, W, pb, pf, F, static_cast<T*>(out), ldo, minmax);
+    else if (pb * pf == 32)
       NSID_LAUNCH((patchify_fwd_kernel<T, 32>), dim3(B), dim3(256), bytes, static_cast<hipStream_t>(stream), spec, w,
                   bias, H, W, pb, pf, F, static_cast<T*>(out), ldo, minmax);
     else
