@@ -350,9 +350,10 @@ def test_eval_mrconv_in_one_launch(ops, B, C, k):
 
 
 @pytest.mark.parametrize("M,C", [(2048, 64), (128, 64), (4096, 128), (65536, 64), (256, 256), (16384, 256), (76800, 256),
-                                 (131072, 256)])
+                                 (131072, 256), (153600, 64), (76800, 128), (384, 128)])
 def test_eval_ffn_in_one_launch(ops, M, C):
-    """csrc/ffn_fused.hip (C = 64 / 128: x tile in LDS) and csrc/ffn256_fused.hip (C = 256: x tile in registers, weights by LDS-DMA):
+    """csrc/ffn256_fused.hip (x tile in registers, weights by LDS-DMA: C = 256, and C = 128 / 64 at whole 256- / 512-row tiles -- 300
+    tiles on one workgroup per CU exercise the persistent form's second tile) and csrc/ffn_fused.hip (x tile in LDS: the other rows):
     out = x + W2 relu(W1 x + b1) + b2 (FFN.forward in eval mode with both BatchNorms folded) in one launch,
     the M x 4C hidden tensor never written: against an fp64 evaluation with the same two bf16 rounding points (hidden, output) and
     against the two-launch form (nsid_linear_fwd with the ReLU epilogue + nsid_linear_fwd_res)"""
