@@ -133,24 +133,24 @@ __global__ __launch_bounds__(256) void ds_unpack_all_kernel(const DsUnpackArgs a
 
 // ------------------------------------------------------------------ GPUPeakExtractorv2
 // torch.linspace(0,1,steps)[i]: start + i*step in the lower half, end - (steps-1-i)*step in the upper half
+// acc + a * b with the product ROUNDED before the addition: no contraction into an fma, whatever the surrounding code (HIP compiles with
+// -ffp-contract=fast-honor-pragmas; __fadd_rn / __fmul_rn are plain operators in this toolchain and do get contracted)
+__device__ __forceinline__ float add_unfused(float acc, float a, float b) {
+#pragma clang fp contract(off)
+  const float p = a * b;
+  return acc + p;
+}
+// (the upper half as one fused multiply-add: the form rounds 1-3 compiled; pinned for the same reason as the accumulation in
+// patchify_fwd_kernel)
 __device__ __forceinline__ float linspace01(int i, int steps) {
   const float step = 1.0f / (float)(steps - 1);
-  return (i < steps / 2) ? (float)i * step : 1.0f - (float)(steps - 1 - i) * step;
+  return (i < steps / 2) ? __fmul_rn((float)i, step) : fmaf(-(float)(steps - 1 - i), step, 1.0f);
 }
 
 // Both kernels stage the whole clip in LDS first (H*W fp32 = 32 KB, vectorised coalesced loads, the min-max
 // normalisation applied once): the per-patch loops then read LDS instead of issuing dependent strided global loads (the
 // first versions were pure load-latency chains: 85 us forward, 214 us backward for a 2 MFLOP op).
 constexpr int PATCH_PAD = 8;     // row stride W+8 floats: the pb rows of a patch fall on different banks
-// v / d for the 8 192 values of a clip that share the divisor d = max - min, 0 <= v <= d: q = v r, q += (v - q d) r with r the correctly
-// rounded 1 / d is the correctly rounded quotient (Markstein; the lone exception, a divisor whose significand is all ones, is off by at
-// most one ulp) -- three operations instead of the ~10 of an IEEE division (32 divisions per thread were a third of the kernel's VALU).
-// d = 0 (a constant clip): r = inf, 0 * inf = NaN, as the reference's 0 / 0.
-__device__ __forceinline__ float patch_div(float v, float d, float r) {
-  const float q = v * r;
-  return fmaf(fmaf(-q, d, v), r, q);
-}
-
 // PB, PF > 0: the patch shape at compile time (GraFP: 4 x 8). The time / frequency ramps of a patch are then PF + PB values instead of
 // two more per-element planes (64 registers less: 216 -> under 128 VGPRs, four workgroups per CU instead of two), same accumulation order.
 template <typename T, int MAXPATCH, int PB = 0, int PF = 0>
@@ -194,7 +194,7 @@ __global__ __launch_bounds__(256) void patchify_fwd_kernel(const float* __restri
   lo = fminf(fminf(red[0], red[1]), fminf(red[2], red[3]));
   hi = fmaxf(fmaxf(red[4], red[5]), fmaxf(red[6], red[7]));
   if (t == 0 && minmax != nullptr) { minmax[2 * b] = lo; minmax[2 * b + 1] = hi; }
-  const float range = hi - lo, rrange = 1.f / range;             // one IEEE reciprocal per clip
+  const float range = hi - lo;
   const int Hp = H / pb, Wp = W / pf, NP = Hp * Wp;
   // MAXPATCH >= pb*pf (host-checked; the instantiation with MAXPATCH == pb*pf has no predicates): the patch's three
   // input planes sit in registers, one division per spectrogram value
@@ -207,7 +207,7 @@ __global__ __launch_bounds__(256) void patchify_fwd_kernel(const float* __restri
     for (int q = 0; q < MAXPATCH; ++q) {
       if (q < pb * pf) {
         const int i = q / pf, j = q % pf;
-        sv[q] = patch_div(xs[(ph * pb + i) * LDW + pw * pf + j] - lo, range, rrange);
+        sv[q] = (xs[(ph * pb + i) * LDW + pw * pf + j] - lo) / range;
         if constexpr (!FIX) {
           lw[q] = linspace01(pw * pf + j, W);
           lh[q] = linspace01(ph * pb + i, H);
@@ -235,9 +235,16 @@ __global__ __launch_bounds__(256) void patchify_fwd_kernel(const float* __restri
 #pragma unroll
           for (int q = 0; q < MAXPATCH; ++q) {
             if (q < pb * pf) {                   // accumulation order: (i, j) row-major, planes time/freq/spec
-              acc += wf[q] * lw[FIX ? q % (FIX ? PF : 1) : q];
-              acc += wf[pb * pf + q] * lh[FIX ? q / (FIX ? PF : 1) : q];
-              acc += wf[2 * pb * pf + q] * sv[q];
+              // Pinned arithmetic: the time-plane term is ONE fused multiply-add, the frequency- and spectrogram-plane products are
+              // rounded before they are added. That is how rounds 1-3 compiled this loop (the compiler packed the two products
+              // into one v_pk_mul_f32 and added them separately); contracting all three moves half of the non-zero outputs by an ulp
+              // or two (max 1.9e-6; 6.0e-7 instead of 8.3e-7 max against the peak_b8 golden, both far inside its 1e-5), and the
+              // B = 256 / bf16-emulation tests carry bounds measured at 3x what THIS rounding gives through 12 max-relative layers
+              // (all-fma: global gradient norm 1.4e-3 instead of 3.5e-4 of the reference's at B = 256). Written out so that the
+              // values no longer depend on what the vectoriser does with the surrounding code.
+              acc = fmaf(wf[q], lw[FIX ? q % (FIX ? PF : 1) : q], acc);
+              acc = add_unfused(acc, wf[pb * pf + q], lh[FIX ? q / (FIX ? PF : 1) : q]);
+              acc = add_unfused(acc, wf[2 * pb * pf + q], sv[q]);
             }
           }
           res[ff] = acc < 0.f ? 0.f : acc;       // NaN (constant clip: 0/0) propagates, as in the reference
