@@ -224,3 +224,37 @@ def test_ntxent_repeats_to_atomics_noise():
         l, a, b = ops.ntxent_fwd_bwd(zi, zj, 0.05, 256, 256)
         worst = torch.maximum(worst, torch.maximum((l - l0).abs().max(), torch.maximum((a - a0).abs().max(), (b - b0).abs().max())))
     assert float(worst) <= 1e-6 * max(1.0, float(a0.abs().max()))
+
+
+@pytest.mark.parametrize("C,M", [(256, 131072), (128, 262144), (64, 524288)])
+def test_register_tile_ffn_repeats_bitwise_under_load(C, M):
+    """csrc/ffn256_fused.hip at the extraction micro-batch (two row tiles per persistent workgroup: the LDS-DMA ring, the per-chunk
+    barrier / vmcnt hand-over and the next-tile x prefetch all run their second-tile paths), repeated REPEATS times while another
+    stream keeps the chip busy with GEMMs (launch timing, L2 and LDS-DMA latency shift from launch to launch): the kernel has no
+    atomics, so every launch must return the first one's bits — a slot overwritten early or read late would show as a differing tile"""
+    from neuralsampleid_amd import ops
+    ops.set_gemm_precision("bf16")
+    H = 4 * C
+    g = torch.Generator().manual_seed(C)
+    x = torch.randn(M, C, generator=g).to(torch.bfloat16).to(DEV)
+    w1 = (torch.randn(H, C, generator=g) * C ** -0.5).to(DEV)
+    w2 = (torch.randn(C, H, generator=g) * H ** -0.5).to(DEV)
+    b1, b2 = (0.3 * torch.randn(H, generator=g)).to(DEV), (0.3 * torch.randn(C, generator=g)).to(DEV)
+    for w in (w1, w2):
+        ops.SHADOWS.register(w, ops.f32_to_bf16(w), owner=w)
+    a = torch.randn(16384, 512, generator=g).to(torch.bfloat16).to(DEV)
+    wa = (torch.randn(512, 512, generator=g) * 512 ** -0.5).to(DEV)
+    ops.SHADOWS.register(wa, ops.f32_to_bf16(wa), owner=wa)
+    first = ops.ffn_fused_fwd(x, w1, b1, w2, b2, M, C, H)
+    assert first is not None
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    bad = 0
+    for r in range(REPEATS):
+        with torch.cuda.stream(side):
+            for _ in range(1 + r % 3):
+                ops.linear_fwd(a, wa, None, 16384, 512, 512)
+        out = ops.ffn_fused_fwd(x, w1, b1, w2, b2, M, C, H)
+        bad += int(not torch.equal(out, first))
+    torch.cuda.synchronize()
+    assert bad == 0, f"{bad} of {REPEATS} launches differ from the first"
