@@ -105,6 +105,7 @@ void ffn256_fused_kernel(const F256Args p) {
   static_assert(MODE == 0 || (F_C == 256 && NW * RT == 16), "the Grapher-tail forms are written for C = 256, 256-row tiles");
   constexpr int F_H = 4 * F_C, F_NCH = F_H / F_HC;
   constexpr int KS1 = F_C / 32;               // k-steps of GEMM 1 = x fragments per row tile
+  constexpr int EP = (GR ? 1 : 2) * KS1 * RT; // global stores (+ next-x loads) a wave issues in a tile's epilogue (when another tile follows)
   constexpr int CT = F_C / 16;                // output-channel tiles of GEMM 2 (= GEMM 1 fragments per chunk: 2 hidden tiles x KS1)
   constexpr int W2OFF = CT * 1024;            // a slot: [W1 chunk image | W2 chunk image]
   constexpr int F_SLOT = 2 * CT * 1024;
@@ -116,7 +117,6 @@ void ffn256_fused_kernel(const F256Args p) {
   constexpr int NP = PRE ? F_NP : 0;          // prologue iterations; chunk index u = 0 .. NP + F_NCH - 1, slot u % 4
   constexpr int PW = 2 * CT / NW;             // LDS-DMA pieces per wave and chunk
   static_assert(2 * CT % NW == 0 && F_NCH % F_NS == 0 && NP % F_NS == 0, "whole pieces per wave; a tile's chunks start on slot 0");
-  constexpr int EP = (GR ? 1 : 2) * 8 * RT;   // global loads + stores a wave issues in a tile's epilogue (when another tile follows)
   __shared__ __attribute__((aligned(1024))) char lds[F_LDS];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
