@@ -315,12 +315,9 @@ int nsid_pack_ds_weight(const float* w, int Cout, int Cin, float* wp, void* stre
 /* All Downsample layers of a model at once (n <= 8; the pointer arrays live in host memory), once per training step instead of per layer
  * and view: nsid_ds_prepack writes the packed forward weight (Cout, 3*Cin) and the packed backward weight [W_2 ; W_0] (2*Cout, Cin) of
  * every layer straight to bf16 and zeroes its packed gradient buffers dwp (TWO of them, contiguous: (2, Cout, 3*Cin) fp32, one per view of a
- * contrastive step; dwp or its entries may be NULL);
- * nsid_ds_unpack_all adds the packed gradients into the (Cout, Cin, 3, 3) gradient tensors (plain adds: call it once, after every
- * view's nsid_downsample3_bwd_weight has accumulated into dwp). */
+ * contrastive step; dwp or its entries may be NULL). Each view unpacks its own packed gradient with nsid_unpack_ds_wgrad (atomic adds). */
 int nsid_ds_prepack(int n, const float* const* w, void* const* wp16, void* const* wb16, float* const* dwp, const int* Cout,
                     const int* Cin, void* stream);
-int nsid_ds_unpack_all(int n, const float* const* dwp, float* const* dw, const int* Cout, const int* Cin, void* stream);
 int nsid_unpack_ds_wgrad(const float* dwp, int Cout, int Cin, float* dw /* += */, void* stream);
 
 /* ---- GPUPeakExtractorv2 (peak_extractor.py:45-70) ------------------------------------------------------

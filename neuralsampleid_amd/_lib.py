@@ -43,7 +43,6 @@ SIGNATURES = {
     "nsid_downsample3_bwd_data": "pppipiiiiis",
     "nsid_unpack_ds_wgrad": "piips",
     "nsid_ds_prepack": "ipppppps",
-    "nsid_ds_unpack_all": "ipppps",
     "nsid_peak_patchify_fwd": "pppiiiiiipipis",
     "nsid_peak_patchify_bwd": "ppppiiiiiiippis",
     "nsid_node_mean_fwd": "piiipis",

@@ -27,6 +27,13 @@ def _numpy_log_globals():
     core = getattr(np, "_core", None) or getattr(np, "core")
     out += [core.multiarray._reconstruct, core.multiarray.scalar]
     out += [type(np.dtype(t)) for t in ("float32", "float64", "int64", "int32", "bool")]
+    # the reference pins numpy 1.26.4 (requirements.txt), whose pickles name the reconstructors `numpy.core.multiarray.*`; torch's
+    # restricted unpickler matches globals by that STRING, and under numpy >= 2 the functions report `numpy._core.multiarray.*`:
+    # register the legacy paths too, in torch's (callable, "full.path") form
+    for fn, name in ((core.multiarray._reconstruct, "_reconstruct"), (core.multiarray.scalar, "scalar")):
+        for mod in ("numpy.core.multiarray", "numpy._core.multiarray"):
+            if f"{fn.__module__}.{fn.__name__}" != f"{mod}.{name}":
+                out.append((fn, f"{mod}.{name}"))
     return out
 
 

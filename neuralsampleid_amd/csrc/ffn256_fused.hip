@@ -145,6 +145,9 @@ void ffn256_fused_kernel(const F256Args p) {
   if (tid < F_C / 4) reinterpret_cast<f32x4*>(b2s)[tid] = reinterpret_cast<const f32x4*>(p.b2)[tid];
   if (PRE && tid < F_C / 4) reinterpret_cast<f32x4*>(bps)[tid] = reinterpret_cast<const f32x4*>(p.bp)[tid];
   if (GR && tid < 2 * F_C / 4) reinterpret_cast<f32x4*>(bgs)[tid] = reinterpret_cast<const f32x4*>(p.bg)[tid];
+  // the staged bias vectors are read by OTHER waves later: fence + barrier here, once per launch and before any LDS-DMA is in flight
+  // (the bare s_barrier of the chunk loop waits for no LDS store, and gfx950 inserts no lgkmcnt(0) in front of it: ADVICE r4)
+  __syncthreads();
 
   // ---- LDS-DMA addressing (gemm256.hip): lane l supplies row l >> 2 of a 16-row sub-block and the logical 16-byte chunk that lives at
   // physical chunk l & 3

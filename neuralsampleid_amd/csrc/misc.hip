@@ -92,7 +92,7 @@ __global__ void unpack_ds_wgrad_kernel(const float* __restrict__ dwp, int Cout, 
 // gradient, per layer AND per view. Here one launch at the start of the step writes, for every layer, the packed forward weight
 // wp[o][t*Cin + c] = w[o][c][t][1] and the packed backward weight wb = [W_2 ; W_0] straight to bf16 and zeroes the layer's two packed
 // gradient buffers (one per view; each view still unpacks its own right after its weight-gradient GEMM, so a parameter's .grad is
-// complete when backward returns). ds_unpack_all_kernel serves callers that prefer one unpack per step.
+// complete when backward returns).
 constexpr int DSP_LAYERS = 8;
 #define NSID_DS_SLOTS 2
 struct DsPrepArgs {
@@ -117,17 +117,6 @@ __global__ __launch_bounds__(256) void ds_prepack_kernel(const DsPrepArgs a) {
       const int tb = r < Cout ? 2 : 0;
       a.wb16[l][q] = (__bf16)w[((ob * Cin + c) * 3 + tb) * 3 + 1];
     }
-  }
-}
-struct DsUnpackArgs { const float* dwp[DSP_LAYERS]; float* dw[DSP_LAYERS]; int Cout[DSP_LAYERS], Cin[DSP_LAYERS]; };
-__global__ __launch_bounds__(256) void ds_unpack_all_kernel(const DsUnpackArgs a) {
-  const int l = blockIdx.y;
-  const int Cout = a.Cout[l], Cin = a.Cin[l];
-  const long total = (long)Cout * 3 * Cin;
-  for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += (long)gridDim.x * blockDim.x) {
-    const int c = (int)(q % Cin), t = (int)((q / Cin) % 3);
-    const long o = q / (3L * Cin);
-    a.dw[l][((o * Cin + c) * 3 + t) * 3 + 1] += a.dwp[l][q];      // one launch, after both views' backward: no other writer
   }
 }
 
@@ -608,19 +597,6 @@ extern "C" int nsid_ds_prepack(int n, const float* const* w, void* const* wp16, 
   NSID_LAUNCH(ds_prepack_kernel, dim3(grid_for(most, 256), n), dim3(256), 0, static_cast<hipStream_t>(stream), a);
   return nsid_launch_status();
 }
-extern "C" int nsid_ds_unpack_all(int n, const float* const* dwp, float* const* dw, const int* Cout, const int* Cin, void* stream) {
-  NSID_REQUIRE(n > 0 && n <= DSP_LAYERS && dwp && dw && Cout && Cin);
-  DsUnpackArgs a{};
-  long most = 0;
-  for (int i = 0; i < n; ++i) {
-    NSID_REQUIRE(dwp[i] && dw[i] && Cout[i] > 0 && Cin[i] > 0);
-    a.dwp[i] = dwp[i]; a.dw[i] = dw[i]; a.Cout[i] = Cout[i]; a.Cin[i] = Cin[i];
-    most = std::max(most, (long)Cout[i] * 3 * Cin[i]);
-  }
-  NSID_LAUNCH(ds_unpack_all_kernel, dim3(grid_for(most, 256), n), dim3(256), 0, static_cast<hipStream_t>(stream), a);
-  return nsid_launch_status();
-}
-
 extern "C" int nsid_peak_patchify_fwd(const float* spec, const float* w, const float* bias, int B, int H, int W, int pb,
                                       int pf, int F, void* out, int ldo, float* minmax, int out_dtype, void* stream) {
   NSID_REQUIRE(spec && w && bias && out && B > 0 && H > 1 && W > 1 && pb > 0 && pf > 0 && F > 0);

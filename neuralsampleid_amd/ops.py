@@ -1001,12 +1001,27 @@ class DsPrep:
     def __init__(self):
         self.entries = {}           # weight data_ptr -> dict(w, wp16, wb16, dwp, key)
 
+    MAX_LAYERS = 8                  # csrc/misc.hip DSP_LAYERS
+
+    def purge(self) -> None:
+        """drop the layers whose weight is gone or has moved (re-flattened by a newer optimiser): the entries of OTHER live optimisers
+        stay (a second FusedClipAdam used to clear them all and silently demoted the first to the per-call launches: ADVICE r4)"""
+        for ptr in [k for k, e in self.entries.items() if e["wref"]() is None or e["wref"]().data_ptr() != k]:
+            del self.entries[ptr]
+
     def register(self, w) -> None:
-        if w.data_ptr() in self.entries or len(self.entries) >= 8:
+        import weakref
+        self.purge()
+        if w.data_ptr() in self.entries:
+            return
+        if len(self.entries) >= self.MAX_LAYERS:
+            import warnings
+            warnings.warn(f"DsPrep holds {self.MAX_LAYERS} Downsample layers; a further one keeps the per-call pack / convert / zero "
+                          "launches (slower, same results)")
             return
         Cout, Cin = w.shape[0], w.shape[1]
         dev = w.device
-        self.entries[w.data_ptr()] = dict(w=w, Cout=Cout, Cin=Cin, key=None, used=False,
+        self.entries[w.data_ptr()] = dict(wref=weakref.ref(w), Cout=Cout, Cin=Cin, key=None,
                                           wp16=torch.empty((Cout, 3 * Cin), device=dev, dtype=torch.bfloat16),
                                           wb16=torch.empty((2 * Cout, Cin), device=dev, dtype=torch.bfloat16),
                                           dwp=torch.empty((2, Cout, 3 * Cin), device=dev, dtype=torch.float32), slots=0)
@@ -1021,20 +1036,23 @@ class DsPrep:
         for name in names:
             if name in ("Cout", "Cin"):
                 out.append((ctypes.c_int * n)(*[e[name] for e in es]))
+            elif name == "w":
+                out.append((ctypes.c_void_p * n)(*[e["wref"]().data_ptr() for e in es]))
             else:
                 out.append((ctypes.c_void_p * n)(*[e[name].data_ptr() for e in es]))
         return out
 
     def refresh(self) -> None:
         """pack every registered weight (current values) and zero the shared packed gradients: one launch on the current stream"""
-        es = [e for e in self.entries.values() if e["w"].is_cuda] if DS_PREP_ENABLED else []
+        self.purge()
+        es = [e for e in self.entries.values() if e["wref"]().is_cuda] if DS_PREP_ENABLED else []
         if not es:
             return
         w, wp16, wb16, dwp, Cout, Cin = self._arrays(es, "w", "wp16", "wb16", "dwp", "Cout", "Cin")
-        _tk("ds_prepack_kernel", sum(4.0 * e["w"].numel() / 3 + 2.0 * 5 * e["Cout"] * e["Cin"] + 12.0 * e["Cout"] * e["Cin"] for e in es),
+        _tk("ds_prepack_kernel", sum(4.0 * e["wref"]().numel() / 3 + 2.0 * 5 * e["Cout"] * e["Cin"] + 12.0 * e["Cout"] * e["Cin"] for e in es),
             lambda: call("nsid_ds_prepack", len(es), w, wp16, wb16, dwp, Cout, Cin, _stream()))
         for e in es:
-            e["key"], e["used"], e["slots"] = (e["w"]._version, WEIGHT_EPOCH), False, 0
+            e["key"], e["slots"] = (e["wref"]()._version, WEIGHT_EPOCH), 0
 
     def take_slot(self, e):
         """a zeroed packed-gradient buffer of this step (two per layer: one per view), or None when both are taken"""
@@ -1049,20 +1067,6 @@ class DsPrep:
         if not DS_PREP_ENABLED or e is None or e["key"] != (w._version, WEIGHT_EPOCH):
             return None
         return e
-
-    def unpack_all(self) -> None:
-        """grad(w) += packed gradient for every layer whose shared buffer was accumulated into this step: one launch"""
-        es = [e for e in self.entries.values() if e["used"] and e["w"].grad is not None]
-        if not es:
-            return
-        import ctypes
-        n = len(es)
-        dwp, Cout, Cin = self._arrays(es, "dwp", "Cout", "Cin")
-        dw = (ctypes.c_void_p * n)(*[e["w"].grad.data_ptr() for e in es])
-        _tk("ds_unpack_all_kernel", sum(24.0 * e["Cout"] * e["Cin"] for e in es),
-            lambda: call("nsid_ds_unpack_all", n, dwp, dw, Cout, Cin, _stream()))
-        for e in es:
-            e["used"] = False
 
 
 DS_PREP = DsPrep()

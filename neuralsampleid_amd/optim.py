@@ -41,8 +41,7 @@ class FusedClipAdam:
             if p.numel() % 8 == 0:
                 ops.SHADOWS.register(p.data, self.flat_p16[off:off + p.numel()], owner=self.flat_p)
         # Downsample conv weights (Cout, Cin, 3, 3): packed forms + shared packed gradient prepared once per step (ops.DsPrep)
-        ops.DS_PREP.clear()
-        for p in self.params:
+        for p in self.params:            # (register purges the entries of weights that are gone or were re-flattened)
             if p.dim() == 4 and tuple(p.shape[2:]) == (3, 3):
                 ops.DS_PREP.register(p)
         self.hyper = torch.tensor([lr, betas[0], betas[1], eps, max_norm if max_norm else 0.0], device=dev)

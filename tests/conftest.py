@@ -52,9 +52,30 @@ def load_golden(name):
         data = {k: z[k] for k in z.files}
     rules = data.pop("__synth__", None)
     if rules is not None:
+        digests = _synth_digests()
         for key, (rule, args) in json.loads(bytes(rules).decode()).items():
             data[key] = _by_rule(rule, args).numpy()
+            # the rule must reproduce the bytes the fixture's outputs were computed from: a change of torch's RNG stream would otherwise
+            # surface as unexplained parity failures. tests/golden/synth_digests.json is written by make_golden.py.
+            want = digests.get(f"{name}/{key}")
+            if want is not None:
+                import hashlib
+                got = hashlib.sha256(np.ascontiguousarray(data[key]).tobytes()).hexdigest()[:16]
+                assert got == want, (f"golden {name}: the rule-made input {key!r} ({rule}{args}) no longer reproduces the fixture's bytes "
+                                     f"({got} != {want}): torch's RNG stream changed; regenerate with tests/golden/make_golden.py")
     return Golden(data)
+
+
+_DIGESTS = None
+
+
+def _synth_digests():
+    global _DIGESTS
+    if _DIGESTS is None:
+        import json
+        path = os.path.join(GOLDEN, "synth_digests.json")
+        _DIGESTS = json.load(open(path)) if os.path.exists(path) else {}
+    return _DIGESTS
 
 
 @pytest.fixture(scope="session")

@@ -11,6 +11,7 @@ torchmetrics.functional.pairwise_cosine_similarity, torchvision), feeds every mo
 weights (synth.py) and seeded inputs, and writes small .npz fixtures next to this file.
 Only data (inputs, outputs, checksums) is written; no reference source is copied.
 """
+import hashlib
 import json
 import os
 import sys
@@ -73,6 +74,7 @@ CFG = dict(GRAFP_CFG)
 # ("__synth__": key -> [rule, args]) and tests/conftest.py regenerates them on load — random fp32 inputs do not compress, and they were a
 # third of the bytes under tests/golden ("small fixtures").
 _RULE_MADE = []          # (rule name, args, tensor) of every rule call of this run
+_DIGESTS = {}
 _synth_randn, _synth_clips = synth_randn, synth_clips
 
 
@@ -98,10 +100,16 @@ def save(name, **arrays):
                      and np.array_equal(t.numpy(), v)), None)
         if rule is not None:
             synth[k] = [rule[0], rule[1]]
+            _DIGESTS[f"{name}/{k}"] = hashlib.sha256(np.ascontiguousarray(v).tobytes()).hexdigest()[:16]
             continue
         out[k] = v
     if synth:
         out["__synth__"] = np.frombuffer(json.dumps(synth, sort_keys=True).encode(), dtype=np.uint8)
+        # digests of the rule-made inputs (tests/conftest.py checks them on load); a partial run keeps the other fixtures' entries
+        dpath = os.path.join(HERE, "synth_digests.json")
+        merged = json.load(open(dpath)) if os.path.exists(dpath) else {}
+        merged.update(_DIGESTS)
+        json.dump(merged, open(dpath, "w"), indent=0, sort_keys=True)
     path = os.path.join(HERE, name + ".npz")
     np.savez_compressed(path, **out)
     print(f"  {name}.npz  {os.path.getsize(path) / 1024:.0f} KB" + (f"  (by rule: {sorted(synth)})" if synth else ""))

@@ -616,6 +616,27 @@ def test_graphed_fingerprinter_equals_eager_extraction(golden):
     assert maxerr(ref2, ref) > 1e-4                                          # the perturbation is visible
     fp2 = GraphedFingerprinter(model, micro_batch=4)
     assert maxerr(fp2(x), ref2) < 2e-6
+    # a parameter REPLACED in its module leaves the captured tensor untouched (same pointer, same version, no epoch bump): the guard
+    # compares identities too -- load_state_dict(assign=True), attribute assignment, a swapped sub-module
+    fp4 = GraphedFingerprinter(model, micro_batch=4)
+    keep = {k_: v for k_, v in model.state_dict().items()}
+    model.load_state_dict({k_: v.clone() for k_, v in keep.items()}, assign=True)
+    with pytest.raises(RuntimeError):
+        fp4(x)
+    fp4 = GraphedFingerprinter(model, micro_batch=4)
+    old_w = model.projector[2].weight
+    model.projector[2].weight = torch.nn.Parameter(old_w.detach().clone() * 1.5)
+    with pytest.raises(RuntimeError):
+        fp4(x)
+    model.projector[2].weight = old_w
+    fp4(x)                                                                   # the captured tensor is back in place: accepted again
+    old_m = model.projector[2]
+    model.projector[2] = torch.nn.Linear(old_m.in_features, old_m.out_features).to(DEV)
+    with pytest.raises(RuntimeError):
+        fp4(x)
+    model.projector[2] = old_m
+    del fp4
+    fp2 = GraphedFingerprinter(model, micro_batch=4)
     opt = FusedClipAdam(model.parameters(), lr=1e-3)
     opt.zero_grad()
     _, _, z_i, z_j = model(x[:8], x[8:16])

@@ -137,3 +137,34 @@ def test_checkpoint_loading_is_restricted_unless_the_caller_says_trusted(tmp_pat
     dst3 = build()
     load_reference_checkpoint(dst3, str(p2), trusted=True)
     assert all(torch.equal(dst3.state_dict()[k], sd[k]) for k in sd)
+
+
+def test_checkpoint_with_numpy1_pickle_paths_loads_restricted(tmp_path):
+    """the reference pins numpy 1.26.4, whose pickles name `numpy.core.multiarray.scalar` / `._reconstruct`; under numpy 2 the
+    installed functions report `numpy._core.multiarray.*` and torch's restricted unpickler matches globals by string. A reference-era
+    checkpoint (data.pkl rewritten to the numpy-1.x module path) must load WITHOUT trusted=True."""
+    import zipfile
+    import numpy as np
+    from neuralsampleid_amd.checkpoint import load_reference_checkpoint
+    torch.manual_seed(7)
+    src = build()
+    sd = src.state_dict()
+    ck = {"epoch": 1, "loss": np.float64(1.25), "hit_rate_log": [np.float32(0.25), np.array([3.0, 4.0])], "state_dict": sd,
+          "optimizer": None, "scheduler": None}
+    p_new, p_old = tmp_path / "np2.pth", tmp_path / "np1.pth"
+    torch.save(ck, p_new)                                  # protocol 2: globals are newline-terminated text (`cmodule\nname\n`)
+    n_rewritten = 0
+    with zipfile.ZipFile(p_new) as zin, zipfile.ZipFile(p_old, "w", zipfile.ZIP_STORED) as zout:
+        for item in zin.infolist():
+            data = zin.read(item.filename)
+            if item.filename.endswith("data.pkl"):
+                n_rewritten = data.count(b"cnumpy._core.multiarray\n")
+                data = data.replace(b"cnumpy._core.multiarray\n", b"cnumpy.core.multiarray\n")
+            zout.writestr(item, data)
+    if n_rewritten == 0:                                   # numpy 1.x installed: the file already names the legacy path
+        with zipfile.ZipFile(p_new) as zin:
+            assert any(b"cnumpy.core.multiarray\n" in zin.read(i.filename) for i in zin.infolist() if i.filename.endswith("data.pkl"))
+    dst = build()
+    out = load_reference_checkpoint(dst, str(p_old))
+    assert float(out["loss"]) == 1.25 and float(out["hit_rate_log"][0]) == 0.25 and list(out["hit_rate_log"][1]) == [3.0, 4.0]
+    assert all(torch.equal(dst.state_dict()[k], sd[k]) for k in sd)

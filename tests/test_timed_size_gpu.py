@@ -74,7 +74,8 @@ TOL_DEEP = {"eval_max_dz": 6e-6, "eval_dloss": 3e-6, "eval_h_clip_norm_rel": 6e-
             "dloss": 6e-6, "max_dz": 3e-5, "h_clip_norm_rel": 2e-5, "gnorm_rel": 5e-3, "bn_norm_rel": 1e-7,
             "grad_late": 5e-5, "grad_early": 3e-2, "grad_norm_late": 4e-4, "grad_norm_worst": 1.3e-2}
 # the same step in bf16 storage against the fp32 reference: |dloss| 0.027, min cos z 0.944, global gradient norm 10 %
-TOL_DEEP16 = {"dloss": 0.08, "min_cos_z": 0.83, "gnorm_rel": 0.3}
+# (min cos z: 1.5x the measured distance from 1, like TOL16 -- at 0.83 nobody would have noticed it breaking: VERDICT r4)
+TOL_DEEP16 = {"dloss": 0.08, "min_cos_z": 0.92, "gnorm_rel": 0.3}
 LATE = ("encoder.backbone.26", "encoder.proj", "projector")
 
 
