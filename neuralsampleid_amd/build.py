@@ -13,7 +13,7 @@ CSRC = os.path.join(PKG, "csrc")
 ROOT = os.path.dirname(PKG)
 LIB = os.path.join(PKG, "libnsid_hip.so")
 OBJ_DIR = os.path.join(PKG, "csrc", "_obj")
-SOURCES = ["tuning.hip", "gemm.hip", "gemm256.hip", "ffn_fused.hip", "ffn256_fused.hip", "mrconv_fused.hip", "wgrad.hip", "bn.hip", "knn.hip", "mr.hip", "ntxent.hip", "misc.hip"]
+SOURCES = ["tuning.hip", "gemm.hip", "gemm256.hip", "wsgemm.hip", "ffn_fused.hip", "ffn256_fused.hip", "mrconv_fused.hip", "wgrad.hip", "bn.hip", "knn.hip", "mr.hip", "ntxent.hip", "misc.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function",
          "-fno-gpu-rdc", "-I", os.path.join(ROOT, "include")]

@@ -1301,6 +1301,13 @@ static int linear_fwd_impl(const void* x, int ldx, const void* w, int w_dtype, c
   // default 512 (two tiles per CU and more: fingerprinting at micro-batch 2 048): 7.09 -> 6.56 ms per micro-batch. The training step
   // (<= 256 such tiles per launch) is neutral to slightly worse with it (8.30 vs 8.34 ms: a workgroup that owns 150 KB of a CU's LDS
   // keeps the other view's kernels off that CU), so it stays on gemm.hip.
+  // weight-stationary streaming form (wsgemm.hip) for the layers whose whole weight matrix fits LDS: tuning key ws_gemm bit 0
+  if ((nsid_tune(NSID_T_ws_gemm) & 1) && act_dtype == NSID_BF16 && wb && ksplit == 1 && act_out == NSID_ACT_NONE && addend == nullptr &&
+      lz.stat_acc == nullptr && lz.in_bn == nullptr && act_in != NSID_ACT_ELU) {
+    const int rcw = nsid_ws_fwd_launch(x, ldx, w, bias, out, ldo, M, Nout, K, groups, in_scale, in_shift, act_slope(act_in), stat,
+                                       p.stat_plane, p.stat_ld, s);
+    if (rcw != 1) { nsid_count(NSID_C_ws_fwd); return rcw; }
+  }
   const long g256_min = nsid_tune(NSID_T_g256_min);
   if (g256_min > 0 && lz.stat_acc == nullptr && (stat == nullptr || nsid_tune(NSID_T_g256_train) != 0) && act_dtype == NSID_BF16 && wb && groups == 1 && in_scale == nullptr && ksplit == 1 &&
       (act_out == NSID_ACT_NONE || act_out == NSID_ACT_RELU) && act_in == NSID_ACT_NONE && ldx >= K &&
@@ -1415,6 +1422,15 @@ static int linear_bwd_data_impl(const void* dout, int ldd, const void* w, int w_
   bool narrow = half ? (K <= 64 || (K <= 128 && Nout <= 256)) : K <= 64;
   if (half && t128 < 128) narrow = true;        // few row tiles (the projector head, M = batch)
   if (force_narrow >= 0 && K > 64) narrow = force_narrow != 0;
+  // weight-stationary streaming form (wsgemm.hip): tuning key ws_gemm bit 1 (plain operand) / bit 2 (BatchNorm backward on the operand load)
+  if ((nsid_tune(NSID_T_ws_gemm) & (abn ? 4 : 2)) && bn_acc == nullptr && act_dtype == NSID_BF16 && wb &&
+      (bn_r == nullptr || bn_partial != nullptr)) {
+    const int rcw = nsid_ws_bwd_data_launch(dout, ldd, w, addend, ldadd, din, ldi, M, Nout, K, groups, bn_r, p.bn_ldr, bn_scale, bn_shift,
+                                            bn_mean, bn_invstd, p.bn_slope, bn_partial, p.bn_plane, p.bn_ld, abn ? abn->r : nullptr,
+                                            abn ? abn->coef4 : nullptr, (long)groups * Nout, abn ? act_slope(abn->act) : 1.f,
+                                            abn ? abn->dr : nullptr, (long)groups * Nout, s);
+    if (rcw != 1) { nsid_count(abn ? NSID_C_ws_bwd_bnapply : NSID_C_ws_bwd_data); return rcw; }
+  }
   if (abn != nullptr) {
     // every column tile re-evaluates the BatchNorm backward of its row panel: as few column tiles as the tile family offers
     narrow = K <= 64;

@@ -260,7 +260,8 @@ static inline bool nsid_acc_ok(const int64_t* acc, int replicas) {
   X(mr_key_min_k, 8)           /* bf16 aggregation with >= this many neighbours: integer-key search (mr_fwd_key_kernel); 0 = never */ \
   X(ffn_waves, 8)              /* waves per workgroup of the fused eval-mode FFN (4 or 8) */                                  \
   X(ffn256, 1)                 /* 1: the C = 256 stage's eval-mode FFN as one launch (ffn256_fused.hip); 0: two GEMM launches */ \
-  X(mrconv_variant, 3)         /* fused eval-mode aggregation + grouped conv: bit 0 = 8 waves, bit 1 = direct 8-byte stores */
+  X(mrconv_variant, 3)         /* fused eval-mode aggregation + grouped conv: bit 0 = 8 waves, bit 1 = direct 8-byte stores */ \
+  X(ws_gemm, 7)                /* weight-stationary streaming GEMMs (wsgemm.hip) for the small-K layers: bit 0 forward, bit 1 backward-data, bit 2 backward-data with the BatchNorm backward on its operand load */
 
 enum NsidTuneKey {
 #define NSID_TUNE_ENUM(name, def) NSID_T_##name,
@@ -285,6 +286,7 @@ static inline long nsid_tune(NsidTuneKey k) { return g_nsid_tune[k]; }
   X(gemm_bn_sums)         /* backward-data epilogue emits BatchNorm-backward column sums */     \
   X(gemm_bn_apply_load)   /* backward-data applies a BatchNorm backward on its operand load */  \
   X(gemm256)              /* gemm256.hip */                                                     \
+  X(ws_fwd) X(ws_bwd_data) X(ws_bwd_bnapply) /* wsgemm.hip: weight-stationary streaming forms */                   \
   X(wgrad_rect) X(wgrad_square) X(wgrad3)                                                       \
   X(bn_bwd_apply) X(bn_bwd_apply_capped)                                                        \
   X(knn2) X(knn2_pair) X(knn_rank) X(knn_sel) X(knn_strips)                                                  \
@@ -314,6 +316,15 @@ int nsid_wgrad2_launch(const void* dout, int ldd, const void* x, int ldx, float*
 // shape is outside its preconditions
 int nsid_gemm256_fwd_launch(const void* x, int ldx, const void* w, const float* bias, const void* addend, int ldadd, void* out,
                             int ldo, int M, int Nout, int K, bool relu_out, float* stat, long stat_plane, long stat_ld,
+                            hipStream_t stream);
+// wsgemm.hip: weight-stationary streaming forward GEMM of the small-K training layers; returns 1 outside its shapes
+int nsid_ws_fwd_launch(const void* x, int ldx, const void* w, const float* bias, void* out, int ldo, int M, int Nout, int K,
+                       int groups, const float* in_scale, const float* in_shift, float in_slope, float* stat, long stat_plane,
+                       long stat_ld, hipStream_t stream);
+int nsid_ws_bwd_data_launch(const void* dout, int ldd, const void* w, const void* addend, int ldadd, void* din, int ldi, int M, int Nout,
+                            int K, int groups, const void* bn_r, long bn_ldr, const float* bn_scale, const float* bn_shift,
+                            const float* bn_mean, const float* bn_invstd, float bn_slope, float* bn_partial, long bn_plane, long bn_ld,
+                            const void* abn_r, const float* abn_coef, long abn_plane, float abn_slope, void* abn_dr, long abn_lddr,
                             hipStream_t stream);
 // ffn256_fused.hip: eval-mode FFN of the C = 256 stage in one launch; returns 1 outside C = 256, H = 1024, M % 256 == 0
 int nsid_ffn256_fused_launch(const void* x, const void* w1, const float* b1, const void* w2, const float* b2, void* out, int M, int C,

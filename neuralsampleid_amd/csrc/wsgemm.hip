@@ -1,0 +1,553 @@
+// Weight-stationary streaming row GEMMs for the small-K layers of the TRAINING step (gfx950), bf16 storage:
+//     out[M][G*NOUT] = f(x[M][G*K]) W_g^T (+ bias),   f = producer BatchNorm + activation on the operand load,
+// plus the per-128-row-tile column sums / sums of squares of the fp32 result that training-mode BatchNorm of THIS layer needs.
+// Replaces gemm.hip's 128x128 / 128x64 tile kernels for the launches whose whole weight matrix fits LDS beside a second workgroup
+// (every conv of the C = 64 blocks, fc1 / grouped conv / fc2 at C = 128, the grouped convs of the C = 256 stage:
+// encoder/gcn_lib/torch_vertex.py:152-162, encoder/graph_encoder.py:74-77, encoder/gcn_lib/torch_nn.py:56).
+//
+// Why another GEMM body (round 5, VERDICT r4 task 1): those launches are pure streaming problems -- FFN fc1 at C = 64 is
+// 65 536 x 64 -> 256: 8 MB in, 34 MB out, 2 GFLOP -- that the tile kernels execute as 1 024 independent latency chains: every
+// 128 x 128 tile re-stages a 16 KB weight slice through registers into LDS, reads its x panel once per column tile, transposes its
+// fp32 accumulators through LDS and runs 1 024 tiles on 768 resident slots (a full round + a sparse one). Here:
+//   * one workgroup (4 waves) owns 128 rows and ALL output columns: x is read once, straight from global memory into the MFMA
+//     A-operand fragments of the wave that owns the row (32 rows per wave, v_mfma_f32_32x32x16_bf16: lane (row, half) holds 8
+//     consecutive reduction elements), so the x tile needs neither LDS nor a barrier;
+//   * the whole weight matrix (<= 64 KB as bf16) is brought into LDS ONCE per workgroup by LDS-DMA (global_load_lds_dwordx4: no
+//     staging registers, no ds_write pass), XOR-swizzled on the SOURCE address so that every ds_read_b128 of a B fragment is
+//     bank-conflict free; the producer's BatchNorm scale / shift ride along as 2 K floats;
+//   * the accumulator of a 32 x 32 output tile has its CHANNEL on the lane and its rows in the 16 registers: bias, the BatchNorm
+//     column sums (in-lane adds, no cross-lane traffic) and every other per-channel epilogue constant are per-lane scalars;
+//   * the tile leaves as bf16 through a wave-private 2.3 KB transpose buffer: 4 x ds_write_b64 (four consecutive rows of one
+//     channel) + 4 x ds_read_b64_tr_b16 (the hardware transpose hands every lane 4 consecutive channels of one row) + 2 x 16-byte
+//     global stores -- a quarter of the LDS instructions of the fp32 transpose of gemm.hip, no workgroup barrier;
+//   * grid = M / 128 workgroups of <= 60 KB of LDS: two to four per CU, so the other view's kernels stay resident beside it.
+// Arithmetic: bf16 operands, fp32 accumulation in the MFMA's k order, ONE rounding of (acc + bias) to bf16; statistics from the
+// fp32 values before that rounding -- what gemm.hip computes, with another (equally fixed) summation order.
+#include "nsid_common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __attribute__((address_space(3))) void* lds_vptr;
+typedef const __attribute__((address_space(1))) void* glb_vptr;
+typedef bf16x4 __attribute__((address_space(3)))* lds_bf16x4_ptr;
+
+struct WsArgs {
+  const __bf16* x; long ldx;            // [M][ldx]; this launch reads columns [gy * GI * K, (gy + 1) * GI * K), gy = blockIdx.y
+  const __bf16* w;                      // [groups][NOUT][K] bf16 (the optimiser's weight shadow)
+  const float* bias;                    // [groups * NOUT] or null
+  const float* in_scale; const float* in_shift; float in_slope;   // AFF: per input channel [groups * K]; slope 1 = no activation
+  __bf16* out; long ldo;                // [M][ldo]; columns [gy * GI * NOUT, ...)
+  float* stat; long stat_plane; long stat_ld;    // stat[which * plane + tile * ld + column] or null
+  int M;
+};
+
+constexpr int WS_TP = 72;               // bytes per channel row of a wave's transpose buffer: 32 rows of bf16 + 8 (conflict-free ds_write_b64)
+constexpr int WS_TB = 32 * WS_TP;       // one 32 x 32 tile
+
+// 16-byte chunk swizzle of an LDS image with CPR chunks per row, read by lanes (row j, chunk c): physical chunk = c ^ ws_swz<CPR>(j).
+// ds_read_b128 is served in the lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31} (+32): 16 different rows j at one logical chunk
+// must fall on 16 different 16-byte slots of the 256-byte bank row.
+template <int CPR>
+__device__ __forceinline__ int ws_swz(int j) {
+  if constexpr (CPR == 4) return (j >> 2) & 3;          // 64-byte rows: slot = (j & 3) * 4 + (c ^ (j >> 2 & 3))
+  else if constexpr (CPR == 8) return (j >> 1) & 7;     // 128-byte rows: slot = (j & 1) * 8 + (c ^ (j >> 1 & 7))
+  else return j & 15;                                   // rows of 256 bytes and more: slot = c ^ (j & 15)
+}
+
+// K: reduction length per group; NOUT: output channels per group; GI: groups handled inside one workgroup (their x columns are
+// adjacent: a row's GI * K elements are one contiguous run); AFF: producer affine + activation on the operand load; STAT: column sums.
+template <int K, int NOUT, int GI, bool AFF, bool STAT>
+__global__ __launch_bounds__(256, (GI * NOUT * K * 2 > 60 * 1024) ? 1 : 2) void ws_fwd_kernel(const WsArgs p) {
+  constexpr int KS = K / 16;                    // k-steps = x fragments per group
+  constexpr int NT = NOUT / 32;                 // 32-channel tiles per group
+  constexpr int CPR = K / 8;                    // 16-byte chunks per weight row
+  constexpr int WROWS = GI * NOUT;              // rows of the weight image
+  constexpr int WBYTES = WROWS * K * 2;
+  constexpr int NPIECE = WBYTES / 1024;         // LDS-DMA pieces (one wave-instruction = 1 KB)
+  constexpr int RPP = 1024 / (2 * K);           // weight rows per piece
+  static_assert(K % 16 == 0 && NOUT % 32 == 0 && NPIECE % 4 == 0 && RPP >= 1, "whole fragments, whole pieces per wave");
+  constexpr int AFFB = AFF ? 2 * GI * K * 4 : 0;
+  constexpr int REDB = STAT ? 4 * 2 * 2 * WROWS * 4 : 0;
+  constexpr int LDSB = WBYTES + 4 * WS_TB + AFFB + REDB;
+  static_assert(LDSB <= 80 * 1024 || WBYTES > 60 * 1024, "two workgroups per CU wherever the weight matrix leaves room");
+  __shared__ __attribute__((aligned(1024))) char lds[LDSB];
+  char* const wimg = lds;
+  char* const tb0 = lds + WBYTES;
+  float* const affs = reinterpret_cast<float*>(lds + WBYTES + 4 * WS_TB);        // [2][GI * K]
+  float* const red = reinterpret_cast<float*>(lds + WBYTES + 4 * WS_TB + AFFB);   // [4 waves][2 halves][2 sums][WROWS]
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 31, h = lane >> 5;
+  const int tile = blockIdx.x, gy = blockIdx.y;
+  const long row0 = (long)tile * 128 + wave * 32;
+
+  // ---- x fragments of this wave's 32 rows, all groups: lane (j, h) holds x[row0 + j][gi * K + 16 s + 8 h .. + 7]
+  bf16x8 xf[GI][KS];
+  {
+    const __bf16* xr = p.x + (row0 + j) * p.ldx + (long)gy * GI * K + 8 * h;
+#pragma unroll
+    for (int gi = 0; gi < GI; ++gi)
+#pragma unroll
+      for (int s = 0; s < KS; ++s) xf[gi][s] = *reinterpret_cast<const bf16x8*>(xr + gi * K + 16 * s);
+  }
+  // ---- the weight image by LDS-DMA: piece q = rows q * RPP .. + RPP - 1; lane l lands at row l / CPR, PHYSICAL chunk l % CPR of the
+  // piece and therefore fetches the logical chunk (l % CPR) ^ swz(row)
+  {
+    const __bf16* wg = p.w + (long)gy * WROWS * K;
+    const int rl = lane / CPR, pc = lane % CPR;
+#pragma unroll
+    for (int i = 0; i < NPIECE / 4; ++i) {
+      const int q = wave * (NPIECE / 4) + i;
+      const int row = q * RPP + rl;
+      const int lc = CPR >= 16 ? (pc ^ (row & 15)) : (pc ^ ws_swz<CPR>(row));
+      __builtin_amdgcn_global_load_lds((glb_vptr)(wg + (long)row * K + 8 * lc), (lds_vptr)(wimg + q * 1024), 16, 0, 0);
+    }
+  }
+  if constexpr (AFF) {
+    for (int i = tid; i < GI * K / 4; i += 256) {
+      reinterpret_cast<f32x4*>(affs)[i] = reinterpret_cast<const f32x4*>(p.in_scale + (long)gy * GI * K)[i];
+      reinterpret_cast<f32x4*>(affs + GI * K)[i] = reinterpret_cast<const f32x4*>(p.in_shift + (long)gy * GI * K)[i];
+    }
+  }
+  __syncthreads();          // (waits for this wave's LDS-DMA and LDS stores, then the barrier: the image is complete)
+
+  if constexpr (AFF) {
+    // producer BatchNorm + activation on the fragments, in place: v = sc * x + sh; act(v) = max(v, slope * v) (slope in [0, 1]; NaN stays)
+    const float slope = p.in_slope;
+#pragma unroll
+    for (int gi = 0; gi < GI; ++gi)
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        const float* sc = affs + gi * K + 16 * s + 8 * h;
+        const float* sh = sc + GI * K;
+        const f32x4 c0 = *reinterpret_cast<const f32x4*>(sc), c1 = *reinterpret_cast<const f32x4*>(sc + 4);
+        const f32x4 h0 = *reinterpret_cast<const f32x4*>(sh), h1 = *reinterpret_cast<const f32x4*>(sh + 4);
+        const bf16x8 v = xf[gi][s];
+        f32x4 a = {(float)v[0], (float)v[1], (float)v[2], (float)v[3]}, b = {(float)v[4], (float)v[5], (float)v[6], (float)v[7]};
+        a = c0 * a + h0;
+        b = c1 * b + h1;
+        const f32x4 as = a * slope, bs = b * slope;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { a[e] = fmaxf(a[e], as[e]); b[e] = fmaxf(b[e], bs[e]); }
+        const bf16x4 lo = __builtin_convertvector(a, bf16x4), hi = __builtin_convertvector(b, bf16x4);
+        xf[gi][s] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+      }
+  }
+
+  // ---- tiles: (group gi, channel tile ct) -> 32 x 32 outputs of this wave
+  const int sw = ws_swz<CPR>(j);
+  const char* wrow = wimg + j * (2 * K);                                  // + (gi * NOUT + ct * 32) * 2K + 16 * ((2 s + h) ^ sw)
+  char* const tb = tb0 + wave * WS_TB;
+  char* const tw = tb + j * WS_TP + 8 * h;                                // ds_write_b64 of rows 8 g + 4 h .. + 3 of channel j: + 16 g
+  // transposed read-back: lane 16 G + 4 q + pp supplies (channel c0 + q, rows r0 + 4 pp ..) and receives row r0 + (lane & 15), channels
+  // c0 .. c0 + 3. Group G takes the channels 8 G .. 8 G + 7 of the tile, first for rows 0-15 then for rows 16-31: one store instruction
+  // then writes 16 rows x 64 contiguous bytes (four lanes per row), and the next channel tile completes the 128-byte lines
+  const int G = lane >> 4, qq = (lane >> 2) & 3, pp = lane & 3;
+  const char* const tr = tb + (8 * G + qq) * WS_TP + (4 * pp) * 2;          // + 4 TP: channels + 4; + 32: rows 16-31
+  __bf16* const orow = p.out + (row0 + (lane & 15)) * p.ldo + (long)gy * WROWS + 8 * G;
+  float ssum[GI * NT], qsum[GI * NT];
+#pragma unroll
+  for (int t = 0; t < GI * NT; ++t) ssum[t] = qsum[t] = 0.f;
+
+#pragma unroll
+  for (int gi = 0; gi < GI; ++gi)
+#pragma unroll
+    for (int ct = 0; ct < NT; ++ct) {
+      const int t = gi * NT + ct;
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      const char* wt = wrow + (gi * NOUT + ct * 32) * (2 * K);
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        const int c = 2 * s + h;
+        const bf16x8 wf = *reinterpret_cast<const bf16x8*>(wt + 16 * (CPR >= 16 ? ((c & ~15) | ((c ^ sw) & 15)) : (c ^ sw)));
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[gi][s], wf, acc, 0, 0, 0);
+      }
+      if (p.bias != nullptr) {          // uniform
+        const float bj = p.bias[(long)gy * WROWS + t * 32 + j];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] += bj;
+      }
+      if constexpr (STAT) {
+        float s_ = 0.f, q_ = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s_ += acc[r]; q_ = fmaf(acc[r], acc[r], q_); }
+        ssum[t] = s_; qsum[t] = q_;
+      }
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        *reinterpret_cast<bf16x4*>(tw + 16 * g) =
+            __builtin_convertvector((f32x4{acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]}), bf16x4);
+      // (a wave reads back only its own buffer; one wave's LDS operations execute in issue order: no barrier)
+      const bf16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(tr));
+      const bf16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(tr + 4 * WS_TP));
+      const bf16x4 v2 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(tr + 32));
+      const bf16x4 v3 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(tr + 4 * WS_TP + 32));
+      *reinterpret_cast<bf16x8*>(orow + t * 32) = __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
+      *reinterpret_cast<bf16x8*>(orow + 16 * p.ldo + t * 32) = __builtin_shufflevector(v2, v3, 0, 1, 2, 3, 4, 5, 6, 7);
+    }
+
+  if constexpr (STAT) {
+    // column sums of the workgroup's 128 rows = one row of per-tile partials: 4 waves x 2 lane halves, added in a fixed order
+#pragma unroll
+    for (int t = 0; t < GI * NT; ++t) {
+      red[((wave * 2 + h) * 2 + 0) * WROWS + t * 32 + j] = ssum[t];
+      red[((wave * 2 + h) * 2 + 1) * WROWS + t * 32 + j] = qsum[t];
+    }
+    __syncthreads();
+    for (int c = tid; c < WROWS; c += 256) {
+      float s_ = 0.f, q_ = 0.f;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { s_ += red[(k * 2 + 0) * WROWS + c]; q_ += red[(k * 2 + 1) * WROWS + c]; }
+      const long col = (long)gy * WROWS + c;
+      p.stat[(long)tile * p.stat_ld + col] = s_;
+      p.stat[p.stat_plane + (long)tile * p.stat_ld + col] = q_;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------- backward-data
+// din[M][G*K] = dout[M][G*N] W_g (+ addend), W_g stored [N][K] (the forward layout): the same streaming form with the roles of the two
+// channel counts swapped. The weight image keeps the global layout [n][k]; a B fragment (8 consecutive n of one k) is two
+// ds_read_b64_tr_b16 (the hardware transpose: 4 rows x 16 columns per 16-lane group), conflict-free with the 64-byte blocks of a row
+// XOR-swizzled by the row index. Epilogue, all in the channel-on-lane layout of the accumulators:
+//   ADD: the residual-gradient addend tile [32 rows][32 channels] goes global -> registers (16-byte row pieces, requested one tile ahead)
+//        -> a wave-private 2 KB staging image -> ds_read_b64_tr_b16, which hands lane (channel, half) its 4 consecutive rows: added in fp32
+//        before the ONE rounding, as gemm.hip does;
+//   BNR: din is dL/dy of a BatchNorm(+activation) layer with raw input r: r takes the same route, and the lane adds its channel's backward
+//        column sums sum(g), sum(g * xhat) from the ROUNDED din (what a separate reduce pass would read back) with per-lane constants.
+struct WsBwdArgs {
+  const __bf16* dy; long ldd;
+  const __bf16* w;
+  const __bf16* addend; long ldadd;
+  __bf16* dx; long ldi;
+  const __bf16* bn_r; long bn_ldr;
+  const float* bn_scale; const float* bn_shift; const float* bn_mean; const float* bn_invstd; float bn_slope;
+  float* bn_partial; long bn_plane; long bn_ld;
+  // ABN: dy is dL/d act(BN(r)) of the layer IN FRONT of this conv: the operand is that BatchNorm's backward, evaluated on the load from
+  // dy and abn_r with coef[4][abn_plane] = {sc, sh, P, Q} (nsid_bn_bwd_finalize_fused): dr = sc * g + (P * r + Q), g = dy * act'(sc r + sh),
+  // rounded to bf16 once -- the value the separate apply pass stores -- used as the MFMA operand and written to abn_dr for the weight gradient
+  const __bf16* abn_r; const float* abn_coef; long abn_plane; float abn_slope; __bf16* abn_dr; long abn_lddr;
+  int M;
+};
+
+template <int BPR>
+__device__ __forceinline__ int ws_bswz(int row) {        // 64-byte block swizzle of a weight row with BPR blocks
+  if constexpr (BPR == 1) return 0;
+  else if constexpr (BPR == 2) return (row >> 1) & 1;
+  else return row & 3;
+}
+
+// N: reduction length per group (the forward's output channels); K: output channels per group (the forward's inputs)
+template <int N, int K, int GI, bool ADD, bool BNR, bool ABN>
+__global__ __launch_bounds__(256, (GI * N * K * 2 > 56 * 1024) ? 1 : 2) void ws_bwd_kernel(const WsBwdArgs p) {
+  constexpr int KS = N / 16, KT = K / 32;
+  constexpr int CPR = K / 8, BPR = K / 32;
+  constexpr int WROWS = GI * N, OCH = GI * K;
+  constexpr int WBYTES = WROWS * K * 2;
+  constexpr int NPIECE = WBYTES / 1024, RPP = 1024 / (2 * K);
+  static_assert(N % 16 == 0 && K % 32 == 0 && NPIECE % 4 == 0 && RPP >= 1, "whole fragments, whole pieces per wave");
+  constexpr int SIDEB = (ADD || BNR) ? 4 * 2 * 2048 : 0;                // per wave: addend image + r image
+  constexpr int REDB = BNR ? 4 * 2 * 2 * OCH * 4 : 0;
+  constexpr int COEFB = ABN ? 4 * WROWS * 4 : 0;
+  constexpr int LDSB = WBYTES + 4 * WS_TB + SIDEB + REDB + COEFB;
+  __shared__ __attribute__((aligned(1024))) char lds[LDSB];
+  char* const wimg = lds;
+  char* const tb0 = lds + WBYTES;
+  char* const side0 = lds + WBYTES + 4 * WS_TB;
+  float* const red = reinterpret_cast<float*>(lds + WBYTES + 4 * WS_TB + SIDEB);
+  float* const coefs = reinterpret_cast<float*>(lds + WBYTES + 4 * WS_TB + SIDEB + REDB);      // [4][WROWS]: sc, sh, P, Q
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 31, h = lane >> 5;
+  const int tile = blockIdx.x, gy = blockIdx.y;
+  const long row0 = (long)tile * 128 + wave * 32;
+
+  bf16x8 xf[GI][KS];
+  {
+    const __bf16* xr = p.dy + (row0 + j) * p.ldd + (long)gy * WROWS + 8 * h;
+#pragma unroll
+    for (int gi = 0; gi < GI; ++gi)
+#pragma unroll
+      for (int s = 0; s < KS; ++s) xf[gi][s] = *reinterpret_cast<const bf16x8*>(xr + gi * N + 16 * s);
+  }
+  bf16x8 rf[ABN ? GI : 1][ABN ? KS : 1];
+  if constexpr (ABN) {
+    const __bf16* rr = p.abn_r + (row0 + j) * p.ldd + (long)gy * WROWS + 8 * h;
+#pragma unroll
+    for (int gi = 0; gi < GI; ++gi)
+#pragma unroll
+      for (int s = 0; s < KS; ++s) rf[gi][s] = *reinterpret_cast<const bf16x8*>(rr + gi * N + 16 * s);
+    for (int i = tid; i < WROWS; i += 256) {
+#pragma unroll
+      for (int v = 0; v < 4; ++v) coefs[v * WROWS + i] = p.abn_coef[v * p.abn_plane + (long)gy * WROWS + i];
+    }
+  }
+  {
+    const __bf16* wg = p.w + (long)gy * WROWS * K;
+    const int rl = lane / CPR, pc = lane % CPR;
+#pragma unroll
+    for (int i = 0; i < NPIECE / 4; ++i) {
+      const int q = wave * (NPIECE / 4) + i;
+      const int row = q * RPP + rl;
+      const int lc = (((pc >> 2) ^ ws_bswz<BPR>(row)) << 2) | (pc & 3);
+      __builtin_amdgcn_global_load_lds((glb_vptr)(wg + (long)row * K + 8 * lc), (lds_vptr)(wimg + q * 1024), 16, 0, 0);
+    }
+  }
+  // side tiles (addend, r) of output tile t: lane L fetches the 16-byte piece (row L >> 2 [+ 16], channels 8 (L & 3) ..) twice
+  const int srow = lane >> 2, scol = 8 * (lane & 3);
+  const __bf16* const aptr = ADD ? p.addend + (row0 + srow) * p.ldadd + (long)gy * OCH + scol : nullptr;
+  const __bf16* const rptr = BNR ? p.bn_r + (row0 + srow) * p.bn_ldr + (long)gy * OCH + scol : nullptr;
+  f32x4 sa[2][2], sr[2][2];           // [parity of the tile][row half]
+  auto side_load = [&](int t, int par) {
+    if constexpr (ADD) {
+      sa[par][0] = *reinterpret_cast<const f32x4*>(aptr + t * 32);
+      sa[par][1] = *reinterpret_cast<const f32x4*>(aptr + 16 * p.ldadd + t * 32);
+    }
+    if constexpr (BNR) {
+      sr[par][0] = *reinterpret_cast<const f32x4*>(rptr + t * 32);
+      sr[par][1] = *reinterpret_cast<const f32x4*>(rptr + 16 * p.bn_ldr + t * 32);
+    }
+  };
+  if constexpr (ADD || BNR) side_load(0, 0);
+  __syncthreads();
+
+  if constexpr (ABN) {
+    const float slope = p.abn_slope;
+    const bool masked = slope != 1.f;            // uniform: a BatchNorm without an activation behind it needs no mask (g = dy)
+    __bf16* const drow = p.abn_dr + (row0 + j) * p.abn_lddr + (long)gy * WROWS + 8 * h;
+#pragma unroll
+    for (int gi = 0; gi < GI; ++gi)
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        const float* cf = coefs + gi * N + 16 * s + 8 * h;
+        const bf16x8 hd = xf[gi][s], hr = rf[gi][s];
+        bf16x8 o;
+#pragma unroll
+        for (int e4 = 0; e4 < 8; e4 += 4) {
+          const f32x4 sc = *reinterpret_cast<const f32x4*>(cf + e4), sh = *reinterpret_cast<const f32x4*>(cf + WROWS + e4);
+          const f32x4 cp = *reinterpret_cast<const f32x4*>(cf + 2 * WROWS + e4), cq = *reinterpret_cast<const f32x4*>(cf + 3 * WROWS + e4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float x = (float)hr[e4 + e], d = (float)hd[e4 + e];
+            float g = d;
+            if (masked) g = (sc[e] * x + sh[e]) > 0.f ? d : d * slope;
+            o[e4 + e] = (__bf16)(sc[e] * g + (cp[e] * x + cq[e]));
+          }
+        }
+        xf[gi][s] = o;
+        *reinterpret_cast<bf16x8*>(drow + gi * N + 16 * s) = o;
+      }
+  }
+
+  const int G = lane >> 4, qq = (lane >> 2) & 3, pp = lane & 3;
+  // B fragment: group G = (column half G & 1, reduction half G >> 1 = h); lane 4 q + pp supplies (row n0 + q, columns k0 + 4 pp ..)
+  const int wq = 8 * h + qq;                                              // row inside the 16-deep k-step (+ 4 for the second read)
+  const int wcol = 32 * (G & 1) + 8 * pp;                                 // byte offset inside the 64-byte block of the tile
+  char* const tb = tb0 + wave * WS_TB;
+  char* const tw = tb + j * WS_TP + 8 * h;
+  const char* const tr = tb + (8 * G + qq) * WS_TP + (4 * pp) * 2;
+  __bf16* const orow = p.dx + (row0 + (lane & 15)) * p.ldi + (long)gy * OCH + 8 * G;
+  // staging images [32 rows][64 bytes]: written as this lane's two pieces, read back transposed: lane (channel 16 (G & 1) + i, half h)
+  // receives rows 8 g + 4 h .. + 3 of its channel from the address (row 8 g + 4 h + q, channels 16 (G & 1) + 4 pp ..)
+  char* const simg = side0 + wave * 4096;
+  char* const sw_ = simg + lane * 16;                                      // + 1024: rows 16-31; + 2048: the r image
+  const char* const sread = simg + (4 * h + qq) * 64 + 32 * (G & 1) + 8 * pp;     // + 512 g
+  float s0[GI * KT], s1[GI * KT];
+#pragma unroll
+  for (int t = 0; t < GI * KT; ++t) s0[t] = s1[t] = 0.f;
+  const bool bn_unit = p.bn_slope == 1.f;
+
+#pragma unroll
+  for (int gi = 0; gi < GI; ++gi)
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) {
+      const int t = gi * KT + kt;
+      if constexpr (ADD || BNR) {
+        if (t + 1 < GI * KT) side_load(t + 1, (t + 1) & 1);
+      }
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        const int ra = gi * N + 16 * s + wq, rb = ra + 4;
+        const bf16x4 w0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+            (lds_bf16x4_ptr)(wimg + ra * (2 * K) + ((kt ^ ws_bswz<BPR>(ra)) << 6) + wcol));
+        const bf16x4 w1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+            (lds_bf16x4_ptr)(wimg + rb * (2 * K) + ((kt ^ ws_bswz<BPR>(rb)) << 6) + wcol));
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[gi][s], __builtin_shufflevector(w0, w1, 0, 1, 2, 3, 4, 5, 6, 7), acc, 0, 0, 0);
+      }
+      if constexpr (ADD) {
+        *reinterpret_cast<f32x4*>(sw_) = sa[t & 1][0];
+        *reinterpret_cast<f32x4*>(sw_ + 1024) = sa[t & 1][1];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const bf16x4 a4 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(sread + 512 * g));
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[4 * g + e] += (float)a4[e];
+        }
+      }
+      bf16x4 o4[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        o4[g] = __builtin_convertvector((f32x4{acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]}), bf16x4);
+        *reinterpret_cast<bf16x4*>(tw + 16 * g) = o4[g];
+      }
+      if constexpr (BNR) {
+        *reinterpret_cast<f32x4*>(sw_ + 2048) = sr[t & 1][0];
+        *reinterpret_cast<f32x4*>(sw_ + 2048 + 1024) = sr[t & 1][1];
+        const long ch = (long)gy * OCH + t * 32 + j;
+        const float bsc = p.bn_scale[ch], bsh = p.bn_shift[ch], bmu = p.bn_mean[ch], bis = p.bn_invstd[ch];
+        float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const bf16x4 r4 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(sread + 2048 + 512 * g));
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float dyv = (float)o4[g][e], xx = (float)r4[e];
+            float gg = dyv;
+            if (!bn_unit) gg = (bsc * xx + bsh) > 0.f ? dyv : dyv * p.bn_slope;
+            a0 += gg;
+            a1 += gg * ((xx - bmu) * bis);
+          }
+        }
+        s0[t] = a0; s1[t] = a1;
+      }
+      const bf16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(tr));
+      const bf16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(tr + 4 * WS_TP));
+      const bf16x4 v2 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(tr + 32));
+      const bf16x4 v3 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(tr + 4 * WS_TP + 32));
+      *reinterpret_cast<bf16x8*>(orow + t * 32) = __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
+      *reinterpret_cast<bf16x8*>(orow + 16 * p.ldi + t * 32) = __builtin_shufflevector(v2, v3, 0, 1, 2, 3, 4, 5, 6, 7);
+    }
+
+  if constexpr (BNR) {
+#pragma unroll
+    for (int t = 0; t < GI * KT; ++t) {
+      red[((wave * 2 + h) * 2 + 0) * OCH + t * 32 + j] = s0[t];
+      red[((wave * 2 + h) * 2 + 1) * OCH + t * 32 + j] = s1[t];
+    }
+    __syncthreads();
+    for (int c = tid; c < OCH; c += 256) {
+      float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { a0 += red[(k * 2 + 0) * OCH + c]; a1 += red[(k * 2 + 1) * OCH + c]; }
+      const long col = (long)gy * OCH + c;
+      p.bn_partial[(long)tile * p.bn_ld + col] = a0;
+      p.bn_partial[p.bn_plane + (long)tile * p.bn_ld + col] = a1;
+    }
+  }
+}
+
+template <int N, int K, int GI>
+int ws_bwd_launch_t(const WsBwdArgs& p, int gy, hipStream_t s) {
+  const dim3 grid(p.M / 128, gy), block(256);
+  const bool add = p.addend != nullptr, bnr = p.bn_r != nullptr;
+#define WS_BWD_GO(ABN_)                                                                                   \
+  do {                                                                                                    \
+    if (add) {                                                                                            \
+      if (bnr) NSID_LAUNCH((ws_bwd_kernel<N, K, GI, true, true, ABN_>), grid, block, 0, s, p);             \
+      else NSID_LAUNCH((ws_bwd_kernel<N, K, GI, true, false, ABN_>), grid, block, 0, s, p);                \
+    } else {                                                                                              \
+      if (bnr) NSID_LAUNCH((ws_bwd_kernel<N, K, GI, false, true, ABN_>), grid, block, 0, s, p);            \
+      else NSID_LAUNCH((ws_bwd_kernel<N, K, GI, false, false, ABN_>), grid, block, 0, s, p);               \
+    }                                                                                                     \
+  } while (0)
+  if (p.abn_r != nullptr) WS_BWD_GO(true);
+  else WS_BWD_GO(false);
+#undef WS_BWD_GO
+  return nsid_launch_status();
+}
+
+template <int K, int NOUT, int GI>
+int ws_launch(const WsArgs& p, int gy, bool aff, bool stat, hipStream_t s) {
+  const dim3 grid(p.M / 128, gy), block(256);
+  if (aff) {
+    if (stat) NSID_LAUNCH((ws_fwd_kernel<K, NOUT, GI, true, true>), grid, block, 0, s, p);
+    else NSID_LAUNCH((ws_fwd_kernel<K, NOUT, GI, true, false>), grid, block, 0, s, p);
+  } else {
+    if (stat) NSID_LAUNCH((ws_fwd_kernel<K, NOUT, GI, false, true>), grid, block, 0, s, p);
+    else NSID_LAUNCH((ws_fwd_kernel<K, NOUT, GI, false, false>), grid, block, 0, s, p);
+  }
+  return nsid_launch_status();
+}
+
+}  // namespace
+
+// returns NSID_OK / NSID_ELAUNCH, or 1 when the shape is outside the weight-stationary forms (the caller then takes gemm.hip)
+__attribute__((visibility("hidden")))
+int nsid_ws_fwd_launch(const void* x, int ldx, const void* w, const float* bias, void* out, int ldo, int M, int Nout, int K,
+                       int groups, const float* in_scale, const float* in_shift, float in_slope, float* stat, long stat_plane,
+                       long stat_ld, hipStream_t stream) {
+  if (M % 128 != 0 || ldx % 8 != 0 || ldo % 8 != 0 || ldx < groups * K || ldo < groups * Nout) return 1;
+  if (!nsid_aligned16(x) || !nsid_aligned16(w) || !nsid_aligned16(out)) return 1;
+  if ((in_scale != nullptr) != (in_shift != nullptr)) return 1;
+  if (in_scale && (!nsid_aligned16(in_scale) || !nsid_aligned16(in_shift))) return 1;
+  WsArgs p{};
+  p.x = static_cast<const __bf16*>(x); p.ldx = ldx;
+  p.w = static_cast<const __bf16*>(w);
+  p.bias = bias;
+  p.in_scale = in_scale; p.in_shift = in_shift; p.in_slope = in_slope;
+  p.out = static_cast<__bf16*>(out); p.ldo = ldo;
+  p.stat = stat; p.stat_plane = stat_plane; p.stat_ld = stat_ld;
+  p.M = M;
+  const bool aff = in_scale != nullptr, st = stat != nullptr;
+  if (!aff && in_slope != 1.f) return 1;            // an activation without an affine: gemm.hip's ReLU-on-load form
+#define WS_CASE(K_, N_, G_, GI_)                                                   \
+  if (K == K_ && Nout == N_ && groups == G_) return ws_launch<K_, N_, GI_>(p, G_ / GI_, aff, st, stream)
+  WS_CASE(64, 64, 1, 1);          // Grapher fc1, C = 64
+  WS_CASE(32, 32, 4, 4);          // grouped conv, C = 64
+  WS_CASE(128, 64, 1, 1);         // Grapher fc2, C = 64
+  WS_CASE(64, 256, 1, 1);         // FFN fc1, C = 64
+  WS_CASE(256, 64, 1, 1);         // FFN fc2, C = 64
+  WS_CASE(128, 128, 1, 1);        // Grapher fc1, C = 128
+  WS_CASE(64, 64, 4, 4);          // grouped conv, C = 128
+  WS_CASE(256, 128, 1, 1);        // Grapher fc2, C = 128 (64 KB of weights: one workgroup per CU)
+  WS_CASE(128, 128, 4, 1);        // grouped conv, C = 256 (one group per workgroup: grid.y = 4)
+#undef WS_CASE
+  return 1;
+}
+
+// backward-data: returns NSID_OK / NSID_ELAUNCH, or 1 outside the weight-stationary forms
+__attribute__((visibility("hidden")))
+int nsid_ws_bwd_data_launch(const void* dout, int ldd, const void* w, const void* addend, int ldadd, void* din, int ldi, int M, int Nout,
+                            int K, int groups, const void* bn_r, long bn_ldr, const float* bn_scale, const float* bn_shift,
+                            const float* bn_mean, const float* bn_invstd, float bn_slope, float* bn_partial, long bn_plane, long bn_ld,
+                            const void* abn_r, const float* abn_coef, long abn_plane, float abn_slope, void* abn_dr, long abn_lddr,
+                            hipStream_t stream) {
+  if (abn_r && (!abn_coef || !abn_dr || ldd != groups * Nout || abn_lddr % 8 != 0 || !nsid_aligned16(abn_r) || !nsid_aligned16(abn_dr) ||
+                !nsid_aligned16(abn_coef) || abn_plane % 4 != 0)) return 1;
+  if (M % 128 != 0 || ldd % 8 != 0 || ldi % 8 != 0 || ldd < groups * Nout || ldi < groups * K) return 1;
+  if (!nsid_aligned16(dout) || !nsid_aligned16(w) || !nsid_aligned16(din)) return 1;
+  if (addend && (ldadd % 8 != 0 || ldadd < groups * K || !nsid_aligned16(addend))) return 1;
+  if (bn_r && (bn_ldr % 8 != 0 || !nsid_aligned16(bn_r) || !bn_scale || !bn_shift || !bn_mean || !bn_invstd || !bn_partial)) return 1;
+  WsBwdArgs p{};
+  p.dy = static_cast<const __bf16*>(dout); p.ldd = ldd;
+  p.w = static_cast<const __bf16*>(w);
+  p.addend = static_cast<const __bf16*>(addend); p.ldadd = ldadd;
+  p.dx = static_cast<__bf16*>(din); p.ldi = ldi;
+  p.bn_r = static_cast<const __bf16*>(bn_r); p.bn_ldr = bn_ldr;
+  p.bn_scale = bn_scale; p.bn_shift = bn_shift; p.bn_mean = bn_mean; p.bn_invstd = bn_invstd; p.bn_slope = bn_slope;
+  p.bn_partial = bn_partial; p.bn_plane = bn_plane; p.bn_ld = bn_ld;
+  p.abn_r = static_cast<const __bf16*>(abn_r); p.abn_coef = abn_coef; p.abn_plane = abn_plane; p.abn_slope = abn_slope;
+  p.abn_dr = static_cast<__bf16*>(abn_dr); p.abn_lddr = abn_lddr;
+  p.M = M;
+#define WS_CASE(N_, K_, G_, GI_)                                                   \
+  if (Nout == N_ && K == K_ && groups == G_) return ws_bwd_launch_t<N_, K_, GI_>(p, G_ / GI_, stream)
+  WS_CASE(64, 64, 1, 1);          // Grapher fc1, C = 64
+  WS_CASE(32, 32, 4, 4);          // grouped conv, C = 64
+  WS_CASE(64, 128, 1, 1);         // Grapher fc2, C = 64
+  WS_CASE(256, 64, 1, 1);         // FFN fc1, C = 64
+  WS_CASE(64, 256, 1, 1);         // FFN fc2, C = 64
+  WS_CASE(128, 128, 1, 1);        // Grapher fc1, C = 128
+  WS_CASE(64, 64, 4, 4);          // grouped conv, C = 128
+  WS_CASE(128, 256, 1, 1);        // Grapher fc2, C = 128
+  WS_CASE(128, 128, 4, 1);        // grouped conv, C = 256
+#undef WS_CASE
+  return 1;
+}

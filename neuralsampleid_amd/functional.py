@@ -306,11 +306,13 @@ def grapher_backward(dx1: Tensor, P, S, G) -> Tensor:
     M, C = x0.shape
     pre = "graph_conv.gconv.nn."
     # fc2 (+BN), input = relu(BN(r2))
-    dr3 = ops.bn_backward(dx1, r3, a3, ACT_NONE, G["fc2.1.weight"], G["fc2.1.bias"], partial=_link_partial(S))
+    # dv is dL/d(relu(BN(r2))): the GEMM that writes it also emits that BatchNorm's backward column sums; where the weight-stationary
+    # form serves the shape (ops.WS_BWD_SHAPES) it evaluates fc2's own BatchNorm backward on its operand load too (no apply pass)
+    dr3, dv, part2 = ops.bn_backward_linear_bwd_data(dx1, r3, a3, ACT_NONE, G["fc2.1.weight"], G["fc2.1.bias"], _link_partial(S),
+                                                     ops.w2d(P["fc2.0.weight"]), M, C, 2 * C, 1, bn=(r2, a2, ACT_RELU),
+                                                     site=ops.SITE_FC2, inplace=False)
     _bias_grad_before_bn(dr3, G["fc2.0.bias"])
     ops.linear_bwd_weight(dr3, r2, ops.w2d(G["fc2.0.weight"]), M, C, 2 * C, 1, a2.scale, a2.shift, ACT_RELU)
-    # dv is dL/d(relu(BN(r2))): the GEMM that writes it also emits that BatchNorm's backward column sums
-    dv, part2 = ops.linear_bwd_data(dr3, ops.w2d(P["fc2.0.weight"]), M, C, 2 * C, bn=(r2, a2, ACT_RELU))
     # grouped conv (+BN+ReLU), input = u
     # (the BatchNorm-backward apply is evaluated on the backward-data GEMM's operand load where the shape allows: ops.py)
     dr2, du, _ = ops.bn_backward_linear_bwd_data(dv, r2, a2, ACT_RELU, G[pre + "1.weight"], G[pre + "1.bias"], part2,
@@ -398,9 +400,10 @@ def ffn_backward(dx2: Tensor, P, S, G) -> Tensor:
     x1, r4, a4, r5, a5 = S["x1"], S["r4"], S["a4"], S["r5"], S["a5"]
     M, C = x1.shape
     H = r4.shape[1]
-    dr5 = ops.bn_backward(dx2, r5, a5, ACT_NONE, G["fc2.1.weight"], G["fc2.1.bias"], partial=_link_partial(S))
+    dr5, dh, part4 = ops.bn_backward_linear_bwd_data(dx2, r5, a5, ACT_NONE, G["fc2.1.weight"], G["fc2.1.bias"], _link_partial(S),
+                                                     ops.w2d(P["fc2.0.weight"]), M, C, H, 1, bn=(r4, a4, ACT_RELU), site=ops.SITE_FFN2,
+                                                     inplace=False)
     ops.linear_bwd_weight(dr5, r4, ops.w2d(G["fc2.0.weight"]), M, C, H, 1, a4.scale, a4.shift, ACT_RELU)
-    dh, part4 = ops.linear_bwd_data(dr5, ops.w2d(P["fc2.0.weight"]), M, C, H, bn=(r4, a4, ACT_RELU))
     dr4, dx1, part = ops.bn_backward_linear_bwd_data(dh, r4, a4, ACT_RELU, G["fc1.1.weight"], G["fc1.1.bias"], part4,
                                                      ops.w2d(P["fc1.0.weight"]), M, H, C, 1, addend=dx2, bn=_link_in(S) or False)
     ops.linear_bwd_weight(dr4, x1, ops.w2d(G["fc1.0.weight"]), M, H, C)

@@ -513,30 +513,38 @@ def linear_bwd_data(dout, w, M, Nout, K, groups=1, addend=None, out=None, bn=Non
 # BatchNorm-backward apply evaluated on the operand load of the backward-data GEMM (bf16 storage): bit mask over the call sites
 # (1: FFN hidden layer, 2: grouped conv, 4: Grapher fc1); True = all, False / 0 = none
 FUSE_BN_BWD_APPLY = 4        # measured in the two-stream step (round 3, one-box A/B x2): none 8.09 / 8.06 ms, FFN 8.35 / 8.35, grouped 8.14 / 8.13, fc1 8.08 / 8.09, all 8.33 / 8.32
-SITE_FFN, SITE_GCONV, SITE_FC1 = 1, 2, 4
+SITE_FFN, SITE_GCONV, SITE_FC1, SITE_FC2, SITE_FFN2 = 1, 2, 4, 8, 16
+# the backward-data shapes (Nout, K, groups) of csrc/wsgemm.hip: there the fused operand load costs one evaluation per ROW (a workgroup owns
+# all output columns), not one per column tile, so every call site takes it (tuning key ws_gemm bit 2); elsewhere FUSE_BN_BWD_APPLY decides
+WS_BWD_SHAPES = {(64, 64, 1), (32, 32, 4), (64, 128, 1), (256, 64, 1), (64, 256, 1), (128, 128, 1), (64, 64, 4), (128, 256, 1),
+                 (128, 128, 4)}
 
 
 def bn_backward_linear_bwd_data(dy, r, aff: "BNAffine", act, dgamma, dbeta, partial, w, M, Nout, K, groups=1, addend=None,
-                                bn=None, site=SITE_FFN):
+                                bn=None, site=SITE_FFN, inplace=True):
     """BatchNorm(+act) backward of a conv+BN layer FOLLOWED by that conv's backward-data GEMM, the two fused where the shape allows:
         dr  = BN-backward(dy, r)        (dy = dL/d act(BN(r)); dgamma / dbeta accumulated)
         din = addend + dr @ w           (+ the column sums for the next BatchNorm backward when bn=(r', aff', act'))
     Returns (dr, din, partial_out). Fused form (csrc/gemm.hip ABN): the GEMM evaluates dr on its operand load from dy and r and
     writes it once for the weight gradient — no bn_bwd_apply pass. `partial` = this layer's column sums (from the GEMM that wrote dy,
     or None: a reduce launch). Falls back to bn_backward + linear_bwd_data (same results up to one fp32 rounding before the bf16
-    store) for fp32 storage and shapes outside the fused form."""
+    store) for fp32 storage and shapes outside the fused form. inplace: the unfused fallback may overwrite dy with dr (False where the
+    caller still needs dy: the residual-stream gradients dx1 / dx2 are also the addends of a later GEMM)."""
     dt = _act(dy, r, addend)
     C = r.shape[1]
     tiles = row_tiles(M)
     s = _stream()
     wop, wdt = _weight(w, dt, K)
     enabled = FUSE_BN_BWD_APPLY is True or (FUSE_BN_BWD_APPLY and (int(FUSE_BN_BWD_APPLY) & site))
+    ws_form = (dt == BF16 and wdt == BF16 and M % 128 == 0 and (Nout, K, groups) in WS_BWD_SHAPES and (get_tuning("ws_gemm") & 4) != 0)
+    enabled = enabled or ws_form
     if isinstance(partial, BwdSums) or (aff.lazy is not None and dt == BF16 and (int(LAZY_BN) & 2)):
         enabled = False        # the fused operand load needs coef4 from a finalize launch; the lazy apply pass needs none
     fusable = (enabled and dt == BF16 and wdt == BF16 and tuple(r.shape) == (M, groups * Nout) and
-               tuple(dy.shape) == (M, groups * Nout) and M % 128 == 0 and Nout % 64 == 0 and K % 64 == 0 and (K <= 64 or K % 128 == 0))
+               tuple(dy.shape) == (M, groups * Nout) and M % 128 == 0 and
+               (ws_form or (Nout % 64 == 0 and K % 64 == 0 and (K <= 64 or K % 128 == 0))))
     if not fusable:
-        dr = bn_backward(dy, r, aff, act, dgamma, dbeta, inplace=True, partial=partial)
+        dr = bn_backward(dy, r, aff, act, dgamma, dbeta, inplace=inplace, partial=partial)
         return (dr,) + linear_bwd_data(dr, w, M, Nout, K, groups, addend=addend, bn=bn if bn is not None else False)
     if partial is None:
         partial = torch.empty((2, tiles, C), device=r.device, dtype=torch.float32)
@@ -566,8 +574,8 @@ def bn_backward_linear_bwd_data(dy, r, aff: "BNAffine", act, dgamma, dbeta, part
             _p(dy), _p(r), _p(coef[2]), act, _p(dr), _p(wop), wdt, _p(addend), 0 if addend is None else addend.shape[-1], _p(din),
             din.shape[-1], M, Nout, K, groups, dt, _p(br), _p(baff.scale) if baff else None, _p(baff.shift) if baff else None,
             _p(baff.mean) if baff else None, _p(baff.invstd) if baff else None, bact, _p(part_out), s)
-    _timed("gemm_kernel<128,%d,true,false> +bn_apply_load" % (64 if K <= 64 else 128), 2.0 * M * Nout * K * groups, nbytes, launch,
-           (M, Nout, K, groups))
+    _timed("ws_bwd_kernel +bn_apply_load" if ws_form else "gemm_kernel<128,%d,true,false> +bn_apply_load" % (64 if K <= 64 else 128),
+           2.0 * M * Nout * K * groups, nbytes, launch, (M, Nout, K, groups))
     if rc[0] == 1:             # outside the fused form after all: apply with the coefficients already computed, then the plain GEMM
         if PROFILE is not None:
             PROFILE.records.pop()          # nothing was launched under that name

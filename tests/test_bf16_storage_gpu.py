@@ -20,6 +20,7 @@ def ops():
     from neuralsampleid_amd import ops as o
     o.set_gemm_precision("bf16")
     yield o
+    o.reset_tuning()
     o.set_gemm_precision("fp32")
     F_.set_activation_dtype("fp32")
 
@@ -255,8 +256,11 @@ def test_bwd_data_emits_bn_backward_sums(ops, M, Nout, K, groups, act, add):
 def test_bn_backward_on_the_backward_data_operand_load(ops, M, Nout, K, groups, act, add, link, fused_expected):
     """ops.bn_backward_linear_bwd_data: BatchNorm(+act) backward evaluated on the backward-data GEMM's operand load (csrc/gemm.hip
     ABN) against the two-call form (bn_bwd_apply pass + plain GEMM): same dr up to one fp32 rounding before the bf16 store, same din,
-    same column sums for the next BatchNorm backward, same dgamma / dbeta; the launch counter says which form ran"""
+    same column sums for the next BatchNorm backward, same dgamma / dbeta; the launch counter says which form ran.
+    (The TILE kernels' form: the weight-stationary one of csrc/wsgemm.hip, which takes these shapes by default where it has them, is
+    held to the same statement by tests/test_wsgemm_gpu.py; ws_gemm = 3 keeps it off the operand-load path here.)"""
     from neuralsampleid_amd._lib import launch_counters
+    ops.set_tuning("ws_gemm", 3)
     C = groups * Nout
     dy = synth_randn(f"ady{M}{C}", M, C).to(BF).to(DEV)
     r = (synth_randn(f"ar{M}{C}", M, C) * 1.3 + 0.2).to(BF).to(DEV)

