@@ -111,24 +111,6 @@ int nsid_linear_fwd_res(const void* x, int ldx, const void* w, int w_dtype, cons
    nsid_linear_fwd_res. */
 int nsid_ffn_fused_fwd(const void* x, const void* w1, const float* b1, const void* w2, const float* b2, void* out, int M, int C,
                        int H, void* stream);
-/* Grapher tail + FFN of one eval-mode block in ONE launch:
-       x1  = x + Wp r2 + bp                   (Grapher.forward: fc2 + BatchNorm folded into (Wp, bp) + shortcut, gcn_lib/torch_vertex.py:183-195)
-       out = x1 + W2 relu(W1 x1 + b1) + b2    (FFN.forward, encoder/graph_encoder.py:82-89)
-   x: M x C bf16 (the block's input), r2: M x 2C bf16 (the graph conv's output, nsid_mrconv_fused_fwd), Wp: C x 2C bf16 row-major,
-   bp fp32[C]; the rest as nsid_ffn_fused_fwd. x1 is rounded to bf16 once (as nsid_linear_fwd_res would store it) and never written.
-   out must not alias x or r2. Returns 1 (nothing launched) outside C = 256, H = 1024, M % 256 == 0: the caller then runs
-   nsid_linear_fwd_res + nsid_ffn_fused_fwd. */
-int nsid_block_tail_fused_fwd(const void* x, const void* r2, const void* wp, const float* bp, const void* w1, const float* b1,
-                              const void* w2, const float* b2, void* out, int M, int C, int H, void* stream);
-/* ... and the max-relative graph conv in front of that: r2 = relu(Wg (*)_4 [y, max_j(y[idx_j] - y)] + bg) (what nsid_mrconv_fused_fwd
-   writes; MRConv2d.forward + BasicConv, gcn_lib/torch_vertex.py:19-34, torch_nn.py:52-76) is evaluated by the same launch, slice by
-   slice, rounded to bf16 and never written. y: M x C bf16 (the Grapher's fc1 output, BatchNorm folded), idx: M x k clip-local ids
-   (nsid_knn_graph), N nodes per clip, Wg: 2C x C/2 bf16, bg fp32[2C]; the rest as nsid_block_tail_fused_fwd. Returns 1 (nothing
-   launched) outside C = 256, H = 1024, M % 256 == 0, 256 % N == 0: the caller then runs nsid_mrconv_fused_fwd +
-   nsid_block_tail_fused_fwd. */
-int nsid_block_gr_fused_fwd(const void* x, const void* y, const int32_t* idx, int k, int N, const void* wg, const float* bg,
-                            const void* wp, const float* bp, const void* w1, const float* b1, const void* w2, const float* b2,
-                            void* out, int M, int C, int H, void* stream);
 /* eval-mode MRConv2d in ONE launch, one workgroup per clip: v = relu(W (*)_4 [y, max_j(y[idx_j] - y)] + b) with the BatchNorm folded
    into (W, b) — MRConv2d.forward (gcn_lib/torch_vertex.py:19-34) + BasicConv (torch_nn.py:52-76) in eval mode. y: (B*N, C) bf16 plain
    values (the producer's BatchNorm folded too), idx: (B, N, k) clip-local, w: (2C, C/2) bf16, bias: (2C) fp32, out: (B*N, 2C) bf16.
@@ -204,63 +186,6 @@ int nsid_bn_bwd_finalize_fused(const float* partial, int tiles, int C, int M, fl
 int nsid_bn_bwd_apply(const void* dout, const void* r, int M, int C, const float* scale, const float* shift,
                       const float* mean, const float* invstd, int act, const float* coef, void* dr, int dtype,
                       void* stream);
-
-/* ---- training-mode BatchNorm WITHOUT finalize launches: fixed-point column sums + consumer-side evaluation (round 4) --------
- * nn.BatchNorm2d in training mode needs the batch mean / variance of a conv output before anything can consume it
- * (torch_vertex.py:154,161, torch_nn.py:32, graph_encoder.py:45,75,77,152). The `stat` / `partial` forms above keep one float row
- * of column sums per 128-row tile and spend one small launch per layer combining them (nsid_bn_finalize*, nsid_bn_bwd_finalize*):
- * 256 launches per training step. In the forms below the producer ADDS its column sums into acc[replicas][2][channels] as 64-bit
- * fixed point with integer atomics (unit 2^-NSID_STAT_FWD_SHIFT for sum / sum of squares of the conv output, 2^-NSID_STAT_BWD_SHIFT
- * for the backward pair sum g / sum g*xhat) — integer addition is associative, so the totals are independent of arrival order and a
- * run is reproducible bit for bit — and the first kernel that CONSUMES the layer evaluates the same arithmetic as nsid_bn_finalize
- * from the totals in its own prologue (every workgroup for itself: same integers, same bits) and leaves scale / shift / mean /
- * invstd / unbiased variance in `out` for the later consumers (backward, nsid_bn_running_update). `acc` must be zero before the
- * producer runs (one nsid_fill_zero per step over an arena of all layers); replicas is a power of two <= NSID_STAT_MAX_REPLICAS
- * (row tile t adds to replica t % replicas: fewer adds per address). Range: |sum of squares over the batch| < 3.4e10, |backward sums| <
- * 5.2e5 (beyond that the integers wrap: such a step is discarded by the caller's non-finite-loss guard, train.py:60-64). */
-#define NSID_STAT_FWD_SHIFT 28
-#define NSID_STAT_BWD_SHIFT 44
-#define NSID_STAT_MAX_REPLICAS 8
-typedef struct nsid_bn_lazy {
-  int64_t* acc;             /* [replicas][2][channels] fixed-point sums; NULL: `out` already holds the five vectors */
-  int replicas, channels;
-  long rows;                /* rows the sums run over (B*N) */
-  const float* gamma; const float* beta; float eps;
-  float* out;               /* [5][channels]: scale, shift, mean, invstd, unbiased variance (16-byte aligned) */
-} nsid_bn_lazy_t;
-typedef struct nsid_bn_bwd_lazy {
-  int64_t* acc;             /* [replicas][2][channels]: sum g, sum g*xhat */
-  int replicas, channels;
-  long rows;
-  float* dgamma; float* dbeta;   /* += (atomic), may be NULL */
-  float* coef;              /* optional out [2][channels] = {sum g / rows, sum g*xhat / rows} */
-} nsid_bn_bwd_lazy_t;
-/* nsid_linear_fwd with the statistics added into stat_acc (may be NULL: none) and the producer's BatchNorm given as in_bn (may be NULL:
-   no affine on load; in_bn->acc != NULL: evaluated in the prologue of this launch). ksplit = 1, act_out = NSID_ACT_NONE. */
-int nsid_linear_fwd_lazy(const void* x, int ldx, const void* w, int w_dtype, const float* bias, void* out, int ldo, int M, int Nout,
-                         int K, int groups, const nsid_bn_lazy_t* in_bn, int act_in, int64_t* stat_acc, int stat_replicas,
-                         int act_dtype, void* stream);
-/* nsid_downsample3_fwd with the statistics added into stat_acc */
-int nsid_downsample3_fwd_lazy(const void* x, int B, int N, int C, const void* wp, int w_dtype, const float* bias, void* out, int Cout,
-                              int64_t* stat_acc, int stat_replicas, int act_dtype, void* stream);
-/* nsid_knn_graph / nsid_bn_apply whose BatchNorm is still a pair of sums: evaluated in the prologue, `bn->out` written */
-int nsid_knn_graph_lazy(const void* r, int ldr, const nsid_bn_lazy_t* bn, int B, int N, int C, int k, int dilation, int32_t* idx,
-                        int dtype, void* stream);
-int nsid_bn_apply_lazy(const void* r, const nsid_bn_lazy_t* bn, int act, const void* residual, void* out, int M, int C, int dtype,
-                       void* stream);
-/* stand-alone evaluation (one small launch) for a consumer that has no prologue form */
-int nsid_bn_materialize(const nsid_bn_lazy_t* bn, void* stream);
-/* backward: nsid_linear_bwd_data_bn / nsid_bn_bwd_reduce adding into bn_acc instead of writing per-tile partials; nsid_bn_bwd_apply
-   evaluating coef0 / coef1 (and adding dgamma / dbeta, one workgroup) from the sums in its prologue; the stand-alone evaluation */
-int nsid_linear_bwd_data_bn_lazy(const void* dout, int ldd, const void* w, int w_dtype, const void* addend, int ldadd, void* din,
-                                 int ldi, int M, int Nout, int K, int groups, int act_dtype, const void* bn_r, const float* bn_scale,
-                                 const float* bn_shift, const float* bn_mean, const float* bn_invstd, int bn_act, int64_t* bn_acc,
-                                 int bn_replicas, void* stream);
-int nsid_bn_bwd_reduce_lazy(const void* dout, const void* r, int M, int C, const float* scale, const float* shift, const float* mean,
-                            const float* invstd, int act, int64_t* acc, int replicas, int dtype, void* stream);
-int nsid_bn_bwd_apply_lazy(const void* dout, const void* r, int M, int C, const float* scale, const float* shift, const float* mean,
-                           const float* invstd, int act, const nsid_bn_bwd_lazy_t* sums, void* dr, int dtype, void* stream);
-int nsid_bn_bwd_materialize(const nsid_bn_bwd_lazy_t* sums, void* stream);
 
 /* ---- dilated kNN graph ---------------------------------------------------------------------------------
  * Replaces DenseDilatedKnnGraph.forward = F.normalize + pairwise_distance + topk + [::dilation]

@@ -62,33 +62,11 @@ SIGNATURES = {
     "nsid_batched_index_select_fwd": "ppiiiiips",
     "nsid_batched_index_select_bwd": "ppiiiiips",
     "nsid_fill_zero": "pzs",
-    # fixed-point BatchNorm sums (include/nsid.h, "lazy" forms): q = pointer to a nsid_bn_lazy_t / nsid_bn_bwd_lazy_t in HOST memory
-    "nsid_linear_fwd_lazy": "pipippiiiiiqipiis",
-    "nsid_downsample3_fwd_lazy": "piiipippipiis",
-    "nsid_knn_graph_lazy": "piqiiiiipis",
-    "nsid_bn_apply_lazy": "pqippiiis",
-    "nsid_bn_materialize": "qs",
-    "nsid_linear_bwd_data_bn_lazy": "pipipipiiiiiipppppipis",
-    "nsid_bn_bwd_reduce_lazy": "ppiippppipiis",
-    "nsid_bn_bwd_apply_lazy": "ppiippppiqpis",
-    "nsid_bn_bwd_materialize": "qs",
     "nsid_scale_f32": "pplps",
 }
 
 _CT = {"p": ctypes.c_void_p, "i": ctypes.c_int, "l": ctypes.c_long, "f": ctypes.c_float, "s": ctypes.c_void_p,
-       "z": ctypes.c_size_t, "q": ctypes.c_void_p}
-
-
-class BnLazyC(ctypes.Structure):
-    """nsid_bn_lazy_t (include/nsid.h)"""
-    _fields_ = [("acc", ctypes.c_void_p), ("replicas", ctypes.c_int), ("channels", ctypes.c_int), ("rows", ctypes.c_long),
-                ("gamma", ctypes.c_void_p), ("beta", ctypes.c_void_p), ("eps", ctypes.c_float), ("out", ctypes.c_void_p)]
-
-
-class BnBwdLazyC(ctypes.Structure):
-    """nsid_bn_bwd_lazy_t (include/nsid.h)"""
-    _fields_ = [("acc", ctypes.c_void_p), ("replicas", ctypes.c_int), ("channels", ctypes.c_int), ("rows", ctypes.c_long),
-                ("dgamma", ctypes.c_void_p), ("dbeta", ctypes.c_void_p), ("coef", ctypes.c_void_p)]
+       "z": ctypes.c_size_t}
 
 
 def _load():
@@ -102,9 +80,9 @@ def _load():
         fn.argtypes = [_CT[c] for c in sig]
         fn.restype = ctypes.c_int
     lib.nsid_version.restype = ctypes.c_int
-    if lib.nsid_version() < 0 and os.environ.get("NSID_ALLOW_DIAGNOSIS_LIB") != "1":
-        raise ImportError(f"{LIB_PATH} is a DIAGNOSIS build (compiled with result-changing -DNSID_* switches: timing only, results "
-                          "wrong). Set NSID_ALLOW_DIAGNOSIS_LIB=1 to load it for a timing experiment; never ship it.")
+    if lib.nsid_version() < 0:      # (builds of rounds 3-4 with result-changing timing switches reported a negative version)
+        raise ImportError(f"{LIB_PATH} reports a negative version: not a product build of this tree; rebuild with "
+                          "`python -m neuralsampleid_amd.build --force`")
     lib.nsid_debug_gemm_trace.argtypes = [ctypes.c_void_p]
     lib.nsid_debug_gemm_trace.restype = ctypes.c_int
     lib.nsid_debug_knn_trace.argtypes = [ctypes.c_void_p]
@@ -137,10 +115,6 @@ def _load():
     lib.nsid_linear_bwd_data_bnapply.restype = ctypes.c_int
     lib.nsid_ffn_fused_fwd.argtypes = [_CT[c] for c in "ppppppiiis"]
     lib.nsid_ffn_fused_fwd.restype = ctypes.c_int
-    lib.nsid_block_tail_fused_fwd.argtypes = [_CT[c] for c in "pppppppppiiis"]
-    lib.nsid_block_tail_fused_fwd.restype = ctypes.c_int
-    lib.nsid_block_gr_fused_fwd.argtypes = [_CT[c] for c in "pppiipppppppppiiis"]
-    lib.nsid_block_gr_fused_fwd.restype = ctypes.c_int
     lib.nsid_mrconv_fused_fwd.argtypes = [_CT[c] for c in "ppiiiippps"]
     lib.nsid_mrconv_fused_fwd.restype = ctypes.c_int
     lib.nsid_row_tiles.argtypes = [ctypes.c_int]
@@ -153,7 +127,7 @@ def _load():
 
 
 lib = _load()
-EXPORTS = list(SIGNATURES) + ["nsid_version", "nsid_debug_gemm_trace", "nsid_debug_knn_trace", "nsid_get_gemm_precision", "nsid_gemm_g256_launches", "nsid_linear_bwd_data_bnapply", "nsid_ffn_fused_fwd", "nsid_block_tail_fused_fwd", "nsid_block_gr_fused_fwd", "nsid_mrconv_fused_fwd", "nsid_debug_counter", "nsid_debug_counters_reset", "nsid_debug_counter_count", "nsid_debug_counter_key", "nsid_set_tuning", "nsid_get_tuning", "nsid_reset_tuning", "nsid_tuning_count", "nsid_tuning_key", "nsid_row_tiles", "nsid_sumsq_blocks", "nsid_ntxent_ws_floats", "nsid_workspace_bytes"]
+EXPORTS = list(SIGNATURES) + ["nsid_version", "nsid_debug_gemm_trace", "nsid_debug_knn_trace", "nsid_get_gemm_precision", "nsid_gemm_g256_launches", "nsid_linear_bwd_data_bnapply", "nsid_ffn_fused_fwd", "nsid_mrconv_fused_fwd", "nsid_debug_counter", "nsid_debug_counters_reset", "nsid_debug_counter_count", "nsid_debug_counter_key", "nsid_set_tuning", "nsid_get_tuning", "nsid_reset_tuning", "nsid_tuning_count", "nsid_tuning_key", "nsid_row_tiles", "nsid_sumsq_blocks", "nsid_ntxent_ws_floats", "nsid_workspace_bytes"]
 
 _ERR = {-1: "NSID_EINVAL (unsupported shape, misaligned pointer or bad argument)",
         -2: "NSID_ELAUNCH (HIP runtime refused the launch)"}

@@ -129,8 +129,7 @@ __global__ __launch_bounds__(256) void col_reduce_kernel(const T* __restrict__ d
                                                          const float* __restrict__ shift,
                                                          const float* __restrict__ mean,
                                                          const float* __restrict__ invstd, float slope,
-                                                         float* __restrict__ partial, int tiles,
-                                                         long long* __restrict__ acc = nullptr, int acc_rep = 0) {
+                                                         float* __restrict__ partial, int tiles) {
   constexpr int N = Chunk<T>::N;
   constexpr int CQ = CR_CH / N;            // chunks across the 64 channels: 16 (fp32) or 8 (bf16)
   constexpr int RG = 256 / CQ;             // row groups: 16 or 32
@@ -186,11 +185,6 @@ __global__ __launch_bounds__(256) void col_reduce_kernel(const T* __restrict__ d
     if (cc < C) {
       float a0 = 0.f, a1 = 0.f;
       for (int g = 0; g < RG; ++g) { a0 += red[0][g][t]; a1 += red[1][g][t]; }
-      if (MODE == 1 && acc != nullptr) {     // uniform: fixed-point sums instead of per-tile partials (nsid_common.h)
-        nsid_acc_add(acc, C, tile & (acc_rep - 1), 0, cc, nsid_fix_bwd(a0));
-        nsid_acc_add(acc, C, tile & (acc_rep - 1), 1, cc, nsid_fix_bwd(a1));
-        return;
-      }
       partial[(long)tile * C + cc] = a0;
       if (MODE == 1) partial[(long)tiles * C + (long)tile * C + cc] = a1;
     }
@@ -318,129 +312,6 @@ __global__ __launch_bounds__(256) void colsum_atomic_kernel(const T* __restrict_
     float a = 0.f;
     for (int g = 0; g < RG; ++g) a += red[g][t];
     atomicAdd(out + blockIdx.y * CR_CH + t, a);
-  }
-}
-
-// ---- consumers of a BatchNorm that is still a pair of fixed-point sums (nsid_common.h) -----------------------------------------
-// bn_apply: the workgroup evaluates the layer ONCE into LDS (C <= LAZY_MAX_C channels over 256 threads), then every thread takes the
-// scale / shift of its own column chunk (a thread keeps ONE chunk for the whole kernel: the launch makes the thread count a multiple of
-// the chunks per row). Workgroup 0 also writes the five vectors for the later consumers (backward, the running-statistics update).
-// (First form: every THREAD evaluated its 8 channels in registers with fp64 division / square root: 23.9 us per launch against 5.7.)
-constexpr int LAZY_MAX_C = 2048;
-template <typename T>
-__global__ __launch_bounds__(256) void bn_apply_lazy_kernel(const T* __restrict__ r, const NsidBnLazy z, int act,
-                                                            const T* __restrict__ residual, T* __restrict__ out, long rows, int CV) {
-  constexpr int N = Chunk<T>::N;
-  __shared__ float aff[2][LAZY_MAX_C];
-  for (int c = threadIdx.x; c < z.C; c += 256) {
-    float sc, sh, mu, is, uv;
-    nsid_bn_lazy_channel(z, c, sc, sh, mu, is, uv);
-    aff[0][c] = sc; aff[1][c] = sh;
-    if (blockIdx.x == 0) { z.out[c] = sc; z.out[z.C + c] = sh; z.out[2 * z.C + c] = mu; z.out[3 * z.C + c] = is; z.out[4 * z.C + c] = uv; }
-  }
-  __syncthreads();
-  const long t = (long)blockIdx.x * blockDim.x + threadIdx.x, total = (long)gridDim.x * blockDim.x;
-  const int cq = (int)(t % CV), c = cq * N;
-  const long rstep = total / CV;                  // total % CV == 0 (host)
-  float sc[N], sh[N];
-#pragma unroll
-  for (int e = 0; e < N; ++e) { sc[e] = aff[0][c + e]; sh[e] = aff[1][c + e]; }
-  constexpr int U = 2;
-  for (long row = t / CV; row < rows; row += U * rstep) {
-    float v[U][N], rs[U][N];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const long rr = row + u * rstep;
-      if (rr < rows) {
-        Chunk<T>::load(r + (rr * CV + cq) * N, v[u]);
-        if (residual != nullptr) Chunk<T>::load(residual + (rr * CV + cq) * N, rs[u]);
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const long rr = row + u * rstep;
-      if (rr < rows) {
-        float o[N];
-#pragma unroll
-        for (int e = 0; e < N; ++e) o[e] = nsid_act(sc[e] * v[u][e] + sh[e], act) + (residual != nullptr ? rs[u][e] : 0.f);
-        Chunk<T>::store(out + (rr * CV + cq) * N, o);
-      }
-    }
-  }
-}
-
-// stand-alone evaluation: one thread per channel
-__global__ __launch_bounds__(256) void bn_materialize_kernel(const NsidBnLazy z) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= z.C) return;
-  float sc, sh, mu, is, uv;
-  nsid_bn_lazy_channel(z, c, sc, sh, mu, is, uv);
-  z.out[c] = sc; z.out[z.C + c] = sh; z.out[2 * z.C + c] = mu; z.out[3 * z.C + c] = is; z.out[4 * z.C + c] = uv;
-}
-__global__ __launch_bounds__(256) void bn_bwd_materialize_kernel(const NsidBnBwdLazy z) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= z.C) return;
-  float c0, c1, sg, sgx;
-  nsid_bn_bwd_lazy_channel(z, c, c0, c1, sg, sgx);
-  if (z.dbeta) atomicAdd(z.dbeta + c, sg);
-  if (z.dgamma) atomicAdd(z.dgamma + c, sgx);
-  if (z.coef) { z.coef[c] = c0; z.coef[z.C + c] = c1; }
-}
-
-// bn_bwd_apply with coef0 / coef1 evaluated from the backward sums once per workgroup (LDS); workgroup 0 adds dgamma / dbeta (atomic:
-// the two views of a step share them) and, when asked, writes coef.
-template <typename T, int U>
-__global__ __launch_bounds__(256) void bn_bwd_apply_lazy_kernel(const T* __restrict__ dout, const T* __restrict__ r, long rows, int CV,
-                                                                const float* __restrict__ scale, const float* __restrict__ shift,
-                                                                const float* __restrict__ mean, const float* __restrict__ invstd,
-                                                                float slope, const NsidBnBwdLazy z, T* __restrict__ dr) {
-  constexpr int N = Chunk<T>::N;
-  __shared__ float cf[2][LAZY_MAX_C];
-  for (int c = threadIdx.x; c < z.C; c += 256) {
-    float c0, c1, sg, sgx;
-    nsid_bn_bwd_lazy_channel(z, c, c0, c1, sg, sgx);
-    cf[0][c] = c0; cf[1][c] = c1;
-    if (blockIdx.x == 0) {
-      if (z.dbeta) atomicAdd(z.dbeta + c, sg);
-      if (z.dgamma) atomicAdd(z.dgamma + c, sgx);
-      if (z.coef) { z.coef[c] = c0; z.coef[z.C + c] = c1; }
-    }
-  }
-  const long t = (long)blockIdx.x * blockDim.x + threadIdx.x, total = (long)gridDim.x * blockDim.x;
-  const int cq = (int)(t % CV), c = cq * N;
-  const long rstep = total / CV;                  // total % CV == 0 (host)
-  float sc[N], sh[N], mu[N], is[N], c0[N], c1[N];
-  load_channels<N>(scale, c, sc);
-  load_channels<N>(shift, c, sh);
-  load_channels<N>(mean, c, mu);
-  load_channels<N>(invstd, c, is);
-  __syncthreads();
-#pragma unroll
-  for (int e = 0; e < N; ++e) { c0[e] = cf[0][c + e]; c1[e] = cf[1][c + e]; }
-  for (long row = t / CV; row < rows; row += U * rstep) {
-    float d[U][N], x[U][N];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const long rr = row + u * rstep;
-      if (rr < rows) {
-        Chunk<T>::load(dout + (rr * CV + cq) * N, d[u]);
-        Chunk<T>::load(r + (rr * CV + cq) * N, x[u]);
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const long rr = row + u * rstep;
-      if (rr < rows) {
-        float o[N];
-#pragma unroll
-        for (int e = 0; e < N; ++e) {
-          const float g = (sc[e] * x[u][e] + sh[e]) > 0.f ? d[u][e] : d[u][e] * slope;
-          const float xh = (x[u][e] - mu[e]) * is[e];
-          o[e] = sc[e] * (g - c0[e] - xh * c1[e]);
-        }
-        Chunk<T>::store(dr + (rr * CV + cq) * N, o);
-      }
-    }
   }
 }
 
@@ -632,80 +503,6 @@ extern "C" int nsid_colsum_acc(const void* x, int ldx, int M, int C, float* out,
   NSID_DISPATCH_DTYPE(dtype, T, {
     NSID_LAUNCH((colsum_atomic_kernel<T>), dim3(nsid_row_tiles(M), (C + CR_CH - 1) / CR_CH), dim3(256), 0,
                 static_cast<hipStream_t>(stream), static_cast<const T*>(x), (long)ldx, M, C, out);
-  });
-  return nsid_launch_status();
-}
-
-// ---- lazy (fixed-point sums) forms: include/nsid.h ----------------------------------------------------------------------------
-extern "C" int nsid_bn_apply_lazy(const void* r, const nsid_bn_lazy_t* bn, int act, const void* residual, void* out, int M, int C,
-                                  int dtype, void* stream) {
-  NSID_REQUIRE(r && out && M > 0 && C > 0 && NSID_DTYPE_OK(dtype) && nsid_lazy_ok(bn, C));
-  NSID_REQUIRE(C % (dtype == NSID_BF16 ? 8 : 4) == 0 && nsid_aligned16(r) && nsid_aligned16(out));
-  if (bn->acc == nullptr) return nsid_bn_apply(r, bn->out, bn->out + C, act, residual, out, M, C, dtype, stream);
-  NSID_REQUIRE(C <= LAZY_MAX_C);
-  nsid_count(NSID_C_bn_lazy_finalize);
-  NSID_DISPATCH_DTYPE(dtype, T, {
-    const int CV = C / Chunk<T>::N;
-    const long grid = chunk_keeping_grid((long)M * CV, CV, 2, nsid_tune(NSID_T_stream_max_wg), nullptr);
-    NSID_LAUNCH((bn_apply_lazy_kernel<T>), dim3((int)grid), dim3(256), 0, static_cast<hipStream_t>(stream), static_cast<const T*>(r),
-                nsid_lazy_view(bn), act, static_cast<const T*>(residual), static_cast<T*>(out), (long)M, CV);
-  });
-  return nsid_launch_status();
-}
-
-extern "C" int nsid_bn_materialize(const nsid_bn_lazy_t* bn, void* stream) {
-  NSID_REQUIRE(bn && nsid_lazy_ok(bn, bn->channels) && bn->acc != nullptr);
-  nsid_count(NSID_C_bn_materialize);
-  NSID_LAUNCH(bn_materialize_kernel, dim3((bn->channels + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), nsid_lazy_view(bn));
-  return nsid_launch_status();
-}
-
-static bool bwd_lazy_ok(const nsid_bn_bwd_lazy_t* z, int C) {
-  return z && nsid_acc_ok(z->acc, z->replicas) && z->channels == C && z->rows > 0;
-}
-
-extern "C" int nsid_bn_bwd_materialize(const nsid_bn_bwd_lazy_t* z, void* stream) {
-  NSID_REQUIRE(z && bwd_lazy_ok(z, z->channels));
-  nsid_count(NSID_C_bn_materialize);
-  NSID_LAUNCH(bn_bwd_materialize_kernel, dim3((z->channels + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream),
-              nsid_bwd_lazy_view(z));
-  return nsid_launch_status();
-}
-
-extern "C" int nsid_bn_bwd_reduce_lazy(const void* dout, const void* r, int M, int C, const float* scale, const float* shift,
-                                       const float* mean, const float* invstd, int act, int64_t* acc, int replicas, int dtype,
-                                       void* stream) {
-  NSID_REQUIRE(dout && r && scale && shift && mean && invstd && nsid_acc_ok(acc, replicas) && M > 0 && C > 0 && NSID_DTYPE_OK(dtype));
-  NSID_REQUIRE(C % (dtype == NSID_BF16 ? 8 : 4) == 0);
-  NSID_REQUIRE(act == NSID_ACT_NONE || act == NSID_ACT_RELU || act == NSID_ACT_LEAKY);
-  const int tiles = nsid_row_tiles(M);
-  nsid_count(NSID_C_bn_stat_acc);
-  NSID_DISPATCH_DTYPE(dtype, T, {
-    NSID_LAUNCH((col_reduce_kernel<1, T>), dim3(tiles, (C + CR_CH - 1) / CR_CH), dim3(256), 0, static_cast<hipStream_t>(stream),
-                static_cast<const T*>(dout), static_cast<const T*>(r), (long)C, M, C, scale, shift, mean, invstd, bn_slope(act),
-                static_cast<float*>(nullptr), tiles, reinterpret_cast<long long*>(acc), replicas);
-  });
-  return nsid_launch_status();
-}
-
-extern "C" int nsid_bn_bwd_apply_lazy(const void* dout, const void* r, int M, int C, const float* scale, const float* shift,
-                                      const float* mean, const float* invstd, int act, const nsid_bn_bwd_lazy_t* sums, void* dr,
-                                      int dtype, void* stream) {
-  NSID_REQUIRE(dout && r && scale && shift && mean && invstd && dr && M > 0 && C > 0 && NSID_DTYPE_OK(dtype) && bwd_lazy_ok(sums, C));
-  NSID_REQUIRE(C % (dtype == NSID_BF16 ? 8 : 4) == 0);
-  NSID_REQUIRE(act == NSID_ACT_NONE || act == NSID_ACT_RELU || act == NSID_ACT_LEAKY);
-  NSID_REQUIRE(C <= LAZY_MAX_C);
-  nsid_count(NSID_C_bn_lazy_finalize);
-  NSID_DISPATCH_DTYPE(dtype, T, {
-    constexpr int U = 4;
-    const int CV = C / Chunk<T>::N;
-    bool capped = false;
-    const long grid = chunk_keeping_grid((long)M * CV, CV, U, nsid_tune(NSID_T_bn_bwd_apply_max_wg), &capped);
-    nsid_count(NSID_C_bn_bwd_apply);
-    if (capped) nsid_count(NSID_C_bn_bwd_apply_capped);
-    NSID_LAUNCH((bn_bwd_apply_lazy_kernel<T, U>), dim3((int)grid), dim3(256), 0, static_cast<hipStream_t>(stream),
-                static_cast<const T*>(dout), static_cast<const T*>(r), (long)M, CV, scale, shift, mean, invstd, bn_slope(act),
-                nsid_bwd_lazy_view(sums), static_cast<T*>(dr));
   });
   return nsid_launch_status();
 }

@@ -210,40 +210,3 @@ extern "C" int nsid_ffn_fused_fwd(const void* x, const void* w1, const float* b1
   if (nsid_tune(NSID_T_ffn_waves) == 4) return C == 64 ? ffn_launch<64, 4>(p, s) : ffn_launch<128, 4>(p, s);
   return C == 64 ? ffn_launch<64, 8>(p, s) : ffn_launch<128, 8>(p, s);
 }
-
-// Grapher tail + FFN of one eval-mode block in ONE launch (C = 256):
-//     x1 = x + Wp r2 + bp                     (the Grapher's fc2 + BatchNorm folded + shortcut, gcn_lib/torch_vertex.py:183-195)
-//     out = x1 + W2 relu(W1 x1 + b1) + b2      (FFN.forward, encoder/graph_encoder.py:82-89)
-// x1 is rounded to bf16 once, as nsid_linear_fwd_res stores it, and never written. Returns 1 (nothing launched) outside C = 256,
-// H = 1024, M % 256 == 0 or with tuning key ffn256 = 0: the caller then runs nsid_linear_fwd_res + nsid_ffn_fused_fwd.
-extern "C" int nsid_block_tail_fused_fwd(const void* x, const void* r2, const void* wp, const float* bp, const void* w1, const float* b1,
-                                         const void* w2, const float* b2, void* out, int M, int C, int H, void* stream) {
-  NSID_REQUIRE(x && r2 && wp && bp && w1 && b1 && w2 && b2 && out && M > 0);
-  NSID_REQUIRE(out != x && out != r2);
-  if (!(C == 256 && H == 1024 && M % 256 == 0 && nsid_tune(NSID_T_ffn256) != 0)) return 1;
-  NSID_REQUIRE(nsid_aligned16(x) && nsid_aligned16(r2) && nsid_aligned16(wp) && nsid_aligned16(bp) && nsid_aligned16(w1) &&
-               nsid_aligned16(w2) && nsid_aligned16(out) && nsid_aligned16(b1) && nsid_aligned16(b2));
-  const int rc = nsid_ffn256_fused_launch(x, w1, b1, w2, b2, out, M, C, H, static_cast<hipStream_t>(stream), r2, wp, bp);
-  if (rc == NSID_OK) { nsid_count(NSID_C_ffn_fused); nsid_count(NSID_C_block_tail_fused); }
-  return rc;
-}
-
-// Graph conv + Grapher tail + FFN of one eval-mode block in ONE launch (C = 256, N nodes per clip with 256 % N == 0):
-//     r2  = relu(Wg (*)_4 [y, max_j(y[idx_j] - y)] + bg)     (MRConv2d.forward + BasicConv, gcn_lib/torch_vertex.py:19-34, torch_nn.py:52-76;
-//                                                            what nsid_mrconv_fused_fwd writes: rounded to bf16, here never written)
-//     x1  = x + Wp r2 + bp,    out = x1 + W2 relu(W1 x1 + b1) + b2          (nsid_block_tail_fused_fwd)
-// y: (M, C) bf16 = the Grapher's fc1 output with its BatchNorm folded; idx: (M, k) clip-local neighbour ids (nsid_knn_graph).
-extern "C" int nsid_block_gr_fused_fwd(const void* x, const void* y, const int32_t* idx, int k, int N, const void* wg, const float* bg,
-                                       const void* wp, const float* bp, const void* w1, const float* b1, const void* w2,
-                                       const float* b2, void* out, int M, int C, int H, void* stream) {
-  NSID_REQUIRE(x && y && idx && wg && bg && wp && bp && w1 && b1 && w2 && b2 && out && M > 0 && k > 0 && N > 0);
-  NSID_REQUIRE(out != x && out != y);
-  if (!(C == 256 && H == 1024 && M % 256 == 0 && 256 % N == 0 && nsid_tune(NSID_T_ffn256) != 0)) return 1;
-  NSID_REQUIRE(nsid_aligned16(x) && nsid_aligned16(y) && nsid_aligned16(wg) && nsid_aligned16(bg) && nsid_aligned16(wp) &&
-               nsid_aligned16(bp) && nsid_aligned16(w1) && nsid_aligned16(w2) && nsid_aligned16(out) && nsid_aligned16(b1) &&
-               nsid_aligned16(b2));
-  const int rc = nsid_ffn256_fused_launch(x, w1, b1, w2, b2, out, M, C, H, static_cast<hipStream_t>(stream), nullptr, wp, bp, y, idx, k,
-                                          N, wg, bg);
-  if (rc == NSID_OK) { nsid_count(NSID_C_ffn_fused); nsid_count(NSID_C_block_tail_fused); nsid_count(NSID_C_block_gr_fused); }
-  return rc;
-}

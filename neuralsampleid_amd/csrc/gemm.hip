@@ -54,12 +54,6 @@ struct GemmArgs {
   // (nsid_bn_bwd_finalize_fused). The workgroups of column tile 0 also write dr (abn_dr, row stride abn_lddr) for the weight
   // gradient: the separate bn_bwd_apply pass (read dy, read r, write dr) disappears.
   const void* abn_r; const float* abn_coef; long abn_plane; float abn_slope; void* abn_dr; long abn_lddr;
-  // Fixed-point BatchNorm sums (nsid_common.h, "lazy" training-mode BatchNorm): stat_acc / bn_acc replace the per-tile float partials
-  // `stat` / `bn_partial` (integer atomics, one replica per row tile modulo *_rep); a_lazy: the A operand's BatchNorm is still a
-  // pair of sums — every workgroup evaluates it in its prologue (a_scale / a_shift then point into a_lazy.out).
-  long long* stat_acc; int stat_rep;
-  long long* bn_acc; int bn_rep;
-  NsidBnLazy a_lazy;
 };
 
 // Precision H = false: fp32 operands, v_mfma_f32_16x16x4_f32, BK = 16 (exact fp32 — the parity path).
@@ -278,14 +272,8 @@ __device__ __forceinline__ void stage_store_abn(char* lds, const StageRegs<ROWS,
       o[e] = (__bf16)v[0];
       o[e + 1] = (__bf16)v[1];
     }
-#ifdef NSID_ABN_NOMATH      // diagnosis builds (tools/build_variant.sh): what the operand transform / the side store cost
-    o = __builtin_bit_cast(bf16x8, dy.v[q]) ;
-    asm volatile("" :: "v"(rr.v[q]));
-#endif
     *reinterpret_cast<bf16x8*>(lds + row * G::STRIDE + kc * 16) = o;
-#ifndef NSID_ABN_NOSIDE
     if (side != nullptr) *reinterpret_cast<bf16x8*>(side + ((long)row * side_ld + kc * 8) * 2) = o;
-#endif
   }
 }
 
@@ -402,9 +390,6 @@ void gemm_kernel(const GemmArgs p) {
   }
   const int ti = bid / tiles_j, tj = bid % tiles_j;
   if (ti >= tiles_i) return;
-  if constexpr (AAFF) {
-    if (p.a_lazy.acc != nullptr) nsid_bn_lazy_finalize_wg(p.a_lazy);      // uniform: the producer's BatchNorm from its fixed-point sums
-  }
   const int g = blockIdx.z;
   const int i0 = ti * BM, j0 = tj * BN;
   const int rbeg = split * p.rchunk;
@@ -670,11 +655,7 @@ void gemm_kernel(const GemmArgs p) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int i = i0 + wm0 + 16 * a + 4 * rq + r;
-#ifdef NSID_WGRAD_PLAINSTORE        // diagnosis build: what the fp32 atomics of the split reduction cost inside the step (results wrong)
-          if ((FULL || i < p.I) && jok) crow[(long)(16 * a + r) * p.ldc + 16 * b] = acc[a][b][r];
-#else
           if ((FULL || i < p.I) && jok) atomicAdd(crow + (long)(16 * a + r) * p.ldc + 16 * b, acc[a][b][r]);
-#endif
         }
     }
   } else {
@@ -690,7 +671,7 @@ void gemm_kernel(const GemmArgs p) {
     const bool jqok = FULL || jq < p.J;          // J % OE == 0: a chunk is all-in or all-out
     char* Cb = reinterpret_cast<char*>(p.C) + g * p.c_goff * OSZ;
     const char* Ab = reinterpret_cast<const char*>(p.addend) + g * p.c_goff * OSZ;
-    if (p.stat != nullptr || p.stat_acc != nullptr) {
+    if (p.stat != nullptr) {
       // BatchNorm partial statistics of (acc + bias) from the accumulator registers, parked in LDS behind the transpose
       // buffers BEFORE the store loop: its barrier publishes them and the stores hide the LDS latency
       float* red = lds + NW * RB * OLD;      // [2 sums][wave-rows][4 row groups][BN]
@@ -852,21 +833,15 @@ void gemm_kernel(const GemmArgs p) {
                   a0 += red2[((0 * NW + (2 * wr + half)) * ROWS_PER_PASS + o) * WN + cw];
                   a1 += red2[((1 * NW + (2 * wr + half)) * ROWS_PER_PASS + o) * WN + cw];
                 }
-              if (p.bn_acc != nullptr) {        // uniform
-                const int rep = (int)(((long)ti * STILES + t2) & (p.bn_rep - 1));
-                nsid_acc_add(p.bn_acc, (int)p.bn_ld, rep, 0, (int)col, nsid_fix_bwd(a0));
-                nsid_acc_add(p.bn_acc, (int)p.bn_ld, rep, 1, (int)col, nsid_fix_bwd(a1));
-              } else {
-                p.bn_partial[((long)ti * STILES + t2) * p.bn_ld + col] = a0;
-                p.bn_partial[p.bn_plane + ((long)ti * STILES + t2) * p.bn_ld + col] = a1;
-              }
+              p.bn_partial[((long)ti * STILES + t2) * p.bn_ld + col] = a0;
+              p.bn_partial[p.bn_plane + ((long)ti * STILES + t2) * p.bn_ld + col] = a1;
             }
           }
         }
       }
     }
   }
-  if (p.stat != nullptr || p.stat_acc != nullptr) {   // uniform branch: the column sums were parked in LDS before the store loop (see above)
+  if (p.stat != nullptr) {   // uniform branch: the column sums were parked in LDS before the store loop (see above)
     const float* red = lds + NW * RB * ((BN / 2) + 4);
     if (threadIdx.x < BN) {
       const int j = j0 + threadIdx.x;
@@ -880,14 +855,8 @@ void gemm_kernel(const GemmArgs p) {
             s += red[(0 * WROWS * 4 + k) * BN + threadIdx.x];
             q += red[(1 * WROWS * 4 + k) * BN + threadIdx.x];
           }
-          if (p.stat_acc != nullptr) {          // uniform
-            const int rep = (int)(((long)ti * STILES + t2) & (p.stat_rep - 1));
-            nsid_acc_add(p.stat_acc, (int)p.stat_ld, rep, 0, (int)col, nsid_fix_fwd(s));
-            nsid_acc_add(p.stat_acc, (int)p.stat_ld, rep, 1, (int)col, nsid_fix_fwd(q));
-          } else {
-            p.stat[((long)ti * STILES + t2) * p.stat_ld + col] = s;
-            p.stat[p.stat_plane + ((long)ti * STILES + t2) * p.stat_ld + col] = q;
-          }
+          p.stat[((long)ti * STILES + t2) * p.stat_ld + col] = s;
+          p.stat[p.stat_plane + ((long)ti * STILES + t2) * p.stat_ld + col] = q;
         }
       }
     }
@@ -1081,11 +1050,7 @@ int launch_pad(GemmArgs p, int groups, hipStream_t s, int act_dtype, bool w_bf16
 
 }  // namespace
 
-#ifdef NSID_DIAGNOSIS_BUILD
-extern "C" int nsid_version(void) { return -4; }      // a timing-only build whose results may be wrong (nsid_common.h)
-#else
-extern "C" int nsid_version(void) { return 4; }
-#endif
+extern "C" int nsid_version(void) { return 5; }
 
 // ---- Downsample (Conv2d 3x3 stride 2 pad 1 on a width-1 map, encoder/graph_encoder.py:44) WITHOUT im2col -------------------
 // Only kernel column 1 meets data: out[b*No + n'] = sum_t x[b*N + 2n'-1+t] . W_t (t = 0,1,2; row -1 of a clip is padding).
@@ -1093,8 +1058,8 @@ extern "C" int nsid_version(void) { return 4; }
 //   col[m][kk] = xflat[(2m - 1)*C + kk],  kk in [0, 3C): row stride 2C, overlapping rows, base x - C,
 // except that the first C columns of the rows m with m % No == 0 are the left padding (zero; they would alias the previous
 // clip's last row). The three GEMMs below read that view through the padded-operand loads of gemm_kernel.
-static int downsample3_fwd_impl(const void* x, int B, int N, int C, const void* wp, int w_dtype, const float* bias,
-                                void* out, int Cout, float* stat, long long* stat_acc, int stat_rep, int act_dtype, void* stream) {
+extern "C" int nsid_downsample3_fwd(const void* x, int B, int N, int C, const void* wp, int w_dtype, const float* bias,
+                                    void* out, int Cout, float* stat, int act_dtype, void* stream) {
   NSID_REQUIRE(x && wp && out && B > 0 && N > 0 && N % 2 == 0 && C > 0 && Cout > 0 && NSID_DTYPE_OK(act_dtype));
   const int ch = act_dtype == NSID_BF16 ? 8 : 4;
   NSID_REQUIRE(C % ch == 0 && C % 4 == 0 && Cout % ch == 0 && Cout % 4 == 0 && nsid_aligned16(x) && nsid_aligned16(wp) &&
@@ -1109,8 +1074,6 @@ static int downsample3_fwd_impl(const void* x, int B, int N, int C, const void* 
   p.a_slope = 1.f;
   p.bias = bias; p.bias_goff = Cout;
   p.stat = stat; p.stat_ld = Cout; p.stat_plane = (long)nsid_row_tiles(M) * Cout;
-  p.stat_acc = stat_acc; p.stat_rep = stat_rep;
-  if (stat_acc != nullptr) nsid_count(NSID_C_bn_stat_acc);
   p.rsplit = 1; p.rchunk = 3 * C;
   p.pad_period = No; p.pad_phase = 0; p.pad_c0 = 0; p.pad_c1 = C; p.pad_safe = C;
   hipStream_t s = static_cast<hipStream_t>(stream);
@@ -1119,16 +1082,6 @@ static int downsample3_fwd_impl(const void* x, int B, int N, int C, const void* 
   return launch_pad<128, 128, true, true, 1>(p, 1, s, act_dtype, wb);
 }
 
-extern "C" int nsid_downsample3_fwd(const void* x, int B, int N, int C, const void* wp, int w_dtype, const float* bias,
-                                    void* out, int Cout, float* stat, int act_dtype, void* stream) {
-  return downsample3_fwd_impl(x, B, N, C, wp, w_dtype, bias, out, Cout, stat, nullptr, 0, act_dtype, stream);
-}
-extern "C" int nsid_downsample3_fwd_lazy(const void* x, int B, int N, int C, const void* wp, int w_dtype, const float* bias, void* out,
-                                         int Cout, int64_t* stat_acc, int stat_replicas, int act_dtype, void* stream) {
-  NSID_REQUIRE(nsid_acc_ok(stat_acc, stat_replicas));
-  return downsample3_fwd_impl(x, B, N, C, wp, w_dtype, bias, out, Cout, nullptr, reinterpret_cast<long long*>(stat_acc), stat_replicas,
-                              act_dtype, stream);
-}
 
 // dwp[o][kk] += sum_m dout[m][o] * col[m][kk]   (fp32 atomics over row splits, like every weight gradient)
 extern "C" int nsid_downsample3_bwd_weight(const void* dout, const void* x, float* dwp, int B, int N, int C, int Cout,
@@ -1204,27 +1157,10 @@ extern "C" int nsid_get_gemm_precision(void) { return g_gemm_precision; }
 extern "C" long nsid_gemm_g256_launches(void) { return g_g256_launches; }
 extern "C" int nsid_row_tiles(int M) { return (M + NSID_ROW_TILE - 1) / NSID_ROW_TILE; }
 
-struct LazyFwd {          // fixed-point statistics / a BatchNorm still held as sums on the operand side (nsid_linear_fwd_lazy)
-  long long* stat_acc = nullptr; int stat_rep = 0; const nsid_bn_lazy_t* in_bn = nullptr;
-};
 static int linear_fwd_impl(const void* x, int ldx, const void* w, int w_dtype, const float* bias, void* out, int ldo,
                            int M, int Nout, int K, int groups, const float* in_scale, const float* in_shift, int act_in,
                            int act_out, float* stat, int ksplit, int act_dtype, const void* addend, int ldadd,
-                           void* stream, const LazyFwd& lz = LazyFwd());
-
-// nsid_linear_fwd with fixed-point statistics and / or a BatchNorm on the operand side that is still a pair of sums
-extern "C" int nsid_linear_fwd_lazy(const void* x, int ldx, const void* w, int w_dtype, const float* bias, void* out, int ldo, int M,
-                                    int Nout, int K, int groups, const nsid_bn_lazy_t* in_bn, int act_in, int64_t* stat_acc,
-                                    int stat_replicas, int act_dtype, void* stream) {
-  NSID_REQUIRE(in_bn == nullptr || nsid_lazy_ok(in_bn, groups * K));
-  NSID_REQUIRE(stat_acc == nullptr || (nsid_acc_ok(stat_acc, stat_replicas) && nsid_aligned16(stat_acc)));
-  LazyFwd lz;
-  lz.stat_acc = reinterpret_cast<long long*>(stat_acc); lz.stat_rep = stat_replicas; lz.in_bn = in_bn;
-  const float* sc = in_bn ? in_bn->out : nullptr;
-  const float* sh = in_bn ? in_bn->out + (long)groups * K : nullptr;
-  return linear_fwd_impl(x, ldx, w, w_dtype, bias, out, ldo, M, Nout, K, groups, sc, sh, act_in, NSID_ACT_NONE, nullptr, 1, act_dtype,
-                         nullptr, 0, stream, lz);
-}
+                           void* stream);
 
 extern "C" int nsid_linear_fwd(const void* x, int ldx, const void* w, int w_dtype, const float* bias, void* out, int ldo,
                                int M, int Nout, int K, int groups, const float* in_scale, const float* in_shift,
@@ -1248,7 +1184,7 @@ extern "C" int nsid_linear_fwd_res(const void* x, int ldx, const void* w, int w_
 static int linear_fwd_impl(const void* x, int ldx, const void* w, int w_dtype, const float* bias, void* out, int ldo,
                            int M, int Nout, int K, int groups, const float* in_scale, const float* in_shift, int act_in,
                            int act_out, float* stat, int ksplit, int act_dtype, const void* addend, int ldadd,
-                           void* stream, const LazyFwd& lz) {
+                           void* stream) {
   NSID_REQUIRE(x && w && out && M > 0 && Nout > 0 && K > 0 && groups > 0 && ksplit >= 1 && NSID_DTYPE_OK(act_dtype));
   NSID_REQUIRE(NSID_DTYPE_OK(w_dtype) && (w_dtype == NSID_F32 || (act_dtype == NSID_BF16 && K % 8 == 0)));
   const int ch = act_dtype == NSID_BF16 ? 8 : 4;     // elements per 16-byte chunk of the activation tensors
@@ -1273,10 +1209,6 @@ static int linear_fwd_impl(const void* x, int ldx, const void* w, int w_dtype, c
   p.bias = bias; p.bias_goff = Nout;
   p.addend = addend; p.ldadd = ldadd;
   p.stat = stat; p.stat_ld = (long)groups * Nout; p.stat_plane = (long)nsid_row_tiles(M) * groups * Nout;
-  p.stat_acc = lz.stat_acc; p.stat_rep = lz.stat_rep;
-  if (lz.stat_acc != nullptr) nsid_count(NSID_C_bn_stat_acc);
-  if (lz.in_bn != nullptr && lz.in_bn->acc != nullptr) { p.a_lazy = nsid_lazy_view(lz.in_bn); nsid_count(NSID_C_bn_lazy_finalize); }
-  const bool any_stat = stat != nullptr || lz.stat_acc != nullptr;
   p.rsplit = ksplit;
   p.rchunk = (K + ksplit - 1) / ksplit;
   p.atomic_out = ksplit > 1;
@@ -1303,13 +1235,13 @@ static int linear_fwd_impl(const void* x, int ldx, const void* w, int w_dtype, c
   // keeps the other view's kernels off that CU), so it stays on gemm.hip.
   // weight-stationary streaming form (wsgemm.hip) for the layers whose whole weight matrix fits LDS: tuning key ws_gemm bit 0
   if ((nsid_tune(NSID_T_ws_gemm) & 1) && act_dtype == NSID_BF16 && wb && ksplit == 1 && act_out == NSID_ACT_NONE && addend == nullptr &&
-      lz.stat_acc == nullptr && lz.in_bn == nullptr && act_in != NSID_ACT_ELU) {
+      act_in != NSID_ACT_ELU) {
     const int rcw = nsid_ws_fwd_launch(x, ldx, w, bias, out, ldo, M, Nout, K, groups, in_scale, in_shift, act_slope(act_in), stat,
                                        p.stat_plane, p.stat_ld, s);
     if (rcw != 1) { nsid_count(NSID_C_ws_fwd); return rcw; }
   }
   const long g256_min = nsid_tune(NSID_T_g256_min);
-  if (g256_min > 0 && lz.stat_acc == nullptr && (stat == nullptr || nsid_tune(NSID_T_g256_train) != 0) && act_dtype == NSID_BF16 && wb && groups == 1 && in_scale == nullptr && ksplit == 1 &&
+  if (g256_min > 0 && (stat == nullptr || nsid_tune(NSID_T_g256_train) != 0) && act_dtype == NSID_BF16 && wb && groups == 1 && in_scale == nullptr && ksplit == 1 &&
       (act_out == NSID_ACT_NONE || act_out == NSID_ACT_RELU) && act_in == NSID_ACT_NONE && ldx >= K &&
       (long)(M / 256) * (Nout / 256) >= g256_min) {
     const int rc256 = nsid_gemm256_fwd_launch(x, ldx, w, bias, addend, ldadd, out, ldo, M, Nout, K, act_out == NSID_ACT_RELU, stat,
@@ -1330,8 +1262,7 @@ struct AbnArgs {          // BatchNorm backward of the layer in front, applied o
 static int linear_bwd_data_impl(const void* dout, int ldd, const void* w, int w_dtype, const void* addend, int ldadd,
                                 void* din, int ldi, int M, int Nout, int K, int groups, int act_dtype, void* stream,
                                 const void* bn_r, const float* bn_scale, const float* bn_shift, const float* bn_mean,
-                                const float* bn_invstd, int bn_act, float* bn_partial, const AbnArgs* abn = nullptr,
-                                long long* bn_acc = nullptr, int bn_rep = 0);
+                                const float* bn_invstd, int bn_act, float* bn_partial, const AbnArgs* abn = nullptr);
 
 extern "C" int nsid_linear_bwd_data(const void* dout, int ldd, const void* w, int w_dtype, const void* addend, int ldadd,
                                     void* din, int ldi, int M, int Nout, int K, int groups, int act_dtype,
@@ -1350,18 +1281,6 @@ extern "C" int nsid_linear_bwd_data_bn(const void* dout, int ldd, const void* w,
   NSID_REQUIRE(bn_act == NSID_ACT_NONE || bn_act == NSID_ACT_RELU || bn_act == NSID_ACT_LEAKY);
   return linear_bwd_data_impl(dout, ldd, w, w_dtype, addend, ldadd, din, ldi, M, Nout, K, groups, act_dtype, stream,
                               bn_r, bn_scale, bn_shift, bn_mean, bn_invstd, bn_act, bn_partial);
-}
-
-// nsid_linear_bwd_data_bn with the column sums ADDED into fixed-point accumulators (no per-tile partial buffer, no finalize launch)
-extern "C" int nsid_linear_bwd_data_bn_lazy(const void* dout, int ldd, const void* w, int w_dtype, const void* addend, int ldadd,
-                                            void* din, int ldi, int M, int Nout, int K, int groups, int act_dtype, const void* bn_r,
-                                            const float* bn_scale, const float* bn_shift, const float* bn_mean,
-                                            const float* bn_invstd, int bn_act, int64_t* bn_acc, int bn_replicas, void* stream) {
-  NSID_REQUIRE(bn_r && bn_scale && bn_shift && bn_mean && bn_invstd && nsid_acc_ok(bn_acc, bn_replicas) && act_dtype == NSID_BF16);
-  NSID_REQUIRE(ldi == groups * K && (groups * K) % 8 == 0 && nsid_aligned16(bn_r));
-  NSID_REQUIRE(bn_act == NSID_ACT_NONE || bn_act == NSID_ACT_RELU || bn_act == NSID_ACT_LEAKY);
-  return linear_bwd_data_impl(dout, ldd, w, w_dtype, addend, ldadd, din, ldi, M, Nout, K, groups, act_dtype, stream, bn_r, bn_scale,
-                              bn_shift, bn_mean, bn_invstd, bn_act, nullptr, nullptr, reinterpret_cast<long long*>(bn_acc), bn_replicas);
 }
 
 // Backward-data of a conv whose OUTPUT gradient still has to go through the BatchNorm(+activation) backward of that conv's own
@@ -1392,8 +1311,7 @@ extern "C" int nsid_linear_bwd_data_bnapply(const void* dy, const void* r, const
 static int linear_bwd_data_impl(const void* dout, int ldd, const void* w, int w_dtype, const void* addend, int ldadd,
                                 void* din, int ldi, int M, int Nout, int K, int groups, int act_dtype, void* stream,
                                 const void* bn_r, const float* bn_scale, const float* bn_shift, const float* bn_mean,
-                                const float* bn_invstd, int bn_act, float* bn_partial, const AbnArgs* abn, long long* bn_acc,
-                                int bn_rep) {
+                                const float* bn_invstd, int bn_act, float* bn_partial, const AbnArgs* abn) {
   NSID_REQUIRE(dout && w && din && M > 0 && Nout > 0 && K > 0 && groups > 0 && NSID_DTYPE_OK(act_dtype));
   NSID_REQUIRE(NSID_DTYPE_OK(w_dtype) && (w_dtype == NSID_F32 || (act_dtype == NSID_BF16 && K % 8 == 0)));
   const bool wb = w_dtype == NSID_BF16;
@@ -1413,8 +1331,6 @@ static int linear_bwd_data_impl(const void* dout, int ldd, const void* w, int w_
   p.bn_scale = bn_scale; p.bn_shift = bn_shift; p.bn_mean = bn_mean; p.bn_invstd = bn_invstd;
   p.bn_slope = act_slope(bn_act);
   p.bn_partial = bn_partial; p.bn_ld = (long)groups * K; p.bn_plane = (long)nsid_row_tiles(M) * groups * K;
-  p.bn_acc = bn_acc; p.bn_rep = bn_rep;
-  if (bn_acc != nullptr) nsid_count(NSID_C_bn_stat_acc);
   hipStream_t s = static_cast<hipStream_t>(stream);
   const long t128 = (long)nsid_row_tiles(M) * ((K + 127) / 128) * groups;
   const bool half = g_gemm_precision == NSID_GEMM_BF16 || act_dtype == NSID_BF16;
@@ -1423,7 +1339,7 @@ static int linear_bwd_data_impl(const void* dout, int ldd, const void* w, int w_
   if (half && t128 < 128) narrow = true;        // few row tiles (the projector head, M = batch)
   if (force_narrow >= 0 && K > 64) narrow = force_narrow != 0;
   // weight-stationary streaming form (wsgemm.hip): tuning key ws_gemm bit 1 (plain operand) / bit 2 (BatchNorm backward on the operand load)
-  if ((nsid_tune(NSID_T_ws_gemm) & (abn ? 4 : 2)) && bn_acc == nullptr && act_dtype == NSID_BF16 && wb &&
+  if ((nsid_tune(NSID_T_ws_gemm) & (abn ? 4 : 2)) && act_dtype == NSID_BF16 && wb &&
       (bn_r == nullptr || bn_partial != nullptr)) {
     const int rcw = nsid_ws_bwd_data_launch(dout, ldd, w, addend, ldadd, din, ldi, M, Nout, K, groups, bn_r, p.bn_ldr, bn_scale, bn_shift,
                                             bn_mean, bn_invstd, p.bn_slope, bn_partial, p.bn_plane, p.bn_ld, abn ? abn->r : nullptr,

@@ -45,9 +45,6 @@ struct G256Args {
 typedef __attribute__((address_space(3))) void* lds_vptr;
 typedef const __attribute__((address_space(1))) void* glb_vptr;
 
-#ifndef NSID_G256_ABLATE
-#define NSID_G256_ABLATE 0        // diagnosis builds (tools/build_variant.sh): 1 = no LDS-DMA in the loop, 2 = no MFMA, 4 = no fragment reads
-#endif
 constexpr int SLOT = 32768;         // bytes per ring slot: A image [16 row-blocks][1 KB], then B image [16 row-blocks][1 KB]
 constexpr int RING = 4 * SLOT;
 constexpr int TROW = 144;           // bytes per row of a wave's bf16 transpose buffer: 64 columns + 16 B (rows stay 16-byte aligned)

@@ -43,8 +43,7 @@ template <typename T>
 __global__ __launch_bounds__(KNN_THREADS) void knn_kernel(const T* __restrict__ r, long ldr,
                                                           const float* __restrict__ scale,
                                                           const float* __restrict__ shift, int N, int C, int k,
-                                                          int dilation, int32_t* __restrict__ idx, const NsidBnLazy lz) {
-  if (lz.acc != nullptr) nsid_bn_lazy_finalize_wg(lz);      // uniform: the BatchNorm in front is still a pair of fixed-point sums (nsid_common.h)
+                                                          int dilation, int32_t* __restrict__ idx) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int LD = C + 4;                 // feature row stride (keeps 16-B alignment, staggers banks)
   const int SLD = N + 4;                // distance strip row stride
@@ -451,8 +450,7 @@ __device__ __forceinline__ void knn_mfma3(const KnnFrag& x, const KnnFrag& y, f3
 template <typename T, int KD, int NT, bool PF>
 __device__ __forceinline__ void knn2_body(const T* __restrict__ r, long ldr, const float* __restrict__ scale,
                                           const float* __restrict__ shift, int N, int C, int k, int dilation,
-                                          int32_t* __restrict__ idx, const NsidBnLazy lz) {
-  if (lz.acc != nullptr) nsid_bn_lazy_finalize_wg(lz);      // uniform: the BatchNorm in front is still a pair of fixed-point sums (nsid_common.h)
+                                          int32_t* __restrict__ idx) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   char* img = reinterpret_cast<char*>(smem);          // [2][C/8][N][8] fp16: the two split images of the normalised features
   float* sq = smem + 2 * (N * C / 2);                 // [N]
@@ -570,15 +568,15 @@ template <typename T, int KD, int NT>
 __global__ __launch_bounds__(KNN2_THREADS) void knn2_kernel(const T* __restrict__ r, long ldr,
                                                             const float* __restrict__ scale,
                                                             const float* __restrict__ shift, int N, int C, int k,
-                                                            int dilation, int32_t* __restrict__ idx, const NsidBnLazy lz) {
-  knn2_body<T, KD, NT, true>(r, ldr, scale, shift, N, C, k, dilation, idx, lz);
+                                                            int dilation, int32_t* __restrict__ idx) {
+  knn2_body<T, KD, NT, true>(r, ldr, scale, shift, N, C, k, dilation, idx);
 }
 // the two-workgroups-per-CU form: four waves per SIMD = at most 128 VGPRs
 template <typename T, int KD, int NT>
 __global__ __launch_bounds__(KNN2_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4)))
 void knn2_pair_kernel(const T* __restrict__ r, long ldr, const float* __restrict__ scale, const float* __restrict__ shift,
-                      int N, int C, int k, int dilation, int32_t* __restrict__ idx, const NsidBnLazy lz) {
-  knn2_body<T, KD, NT, false>(r, ldr, scale, shift, N, C, k, dilation, idx, lz);
+                      int N, int C, int k, int dilation, int32_t* __restrict__ idx) {
+  knn2_body<T, KD, NT, false>(r, ldr, scale, shift, N, C, k, dilation, idx);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -593,8 +591,7 @@ template <typename T, int NT>
 __global__ __launch_bounds__(KNN2_THREADS) void knn_rank_kernel(const T* __restrict__ r, long ldr,
                                                                 const float* __restrict__ scale,
                                                                 const float* __restrict__ shift, int N, int C, int k,
-                                                                int dilation, int32_t* __restrict__ idx, const NsidBnLazy lz) {
-  if (lz.acc != nullptr) nsid_bn_lazy_finalize_wg(lz);      // uniform: the BatchNorm in front is still a pair of fixed-point sums (nsid_common.h)
+                                                                int dilation, int32_t* __restrict__ idx) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int SLD = N + 4;
   char* img = reinterpret_cast<char*>(smem);   // [2][C/8][N][8] fp16 split images (see knn2_kernel)
@@ -805,8 +802,7 @@ template <typename T, int TILES>
 __global__ __launch_bounds__(KNN2_THREADS) void knn_sel_kernel(const T* __restrict__ r, long ldr,
                                                                const float* __restrict__ scale,
                                                                const float* __restrict__ shift, int N, int C, int k,
-                                                               int dilation, int32_t* __restrict__ idx, const NsidBnLazy lz) {
-  if (lz.acc != nullptr) nsid_bn_lazy_finalize_wg(lz);      // uniform: the BatchNorm in front is still a pair of fixed-point sums (nsid_common.h)
+                                                               int dilation, int32_t* __restrict__ idx) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int SLOT = 16 * TILES + 2 * KSEL_CH;            // candidates of a row + padding + the dump word
   char* img = reinterpret_cast<char*>(smem);         // [2][C/8][N][8] fp16 split images (see knn2_kernel)
@@ -962,7 +958,7 @@ __global__ __launch_bounds__(KNN2_THREADS) void knn_sel_kernel(const T* __restri
 
 template <typename T, int TILES>
 int launch_knn_sel(const void* r, int ldr, const float* scale, const float* shift, int B, int N, int C, int k,
-                   int dilation, int32_t* idx, hipStream_t s, const NsidBnLazy& lz) {
+                   int dilation, int32_t* idx, hipStream_t s) {
   const size_t bytes = (size_t)2 * N * C * 2 + (size_t)N * sizeof(float) +
                        (size_t)KNN2_WAVES * 4 * (16 * TILES + 2 * KSEL_CH) * sizeof(unsigned long long);
   if (bytes > 160 * 1024 || N != 16 * TILES) return 1;
@@ -974,13 +970,13 @@ int launch_knn_sel(const void* r, int ldr, const float* scale, const float* shif
     configured = true;
   }
   NSID_LAUNCH((knn_sel_kernel<T, TILES>), dim3(B), dim3(KNN2_THREADS), bytes, s, static_cast<const T*>(r), (long)ldr, scale,
-              shift, N, C, k, dilation, idx, lz);
+              shift, N, C, k, dilation, idx);
   return nsid_launch_status();
 }
 
 template <typename T, int NT>
 int launch_knn_rank_nt(const void* r, int ldr, const float* scale, const float* shift, int B, int N, int C, int k,
-                       int dilation, int32_t* idx, hipStream_t s, const NsidBnLazy& lz) {
+                       int dilation, int32_t* idx, hipStream_t s) {
   const size_t bytes = (size_t)2 * N * C * 2 + ((size_t)N + (size_t)KNN2_WAVES * 16 * (N + 4)) * sizeof(float);
   static bool configured = false;
   if (!configured) {
@@ -990,19 +986,19 @@ int launch_knn_rank_nt(const void* r, int ldr, const float* scale, const float* 
     configured = true;
   }
   NSID_LAUNCH((knn_rank_kernel<T, NT>), dim3(B), dim3(KNN2_THREADS), bytes, s, static_cast<const T*>(r), (long)ldr, scale,
-              shift, N, C, k, dilation, idx, lz);
+              shift, N, C, k, dilation, idx);
   return nsid_launch_status();
 }
 template <typename T>
 int launch_knn_rank(const void* r, int ldr, const float* scale, const float* shift, int B, int N, int C, int k,
-                    int dilation, int32_t* idx, hipStream_t s, const NsidBnLazy& lz) {
-  return (N >> 4) >= 4 ? launch_knn_rank_nt<T, 4>(r, ldr, scale, shift, B, N, C, k, dilation, idx, s, lz)
-                       : launch_knn_rank_nt<T, 2>(r, ldr, scale, shift, B, N, C, k, dilation, idx, s, lz);
+                    int dilation, int32_t* idx, hipStream_t s) {
+  return (N >> 4) >= 4 ? launch_knn_rank_nt<T, 4>(r, ldr, scale, shift, B, N, C, k, dilation, idx, s)
+                       : launch_knn_rank_nt<T, 2>(r, ldr, scale, shift, B, N, C, k, dilation, idx, s);
 }
 
 template <typename T, int KD, int NT>
 int launch_knn2_nt(const void* r, int ldr, const float* scale, const float* shift, int B, int N, int C, int k,
-                   int dilation, int32_t* idx, hipStream_t s, const NsidBnLazy& lz) {
+                   int dilation, int32_t* idx, hipStream_t s) {
   const size_t bytes = (size_t)2 * N * C * 2 + ((size_t)N + 2 * 4 * 16 * KD) * sizeof(float);      // two fp16 images + |y|^2 + hand-over lists
   static bool configured = false;      // raise the dynamic-LDS cap once per instantiation (not a per-call sync)
   if (!configured) {
@@ -1022,20 +1018,20 @@ int launch_knn2_nt(const void* r, int ldr, const float* scale, const float* shif
     }
     nsid_count(NSID_C_knn2_pair);
     NSID_LAUNCH((knn2_pair_kernel<T, KD, NT>), dim3(B), dim3(KNN2_THREADS), bytes, s, static_cast<const T*>(r), (long)ldr,
-                scale, shift, N, C, k, dilation, idx, lz);
+                scale, shift, N, C, k, dilation, idx);
     return nsid_launch_status();
   }
   NSID_LAUNCH((knn2_kernel<T, KD, NT>), dim3(B), dim3(KNN2_THREADS), bytes, s, static_cast<const T*>(r), (long)ldr, scale,
-              shift, N, C, k, dilation, idx, lz);
+              shift, N, C, k, dilation, idx);
   return nsid_launch_status();
 }
 template <typename T, int KD>
 int launch_knn2(const void* r, int ldr, const float* scale, const float* shift, int B, int N, int C, int k, int dilation,
-                int32_t* idx, hipStream_t s, const NsidBnLazy& lz) {
+                int32_t* idx, hipStream_t s) {
   const int RT = N >> 4, CTG = RT / (RT >= KNN2_WAVES ? 1 : 2);      // column tiles per wave and row tile (kernel: G, CTG)
-  if (CTG >= 4) return launch_knn2_nt<T, KD, 4>(r, ldr, scale, shift, B, N, C, k, dilation, idx, s, lz);
-  if (CTG == 2) return launch_knn2_nt<T, KD, 2>(r, ldr, scale, shift, B, N, C, k, dilation, idx, s, lz);
-  return launch_knn2_nt<T, KD, 1>(r, ldr, scale, shift, B, N, C, k, dilation, idx, s, lz);
+  if (CTG >= 4) return launch_knn2_nt<T, KD, 4>(r, ldr, scale, shift, B, N, C, k, dilation, idx, s);
+  if (CTG == 2) return launch_knn2_nt<T, KD, 2>(r, ldr, scale, shift, B, N, C, k, dilation, idx, s);
+  return launch_knn2_nt<T, KD, 1>(r, ldr, scale, shift, B, N, C, k, dilation, idx, s);
 }
 
 }  // namespace
@@ -1045,7 +1041,7 @@ extern "C" int nsid_debug_knn_trace(void* buf) {
 }
 
 static int knn_graph_impl(const void* r, int ldr, const float* scale, const float* shift, int B, int N, int C,
-                          int k, int dilation, int32_t* idx, int dtype, void* stream, const NsidBnLazy& lz) {
+                          int k, int dilation, int32_t* idx, int dtype, void* stream) {
   NSID_REQUIRE(r && idx && B > 0 && k > 0 && dilation > 0 && NSID_DTYPE_OK(dtype));
   NSID_REQUIRE(ldr % (dtype == NSID_BF16 ? 8 : 4) == 0);
   NSID_REQUIRE(N % 32 == 0 && N <= 256 && C % 16 == 0 && ldr % 4 == 0 && ldr >= C && nsid_aligned16(r));
@@ -1061,8 +1057,8 @@ static int knn_graph_impl(const void* r, int ldr, const float* scale, const floa
     int rc = 1;
 #define NSID_KSEL_CASE(TL)                                                                                            \
     case 16 * TL:                                                                                                    \
-      rc = dtype == NSID_BF16 ? launch_knn_sel<__bf16, TL>(r, ldr, scale, shift, B, N, C, k, dilation, idx, s, lz)       \
-                              : launch_knn_sel<float, TL>(r, ldr, scale, shift, B, N, C, k, dilation, idx, s, lz);       \
+      rc = dtype == NSID_BF16 ? launch_knn_sel<__bf16, TL>(r, ldr, scale, shift, B, N, C, k, dilation, idx, s)       \
+                              : launch_knn_sel<float, TL>(r, ldr, scale, shift, B, N, C, k, dilation, idx, s);       \
       break;
     switch (N) { NSID_KSEL_CASE(16) NSID_KSEL_CASE(8) NSID_KSEL_CASE(4) NSID_KSEL_CASE(2) default: break; }
 #undef NSID_KSEL_CASE
@@ -1071,20 +1067,20 @@ static int knn_graph_impl(const void* r, int ldr, const float* scale, const floa
   if (use_fast && pow2 && kd > 8 && N <= 128) {              // small graphs: rank counting
     nsid_count(NSID_C_knn_rank);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    return dtype == NSID_BF16 ? launch_knn_rank<__bf16>(r, ldr, scale, shift, B, N, C, k, dilation, idx, s, lz)
-                              : launch_knn_rank<float>(r, ldr, scale, shift, B, N, C, k, dilation, idx, s, lz);
+    return dtype == NSID_BF16 ? launch_knn_rank<__bf16>(r, ldr, scale, shift, B, N, C, k, dilation, idx, s)
+                              : launch_knn_rank<float>(r, ldr, scale, shift, B, N, C, k, dilation, idx, s);
   }
   if (use_fast && kd <= 8 && pow2) {
     nsid_count(NSID_C_knn2);
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (dtype == NSID_BF16) {
-      if (kd <= 3) return launch_knn2<__bf16, 3>(r, ldr, scale, shift, B, N, C, k, dilation, idx, s, lz);
-      if (kd <= 5) return launch_knn2<__bf16, 5>(r, ldr, scale, shift, B, N, C, k, dilation, idx, s, lz);
-      return launch_knn2<__bf16, 8>(r, ldr, scale, shift, B, N, C, k, dilation, idx, s, lz);
+      if (kd <= 3) return launch_knn2<__bf16, 3>(r, ldr, scale, shift, B, N, C, k, dilation, idx, s);
+      if (kd <= 5) return launch_knn2<__bf16, 5>(r, ldr, scale, shift, B, N, C, k, dilation, idx, s);
+      return launch_knn2<__bf16, 8>(r, ldr, scale, shift, B, N, C, k, dilation, idx, s);
     }
-    if (kd <= 3) return launch_knn2<float, 3>(r, ldr, scale, shift, B, N, C, k, dilation, idx, s, lz);
-    if (kd <= 5) return launch_knn2<float, 5>(r, ldr, scale, shift, B, N, C, k, dilation, idx, s, lz);
-    return launch_knn2<float, 8>(r, ldr, scale, shift, B, N, C, k, dilation, idx, s, lz);
+    if (kd <= 3) return launch_knn2<float, 3>(r, ldr, scale, shift, B, N, C, k, dilation, idx, s);
+    if (kd <= 5) return launch_knn2<float, 5>(r, ldr, scale, shift, B, N, C, k, dilation, idx, s);
+    return launch_knn2<float, 8>(r, ldr, scale, shift, B, N, C, k, dilation, idx, s);
   }
   const size_t bytes = ((size_t)N * (C + 4) + N + (size_t)KNN_WAVES * 16 * (N + 4)) * sizeof(float);
   NSID_REQUIRE(bytes <= 160 * 1024);
@@ -1100,22 +1096,13 @@ static int knn_graph_impl(const void* r, int ldr, const float* scale, const floa
   }
   NSID_DISPATCH_DTYPE(dtype, T, {
     NSID_LAUNCH((knn_kernel<T>), dim3(B), dim3(KNN_THREADS), bytes, static_cast<hipStream_t>(stream),
-                static_cast<const T*>(r), (long)ldr, scale, shift, N, C, k, dilation, idx, lz);
+                static_cast<const T*>(r), (long)ldr, scale, shift, N, C, k, dilation, idx);
   });
   return nsid_launch_status();
 }
 
 extern "C" int nsid_knn_graph(const void* r, int ldr, const float* scale, const float* shift, int B, int N, int C,
                               int k, int dilation, int32_t* idx, int dtype, void* stream) {
-  return knn_graph_impl(r, ldr, scale, shift, B, N, C, k, dilation, idx, dtype, stream, NsidBnLazy{});
+  return knn_graph_impl(r, ldr, scale, shift, B, N, C, k, dilation, idx, dtype, stream);
 }
 
-// the BatchNorm in front of the graph is still a pair of fixed-point column sums (include/nsid.h): every workgroup (= clip) evaluates
-// it in its prologue and leaves scale / shift / mean / invstd / unbiased variance in bn->out for the later consumers
-extern "C" int nsid_knn_graph_lazy(const void* r, int ldr, const nsid_bn_lazy_t* bn, int B, int N, int C, int k, int dilation,
-                                   int32_t* idx, int dtype, void* stream) {
-  NSID_REQUIRE(nsid_lazy_ok(bn, C));
-  NsidBnLazy lz{};
-  if (bn->acc != nullptr) { lz = nsid_lazy_view(bn); nsid_count(NSID_C_bn_lazy_finalize); }
-  return knn_graph_impl(r, ldr, bn->out, bn->out + C, B, N, C, k, dilation, idx, dtype, stream, lz);
-}

@@ -6,14 +6,9 @@
 
 #include "../../include/nsid.h"
 
-// Diagnosis switches that CHANGE RESULTS (timing-only builds of tools/build_variant.sh: NSID_ABN_NOMATH / NSID_ABN_NOSIDE,
-// NSID_WGRAD_PLAINSTORE, NSID_G256_ABLATE, NSID_F256_NCH, NSID_F256_NOBARRIER) compile only together with -DNSID_DIAGNOSIS_BUILD, and such a library says so:
-// nsid_version() is negative, which neuralsampleid_amd/_lib.py refuses to load as the product library (hygiene).
-#if (defined(NSID_ABN_NOMATH) || defined(NSID_ABN_NOSIDE) || defined(NSID_WGRAD_PLAINSTORE) || defined(NSID_G256_ABLATE) || defined(NSID_F256_NCH) || \
-     defined(NSID_F256_NOBARRIER)) && \
-    !defined(NSID_DIAGNOSIS_BUILD)
-#error "result-changing diagnosis switches need -DNSID_DIAGNOSIS_BUILD (tools/build_variant.sh adds it); the library then reports a negative nsid_version()"
-#endif
+// (Rounds 3-4 kept result-changing timing switches -- NSID_ABN_NOMATH / NOSIDE, NSID_WGRAD_PLAINSTORE, NSID_G256_ABLATE, NSID_F256_* --
+// behind #ifdefs in the product kernels; their measurements are in docs/experiments.md and the switches are gone: the product sources
+// compile one arithmetic. Timing experiments belong in tools/variants/.)
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -136,96 +131,6 @@ static inline bool nsid_aligned16(const void* p) { return (reinterpret_cast<uint
     if (!(cond)) return NSID_EINVAL; \
   } while (0)
 
-// ---- training-mode BatchNorm statistics as FIXED-POINT column sums (round 4) ---------------------------------------------------
-// The per-row-tile float partials + one finalize launch per BatchNorm layer (256 launches of ~5 us per step, 0.57 ms of the
-// two-stream step by a skip-the-launch diagnosis) are replaced by: the producing kernel ADDS its column sums, converted to 64-bit
-// fixed point, into acc[replica][2][C] with integer atomics — integer addition is associative, so the totals do not depend on
-// the order the workgroups arrive in (the float-atomic form would) — and the FIRST kernel that consumes the layer evaluates
-// mean / variance / scale / shift from the totals itself, every workgroup for itself (same integers, same arithmetic: same
-// bits), and writes them where the later consumers (backward, the deferred running-statistics update) expect them.
-// Forward sums use 2^-28 as the unit (|sum of squares| < 3.4e10 over the batch), backward sums 2^-44 (|sum| < 5.2e5).
-struct NsidBnLazy {                 // device view of nsid_bn_lazy_t; acc == nullptr: `out` already holds the five vectors
-  const long long* acc; int R; int C; long rows;
-  double inv_rows_unit, unbias;                       // host-side constants: 2^-shift / rows, rows / (rows - 1)
-  const float* gamma; const float* beta; float eps;
-  float* out;                       // [5][C]: scale, shift, mean, invstd, unbiased variance
-};
-struct NsidBnBwdLazy {              // device view of nsid_bn_bwd_lazy_t
-  const long long* acc; int R; int C; long rows;
-  double unit, inv_rows_unit;                         // 2^-NSID_STAT_BWD_SHIFT, and that over rows
-  float* dgamma; float* dbeta;      // += (atomic: the two views of a step may add concurrently); either may be null
-  float* coef;                      // optional [2][C]: c0 = sum(g) / rows, c1 = sum(g * xhat) / rows
-};
-__device__ __forceinline__ long long nsid_fix_fwd(float v) { return __double2ll_rn((double)v * (double)(1LL << NSID_STAT_FWD_SHIFT)); }
-__device__ __forceinline__ long long nsid_fix_bwd(float v) { return __double2ll_rn((double)v * (double)(1LL << NSID_STAT_BWD_SHIFT)); }
-// acc[replica][which][C] += v (no-return 64-bit integer atomic: executes at the memory side, any order gives the same total)
-__device__ __forceinline__ void nsid_acc_add(long long* acc, int C, int replica, int which, int c, long long v) {
-  atomicAdd(reinterpret_cast<unsigned long long*>(acc) + ((long)(2 * replica + which) * C + c), (unsigned long long)v);
-}
-__device__ __forceinline__ void nsid_acc_total(const long long* acc, int R, int C, int c, long long& s, long long& q) {
-  s = 0; q = 0;
-  for (int r = 0; r < R; ++r) { s += acc[(long)(2 * r) * C + c]; q += acc[(long)(2 * r + 1) * C + c]; }
-}
-// The arithmetic of bn_finalize_kernel (bn.hip) on the totals of one channel, arranged for a prologue that EVERY workgroup of the
-// consuming launch runs: the integer totals are exact; mean, variance and 1 / sqrt(var + eps) are formed in fp64 with multiplications
-// only — 1 / rows arrives as a constant from the host, and the reciprocal square root is the fp32 hardware estimate refined by two
-// Newton steps in fp64 (relative error ~1e-16, i.e. the same fp32 value as the finalize kernel's (float)(1.0 / sqrt(x)) except within
-// 1e-16 of a rounding boundary). Round 4 measurement: with fp64 division / square-root sequences per channel this prologue cost +5.5 us
-// on the FFN GEMMs (8 channels per thread at K = 2 048) and 24 us instead of 5.7 in the streaming kernels.
-__device__ __forceinline__ void nsid_bn_lazy_channel(const NsidBnLazy& z, int c, float& sc, float& sh, float& mu, float& is, float& uv) {
-  long long s, q;
-  nsid_acc_total(z.acc, z.R, z.C, c, s, q);
-  const double inv = z.inv_rows_unit;                 // 2^-NSID_STAT_FWD_SHIFT / rows
-  const double mean = (double)s * inv;
-  double var = (double)q * inv - mean * mean;
-  if (var < 0.0) var = 0.0;
-  const double x = var + (double)z.eps;
-  double y = (double)__frsqrt_rn((float)x);
-  y = y * (1.5 - 0.5 * x * y * y);
-  y = y * (1.5 - 0.5 * x * y * y);
-  is = (float)y;
-  sc = z.gamma[c] * is;
-  mu = (float)mean;
-  sh = z.beta[c] - mu * sc;
-  uv = (float)(var * z.unbias);                       // rows / (rows - 1)
-}
-// Whole workgroup: evaluate every channel, write the five vectors, and make them readable by this workgroup's own later loads.
-// Every workgroup of the consuming launch does this; they all write the same bits, so the writes need no ordering between
-// workgroups, and a workgroup reads only what it has written itself (drained + barrier).
-__device__ __forceinline__ void nsid_bn_lazy_finalize_wg(const NsidBnLazy& z) {
-  for (int c = threadIdx.x; c < z.C; c += blockDim.x) {
-    float sc, sh, mu, is, uv;
-    nsid_bn_lazy_channel(z, c, sc, sh, mu, is, uv);
-    z.out[c] = sc; z.out[z.C + c] = sh; z.out[2 * z.C + c] = mu; z.out[3 * z.C + c] = is; z.out[4 * z.C + c] = uv;
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-}
-__device__ __forceinline__ void nsid_bn_bwd_lazy_channel(const NsidBnBwdLazy& z, int c, float& c0, float& c1, float& sg, float& sgx) {
-  long long s, q;
-  nsid_acc_total(z.acc, z.R, z.C, c, s, q);
-  sg = (float)((double)s * z.unit); sgx = (float)((double)q * z.unit);
-  c0 = (float)((double)s * z.inv_rows_unit); c1 = (float)((double)q * z.inv_rows_unit);
-}
-static inline NsidBnLazy nsid_lazy_view(const nsid_bn_lazy_t* z) {
-  const double unit = 1.0 / (double)(1LL << NSID_STAT_FWD_SHIFT), M = (double)z->rows;
-  return NsidBnLazy{reinterpret_cast<const long long*>(z->acc), z->replicas, z->channels, z->rows, unit / M,
-                    M / (z->rows > 1 ? M - 1.0 : 1.0), z->gamma, z->beta, z->eps, z->out};
-}
-static inline NsidBnBwdLazy nsid_bwd_lazy_view(const nsid_bn_bwd_lazy_t* z) {
-  const double unit = 1.0 / (double)(1LL << NSID_STAT_BWD_SHIFT);
-  return NsidBnBwdLazy{reinterpret_cast<const long long*>(z->acc), z->replicas, z->channels, z->rows, unit, unit / (double)z->rows,
-                       z->dgamma, z->dbeta, z->coef};
-}
-static inline bool nsid_lazy_ok(const nsid_bn_lazy_t* z, int C) {
-  return z && z->out && z->channels == C && nsid_aligned16(z->out) && C % 4 == 0 &&
-         (z->acc == nullptr || (z->gamma && z->beta && z->rows > 0 && z->replicas >= 1 && z->replicas <= NSID_STAT_MAX_REPLICAS &&
-                                (z->replicas & (z->replicas - 1)) == 0));
-}
-static inline bool nsid_acc_ok(const int64_t* acc, int replicas) {
-  return acc && replicas >= 1 && replicas <= NSID_STAT_MAX_REPLICAS && (replicas & (replicas - 1)) == 0;
-}
-
 // ---- tuning table (include/nsid.h: nsid_set_tuning / nsid_get_tuning / nsid_reset_tuning; defined in tuning.hip) -----------
 // Every launch heuristic that has a number in it reads that number from here. The defaults are the values that won their one-box
 // A/B of the whole two-stream step (docs/experiments.md); the library never reads the environment, so the arithmetic and the kernel
@@ -292,12 +197,7 @@ static inline long nsid_tune(NsidTuneKey k) { return g_nsid_tune[k]; }
   X(knn2) X(knn2_pair) X(knn_rank) X(knn_sel) X(knn_strips)                                                  \
   X(mr_fwd_lds) X(mr_fwd_grid) X(mr_fwd_key)                                                                  \
   X(ffn_fused)            /* eval-mode FFN in one launch (ffn_fused.hip) */                     \
-  X(block_tail_fused)     /* ... with the Grapher's fc2 + shortcut in front of it (ffn256_fused.hip PRE form) */ \
-  X(block_gr_fused)       /* ... and the max-relative graph conv in front of that (GR form) */          \
-  X(mrconv_fused)         /* eval-mode max-relative aggregation + grouped conv in one launch (mrconv_fused.hip) */ \
-  X(bn_stat_acc)          /* producers that ADD BatchNorm column sums in fixed point (no partial-sum buffer) */ \
-  X(bn_lazy_finalize)     /* consumers that evaluate a BatchNorm from those sums in their own prologue (no finalize launch) */ \
-  X(bn_materialize)       /* stand-alone finalize launches from fixed-point sums (a consumer without the prologue) */
+  X(mrconv_fused)         /* eval-mode max-relative aggregation + grouped conv in one launch (mrconv_fused.hip) */
 
 enum NsidCounterKey {
 #define NSID_CNT_ENUM(name) NSID_C_##name,
@@ -328,7 +228,5 @@ int nsid_ws_bwd_data_launch(const void* dout, int ldd, const void* w, const void
                             hipStream_t stream);
 // ffn256_fused.hip: eval-mode FFN of the C = 256 stage in one launch; returns 1 outside C = 256, H = 1024, M % 256 == 0
 int nsid_ffn256_fused_launch(const void* x, const void* w1, const float* b1, const void* w2, const float* b2, void* out, int M, int C,
-                             int H, hipStream_t stream, const void* r2 = nullptr, const void* wp = nullptr, const float* bp = nullptr,
-                             const void* y = nullptr, const int32_t* idx = nullptr, int k = 0, int N = 0, const void* wg = nullptr,
-                             const float* bg = nullptr);
+                             int H, hipStream_t stream);
 extern void* g_gemm_trace_host;        // gemm.hip: the buffer installed by nsid_debug_gemm_trace (nullptr = none)

@@ -120,15 +120,7 @@ class GraphEncoder(nn.Module):
                     x = entry.forward_rows(x, B, N)
                     N = (N - 1) // 2 + 1
                 else:
-                    y = None
-                    if not self.training and not torch.is_grad_enabled():   # forward-only: Grapher tail + FFN in one launch where it applies
-                        pg, bg = _split(entry[0])
-                        pf, bf = _split(entry[1])
-                        y = F_.block_eval_fused(x.contiguous(), {**pg, **bg}, {**pf, **bf}, B, N, entry[0].graph_conv.k,
-                                                entry[0].graph_conv.d)
-                    if y is None:
-                        y = entry[1].forward_rows(entry[0].forward_rows(x, B, N))
-                    x = y
+                    x = entry[1].forward_rows(entry[0].forward_rows(x, B, N))
         finally:
             F_.CHAIN = prev_chain
         params, buffers = _split(self.proj)

@@ -192,31 +192,10 @@ def conv_bn(x: Tensor, M: int, K: int, Nout: int, w: Tensor, bias: Optional[Tens
         r, _ = ops.linear_fwd(x, wf, bf, M, Nout, K, groups, sc, sh, act_in, folded_act, addend=residual)
         return r, (None if folded_act != ACT_NONE else ops.identity_affine(groups * Nout, x.device))
     assert residual is None
-    if lazy_stats(training, rm):
-        # statistics as fixed-point sums added by the GEMM; the BatchNorm in front (in_aff), if still unevaluated, is evaluated in this
-        # launch's prologue: no finalize launch on either side (ops.LAZY_BN)
-        acc = (ops.STAT_ARENA.take(ops.stat_replicas(M) * 2 * groups * Nout, x.device), ops.stat_replicas(M))
-        if in_aff is not None and in_aff.lazy is None:
-            in_aff = None if in_aff.identity and act_in == ACT_NONE else in_aff
-        if in_aff is None or in_aff.lazy is not None:
-            r, _ = ops.linear_fwd(x, ops.w2d(w), bias, M, Nout, K, groups, act_in=act_in, in_aff=in_aff, stat_acc=acc)
-            return r, lazy_affine_from(acc, M, gamma, beta, rm, rv, nbt)
     r, stat = ops.linear_fwd(x, ops.w2d(w), bias, M, Nout, K, groups,
                              in_aff.scale if in_aff else None, in_aff.shift if in_aff else None, act_in,
                              ACT_NONE, want_stat=training)
     return r, bn_affine_from(stat, M, gamma, beta, rm, rv, nbt, training)
-
-
-def lazy_stats(training: bool, rm) -> bool:
-    """training-mode BatchNorm statistics as fixed-point sums, evaluated by the consuming kernel (ops.LAZY_BN): bf16 storage, the two
-    views on two streams (deferred running-statistics update), a zeroed accumulator arena"""
-    return training and VIEW_ORDER.mode is not None and rm is not None and ops.lazy_bn_enabled(ACT_DTYPE == torch.bfloat16)
-
-
-def lazy_affine_from(acc, M, gamma, beta, rm, rv, nbt) -> BNAffine:
-    aff, uvar = ops.lazy_affine(acc[0], acc[1], M, gamma, beta)
-    VIEW_ORDER.pending[VIEW_ORDER.mode].append((rm, rv, nbt, aff._mean, uvar))     # filled by the layer's first consumer
-    return aff
 
 
 def bn_affine_from(stat, M, gamma, beta, rm, rv, nbt, training: bool) -> BNAffine:
@@ -255,11 +234,7 @@ def stem_backward(dx0: Tensor, P, S, G, need_input_grad: bool = True) -> Optiona
 
 
 # ------------------------------------------------------------------------------------------------ Grapher
-def grapher_forward(x0: Tensor, P, S: Optional[dict], B: int, N: int, k: int, dilation: int, training: bool,
-                    defer_tail: Optional[list] = None) -> Tensor:
-    """defer_tail (a list, eval mode without a backward only): when the folded path produced r2 = relu(BN(graph conv)), the last
-    conv + shortcut is NOT evaluated here -- r2 is appended to the list and x0 returned; the caller evaluates it inside the FFN
-    launch (block_eval_fused)."""
+def grapher_forward(x0: Tensor, P, S: Optional[dict], B: int, N: int, k: int, dilation: int, training: bool) -> Tensor:
     M, C = x0.shape
     r1, a1 = conv_bn(x0, M, C, C, P["fc1.0.weight"], P["fc1.0.bias"], _bn(P, S, "fc1.1."), training)
     idx = ops.knn_graph(r1, B, N, C, k, dilation, a1)
@@ -274,18 +249,12 @@ def grapher_forward(x0: Tensor, P, S: Optional[dict], B: int, N: int, k: int, di
         # forward-only, BatchNorms folded: aggregation + grouped conv in one launch per clip, the interleaved tensor u never formed
         gg, gb, grm, grv, _, _ = _bn(P, S, pre + "1.")
         wgf, bgf = ops.folded_conv_bn(ops.w2d(P[pre + "0.weight"]), P[pre + "0.bias"], gg, gb, grm, grv)
-        if defer_tail is not None and ops.FUSE_BLOCK_GR and C == 256 and 256 % N == 0 and idx.dtype == torch.int32:
-            defer_tail.append(("gr", r1, idx, wgf, bgf))       # evaluated inside the FFN launch too (block_eval_fused)
-            return x0
         r2, a2 = ops.mrconv_fused_fwd(r1, idx, B, N, C, wgf, bgf), None
     if r2 is None:
         u, amax = ops.mr_aggregate_fwd(r1, idx, B, N, C, a1, want_argmax=S is not None)
         r2, a2 = conv_bn(u, M, C // 2, C // 2, P[pre + "0.weight"], P[pre + "0.bias"], _bn(P, S, pre + "1."), training,
                          groups=4, folded_act=ACT_RELU)
     if fold_eval(training, S):   # conv + BatchNorm + shortcut in one launch; r2 already is relu(BN(conv)) (a2 is None)
-        if defer_tail is not None and a2 is None:
-            defer_tail.append(("pre", r2))
-            return x0
         return conv_bn(r2, M, 2 * C, C, P["fc2.0.weight"], P["fc2.0.bias"], _bn(P, S, "fc2.1."), training,
                        in_aff=a2, act_in=ACT_RELU, residual=x0)[0]
     r3, a3 = conv_bn(r2, M, 2 * C, C, P["fc2.0.weight"], P["fc2.0.bias"], _bn(P, S, "fc2.1."), training,
@@ -358,44 +327,6 @@ def ffn_forward(x1: Tensor, P, S: Optional[dict], training: bool) -> Tensor:
     return x2
 
 
-def block_eval_fused(x0: Tensor, PG, PF, B: int, N: int, k: int, dilation: int) -> Optional[Tensor]:
-    """One eval-mode block (Grapher + FFN, no backward) with the Grapher's fc2 + BatchNorm + shortcut evaluated inside the FFN launch
-    (csrc/ffn256_fused.hip PRE form; reference: torch_vertex.py:183-195 + graph_encoder.py:82-89). PG / PF: the two modules'
-    parameters and buffers. None when the block is outside the fused form (C = 256, M % 256 == 0, bf16 storage, folded BatchNorms):
-    the caller then runs the two modules as usual."""
-    M, C = x0.shape
-    H = PF["fc1.0.weight"].shape[0]
-    if not (ops.FUSE_BLOCK_TAIL and fold_eval(False, None) and C == 256 and H == 4 * C and M % 256 == 0
-            and ops.get_tuning("ffn256") != 0):
-        return None
-    tail: list = []
-    x = grapher_forward(x0, PG, None, B, N, k, dilation, False, defer_tail=tail)
-    if tail:
-        g, be, rm, rv, _, _ = _bn(PG, None, "fc2.1.")
-        wpf, bpf = ops.folded_conv_bn(ops.w2d(PG["fc2.0.weight"]), PG["fc2.0.bias"], g, be, rm, rv)
-        g1, be1, rm1, rv1, _, _ = _bn(PF, None, "fc1.1.")
-        g2, be2, rm2, rv2, _, _ = _bn(PF, None, "fc2.1.")
-        w1f, b1f = ops.folded_conv_bn(ops.w2d(PF["fc1.0.weight"]), None, g1, be1, rm1, rv1)
-        w2f, b2f = ops.folded_conv_bn(ops.w2d(PF["fc2.0.weight"]), None, g2, be2, rm2, rv2)
-        r2 = None
-        if tail[0][0] == "gr":
-            _, r1, idx, wgf, bgf = tail[0]
-            out = ops.block_gr_fused_fwd(x0, r1, idx, B, N, wgf, bgf, wpf, bpf, w1f, b1f, w2f, b2f, M, C, H)
-            if out is not None:
-                return out
-            r2 = ops.mrconv_fused_fwd(r1, idx, B, N, C, wgf, bgf)
-            if r2 is None:
-                raise RuntimeError("block_eval_fused: the graph conv of a C = 256 block fell outside nsid_mrconv_fused_fwd")
-        else:
-            r2 = tail[0][1]
-        out = ops.block_tail_fused_fwd(x0, r2, wpf, bpf, w1f, b1f, w2f, b2f, M, C, H)
-        if out is not None:
-            return out
-        x = conv_bn(r2, M, 2 * C, C, PG["fc2.0.weight"], PG["fc2.0.bias"], _bn(PG, None, "fc2.1."), False, in_aff=None,
-                    act_in=ACT_RELU, residual=x0)[0]
-    return ffn_forward(x, PF, None, False)
-
-
 def ffn_backward(dx2: Tensor, P, S, G) -> Tensor:
     x1, r4, a4, r5, a5 = S["x1"], S["r4"], S["a4"], S["r5"], S["a5"]
     M, C = x1.shape
@@ -432,13 +363,8 @@ def downsample_forward(x: Tensor, P, S: Optional[dict], B: int, N: int, training
     if prep is not None:
         # prepared once per step for both views (ops.DsPrep): packed weights already in bf16, one shared packed gradient buffer
         gamma, beta, rm, rv, nbt, _ = _bn(P, S, "conv.1.")
-        if lazy_stats(training, rm):
-            acc = (ops.STAT_ARENA.take(ops.stat_replicas(B * No) * 2 * Co, x.device), ops.stat_replicas(B * No))
-            r, _ = ops.downsample3_fwd(x, B, N, C, None, P["conv.0.bias"], Co, stat_acc=acc, w16=prep["wp16"])
-            aff = lazy_affine_from(acc, B * No, gamma, beta, rm, rv, nbt)
-        else:
-            r, stat = ops.downsample3_fwd(x, B, N, C, None, P["conv.0.bias"], Co, want_stat=training, w16=prep["wp16"])
-            aff = bn_affine_from(stat, B * No, gamma, beta, rm, rv, nbt, training)
+        r, stat = ops.downsample3_fwd(x, B, N, C, None, P["conv.0.bias"], Co, want_stat=training, w16=prep["wp16"])
+        aff = bn_affine_from(stat, B * No, gamma, beta, rm, rv, nbt, training)
         out = ops.bn_apply(r, aff, ACT_NONE)
         S.update(col=None, x=x, wp=None, prep=prep, dwp_slot=ops.DS_PREP.take_slot(prep), r=r, aff=aff, B=B, N=N, C=C)
         if CHAIN is not None:
@@ -451,13 +377,8 @@ def downsample_forward(x: Tensor, P, S: Optional[dict], B: int, N: int, training
         ops.SHADOWS.register(wp, ops.f32_to_bf16(wp), owner=wp, fresh=True)
     if view:
         gamma, beta, rm, rv, nbt, _ = _bn(P, S, "conv.1.")
-        if lazy_stats(training, rm):
-            acc = (ops.STAT_ARENA.take(ops.stat_replicas(B * No) * 2 * Co, x.device), ops.stat_replicas(B * No))
-            r, _ = ops.downsample3_fwd(x, B, N, C, wp, P["conv.0.bias"], Co, stat_acc=acc)
-            aff = lazy_affine_from(acc, B * No, gamma, beta, rm, rv, nbt)
-        else:
-            r, stat = ops.downsample3_fwd(x, B, N, C, wp, P["conv.0.bias"], Co, want_stat=training)
-            aff = bn_affine_from(stat, B * No, gamma, beta, rm, rv, nbt, training)
+        r, stat = ops.downsample3_fwd(x, B, N, C, wp, P["conv.0.bias"], Co, want_stat=training)
+        aff = bn_affine_from(stat, B * No, gamma, beta, rm, rv, nbt, training)
     else:
         r, aff = conv_bn(col, B * No, 3 * C, Co, wp, P["conv.0.bias"], _bn(P, S, "conv.1."), training)
     out = ops.bn_apply(r, aff, ACT_NONE)

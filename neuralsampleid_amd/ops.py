@@ -267,14 +267,10 @@ def _weight(w: torch.Tensor, dt: int, K: int):
 
 # ------------------------------------------------------------------------------------------------ linear
 def linear_fwd(x, w, bias, M, Nout, K, groups=1, in_scale=None, in_shift=None, act_in=ACT_NONE, act_out=ACT_NONE,
-               want_stat=False, ksplit=1, out=None, addend=None, in_aff=None, stat_acc=None) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+               want_stat=False, ksplit=1, out=None, addend=None, in_aff=None) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
     """out = f(x) w^T + bias (+ addend, same layout and storage as out: the residual stream, nsid_linear_fwd_res).
-    in_aff: the producer's BNAffine instead of (in_scale, in_shift); when its statistics are still fixed-point sums this launch evaluates
-    them in its prologue. stat_acc = (int64 accumulators, replicas): the statistics of THIS layer are added there (no partial buffer)."""
-    lazy_in = in_aff is not None and in_aff.lazy is not None and in_aff.lazy.pending
-    if (lazy_in or stat_acc is not None) and (ksplit != 1 or act_out != ACT_NONE or addend is not None or want_stat):
-        raise ValueError("the fixed-point statistics forms ride with a plain epilogue")
-    if in_aff is not None and not (lazy_in or stat_acc is not None):
+    in_aff: the producer's BNAffine instead of (in_scale, in_shift)."""
+    if in_aff is not None:
         in_scale, in_shift = in_aff.scale, in_aff.shift
     _chk(w, bias, in_scale, in_shift)
     dt = _act(x, out, addend)
@@ -303,17 +299,6 @@ def linear_fwd(x, w, bias, M, Nout, K, groups=1, in_scale=None, in_shift=None, a
         if not (act_in == ACT_RELU and dt == BF16 and wdt == BF16 and M % bm_ == 0 and Nout % bn_ == 0 and K % 64 == 0
                 and ksplit == 1):
             raise ValueError("activation-on-load without an affine needs ReLU, bf16 storage, bf16 weights and whole tiles")
-    if lazy_in or stat_acc is not None:
-        import ctypes
-        zc = in_aff.lazy.cstruct(consume=True) if (in_aff is not None and in_aff.lazy is not None) else None
-        if in_aff is not None and zc is None:        # a BNAffine that never was lazy: wrap its vectors (they must be one (5, C) block)
-            raise ValueError("stat_acc with an eager in_aff: pass in_scale / in_shift to the plain form instead")
-        acc, rep = stat_acc if stat_acc is not None else (None, 0)
-        _timed(name, 2.0 * M * Nout * K * groups,
-               groups * (esz * M * K + float(wop.element_size()) * Nout * K + esz * M * Nout), lambda: call(
-            "nsid_linear_fwd_lazy", _p(x), ldx, _p(wop), wdt, _p(bias), _p(out), out.shape[-1], M, Nout, K, groups,
-            ctypes.addressof(zc) if zc is not None else None, act_in, _p(acc), rep, dt, _stream()), (M, Nout, K, groups))
-        return out, None
     if addend is not None:
         _timed(name, 2.0 * M * Nout * K * groups,
                groups * (esz * M * K + float(wop.element_size()) * Nout * K + 2 * esz * M * Nout), lambda: call(
@@ -351,82 +336,6 @@ def ffn_fused_fwd(x, w1f, b1f, w2f, b2f, M, C, H):
         return None
     if rc[0] != 0:
         raise RuntimeError(f"nsid_ffn_fused_fwd failed: {rc[0]}")
-    return out
-
-
-# eval mode, C = 256: the Grapher's fc2 + shortcut evaluated inside the FFN launch (csrc/ffn256_fused.hip PRE form). Opt-in: one launch
-# and 0.5 GB of traffic less per micro-batch, but 199 us against 54 + 132 us stand-alone (the 16 extra ring iterations carry half the MFMAs
-# of an FFN chunk behind the same barrier and LDS-DMA issue), and 451 k against 454 k clips/s in the two-stream extraction
-FUSE_BLOCK_TAIL = False       # (the planner's switch, functional.block_eval_fused; the op itself is always available)
-
-
-def block_tail_fused_fwd(x0, r2, wpf, bpf, w1f, b1f, w2f, b2f, M, C, H):
-    """out = x1 + w2f relu(w1f x1 + b1f) + b2f with x1 = x0 + wpf r2 + bpf (one rounding to bf16, never written) in one launch: the tail
-    of an eval-mode Grapher and the FFN behind it. None when the shape is outside the fused form."""
-    _chk(wpf, bpf, w1f, b1f, w2f, b2f)
-    if not FUSE_EVAL_FFN or _act(x0) != BF16 or _act(r2) != BF16 or x0.shape != (M, C) or r2.shape != (M, 2 * C):
-        return None
-    if not (x0.is_contiguous() and r2.is_contiguous()):
-        return None
-    wp, dp = _weight(wpf, BF16, 2 * C)
-    w1, d1 = _weight(w1f, BF16, C)
-    w2, d2 = _weight(w2f, BF16, H)
-    if dp != BF16 or d1 != BF16 or d2 != BF16:
-        return None
-    out = torch.empty_like(x0)
-    rc = [0]
-
-    def launch():
-        rc[0] = lib.nsid_block_tail_fused_fwd(_p(x0), _p(r2), _p(wp), _p(bpf), _p(w1), _p(b1f), _p(w2), _p(b2f), _p(out), M, C, H, _stream())
-    esz = x0.element_size()
-    _timed("ffn256_fused_kernel<pre>", 4.0 * M * C * H + 4.0 * M * C * C, esz * M * (C + 2 * C + C) + 2.0 * (2 * C * H + 2 * C * C), launch,
-           (M, C, H, 2))
-    if rc[0] == 1:
-        if PROFILE is not None:
-            PROFILE.records.pop()
-        return None
-    if rc[0] != 0:
-        raise RuntimeError(f"nsid_block_tail_fused_fwd failed: {rc[0]}")
-    return out
-
-
-# ... and the max-relative graph conv in front of that (GR form): no mrconv launch, r2 never written (needs FUSE_BLOCK_TAIL). Opt-in:
-# 290 us against 80 + 199 us stand-alone, 433 k clips/s (docs/experiments.md, round 4 part 2)
-FUSE_BLOCK_GR = False
-
-
-def block_gr_fused_fwd(x0, y, idx, B, N, wgf, bgf, wpf, bpf, w1f, b1f, w2f, b2f, M, C, H):
-    """graph conv + Grapher tail + FFN of one eval-mode block in one launch (csrc/ffn256_fused.hip GR form): r2 = relu(wgf (*)_4 [y,
-    max-relative(y)] + bgf) evaluated slice by slice where block_tail_fused_fwd reads it. None outside the fused form."""
-    _chk(wgf, bgf, wpf, bpf, w1f, b1f, w2f, b2f)
-    if not (FUSE_EVAL_FFN and FUSE_EVAL_MRCONV) or _act(x0) != BF16 or _act(y) != BF16:
-        return None
-    if x0.shape != (M, C) or y.shape != (M, C) or M != B * N or 256 % N != 0 or idx.dtype != torch.int32 or not idx.is_contiguous():
-        return None
-    if not (x0.is_contiguous() and y.is_contiguous()):
-        return None
-    wg, dg = _weight(wgf, BF16, C // 2)
-    wp, dp = _weight(wpf, BF16, 2 * C)
-    w1, d1 = _weight(w1f, BF16, C)
-    w2, d2 = _weight(w2f, BF16, H)
-    if dg != BF16 or dp != BF16 or d1 != BF16 or d2 != BF16:
-        return None
-    k = idx.shape[-1]
-    out = torch.empty_like(x0)
-    rc = [0]
-
-    def launch():
-        rc[0] = lib.nsid_block_gr_fused_fwd(_p(x0), _p(y), _p(idx), k, N, _p(wg), _p(bgf), _p(wp), _p(bpf), _p(w1), _p(b1f), _p(w2),
-                                            _p(b2f), _p(out), M, C, H, _stream())
-    esz = x0.element_size()
-    _timed("ffn256_fused_kernel<gr>", 4.0 * M * C * H + 4.0 * M * C * C + 2.0 * M * C * C, esz * M * 3 * C + 4.0 * M * k +
-           2.0 * (2 * C * H + 2 * C * C + C * C), launch, (M, C, H, 3))
-    if rc[0] == 1:
-        if PROFILE is not None:
-            PROFILE.records.pop()
-        return None
-    if rc[0] != 0:
-        raise RuntimeError(f"nsid_block_gr_fused_fwd failed: {rc[0]}")
     return out
 
 
@@ -483,16 +392,6 @@ def linear_bwd_data(dout, w, M, Nout, K, groups=1, addend=None, out=None, bn=Non
         fuse = False
     nbytes = groups * (esz * M * Nout + float(wop.element_size()) * Nout * K
                        + esz * M * K * ((2 if addend is not None else 1) + (1 if fuse else 0)))
-    if fuse and bn[1].lazy is not None and (int(LAZY_BN) & 2):      # the layer's forward statistics were fixed-point sums: so are its backward sums
-        r, aff, act = bn
-        _act(r, out)
-        sums = BwdSums(groups * K, M, dout.device)
-        _timed(name, 2.0 * M * Nout * K * groups, nbytes, lambda: call(
-            "nsid_linear_bwd_data_bn_lazy", _p(dout), dout.shape[-1], _p(wop), wdt, _p(addend),
-            0 if addend is None else addend.shape[-1], _p(out), out.shape[-1], M, Nout, K, groups, dt, _p(r),
-            _p(aff.scale), _p(aff.shift), _p(aff.mean), _p(aff.invstd), act, _p(sums.acc), sums.R, _stream()),
-            (M, Nout, K, groups))
-        return out, sums
     if fuse:
         r, aff, act = bn
         _act(r, out)
@@ -538,8 +437,6 @@ def bn_backward_linear_bwd_data(dy, r, aff: "BNAffine", act, dgamma, dbeta, part
     enabled = FUSE_BN_BWD_APPLY is True or (FUSE_BN_BWD_APPLY and (int(FUSE_BN_BWD_APPLY) & site))
     ws_form = (dt == BF16 and wdt == BF16 and M % 128 == 0 and (Nout, K, groups) in WS_BWD_SHAPES and (get_tuning("ws_gemm") & 4) != 0)
     enabled = enabled or ws_form
-    if isinstance(partial, BwdSums) or (aff.lazy is not None and dt == BF16 and (int(LAZY_BN) & 2)):
-        enabled = False        # the fused operand load needs coef4 from a finalize launch; the lazy apply pass needs none
     fusable = (enabled and dt == BF16 and wdt == BF16 and tuple(r.shape) == (M, groups * Nout) and
                tuple(dy.shape) == (M, groups * Nout) and M % 128 == 0 and
                (ws_form or (Nout % 64 == 0 and K % 64 == 0 and (K <= 64 or K % 128 == 0))))
@@ -615,124 +512,14 @@ def colsum_acc(x, out) -> None:
 
 
 # ------------------------------------------------------------------------------------------------ batch norm
-# Training-mode BatchNorm without finalize launches (csrc/nsid_common.h, include/nsid.h "lazy" forms): the producing GEMM ADDS its
-# column sums into 64-bit fixed-point accumulators (integer atomics: order-independent totals), and the first kernel that consumes the
-# layer evaluates mean / variance / scale / shift from the totals in its own prologue: 1 006 -> 775 launches per step.
-# MEASURED (round 4, one-box A/B x2, docs/experiments.md): 8.20 / 8.24 ms without, 8.23 / 8.21 (forward), 8.22 / 8.20 (backward),
-# 8.22 / 8.21 (both) — NEUTRAL. Skipping the finalize launches outright is worth 0.57 ms, but that removes the dependency, not just the
-# launch: what a finalize launch costs (~4.7 us) is mostly the chain read-the-sums -> arithmetic -> publish, and a consumer prologue pays
-# the same chain in EVERY workgroup (+1.7 us in the streaming kernels, +2 ... +5.7 us in the GEMMs, +3 ... +4 us in the kNN kernels).
-# Off by default (bit 0: forward statistics, bit 1: backward sums); bench.py --flag ops.LAZY_BN=3 and tests/test_lazy_bn_gpu.py use it.
-# Taken only for bf16 storage while the two views run on two streams (the deferred running-statistics update of functional.ViewOrder)
-# and a zeroed accumulator arena is active; everything else keeps the per-tile float partials + finalize kernels.
-LAZY_BN = 0
-
-
-class StatArena:
-    """int64 accumulators of all BatchNorm layers of one training step, zeroed by ONE launch at the start of the step
-    (begin_step) and handed out in program order (take). Outside a step, or past its capacity, take() falls back to torch.zeros."""
-
-    def __init__(self, entries: int = 2 * 1024 * 1024):
-        self.entries, self.buf, self.off, self.active = entries, None, 0, False
-
-    def begin_step(self, device) -> None:
-        if self.buf is None or self.buf.device != torch.device(device):
-            self.buf = torch.empty(self.entries, device=device, dtype=torch.int64)
-        fill_zero(self.buf)
-        self.off, self.active = 0, True
-
-    def end(self) -> None:
-        self.active = False
-
-    def take(self, n: int, device) -> torch.Tensor:
-        n = (n + 15) // 16 * 16                       # 128-byte granules
-        if not self.active or self.buf is None or self.buf.device != torch.device(device) or self.off + n > self.entries:
-            return fill_zero(torch.empty(n, device=device, dtype=torch.int64))
-        v = self.buf[self.off:self.off + n]
-        self.off += n
-        return v
-
-
-STAT_ARENA = StatArena()
-
-
-def stat_replicas(M: int) -> int:
-    """replicas of a layer's accumulators: row tile t adds to replica t % R, about 64 adds per address"""
-    want, r = max(1, min(8, row_tiles(M) // 64)), 1
-    while 2 * r <= want:
-        r *= 2
-    return r
-
-
-def lazy_bn_enabled(dt_is_bf16: bool) -> bool:
-    return bool(int(LAZY_BN) & 1) and dt_is_bf16 and STAT_ARENA.active
-
-
-class LazyStats:
-    """forward sums of one BatchNorm layer that no kernel has evaluated yet"""
-    __slots__ = ("acc", "R", "C", "rows", "gamma", "beta", "eps", "out", "pending")
-
-    def __init__(self, acc, R, C, rows, gamma, beta, eps, out):
-        self.acc, self.R, self.C, self.rows, self.gamma, self.beta, self.eps, self.out = acc, R, C, rows, gamma, beta, eps, out
-        self.pending = True
-
-    def cstruct(self, consume: bool):
-        """the nsid_bn_lazy_t of this layer; consume: the receiving launch evaluates the sums (acc set) and `out` is valid after it"""
-        from ._lib import BnLazyC
-        take = consume and self.pending
-        z = BnLazyC(_p(self.acc) if take else None, self.R, self.C, self.rows, _p(self.gamma), _p(self.beta), self.eps, _p(self.out))
-        if take:
-            self.pending = False
-        return z
-
-
 class BNAffine:
     """What a consumer needs to apply a producer's BatchNorm on load, plus what backward needs.
     identity: scale == 1, shift == 0 (an eval-mode BatchNorm folded into its conv): consumers that only normalise skip it,
-    consumers that also apply an activation on load use the ones/zeros vectors.
-    lazy: the layer's statistics are still fixed-point sums (LazyStats): a consumer with a prologue form takes `lazy` and evaluates
-    them itself; reading scale / shift / mean / invstd any other way first runs the stand-alone evaluation (one small launch)."""
-    __slots__ = ("_scale", "_shift", "_mean", "_invstd", "identity", "lazy")
+    consumers that also apply an activation on load use the ones/zeros vectors."""
+    __slots__ = ("scale", "shift", "mean", "invstd", "identity")
 
-    def __init__(self, scale, shift, mean=None, invstd=None, identity=False, lazy=None):
-        self._scale, self._shift, self._mean, self._invstd, self.identity, self.lazy = scale, shift, mean, invstd, identity, lazy
-
-    def materialize(self):
-        z = self.lazy
-        if z is not None and z.pending:
-            import ctypes
-            c = z.cstruct(consume=True)
-            call("nsid_bn_materialize", ctypes.addressof(c), _stream())
-        return self
-
-    scale = property(lambda self: self.materialize()._scale)
-    shift = property(lambda self: self.materialize()._shift)
-    mean = property(lambda self: self.materialize()._mean)
-    invstd = property(lambda self: self.materialize()._invstd)
-
-
-def lazy_affine(acc, R, M, gamma, beta, eps=BN_EPS):
-    """(BNAffine, unbiased variance) of a layer whose statistics a GEMM has just ADDED into acc[R][2][C]; nothing is evaluated yet"""
-    C = gamma.numel()
-    out = torch.empty((5, C), device=gamma.device, dtype=torch.float32)
-    z = LazyStats(acc, R, C, M, gamma, beta, eps, out)
-    return BNAffine(out[0], out[1], out[2], out[3], lazy=z), out[4]
-
-
-def _lazy_arg(aff):
-    """ctypes struct (kept alive by the caller) + its address for an entry point that takes a nsid_bn_lazy_t"""
-    import ctypes
-    c = aff.lazy.cstruct(consume=True)
-    return c, ctypes.addressof(c)
-
-
-class BwdSums:
-    """backward column sums (sum g, sum g*xhat) of one BatchNorm layer as fixed-point accumulators"""
-    __slots__ = ("acc", "R", "C")
-
-    def __init__(self, C, M, device):
-        self.R, self.C = stat_replicas(M), C
-        self.acc = STAT_ARENA.take(self.R * 2 * C, device)
+    def __init__(self, scale, shift, mean=None, invstd=None, identity=False):
+        self.scale, self.shift, self.mean, self.invstd, self.identity = scale, shift, mean, invstd, identity
 
 
 _IDENTITY_AFFINE = {}
@@ -882,11 +669,6 @@ def bn_apply(r, aff: BNAffine, act=ACT_NONE, residual=None, out=None) -> torch.T
     M, C = r.shape
     if out is None:
         out = torch.empty_like(r)
-    if aff.lazy is not None and aff.lazy.pending:        # evaluated in this launch's prologue: no finalize launch
-        zc, addr = _lazy_arg(aff)
-        _tk("bn_apply_lazy_kernel", r.element_size() * M * C * (3 if residual is not None else 2), lambda: call(
-            "nsid_bn_apply_lazy", _p(r), addr, act, _p(residual), _p(out), M, C, dt, _stream()), (M, C, 0, 1))
-        return out
     _tk("bn_apply_kernel", r.element_size() * M * C * (3 if residual is not None else 2), lambda: call(
         "nsid_bn_apply", _p(r), _p(aff.scale), _p(aff.shift), act, _p(residual), _p(out), M, C, dt, _stream()), (M, C, 0, 1))
     return out
@@ -899,22 +681,6 @@ def bn_backward(dout, r, aff: BNAffine, act, dgamma, dbeta, inplace=False, parti
     M, C = r.shape
     tiles = row_tiles(M)
     s = _stream()
-    if isinstance(partial, BwdSums) or (partial is None and aff.lazy is not None and dt == BF16 and (int(LAZY_BN) & 2)):
-        # fixed-point column sums: no finalize launch, the apply pass evaluates coef0 / coef1 (and adds dgamma / dbeta) in its prologue
-        import ctypes
-        from ._lib import BnBwdLazyC
-        if partial is None:
-            partial = BwdSums(C, M, r.device)
-            part_ = partial
-            _tk("col_reduce_kernel", 2.0 * r.element_size() * M * C, lambda: call(
-                "nsid_bn_bwd_reduce_lazy", _p(dout), _p(r), M, C, _p(aff.scale), _p(aff.shift), _p(aff.mean), _p(aff.invstd), act,
-                _p(part_.acc), part_.R, dt, s), (M, C, 0, 1))
-        zc = BnBwdLazyC(_p(partial.acc), partial.R, C, M, _p(dgamma), _p(dbeta), None)
-        dr = dout if inplace else torch.empty_like(dout)
-        _tk("bn_bwd_apply_lazy_kernel", 3.0 * r.element_size() * M * C, lambda: call(
-            "nsid_bn_bwd_apply_lazy", _p(dout), _p(r), M, C, _p(aff.scale), _p(aff.shift), _p(aff.mean), _p(aff.invstd), act,
-            ctypes.addressof(zc), _p(dr), dt, s), (M, C, 0, 1))
-        return dr
     coef = torch.empty((2, C), device=r.device, dtype=torch.float32)
     if partial is None:
         partial = torch.empty((2, tiles, C), device=r.device, dtype=torch.float32)
@@ -945,11 +711,6 @@ def knn_graph(r, B, N, C, k, dilation=1, aff: Optional[BNAffine] = None) -> torc
     sel = 8 < kd <= 64 and N >= get_tuning("knn_sel_min_n")      # csrc/knn.hip nsid_knn_graph
     name = "knn2_kernel" if kd <= 8 else ("knn_sel_kernel" if sel else ("knn_rank_kernel" if N <= 128 else "knn_kernel"))
     # read the features once, write int32 ids; 2*N^2*C flop on the fp32 matrix pipe
-    if aff is not None and aff.lazy is not None and aff.lazy.pending:
-        zc, addr = _lazy_arg(aff)
-        _timed(name, 2.0 * B * N * N * C, float(B) * (N * C * r.element_size() + N * k * 4), lambda: call(
-            "nsid_knn_graph_lazy", _p(r), r.shape[-1], addr, B, N, C, k, dilation, _p(idx), dt, _stream()), (B * N, N, C, 1))
-        return idx
     _timed(name, 2.0 * B * N * N * C, float(B) * (N * C * r.element_size() + N * k * 4), lambda: call(
         "nsid_knn_graph", _p(r), r.shape[-1], _p(aff.scale) if aff else None, _p(aff.shift) if aff else None,
         B, N, C, k, dilation, _p(idx), dt, _stream()), (B * N, N, C, 1))
@@ -1081,7 +842,7 @@ DS_PREP = DsPrep()
 DS_PREP_ENABLED = 1        # bench.py --flag ops.DS_PREP_ENABLED=0: the per-call pack / convert / zero launches instead (one-box A/B)
 
 
-def downsample3_fwd(x, B, N, C, wp, bias, Cout, want_stat=False, stat_acc=None, w16=None):
+def downsample3_fwd(x, B, N, C, wp, bias, Cout, want_stat=False, w16=None):
     """Conv2d 3x3 s2 p1 on a width-1 map as ONE GEMM over a zero-padded strided view of x (no im2col): (B*N, C) ->
     (B*N/2, Cout) raw conv output (+ BatchNorm partial statistics). wp: packed weight (Cout, 3C) fp32 (pack_ds_weight); w16: the same
     already in bf16 (DsPrep; wp may then be None)."""
@@ -1090,15 +851,9 @@ def downsample3_fwd(x, B, N, C, wp, bias, Cout, want_stat=False, stat_acc=None, 
     No = N // 2
     M = B * No
     out = torch.empty((M, Cout), device=x.device, dtype=x.dtype)
-    stat = torch.empty((2, row_tiles(M), Cout), device=x.device, dtype=torch.float32) if (want_stat and stat_acc is None) else None
+    stat = torch.empty((2, row_tiles(M), Cout), device=x.device, dtype=torch.float32) if want_stat else None
     wop, wdt = (w16, BF16) if (w16 is not None and dt == BF16) else _weight(wp, dt, 3 * C)      # w16: prepared bf16 packed weight (DsPrep)
     esz = x.element_size()
-    if stat_acc is not None:       # statistics added into fixed-point accumulators (stat_acc = (int64 tensor, replicas))
-        _timed("gemm_kernel<128,%d,true,true>" % (64 if Cout <= 64 else 128), 2.0 * M * Cout * 3 * C,
-               esz * B * N * C + float(wop.element_size()) * Cout * 3 * C + esz * M * Cout, lambda: call(
-            "nsid_downsample3_fwd_lazy", _p(x), B, N, C, _p(wop), wdt, _p(bias), _p(out), Cout, _p(stat_acc[0]), stat_acc[1], dt,
-            _stream()), (M, Cout, 3 * C, 1))
-        return out, None
     _timed("gemm_kernel<128,%d,true,true>" % (64 if Cout <= 64 else 128), 2.0 * M * Cout * 3 * C,
            esz * B * N * C + float(wop.element_size()) * Cout * 3 * C + esz * M * Cout, lambda: call(
         "nsid_downsample3_fwd", _p(x), B, N, C, _p(wop), wdt, _p(bias), _p(out), Cout, _p(stat), dt, _stream()),

@@ -39,7 +39,6 @@ class SimCLR(nn.Module):
     def forward(self, x_i, x_j):
         if self.overlap_views and x_i.is_cuda and self.training:
             return self._forward_two_streams(x_i, x_j)
-        ops.STAT_ARENA.end()
         h_i, z_i = self._embed(x_i)     # the encoder runs once per view: BatchNorm statistics are per view
         h_j, z_j = self._embed(x_j)
         return h_i, h_j, z_i, z_j
@@ -50,10 +49,6 @@ class SimCLR(nn.Module):
             self._side_stream = torch.cuda.Stream(device=x_i.device)
             F_.SIDE_STREAMS.append(self._side_stream)
         side = self._side_stream
-        if ops.LAZY_BN and F_.ACT_DTYPE == torch.bfloat16:
-            ops.STAT_ARENA.begin_step(x_i.device)    # one launch zeroes the fixed-point BatchNorm accumulators of the whole step
-        else:
-            ops.STAT_ARENA.end()
         side.wait_stream(main)                       # inputs/weights written on the main stream are visible
         vo = F_.VIEW_ORDER
         vo.mode, vo.pending = "a", {"a": [], "b": []}

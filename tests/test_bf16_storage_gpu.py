@@ -385,86 +385,6 @@ def test_eval_ffn_in_one_launch(ops, M, C):
                              M, 32, 128) is None                            # outside the fused form: the caller falls back
 
 
-@pytest.mark.parametrize("M", [256, 16384, 76800])
-def test_block_tail_in_the_ffn_launch(ops, M):
-    """csrc/ffn256_fused.hip PRE form (nsid_block_tail_fused_fwd): x1 = x0 + Wp r2 + bp (the Grapher's fc2 + folded BatchNorm +
-    shortcut, torch_vertex.py:183-195) evaluated in front of the FFN by the same launch and never written -- against an fp64
-    evaluation with the same three bf16 rounding points (x1, hidden, output), and against the two-launch form (nsid_linear_fwd_res,
-    then nsid_ffn_fused_fwd), whose x1 it must reproduce up to the summation order"""
-    from neuralsampleid_amd._lib import launch_counters
-    C, H = 256, 1024
-    x0 = synth_randn(f"btx{M}", M, C).to(BF).to(DEV)
-    r2 = synth_randn(f"btr{M}", M, 2 * C).clamp_min(0).to(BF).to(DEV)
-    wp = (synth_randn("btwp", C, 2 * C) * (2 * C) ** -0.5).to(DEV)
-    w1 = (synth_randn(f"ffw1{C}", H, C) * C ** -0.5).to(DEV)
-    w2 = (synth_randn(f"ffw2{C}", C, H) * H ** -0.5).to(DEV)
-    bp, b1, b2 = (0.3 * synth_randn("btbp", C)).to(DEV), (0.3 * synth_randn(f"ffb1{C}", H)).to(DEV), (0.3 * synth_randn(f"ffb2{C}", C)).to(DEV)
-    for w in (wp, w1, w2):
-        ops.SHADOWS.register(w, ops.f32_to_bf16(w), owner=w)
-    launch_counters(reset=True)
-    out = ops.block_tail_fused_fwd(x0, r2, wp, bp, w1, b1, w2, b2, M, C, H)
-    torch.cuda.synchronize()
-    cnt = launch_counters()
-    assert out is not None and cnt["block_tail_fused"] == 1 and cnt["ffn_fused"] == 1 and cnt["gemm_fwd"] == 0
-    x1 = bfr((x0.double() + r2.double() @ bfr(wp).t() + bp.double()).float())
-    hid = torch.relu(x1 @ bfr(w1).t() + b1.double())
-    ref = x1 + bfr(hid.float()) @ bfr(w2).t() + b2.double()
-    assert relerr(out, ref) < 3e-3, relerr(out, ref)
-    err = (out.double() - ref).abs() / (ref.abs() + 1.0)
-    assert float(err.max()) < 3e-2                                           # no stray element (a mis-indexed tile would be O(1))
-    x1_two, _ = ops.linear_fwd(r2, wp, bp, M, C, 2 * C, addend=x0)
-    two = ops.ffn_fused_fwd(x1_two, w1, b1, w2, b2, M, C, H)
-    assert relerr(out, two) < 1.5e-3 and float((out != two).float().mean()) < 0.05
-    try:                                      # the 4-wave form: the same sums in the same order
-        ops.set_tuning("ffn256", 4)
-        out4 = ops.block_tail_fused_fwd(x0, r2, wp, bp, w1, b1, w2, b2, M, C, H)
-        ops.set_tuning("ffn256", 0)
-        assert ops.block_tail_fused_fwd(x0, r2, wp, bp, w1, b1, w2, b2, M, C, H) is None      # switched off: the caller falls back
-    finally:
-        ops.set_tuning("ffn256", 1)
-    assert torch.equal(out, out4)
-
-
-@pytest.mark.parametrize("M,k", [(256, 3), (16384, 3), (76800, 5)])
-def test_graph_conv_and_block_tail_in_the_ffn_launch(ops, M, k):
-    """csrc/ffn256_fused.hip GR form (nsid_block_gr_fused_fwd): the eval-mode max-relative graph conv (MRConv2d + BasicConv,
-    torch_vertex.py:19-34) evaluated slice by slice in front of the Grapher tail and the FFN, r2 never written -- against the
-    two-launch form (nsid_mrconv_fused_fwd, then nsid_block_tail_fused_fwd): the same r2 values (same operands, same rounding point),
-    so the outputs agree up to the summation order of the tail, and the 4-wave form reproduces the 8-wave one bit for bit"""
-    from neuralsampleid_amd._lib import launch_counters
-    C, H, N = 256, 1024, 64
-    B = M // N
-    x0 = synth_randn(f"grx{M}", M, C).to(BF).to(DEV)
-    y = synth_randn(f"gry{M}", M, C).to(BF).to(DEV)
-    g = torch.Generator().manual_seed(M + k)
-    idx = torch.randint(0, N, (B, N, k), generator=g).to(torch.int32).to(DEV)
-    wg = (synth_randn("grwg", 2 * C, C // 2) * (C // 2) ** -0.5).to(DEV)
-    wp = (synth_randn("btwp", C, 2 * C) * (2 * C) ** -0.5).to(DEV)
-    w1 = (synth_randn(f"ffw1{C}", H, C) * C ** -0.5).to(DEV)
-    w2 = (synth_randn(f"ffw2{C}", C, H) * H ** -0.5).to(DEV)
-    bg, bp = (0.3 * synth_randn("grbg", 2 * C)).to(DEV), (0.3 * synth_randn("btbp", C)).to(DEV)
-    b1, b2 = (0.3 * synth_randn(f"ffb1{C}", H)).to(DEV), (0.3 * synth_randn(f"ffb2{C}", C)).to(DEV)
-    for w in (wg, wp, w1, w2):
-        ops.SHADOWS.register(w, ops.f32_to_bf16(w), owner=w)
-    launch_counters(reset=True)
-    out = ops.block_gr_fused_fwd(x0, y, idx, B, N, wg, bg, wp, bp, w1, b1, w2, b2, M, C, H)
-    torch.cuda.synchronize()
-    cnt = launch_counters()
-    assert out is not None and cnt["block_gr_fused"] == 1 and cnt["mrconv_fused"] == 0 and cnt["gemm_fwd"] == 0
-    r2 = ops.mrconv_fused_fwd(y, idx, B, N, C, wg, bg)
-    two = ops.block_tail_fused_fwd(x0, r2, wp, bp, w1, b1, w2, b2, M, C, H)
-    assert r2 is not None and two is not None
-    assert relerr(out, two) < 1.5e-3 and float((out != two).float().mean()) < 0.05, (relerr(out, two), float((out != two).float().mean()))
-    err = (out.double() - two.double()).abs() / (two.double().abs() + 1.0)
-    assert float(err.max()) < 3e-2
-    try:
-        ops.set_tuning("ffn256", 4)
-        out4 = ops.block_gr_fused_fwd(x0, y, idx, B, N, wg, bg, wp, bp, w1, b1, w2, b2, M, C, H)
-    finally:
-        ops.set_tuning("ffn256", 1)
-    assert torch.equal(out, out4)
-
-
 @pytest.mark.parametrize("N,C,k,case", [(256, 64, 18, "random"), (128, 128, 18, "random"), (64, 256, 18, "ties"), (32, 512, 18, "ties"),
                                          (256, 64, 18, "collapse"), (128, 128, 9, "special"), (64, 256, 18, "noaffine")])
 def test_integer_key_max_relative_equals_the_scalar_search(ops, N, C, k, case):

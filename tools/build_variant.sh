@@ -6,10 +6,8 @@ set -e
 name=$1; shift
 root=$(cd "$(dirname "$0")/.." && pwd)
 obj=/tmp/nsid_variant_$name; mkdir -p $obj
-# result-changing diagnosis switches compile only with NSID_DIAGNOSIS_BUILD, and the library then reports a negative version
-# (load it with NSID_ALLOW_DIAGNOSIS_LIB=1 NSID_LIB=...)
-case " $* " in *" -DNSID_ABN_"*|*" -DNSID_WGRAD_PLAINSTORE"*|*" -DNSID_G256_ABLATE"*|*" -DNSID_F256_"*) set -- "$@" -DNSID_DIAGNOSIS_BUILD; ONLY="${ONLY:+$ONLY gemm}";; esac
-all="tuning gemm gemm256 ffn_fused ffn256_fused mrconv_fused wgrad bn knn mr ntxent misc"
+# (the product sources no longer carry result-changing timing switches: a timing experiment edits a copy under tools/variants/)
+all="tuning gemm gemm256 wsgemm ffn_fused ffn256_fused mrconv_fused wgrad bn knn mr ntxent misc"
 for s in $all; do
   if [ -n "$ONLY" ] && ! echo " $ONLY " | grep -q " $s "; then
     cp $root/neuralsampleid_amd/csrc/_obj/$s.o $obj/$s.o

@@ -1,6 +1,6 @@
 #!/bin/bash
 # extraction bench under alternative host flags / tuning keys, interleaved on one box; each argument is a bench.py option string:
-#   tools/gpu_flag_ab.sh "" "--flag ops.FUSE_BLOCK_GR=0" "--flag ops.FUSE_BLOCK_TAIL=0" "--tune ffn256=0"
+#   tools/gpu_flag_ab.sh "" "--tune ws_gemm=0" "--tune ffn256=0"
 set -e
 for rep in 1 2; do
   for opt in "$@"; do

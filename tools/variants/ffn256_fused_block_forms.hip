@@ -32,6 +32,10 @@ namespace {
 struct F256Args {
   const __bf16* x; const __bf16* w1; const float* b1; const __bf16* w2; const float* b2; __bf16* out;
   int M;
+  // PRE form (Grapher tail + FFN): the FFN's input is x1 = x + Wp r2 + bp, evaluated by the same launch
+  const __bf16* r2; const __bf16* wp; const float* bp;
+  // GR form (graph conv + Grapher tail + FFN): r2 itself is evaluated by the launch from the fc1 features y and the neighbour lists
+  const __bf16* y; const int32_t* idx; const __bf16* wg; const float* bg; int k; int N;
 };
 
 typedef __attribute__((address_space(3))) void* lds_vptr;
@@ -40,7 +44,10 @@ constexpr int F_HC = 32;                      // hidden units per chunk
 constexpr int F_NS = 4;                       // ring slots: chunk ch (GEMM 1), chunk ch - 1 (GEMM 2), chunks ch + 1 and ch + 2 in flight
 // per channel count C (H = 4 C): a chunk's W1 image is 32 hidden rows x C = C / 16 sub-blocks of [16 rows][32 k] (1 KB each), its W2
 // image C rows x 32 hidden = C / 16 sub-blocks: a ring slot is C / 8 KB (32 KB at C = 256)
-constexpr int F_PF = 1;            // fragment prefetch distance in steps (one step = 2 LDS reads, 4 MFMAs)
+#ifndef NSID_F256_PF
+#define NSID_F256_PF 1
+#endif
+constexpr int F_PF = NSID_F256_PF;            // fragment prefetch distance in steps (one step = 2 LDS reads, 4 MFMAs)
 
 template <int N>
 __device__ __forceinline__ void f_wait_vm() {
@@ -70,26 +77,46 @@ __device__ __forceinline__ void f_mfma_acc(f32x4& acc, const bf16x8& a, const bf
 //   NW = 4: 64 rows per wave, ONE wave per SIMD with the whole 512-register budget (128 of x fragments, 256 of output accumulators):
 //           every weight fragment read from LDS feeds four MFMAs instead of two, which halves the LDS reads per matrix cycle.
 //
-// (Round 4 also widened this launch BACKWARDS -- the Grapher's fc2 + shortcut as 16 more ring iterations, then the max-relative graph conv
-// on top: bit-identical, measured slower (docs/experiments.md); those forms live in tools/variants/ffn256_fused_block_forms.hip.)
+// PRE = true (nsid_block_tail_fused_fwd): the Grapher's last conv + shortcut in front of the FFN (torch_vertex.py:183-195),
+//     x1 = bf16((Wp r2 + bp) + x)      (gemm256.hip's residual epilogue: one rounding),     out = x1 + W2 relu(W1 x1 + b1) + b2,
+// as F_NP = 16 more iterations of the same ring in front of the 32 FFN chunks: iteration u brings the k-step image of Wp (256 x 32,
+// rows permuted like W2's: 16 KB) and the r2 slice of the workgroup's 256 rows (16 sub-blocks of [16 rows][32 k]: 16 KB) by LDS-DMA
+// into slot u % 4 -- the same 32 pieces, so the vmcnt / barrier protocol does not change -- and runs 16 x RT MFMAs per wave into the
+// output accumulators. Their channel order is that of the lane's own x fragments, so x1 replaces x in registers without leaving
+// the lane. x1 itself is never written: per block that removes a launch, a write of M x 256 and two reads (55.6 us stand-alone).
+//
+// MODE 2 = GR (nsid_block_gr_fused_fwd): r2 is not read but EVALUATED, slice by slice, where PRE consumes it -- the eval-mode MRConv2d
+// (gcn_lib/torch_vertex.py:19-34 + BasicConv, torch_nn.py:52-76; csrc/mrconv_fused.hip is the stand-alone form):
+//     r2[n, 128 g + j] = relu( sum_k Wg[128 g + j][k] u[n, 128 g + k] + bg ),   u[n, 2c] = y[n, c],  u[n, 2c + 1] = max_j (y[idx[n, j], c] - y[n, c])
+// Every fourth prologue iteration a lane gathers its rows' and their neighbours' 4-channel pieces of y straight from global memory (a
+// clip is 32 KB: L2 hits after the first touch), forms the max-relative in fp32 and keeps the group's eight B fragments (32 VGPRs).
+// The slot's second half then carries the 32-row slice of Wg (8 sub-blocks, rows permuted so that the two accumulator tiles of a lane
+// are 8 CONSECUTIVE r2 channels of its row): 4 x 2 x RT MFMAs give the slice, bias + ReLU + bf16 pack turn it into the B fragment of
+// the Wp MFMAs in the lane's own registers. r2 (M x 512: 134 MB written and read back per block at a 2 048-clip micro-batch) and the
+// mrconv launch are gone; x is read late (its registers hold the gathered fragments until the last slice).
 //
 // C = 128 / 64 (round 4): the same kernel with RT = 2 / 4 row tiles per wave (256- / 512-row workgroup tiles; C = 128 with RT = 4 needs
 // 55 registers more than a wave has at two per SIMD); a chunk is 16 / 8 LDS-DMA pieces. They replace ffn_fused.hip's
 // x-tile-in-LDS form for these widths (tuning key ffn_regs).
-template <int F_C, int NW, int RT>
+template <int F_C, int NW, int RT, int MODE>
 __global__ __attribute__((amdgpu_flat_work_group_size(64 * NW, 64 * NW), amdgpu_waves_per_eu(NW / 4, NW / 4)))
 void ffn256_fused_kernel(const F256Args p) {
+  constexpr bool PRE = MODE >= 1, GR = MODE == 2;
+  static_assert(MODE == 0 || (F_C == 256 && NW * RT == 16), "the Grapher-tail forms are written for C = 256, 256-row tiles");
   constexpr int F_H = 4 * F_C, F_NCH = F_H / F_HC;
   constexpr int KS1 = F_C / 32;               // k-steps of GEMM 1 = x fragments per row tile
-  constexpr int EP = 2 * KS1 * RT; // global stores (+ next-x loads) a wave issues in a tile's epilogue (when another tile follows)
+  constexpr int EP = (GR ? 1 : 2) * KS1 * RT; // global stores (+ next-x loads) a wave issues in a tile's epilogue (when another tile follows)
   constexpr int CT = F_C / 16;                // output-channel tiles of GEMM 2 (= GEMM 1 fragments per chunk: 2 hidden tiles x KS1)
   constexpr int W2OFF = CT * 1024;            // a slot: [W1 chunk image | W2 chunk image]
   constexpr int F_SLOT = 2 * CT * 1024;
   constexpr int TR = NW * RT * 16;            // rows per workgroup tile
   constexpr int F_HB = NW * RT * 1024;        // every wave its own hidden sub-blocks (one per row tile)
-  constexpr int F_LDS = F_NS * F_SLOT + F_HB + F_H * 4 + F_C * 4;
+  constexpr int F_KP = 2 * F_C;               // PRE form: width of r2 (the Grapher's 2C-channel graph-conv output)
+  constexpr int F_NP = F_KP / 32;             // its k-steps = prologue iterations
+  constexpr int F_LDS = F_NS * F_SLOT + F_HB + F_H * 4 + F_C * 4 + (PRE ? F_C * 4 : 0) + (GR ? 2 * F_C * 4 : 0);
+  constexpr int NP = PRE ? F_NP : 0;          // prologue iterations; chunk index u = 0 .. NP + F_NCH - 1, slot u % 4
   constexpr int PW = 2 * CT / NW;             // LDS-DMA pieces per wave and chunk
-  static_assert(2 * CT % NW == 0 && F_NCH % F_NS == 0, "whole pieces per wave; a tile's chunks start on slot 0");
+  static_assert(2 * CT % NW == 0 && F_NCH % F_NS == 0 && NP % F_NS == 0, "whole pieces per wave; a tile's chunks start on slot 0");
   __shared__ __attribute__((aligned(1024))) char lds[F_LDS];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -98,6 +125,8 @@ void ffn256_fused_kernel(const F256Args p) {
   char* const hb = lds + F_NS * F_SLOT + wave * (RT * 1024);
   float* const b1s = reinterpret_cast<float*>(lds + F_NS * F_SLOT + F_HB);
   float* const b2s = b1s + F_H;
+  float* const bps = b2s + F_C;
+  float* const bgs = bps + F_C;
   const unsigned lds0 = (unsigned)(size_t)(lds_vptr)lds;
 
   // ---- x fragments: lane (lr, rq) of row tile b holds x[row0 + 16 b + lr][32 ks + 8 rq .. + 7]
@@ -105,7 +134,7 @@ void ffn256_fused_kernel(const F256Args p) {
   bf16x8 xf[KS1][RT];
   // a lane's byte offset inside a tile's x / out rows (uniform 64-bit tile base + 32-bit lane offset + immediate)
   const unsigned xo = (unsigned)((wave * (16 * RT) + lr) * F_C + 8 * rq) * 2u;
-  {
+  if constexpr (!GR) {
     const char* xt = reinterpret_cast<const char*>(p.x + (long)blockIdx.x * TR * F_C);
 #pragma unroll
     for (int b = 0; b < RT; ++b)
@@ -114,6 +143,8 @@ void ffn256_fused_kernel(const F256Args p) {
   }
   for (int i = tid; i < F_H / 4; i += 64 * NW) reinterpret_cast<f32x4*>(b1s)[i] = reinterpret_cast<const f32x4*>(p.b1)[i];
   if (tid < F_C / 4) reinterpret_cast<f32x4*>(b2s)[tid] = reinterpret_cast<const f32x4*>(p.b2)[tid];
+  if (PRE && tid < F_C / 4) reinterpret_cast<f32x4*>(bps)[tid] = reinterpret_cast<const f32x4*>(p.bp)[tid];
+  if (GR && tid < 2 * F_C / 4) reinterpret_cast<f32x4*>(bgs)[tid] = reinterpret_cast<const f32x4*>(p.bg)[tid];
   // the staged bias vectors are read by OTHER waves later: fence + barrier here, once per launch and before any LDS-DMA is in flight
   // (the bare s_barrier of the chunk loop waits for no LDS store, and gfx950 inserts no lgkmcnt(0) in front of it: ADVICE r4)
   __syncthreads();
@@ -125,9 +156,29 @@ void ffn256_fused_kernel(const F256Args p) {
   // W2: row stride 1024 elements; sub-block c = 2 ks + half takes its row 4 q + e from output channel 32 ks + 8 q + 4 half + e, so
   // that a lane's accumulators are the channels of its own x fragments (epilogue)
   const unsigned voff2 = (unsigned)((8 * (grow >> 2) + (grow & 3)) * F_H + lc * 8) * 2u;
+  // Wp: row stride 512 elements, rows permuted like W2's; r2: sub-block sb = rows 16 sb .. 16 sb + 15 of the tile, row stride 512
+  const unsigned voffp = (unsigned)((8 * (grow >> 2) + (grow & 3)) * F_KP + lc * 8) * 2u;
+  const unsigned voffr = (unsigned)(grow * F_KP + lc * 8) * 2u;
+  // Wg (GR): row stride 128 elements; sub-block (a, ks) of slice sl of group g takes its row 4 q + e from output channel
+  // 128 g + 32 sl + 8 q + 4 a + e
+  const unsigned voffg = (unsigned)((8 * (grow >> 2) + (grow & 3)) * (F_C / 2) + lc * 8) * 2u;
   auto issue = [&](int u, int tile) {                                   // this wave's PW pieces of chunk u (of row tile `tile`)
     const unsigned dst = lds0 + (u % F_NS) * F_SLOT;
-    const int h0 = u * F_HC;
+    if (PRE && u < NP) {
+#pragma unroll
+      for (int i = 0; i < PW; ++i) {
+        const int q = PW * wave + i;                                    // 0-15: Wp sub-block (channel tile q); 16-31: r2 sub-block q - 16
+        if (q < 16)
+          f_glds16(reinterpret_cast<const char*>(p.wp + (long)(32 * (q >> 1) + 4 * (q & 1)) * F_KP + 32 * u), voffp, dst + q * 1024);
+        else if (!GR)
+          f_glds16(reinterpret_cast<const char*>(p.r2 + ((long)tile * 256 + 16 * (q - 16)) * F_KP + 32 * u), voffr, dst + q * 1024);
+        else if (q < 24)      // (GR: waves 6 and 7 have no piece of a prologue chunk)
+          f_glds16(reinterpret_cast<const char*>(p.wg + (long)(32 * u + 4 * ((q - 16) >> 2)) * (F_C / 2) + 32 * ((q - 16) & 3)), voffg,
+                   dst + q * 1024);
+      }
+      return;
+    }
+    const int h0 = (u - NP) * F_HC;
 #pragma unroll
     for (int i = 0; i < PW; ++i) {
       const int q = PW * wave + i;            // 0 .. CT - 1: W1 sub-block (hidden tile a, k-step ks); CT .. 2 CT - 1: W2 sub-block (channel tile c)
@@ -163,13 +214,132 @@ void ffn256_fused_kernel(const F256Args p) {
 #pragma unroll
     for (int b = 0; b < RT; ++b) hf[b] = bf16x8{};
 
+    if constexpr (PRE) {
+      // ---- x1 = bf16((Wp r2 + bp) + x): 16 k-steps, each one slot = [Wp k-step image | r2 slice], into the output accumulators
+      bf16x8 ug[4][RT];                       // GR: the current group's max-relative B fragments (k-step, row tile)
+      auto pre_iter = [&](const int u, auto LAST) {
+        constexpr bool last = decltype(LAST)::value;      // peeled: only there are the x registers written (GR)
+        if (u < 2 && !first) f_wait_vm<(PW + EP < 63 ? PW + EP : 63)>();     // (see the chunk loop below)
+        else f_wait_vm<PW>();
+        __builtin_amdgcn_s_barrier();
+        const char* sp = lds + (u % F_NS) * F_SLOT;
+        bf16x8 rb[RT];
+        if constexpr (GR) {
+          if ((u & 3) == 0) {
+            // this lane's fragments of group g: interleaved channels 32 ks + 8 rq .. + 7 = y channels c0 .. c0 + 3 of its row and of the
+            // row's neighbours (clip-local ids, clamped as in mrconv_fused.hip); max-relative in fp32, strict > from -inf (the first
+            // maximum wins, NaN never enters), ONE rounding to bf16 -- where the two-launch form rounds u
+            const int g = u >> 2, k = p.k, N = p.N;
+#pragma unroll
+            for (int b = 0; b < RT; ++b) {
+              const int nl = wave * (16 * RT) + 16 * b + lr;            // row inside the tile; its clip starts at row nl - nl % N
+              const long nrow = (long)tile * 256 + nl, crow = nrow - nl % N;
+#pragma unroll
+              for (int ks = 0; ks < 4; ++ks) {
+                const int c0 = 64 * g + 16 * ks + 4 * rq;
+                const bf16x4 own = *reinterpret_cast<const bf16x4*>(p.y + nrow * F_C + c0);
+                float ys[4], best[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { ys[e] = (float)own[e]; best[e] = -__builtin_inff(); }
+                for (int j = 0; j < k; ++j) {
+                  int m = p.idx[nrow * k + j];
+                  m = m < 0 ? 0 : (m >= N ? N - 1 : m);
+                  const bf16x4 v = *reinterpret_cast<const bf16x4*>(p.y + (crow + m) * F_C + c0);
+#pragma unroll
+                  for (int e = 0; e < 4; ++e) {
+                    const float d = (float)v[e] - ys[e];
+                    best[e] = d > best[e] ? d : best[e];
+                  }
+                }
+                bf16x8 fb;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { fb[2 * e] = own[e]; fb[2 * e + 1] = (__bf16)best[e]; }
+                ug[ks][b] = fb;
+              }
+            }
+          }
+          issue(u + 2, tile);                 // behind the gathers: the waits for their data do not cover these pieces
+          // the slice: D[8 q + 4 a + e][row] per accumulator tile a
+          f32x4 gacc[2][RT];
+#pragma unroll
+          for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < RT; ++b) gacc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+              const bf16x8 fg = *reinterpret_cast<const bf16x8*>(sp + 16384 + (4 * a + ks) * 1024 + lo);
+#pragma unroll
+              for (int b = 0; b < RT; ++b) gacc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fg, ug[ks][b], gacc[a][b], 0, 0, 0);
+            }
+          const f32x4 bb0 = *reinterpret_cast<const f32x4*>(bgs + 32 * u + 8 * rq);
+          const f32x4 bb1 = *reinterpret_cast<const f32x4*>(bgs + 32 * u + 8 * rq + 4);
+#pragma unroll
+          for (int b = 0; b < RT; ++b) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              rb[b][e] = (__bf16)fmaxf(gacc[0][b][e] + bb0[e], 0.f);
+              rb[b][4 + e] = (__bf16)fmaxf(gacc[1][b][e] + bb1[e], 0.f);
+            }
+          }
+          if constexpr (last) {               // the gathered fragments are dead: x arrives behind the last Wp MFMAs
+            const char* xt = reinterpret_cast<const char*>(p.x + (long)tile * 256 * F_C);
+#pragma unroll
+            for (int b = 0; b < RT; ++b)
+#pragma unroll
+              for (int ks = 0; ks < KS1; ++ks) xf[ks][b] = *reinterpret_cast<const bf16x8*>(xt + xo + b * (16 * F_C * 2) + ks * 64);
+          }
+        } else {
+          issue(u + 2, tile);
+#pragma unroll
+          for (int b = 0; b < RT; ++b) rb[b] = *reinterpret_cast<const bf16x8*>(sp + 16384 + (RT * wave + b) * 1024 + lo);
+        }
+        bf16x8 fa = *reinterpret_cast<const bf16x8*>(sp + lo);
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+          const bf16x8 f = fa;
+          if (c + 1 < 16) fa = *reinterpret_cast<const bf16x8*>(sp + (c + 1) * 1024 + lo);
+#pragma unroll
+          for (int b = 0; b < RT; ++b) {
+            if constexpr (NW == 4) f_mfma_acc(acc2[c][b], f, rb[b]);
+            else acc2[c][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f, rb[b], acc2[c][b], 0, 0, 0);
+          }
+        }
+      };
+      for (int u = 0; u < NP - 1; ++u) pre_iter(u, std::false_type{});
+      pre_iter(NP - 1, std::true_type{});
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        const f32x4 bc0 = *reinterpret_cast<const f32x4*>(bps + 32 * ks + 8 * rq);
+        const f32x4 bc1 = *reinterpret_cast<const f32x4*>(bps + 32 * ks + 8 * rq + 4);
+#pragma unroll
+        for (int b = 0; b < RT; ++b) {
+          const f32x4 y0 = acc2[2 * ks][b] + bc0, y1 = acc2[2 * ks + 1][b] + bc1;
+          const bf16x8 xr = xf[ks][b];
+          bf16x8 x1;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            x1[e] = (__bf16)(y0[e] + (float)xr[e]);
+            x1[4 + e] = (__bf16)(y1[e] + (float)xr[4 + e]);
+          }
+          xf[ks][b] = x1;
+          acc2[2 * ks][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+          acc2[2 * ks + 1][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+      }
+    }
 
     // Software pipeline over the chunks: iteration ch runs GEMM 1 of chunk ch (W1 image of slot ch % 4) interleaved with GEMM 2 of
     // chunk ch - 1 (W2 image of slot (ch - 1) % 4, hidden fragments in registers): the two are independent, so the matrix pipe never
     // waits for the bias / ReLU / pack / LDS round trip of the hidden chunk, and 16 steps of {2 fragment reads, 4 RT/2 MFMAs} hide the
     // LDS latency. Iteration F_NCH only drains GEMM 2 of the last chunk -- and starts the NEXT tile's first two chunks: after its
     // barrier every wave is past iteration F_NCH - 1, so slots 0 and 1 (chunks F_NCH - 4, F_NCH - 3) are free.
+#ifdef NSID_F256_NCH                         // diagnosis build: fewer chunks (wrong results) to split the loop from the rest
+    constexpr int NCH = NSID_F256_NCH;
+#else
     constexpr int NCH = F_NCH;
+#endif
     auto iter = [&](auto G1, auto G2, const int ch) {
       constexpr bool g1 = decltype(G1)::value, g2 = decltype(G2)::value;     // GEMM 1 of chunk ch / GEMM 2 of chunk ch - 1 in this iteration
       // chunk ch has landed for THIS wave when at most the PW pieces of chunk ch + 1 are still in flight; the barrier then says so
@@ -179,14 +349,16 @@ void ffn256_fused_kernel(const F256Args p) {
       // tile before issued EP operations -- the next x fragments and the output stores -- AFTER chunks 0 and 1: they are younger than
       // what iterations 0 and 1 wait for and stay in flight; waiting them out here would put every tile's store tail on the critical
       // path)
-      if (ch < 2 && !first) f_wait_vm<(PW + EP < 63 ? PW + EP : 63)>();
+      if (!PRE && ch < 2 && !first) f_wait_vm<(PW + EP < 63 ? PW + EP : 63)>();
       else if (ch + 1 < F_NCH) f_wait_vm<PW>();
       else f_wait_vm<0>();
+#ifndef NSID_F256_NOBARRIER                  // diagnosis build: what the per-chunk barrier costs (wrong results)
       __builtin_amdgcn_s_barrier();
-      if (ch + 2 < F_NCH) issue(ch + 2, tile);
+#endif
+      if (ch + 2 < F_NCH) issue(NP + ch + 2, tile);
       else if (!g1 && more) { issue(0, tile + gridDim.x); issue(1, tile + gridDim.x); }
-      const char* s1 = lds + (ch % F_NS) * F_SLOT;                       // W1 image of chunk ch
-      const char* s2 = lds + ((ch + F_NS - 1) % F_NS) * F_SLOT + W2OFF;    // W2 image of chunk ch - 1
+      const char* s1 = lds + ((NP + ch) % F_NS) * F_SLOT;                       // W1 image of chunk ch
+      const char* s2 = lds + ((NP + ch + F_NS - 1) % F_NS) * F_SLOT + W2OFF;    // W2 image of chunk ch - 1
       f32x4 acc1[2][RT];
 #pragma unroll
       for (int a = 0; a < 2; ++a)
@@ -267,7 +439,7 @@ void ffn256_fused_kernel(const F256Args p) {
           o[4 + e] = (__bf16)(y1[e] + (float)xr[4 + e]);
         }
         *reinterpret_cast<bf16x8*>(ot + xo + b * (16 * F_C * 2) + ks * 64) = o;
-        if (more) xf[ks][b] = *reinterpret_cast<const bf16x8*>(xn + xo + b * (16 * F_C * 2) + ks * 64);
+        if (!GR && more) xf[ks][b] = *reinterpret_cast<const bf16x8*>(xn + xo + b * (16 * F_C * 2) + ks * 64);
       }
     }
   }  // tile
@@ -276,14 +448,21 @@ void ffn256_fused_kernel(const F256Args p) {
 }  // namespace
 
 // returns NSID_OK / NSID_ELAUNCH, or 1 (nothing launched) outside {C = 256 or 128, M % 256 == 0} / {C = 64, M % 512 == 0} with H = 4 C.
+// r2 != nullptr: the PRE form (x1 = x + wp r2 + bp in front of the FFN; r2: M x 512 bf16, wp: 256 x 512 bf16, bp: fp32[256]);
+// y != nullptr: the GR form (r2 evaluated from y (M x 256 bf16), idx (M x k, clip-local), wg (512 x 128 bf16), bg (fp32[512]); N nodes
+// per clip, 256 % N == 0) -- both C = 256 only
 __attribute__((visibility("hidden")))
 int nsid_ffn256_fused_launch(const void* x, const void* w1, const float* b1, const void* w2, const float* b2, void* out, int M, int C,
-                             int H, hipStream_t stream) {
+                             int H, hipStream_t stream, const void* r2, const void* wp, const float* bp, const void* y,
+                             const int32_t* idx, int k, int N, const void* wg, const float* bg) {
   if (!(C == 256 || C == 128 || C == 64) || H != 4 * C || M <= 0) return 1;
   const int tr = C == 64 ? 512 : 256;         // rows per workgroup tile
   if (M % tr != 0) return 1;
+  if ((r2 != nullptr || y != nullptr) && C != 256) return 1;
+  if (y != nullptr && (N <= 0 || 256 % N != 0 || k <= 0)) return 1;
   F256Args p{static_cast<const __bf16*>(x), static_cast<const __bf16*>(w1), b1, static_cast<const __bf16*>(w2), b2,
-             static_cast<__bf16*>(out), M};
+             static_cast<__bf16*>(out), M, static_cast<const __bf16*>(r2), static_cast<const __bf16*>(wp), bp,
+             static_cast<const __bf16*>(y), idx, static_cast<const __bf16*>(wg), bg, k, N};
   static int n_cu = 0;
   if (n_cu == 0) {
     int dev = 0, n = 0;               // an attribute query: legal whatever the stream is doing (capture)
@@ -297,12 +476,18 @@ int nsid_ffn256_fused_launch(const void* x, const void* w1, const float* b1, con
   const int wgs = (nsid_tune(NSID_T_ffn256) == 2 || ntiles < n_cu) ? ntiles : n_cu;
   const bool w4 = nsid_tune(NSID_T_ffn256) == 4;
   if (C == 128) {
-    NSID_LAUNCH((ffn256_fused_kernel<128, 8, 2>), dim3(wgs), dim3(512), 0, stream, p);
+    NSID_LAUNCH((ffn256_fused_kernel<128, 8, 2, 0>), dim3(wgs), dim3(512), 0, stream, p);
   } else if (C == 64) {
-    NSID_LAUNCH((ffn256_fused_kernel<64, 8, 4>), dim3(wgs), dim3(512), 0, stream, p);
+    NSID_LAUNCH((ffn256_fused_kernel<64, 8, 4, 0>), dim3(wgs), dim3(512), 0, stream, p);
+  } else if (y != nullptr) {
+    if (w4) NSID_LAUNCH((ffn256_fused_kernel<256, 4, 4, 2>), dim3(wgs), dim3(256), 0, stream, p);
+    else NSID_LAUNCH((ffn256_fused_kernel<256, 8, 2, 2>), dim3(wgs), dim3(512), 0, stream, p);
+  } else if (r2 != nullptr) {
+    if (w4) NSID_LAUNCH((ffn256_fused_kernel<256, 4, 4, 1>), dim3(wgs), dim3(256), 0, stream, p);
+    else NSID_LAUNCH((ffn256_fused_kernel<256, 8, 2, 1>), dim3(wgs), dim3(512), 0, stream, p);
   } else {
-    if (w4) NSID_LAUNCH((ffn256_fused_kernel<256, 4, 4>), dim3(wgs), dim3(256), 0, stream, p);
-    else NSID_LAUNCH((ffn256_fused_kernel<256, 8, 2>), dim3(wgs), dim3(512), 0, stream, p);
+    if (w4) NSID_LAUNCH((ffn256_fused_kernel<256, 4, 4, 0>), dim3(wgs), dim3(256), 0, stream, p);
+    else NSID_LAUNCH((ffn256_fused_kernel<256, 8, 2, 0>), dim3(wgs), dim3(512), 0, stream, p);
   }
   return nsid_launch_status();
 }
