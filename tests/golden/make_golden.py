@@ -343,6 +343,42 @@ def gold_e2e():
         print("   losses", losses, "gnorm", gnorms)
 
 
+def gold_e2e_s():
+    """A second encoder size end to end (VERDICT r4 task 5): size 's' = channels 80 / 160 / 400 / 640 (encoder/graph_encoder.py:121-123),
+    B = 8, k = 3: eval embeddings, then step 0 of train.py:53-75; neighbour ids + margins of both passes for teacher forcing, per-clip
+    embedding checksums instead of the h matrices, gradient / running-statistics checksums and three full gradients."""
+    print("e2e_s")
+    B, k = 8, 3
+    x_i, x_j = synth_clips(B)
+    torch.manual_seed(1234)
+    model = SimCLR(CFG, GraphEncoder(CFG, in_channels=CFG["n_filters"], k=k, size="s"))
+    load_synth(model)
+    tape = KnnTape(model)
+    model.eval()
+    with torch.no_grad():
+        h_i, h_j, z_i, z_j = model(x_i, x_j)
+        loss_eval = ntxent_loss(z_i, z_j, CFG)
+    ev = dict(h_i_eval_pc=_per_clip(h_i), h_j_eval_pc=_per_clip(h_j), z_i_eval=z_i, z_j_eval=z_j, loss_eval=loss_eval.reshape(1))
+    ev.update(tape.take("eval"))
+    model.train()
+    model.zero_grad()
+    h_i, h_j, z_i, z_j = model(x_i, x_j)
+    loss = ntxent_loss(z_i, z_j, CFG)
+    loss.backward()
+    tr = dict(h_i_train_pc=_per_clip(h_i), h_j_train_pc=_per_clip(h_j), z_i_train=z_i, z_j_train=z_j, loss_train=loss.detach().reshape(1))
+    tr.update(tape.take("s0"))
+    sums = _checksums((n, p.grad) for n, p in model.named_parameters() if p.grad is not None)
+    full = {"grad." + n: p.grad.clone() for n, p in model.named_parameters() if n in (
+        "encoder.backbone.0.0.fc1.0.weight", "encoder.backbone.14.1.fc2.1.weight", "projector.2.bias")}
+    stats1 = _checksums((n, t.float()) for n, t in model.state_dict().items() if n.endswith(("running_mean", "running_var")))
+    gn = float(torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=1.0))
+    save("e2e_b8_s_k3", x_i=x_i, x_j=x_j, **ev, **tr, **full, gnorm=np.array([gn], np.float64))
+    with open(os.path.join(HERE, "e2e_b8_s_k3_checksums.json"), "w") as f:
+        json.dump({"grad": sums, "bn_after_step1": stats1, "state_shapes": {n: list(t.shape) for n, t in model.state_dict().items()}},
+                  f, indent=0)
+    print("   loss eval", float(loss_eval), "train", float(loss), "gnorm", gn)
+
+
 def bench_clips(batch, seed):
     """bench.py's synth_clips — the inputs of the TIMED step: seeds (seed, seed + 1)"""
     gi = torch.Generator().manual_seed(seed)
@@ -709,7 +745,7 @@ def gold_relpos():
 
 if __name__ == "__main__":
     torch.manual_seed(0)
-    only = sys.argv[1:] or ["shapes", "init", "relpos", "knn", "mrconv", "block", "downsample", "peak", "ntxent", "e2e",
+    only = sys.argv[1:] or ["shapes", "init", "relpos", "knn", "mrconv", "block", "downsample", "peak", "ntxent", "e2e", "e2e_s",
                             "deep", "fpdb", "b256", "deep_b256"]
     for name in only:
         globals()["gold_" + name]()

@@ -644,3 +644,96 @@ def test_graphed_fingerprinter_equals_eager_extraction(golden):
     opt.step()
     with pytest.raises(RuntimeError):
         fp2(x)
+
+
+def test_simclr_e2e_size_s(golden):
+    """A second encoder size end to end (VERDICT r4 task 5): GraphEncoder(size='s') = channels 80 / 160 / 400 / 640
+    (encoder/graph_encoder.py:121-123) -- none of them a shape the fused / weight-stationary kernels are specialised for, so every layer
+    takes the generic tile kernels, the strip / rank kNN forms and the plain aggregation. Against the reference's own outputs
+    (make_golden.py::gold_e2e_s): eval embeddings with the HIP kNN's own neighbour sets checked, then step 0 of train.py:53-75."""
+    from neuralsampleid_amd import functional as F_
+    from neuralsampleid_amd.encoder.graph_encoder import GraphEncoder
+    from neuralsampleid_amd.simclr.ntxent import ntxent_loss
+    from neuralsampleid_amd.simclr.simclr import SimCLR
+    g = golden("e2e_b8_s_k3")
+    with open(os.path.join(GOLDEN, "e2e_b8_s_k3_checksums.json")) as f:
+        chk = json.load(f)
+    model = SimCLR(GRAFP_CFG, GraphEncoder(GRAFP_CFG, in_channels=GRAFP_CFG["n_filters"], k=3, size="s"))
+    assert {k_: list(v.shape) for k_, v in model.state_dict().items()} == chk["state_shapes"]        # the reference's key set and shapes
+    model = load_synth(model).to(DEV)
+    x_i, x_j = g.t("x_i").to(DEV), g.t("x_j").to(DEV)
+    pc = lambda t: torch.stack([t.detach().double().sum(1), t.detach().double().norm(dim=1)], 1).cpu()
+    gold_idx, gaps = tape_of(g, "eval")
+    model.eval()
+    F_.TAPE = F_.KnnTape(replay=gold_idx)
+    with torch.no_grad():
+        h_i, h_j, z_i, z_j = model(x_i, x_j)
+        loss = ntxent_loss(z_i, z_j, GRAFP_CFG)
+    rec = F_.TAPE.recorded
+    F_.TAPE = None
+    assert len(rec) == 24
+    hard, soft, rows = check_tape(rec, gold_idx, gaps)
+    assert hard == 0 and soft <= rows * 2e-3, (hard, soft, rows)
+    assert (pc(h_i) - g.t("h_i_eval_pc")).abs().max() < 2e-3 and (pc(h_j) - g.t("h_j_eval_pc")).abs().max() < 2e-3
+    assert maxerr(z_i, g.t("z_i_eval")) < 1e-5 and maxerr(z_j, g.t("z_j_eval")) < 1e-5
+    assert abs(float(loss.detach()) - float(g["loss_eval"][0])) < 1e-5
+    # step 0
+    model.train()
+    model.zero_grad()
+    gold_idx, gaps = tape_of(g, "s0")
+    F_.TAPE = F_.KnnTape(replay=gold_idx)
+    h_i, h_j, z_i, z_j = model(x_i, x_j)
+    loss = ntxent_loss(z_i, z_j, GRAFP_CFG)
+    loss.backward()
+    rec = F_.TAPE.recorded
+    F_.TAPE = None
+    hard, soft, rows = check_tape(rec, gold_idx, gaps)
+    assert hard == 0 and soft <= rows * 2e-3, (hard, soft, rows)
+    assert maxerr(z_i, g.t("z_i_train")) < 2e-5 and abs(float(loss.detach()) - float(g["loss_train"][0])) < 5e-5
+    grads = {n: p.grad for n, p in model.named_parameters() if p.grad is not None}
+    for name in [n for n in g if n.startswith("grad.")]:
+        late = name.startswith(("grad.encoder.backbone.14", "grad.encoder.proj", "grad.projector"))
+        assert relerr(grads[name[5:]], g.t(name)) < (5e-4 if late else 4e-2), (name, relerr(grads[name[5:]], g.t(name)))
+    worst = max(abs(float(grads[n].double().norm()) - nrm) / nrm for n, (s_, nrm) in chk["grad"].items() if nrm > 1e-3)
+    assert worst < 2e-2, worst
+    sd = model.state_dict()
+    for name, (s_, nrm) in chk["bn_after_step1"].items():
+        assert abs(float(sd[name].double().norm()) - nrm) <= 1e-4 * max(nrm, 1.0), name
+    gn = float(torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=1.0))
+    assert abs(gn - float(g["gnorm"][0])) / float(g["gnorm"][0]) < 5e-3
+
+
+def test_size_s_bf16_storage_runs_the_generic_kernels(golden):
+    """the same model in the timed arithmetic (bf16 storage): eval embeddings stay within cos 0.999 of the reference's fp32 ones and a
+    training step runs (finite loss, every parameter receives a gradient) -- the C = 80 / 160 / 400 / 640 shapes on the generic bf16 paths"""
+    from neuralsampleid_amd import functional as F_
+    from neuralsampleid_amd import ops
+    from neuralsampleid_amd.encoder.graph_encoder import GraphEncoder
+    from neuralsampleid_amd.simclr.ntxent import ntxent_loss
+    from neuralsampleid_amd.simclr.simclr import SimCLR
+    g = golden("e2e_b8_s_k3")
+    model = load_synth(SimCLR(GRAFP_CFG, GraphEncoder(GRAFP_CFG, in_channels=GRAFP_CFG["n_filters"], k=3, size="s"))).to(DEV)
+    x_i, x_j = g.t("x_i").to(DEV), g.t("x_j").to(DEV)
+    ops.set_gemm_precision("bf16")
+    F_.set_activation_dtype("bf16")
+    try:
+        model.eval()
+        gold_idx, _ = tape_of(g, "eval")
+        F_.TAPE = F_.KnnTape(replay=gold_idx)
+        with torch.no_grad():
+            _, _, z_i, z_j = model(x_i, x_j)
+        F_.TAPE = None
+        cos = torch.nn.functional.cosine_similarity(torch.cat([z_i, z_j]).float().cpu(), torch.cat([g.t("z_i_eval"), g.t("z_j_eval")]), dim=1)
+        assert float(cos.min()) > 0.999, float(cos.min())
+        model.train()
+        model.zero_grad()
+        _, _, z_i, z_j = model(x_i, x_j)
+        loss = ntxent_loss(z_i, z_j, GRAFP_CFG)
+        loss.backward()
+        assert torch.isfinite(loss.detach()).item()
+        missing = [n for n, p in model.named_parameters() if p.requires_grad and (p.grad is None or not torch.isfinite(p.grad).all())]
+        assert not missing, missing[:5]
+    finally:
+        F_.TAPE = None
+        ops.set_gemm_precision("fp32")
+        F_.set_activation_dtype("fp32")

@@ -348,3 +348,55 @@ def test_deep_config4(golden):
         assert rel < (1e-3 if late else 8e-2), (name, rel)         # B = 4, 24 blocks: twice the depth of test_e2e's floor
     for name, (s_, nrm) in chk["bn_after_step1"].items():
         assert abs(float(st.updates[name].double().norm()) - nrm) <= 1e-4 * max(nrm, 1.0), name
+
+
+def test_e2e_size_s(golden):
+    """A second encoder size ('s': channels 80 / 160 / 400 / 640, encoder/graph_encoder.py:121-123) end to end against the reference's
+    own outputs (tests/golden/make_golden.py::gold_e2e_s): eval embeddings and step 0 of train.py:53-75, neighbour ids forced."""
+    g = golden("e2e_b8_s_k3")
+    with open(os.path.join(GOLDEN, "e2e_b8_s_k3_checksums.json")) as f:
+        chk = json.load(f)
+    P = synth_P({k_: tuple(v) for k_, v in chk["state_shapes"].items()})
+    plan = R.encoder_plan("s", 3)
+    x_i, x_j = g.t("x_i"), g.t("x_j")
+    tau = GRAFP_CFG["tau"]
+    pc = lambda t: torch.stack([t.detach().double().sum(1), t.detach().double().norm(dim=1)], 1)
+    gold_idx, gaps = tape_of(g, "eval")
+    R.TAPE = R.KnnTape(replay=gold_idx)
+    try:
+        with torch.no_grad():
+            h_i, h_j, z_i, z_j = R.simclr_forward(x_i, x_j, P, GRAFP_CFG, plan, False)
+            loss = R.ntxent(z_i, z_j, tau)
+        recorded = R.TAPE.recorded
+    finally:
+        R.TAPE = None
+    assert len(recorded) == len(gold_idx) == 24
+    hard, soft, rows = check_tape(recorded, gold_idx, gaps)
+    assert hard == 0 and soft <= rows * 2e-3, (hard, soft, rows)
+    assert (pc(h_i) - g.t("h_i_eval_pc")).abs().max() < 2e-3 and (pc(h_j) - g.t("h_j_eval_pc")).abs().max() < 2e-3
+    assert (z_i - g.t("z_i_eval")).abs().max() < 1e-5 and (z_j - g.t("z_j_eval")).abs().max() < 1e-5
+    assert abs(float(loss) - float(g["loss_eval"][0])) < 1e-5
+    # step 0
+    gold_idx, gaps = tape_of(g, "s0")
+    keys = R.trainable_keys(P)
+    for k_ in keys:
+        P[k_].requires_grad_(True)
+    R.TAPE = R.KnnTape(replay=gold_idx)
+    try:
+        st = R.BNState()
+        h_i, h_j, z_i, z_j = R.simclr_forward(x_i, x_j, P, GRAFP_CFG, plan, True, st)
+        loss = R.ntxent(z_i, z_j, tau)
+        loss.backward()
+        hard, soft, rows = check_tape(R.TAPE.recorded, gold_idx, gaps)
+    finally:
+        R.TAPE = None
+    assert hard == 0 and soft <= rows * 2e-3, (hard, soft, rows)
+    assert (z_i - g.t("z_i_train")).abs().max() < 2e-5 and abs(float(loss) - float(g["loss_train"][0])) < 2e-5
+    for name in [n for n in g if n.startswith("grad.")]:
+        ref, got = g.t(name), P[name[5:]].grad
+        late = name.startswith(("grad.encoder.backbone.14", "grad.encoder.proj", "grad.projector"))
+        assert float((got - ref).norm() / ref.norm()) < (5e-4 if late else 4e-2), name
+    worst = max(abs(float(P[n].grad.double().norm()) - nrm) / nrm for n, (s_, nrm) in chk["grad"].items() if nrm > 1e-3)
+    assert worst < 2e-2, worst
+    for name, (s_, nrm) in chk["bn_after_step1"].items():
+        assert abs(float(st.updates[name].double().norm()) - nrm) <= 1e-4 * max(nrm, 1.0), name
