@@ -4,6 +4,7 @@
 // reaching HBM.  Algorithmic HBM traffic = read N*C*4 B, write N*k*4 B per clip.
 #include <cstdlib>
 #include "nsid_common.h"
+#include <type_traits>
 
 namespace {
 
@@ -415,6 +416,60 @@ __device__ __forceinline__ void knn_stage_split_wide(const T* __restrict__ src, 
   }
 }
 
+// RAW (round 5, forward-only extraction): the features are the STORED bf16 values themselves (eval mode: the BatchNorm in front is folded
+// into its conv, no affine on the load). bf16 x bf16 products are exact in fp32, so ONE bf16 MFMA pass on the raw features gives
+// y_i . y_j to fp32 accumulation accuracy, and the normalisation becomes two fp32 factors per distance:
+//     y^_i . y^_j = (y_i . y_j) / (|y_i| |y_j|),        D_ij = (|y^_i|^2 - 2 y^_i . y^_j) + |y^_j|^2      (torch_edge.py:281-284, 16-18)
+// -- a third of the matrix work of the two-part fp16 split, half its LDS image, and no per-element divide / split in the staging pass
+// (5-10 us of a clip's 13-27 us). Error against fp64 on unit-norm rows: that of one fp32 accumulation chain (<= 1.5e-7 |y_i||y_j|),
+// the same order as the split product's and as the reference's own fp32 GEMM.
+template <int JN>
+__device__ __forceinline__ void knn_stage_raw(const __bf16* __restrict__ src, long ldr, int N, int nwaves, char* img, float* sq, float* inv) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nl = lane & 7, kl = lane >> 3;
+  constexpr int KC = 8 * JN;
+  constexpr int RU = JN <= 2 ? 2 : 1;
+  for (int n0 = wave * 8; n0 < N; n0 += RU * nwaves * 8) {
+    bf16x8 raw[RU][JN];
+    int nn[RU];
+    float ss[RU];
+#pragma unroll
+    for (int u = 0; u < RU; ++u) {
+      const int n = n0 + u * nwaves * 8 + nl;
+      nn[u] = n < N ? n : -1;
+      const __bf16* rowp = src + (long)(n < N ? n : N - 1) * ldr;
+#pragma unroll
+      for (int j = 0; j < JN; ++j) raw[u][j] = *reinterpret_cast<const bf16x8*>(rowp + (kl + 8 * j) * 8);
+    }
+#pragma unroll
+    for (int u = 0; u < RU; ++u) {
+      ss[u] = 0.f;
+#pragma unroll
+      for (int j = 0; j < JN; ++j) {
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (float)raw[u][j][e];
+        ss[u] += ((v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3])) + ((v[4] * v[4] + v[5] * v[5]) + (v[6] * v[6] + v[7] * v[7]));
+      }
+    }
+#pragma unroll
+    for (int o = 8; o < 64; o <<= 1)
+#pragma unroll
+      for (int u = 0; u < RU; ++u) ss[u] += __shfl_xor(ss[u], o, 64);
+#pragma unroll
+    for (int u = 0; u < RU; ++u) {
+      if (nn[u] < 0) continue;
+      if (kl == 0) {
+        const float rn = 1.f / fmaxf(sqrtf(ss[u]), 1e-12f);            // F.normalize's max(|y|, eps)
+        inv[nn[u]] = rn;
+        sq[nn[u]] = (ss[u] * rn) * rn;                                 // |y^|^2: 1 up to rounding, 0 for an all-zero row
+      }
+#pragma unroll
+      for (int j = 0; j < JN; ++j) *reinterpret_cast<bf16x8*>(knn_img(img, 0, kl + 8 * j, nn[u], KC, N)) = raw[u][j];
+    }
+  }
+}
+
 template <typename T>
 __device__ __forceinline__ void knn_stage_split_any(const T* src, long ldr, const float* scale, const float* shift, int N, int C,
                                                     int nwaves, char* img, float* sq) {
@@ -447,14 +502,16 @@ __device__ __forceinline__ void knn_mfma3(const KnnFrag& x, const KnnFrag& y, f3
 // workgroup per CU). Without it the kernel fits 128 VGPRs and TWO workgroups share a CU, which is what hides latency when a launch
 // has more clips than CUs (fingerprint extraction: 2 048 clips per micro-batch); with one clip per CU (a training step) the
 // prefetch wins. The launcher picks by the clip count.
-template <typename T, int KD, int NT, bool PF>
+template <typename T, int KD, int NT, bool PF, bool RAW = false>
 __device__ __forceinline__ void knn2_body(const T* __restrict__ r, long ldr, const float* __restrict__ scale,
                                           const float* __restrict__ shift, int N, int C, int k, int dilation,
                                           int32_t* __restrict__ idx) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  char* img = reinterpret_cast<char*>(smem);          // [2][C/8][N][8] fp16: the two split images of the normalised features
-  float* sq = smem + 2 * (N * C / 2);                 // [N]
-  float* xkey = sq + N;                               // [4 row tiles][16 rows][KD] lists handed over by the second column group
+  static_assert(!RAW || (std::is_same<T, __bf16>::value && !PF), "the raw-feature form reads stored bf16 values, two workgroups per CU");
+  char* img = reinterpret_cast<char*>(smem);          // [2][C/8][N][8] fp16: the two split images of the normalised features (RAW: one bf16 image)
+  float* sq = smem + (RAW ? 1 : 2) * (N * C / 2);     // [N]
+  float* inv = sq + N;                                // RAW: [N] 1 / max(|y|, 1e-12)
+  float* xkey = sq + (RAW ? 2 : 1) * N;               // [4 row tiles][16 rows][KD] lists handed over by the second column group
   int* xid = reinterpret_cast<int*>(xkey + 4 * 16 * KD);
   unsigned long long* const trace = g_knn_trace;
   unsigned long long tt[3] = {0, 0, 0};
@@ -466,7 +523,16 @@ __device__ __forceinline__ void knn2_body(const T* __restrict__ r, long ldr, con
   const int KC = C >> 3;
 
   // ---- phase 1: y = scale*r + shift, F.normalize, |y^|^2, two-way fp16 split — one pass from global memory into the LDS images
-  knn_stage_split_any<T>(src, ldr, scale, shift, N, C, KNN2_WAVES, img, sq);
+  if constexpr (RAW) {
+    switch (C) {            // uniform (host-checked: 64, 128, 256 or 512)
+      case 64: knn_stage_raw<1>(src, ldr, N, KNN2_WAVES, img, sq, inv); break;
+      case 128: knn_stage_raw<2>(src, ldr, N, KNN2_WAVES, img, sq, inv); break;
+      case 256: knn_stage_raw<4>(src, ldr, N, KNN2_WAVES, img, sq, inv); break;
+      default: knn_stage_raw<8>(src, ldr, N, KNN2_WAVES, img, sq, inv); break;
+    }
+  } else {
+    knn_stage_split_any<T>(src, ldr, scale, shift, N, C, KNN2_WAVES, img, sq);
+  }
   if (trace) tt[1] = __builtin_amdgcn_s_memrealtime();
   __syncthreads();
 
@@ -483,11 +549,21 @@ __device__ __forceinline__ void knn2_body(const T* __restrict__ r, long ldr, con
     top.init();
     const int i = 16 * rt + lr;                           // this lane's row node
     const float si = sq[i];
+    float m2ri = 0.f;
+    if constexpr (RAW) m2ri = -2.f * inv[i];
     for (int ct0 = cg * CTG; ct0 < (cg + 1) * CTG; ct0 += NT) {
       f32x4 lead[NT], corr[NT];
 #pragma unroll
       for (int u = 0; u < NT; ++u) lead[u] = corr[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if constexpr (PF) {
+      if constexpr (RAW) {
+        for (int kc = 0; kc < KC; kc += 4) {
+          const bf16x8 fa = *reinterpret_cast<const bf16x8*>(knn_img(img, 0, kc + rq, i, KC, N));
+#pragma unroll
+          for (int u = 0; u < NT; ++u)
+            lead[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                *reinterpret_cast<const bf16x8*>(knn_img(img, 0, kc + rq, 16 * (ct0 + u) + lr, KC, N)), fa, lead[u], 0, 0, 0);
+        }
+      } else if constexpr (PF) {
         KnnFrag fa = knn_frag(img, rq, i, KC, N), fb[NT];
 #pragma unroll
         for (int u = 0; u < NT; ++u) fb[u] = knn_frag(img, rq, 16 * (ct0 + u) + lr, KC, N);
@@ -515,8 +591,14 @@ __device__ __forceinline__ void knn2_body(const T* __restrict__ r, long ldr, con
       for (int u = 0; u < NT; ++u) {
         const int j0 = 16 * (ct0 + u) + 4 * rq;
         const f32x4 sj = *reinterpret_cast<const f32x4*>(sq + j0);
+        if constexpr (RAW) {
+          const f32x4 rj = *reinterpret_cast<const f32x4*>(inv + j0);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) top.push_ordered((si + (-2.f * (lead[u][e] + corr[u][e]))) + sj[e], j0 + e);
+          for (int e = 0; e < 4; ++e) top.push_ordered(fmaf(m2ri, lead[u][e] * rj[e], si) + sj[e], j0 + e);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) top.push_ordered((si + (-2.f * (lead[u][e] + corr[u][e]))) + sj[e], j0 + e);
+        }
       }
     }
     // ---- merge the four quarter lists of every row (lanes lr + 16q): two butterfly exchanges, after which all four
@@ -577,6 +659,13 @@ __global__ __launch_bounds__(KNN2_THREADS) __attribute__((amdgpu_waves_per_eu(4,
 void knn2_pair_kernel(const T* __restrict__ r, long ldr, const float* __restrict__ scale, const float* __restrict__ shift,
                       int N, int C, int k, int dilation, int32_t* __restrict__ idx) {
   knn2_body<T, KD, NT, false>(r, ldr, scale, shift, N, C, k, dilation, idx);
+}
+
+// the raw-feature form (stored bf16 features, no affine: forward-only extraction), two workgroups per CU
+template <int KD, int NT>
+__global__ __launch_bounds__(KNN2_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4)))
+void knn2_raw_kernel(const __bf16* __restrict__ r, long ldr, int N, int C, int k, int dilation, int32_t* __restrict__ idx) {
+  knn2_body<__bf16, KD, NT, false, true>(r, ldr, nullptr, nullptr, N, C, k, dilation, idx);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -1008,6 +1097,24 @@ int launch_knn2_nt(const void* r, int ldr, const float* scale, const float* shif
     configured = true;
   }
   const int pair_min = nsid_tune(NSID_T_knn_pair_min);      // clips from which two workgroups share a CU (0 = never)
+  if constexpr (std::is_same<T, __bf16>::value) {
+    // stored bf16 features without an affine (eval mode, BatchNorm folded) and a launch of many clips: one bf16 MFMA pass on the raw
+    // features (knn2_raw_kernel); a training step (affine on the load, <= 256 clips) never takes it, so its arithmetic does not change
+    if (scale == nullptr && nsid_tune(NSID_T_knn_raw16) != 0 && pair_min > 0 && B >= pair_min) {
+      const size_t rbytes = (size_t)N * C * 2 + ((size_t)2 * N + 2 * 4 * 16 * KD) * sizeof(float);
+      static bool configured3 = false;
+      if (!configured3) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(knn2_raw_kernel<KD, NT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                160 * 1024) != hipSuccess)
+          return NSID_ELAUNCH;
+        configured3 = true;
+      }
+      nsid_count(NSID_C_knn2_raw);
+      NSID_LAUNCH((knn2_raw_kernel<KD, NT>), dim3(B), dim3(KNN2_THREADS), rbytes, s, static_cast<const __bf16*>(r), (long)ldr, N, C, k,
+                  dilation, idx);
+      return nsid_launch_status();
+    }
+  }
   if (pair_min > 0 && B >= pair_min && 2 * bytes <= 160 * 1024) {
     static bool configured2 = false;
     if (!configured2) {

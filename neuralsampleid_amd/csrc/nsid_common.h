@@ -158,6 +158,7 @@ static inline bool nsid_aligned16(const void* p) { return (reinterpret_cast<uint
   X(w3_min_tiles, 64)                                                                                                         \
   X(knn_strips, 0)             /* 1: always the general strip kernel (tests of the fallback) */                               \
   X(knn_pair_min, 512)         /* clips per launch from which knn2 runs as two 128-VGPR workgroups per CU; 0 = never */        \
+  X(knn_raw16, 1)              /* forward-only launches (bf16 features, no affine, >= knn_pair_min clips): one bf16 MFMA pass on the raw features */ \
   X(knn_sel_min_n, 128)        /* graphs of at least this many nodes take the in-register threshold select for k*d > 8 */       \
   X(mr_grid_stride, 0)         /* 1: grid-stride aggregation instead of the LDS-staged per-clip kernel */                     \
   X(mr_split, 0)               /* channel split of the LDS-staged aggregation (0 = heuristic) */                              \
@@ -194,7 +195,7 @@ static inline long nsid_tune(NsidTuneKey k) { return g_nsid_tune[k]; }
   X(ws_fwd) X(ws_bwd_data) X(ws_bwd_bnapply) /* wsgemm.hip: weight-stationary streaming forms */                   \
   X(wgrad_rect) X(wgrad_square) X(wgrad3)                                                       \
   X(bn_bwd_apply) X(bn_bwd_apply_capped)                                                        \
-  X(knn2) X(knn2_pair) X(knn_rank) X(knn_sel) X(knn_strips)                                                  \
+  X(knn2) X(knn2_pair) X(knn2_raw) X(knn_rank) X(knn_sel) X(knn_strips)                                                  \
   X(mr_fwd_lds) X(mr_fwd_grid) X(mr_fwd_key)                                                                  \
   X(ffn_fused)            /* eval-mode FFN in one launch (ffn_fused.hip) */                     \
   X(mrconv_fused)         /* eval-mode max-relative aggregation + grouped conv in one launch (mrconv_fused.hip) */

@@ -127,7 +127,8 @@ def test_max_relative_aggregation_both_libraries(libs, golden):
     dyo = np.zeros((B * N, C), np.float32)
     assert orc.oracle_mr_aggregate_bwd(hp(gu), hp(idx, IP), hp(ao, UP), B, N, C, k, hp(dyo)) == 0
     dyh = torch.zeros((B * N, C), device=DEV)
-    run(hip.nsid_mr_aggregate_bwd(dp(dev(gu)), dp(id_), dp(ah), B, N, C, k, dp(dyh), NSID_F32, None))
+    gud = dev(gu)                    # (every device buffer keeps a name until the launch has run: a temporary would be freed, and its
+    run(hip.nsid_mr_aggregate_bwd(dp(gud), dp(id_), dp(ah), B, N, C, k, dp(dyh), NSID_F32, None))      # block reused, behind a raw pointer)
     assert np.abs(dyh.cpu().numpy() - dyo).max() < 1e-6
 
 
@@ -143,8 +144,8 @@ def test_grouped_linear_both_libraries(libs, golden):
     oo = np.zeros((M, C2), np.float32)
     assert orc.oracle_linear_fwd(hp(u.reshape(M, C2)), hp(w), hp(b), M, K, K, G, hp(oo)) == 0
     oh = torch.zeros((M, C2), device=DEV)
-    run(hip.nsid_linear_fwd(dp(dev(u.reshape(M, C2))), C2, dp(dev(w)), NSID_F32, dp(dev(b)), dp(oh), C2, M, K, K, G, None, None, 0, 0,
-                            None, 1, NSID_F32, None))
+    ud, wd, bd = dev(u.reshape(M, C2)), dev(w), dev(b)
+    run(hip.nsid_linear_fwd(dp(ud), C2, dp(wd), NSID_F32, dp(bd), dp(oh), C2, M, K, K, G, None, None, 0, 0, None, 1, NSID_F32, None))
     assert np.abs(oh.cpu().numpy() - oo).max() <= 5e-6 * max(1.0, np.abs(oo).max())
 
 
@@ -163,7 +164,8 @@ def test_downsample_both_libraries(libs, golden):
     wp = torch.zeros((2 * C, 3 * C), device=DEV)
     run(hip.nsid_pack_ds_weight(dp(wd), 2 * C, C, dp(wp), None))
     oh = torch.zeros((B * No, 2 * C), device=DEV)
-    run(hip.nsid_downsample3_fwd(dp(dev(x.reshape(B * N, C))), B, N, C, dp(wp), NSID_F32, dp(dev(b)), dp(oh), 2 * C, None, NSID_F32, None))
+    xd, bd = dev(x.reshape(B * N, C)), dev(b)
+    run(hip.nsid_downsample3_fwd(dp(xd), B, N, C, dp(wp), NSID_F32, dp(bd), dp(oh), 2 * C, None, NSID_F32, None))
     assert np.abs(oh.cpu().numpy() - oo).max() <= 5e-6 * max(1.0, np.abs(oo).max())
 
 
@@ -178,7 +180,8 @@ def test_peak_patchify_both_libraries(libs, golden):
     assert orc.oracle_peak_patchify_fwd(hp(x), hp(w), hp(b), B, H, W, 4, 8, 8, hp(oo)) == 0
     oh = torch.zeros((B * 256, 8), device=DEV)
     mm = torch.zeros((B, 2), device=DEV)
-    run(hip.nsid_peak_patchify_fwd(dp(dev(x)), dp(dev(w)), dp(dev(b)), B, H, W, 4, 8, 8, dp(oh), 8, dp(mm), NSID_F32, None))
+    xd, wd, bd = dev(x), dev(w), dev(b)
+    run(hip.nsid_peak_patchify_fwd(dp(xd), dp(wd), dp(bd), B, H, W, 4, 8, 8, dp(oh), 8, dp(mm), NSID_F32, None))
     assert np.abs(oh.cpu().numpy() - oo).max() < 1e-5
     assert np.abs(oh.cpu().numpy().reshape(B, 256, 8).transpose(0, 2, 1) - g["y"]).max() < 1e-5      # and the reference's own output
 
@@ -194,6 +197,7 @@ def test_ntxent_both_libraries(libs, golden, B):
     ws = torch.zeros(int(hip.nsid_ntxent_ws_floats(B)), device=DEV)
     lh = torch.zeros(1, device=DEV)
     dih, djh = torch.zeros((B, d), device=DEV), torch.zeros((B, d), device=DEV)
-    run(hip.nsid_ntxent_fwd_bwd(dp(dev(zi)), dp(dev(zj)), B, d, tau, 0, B, dp(ws), dp(lh), dp(dih), dp(djh), None))
+    zid, zjd = dev(zi), dev(zj)
+    run(hip.nsid_ntxent_fwd_bwd(dp(zid), dp(zjd), B, d, tau, 0, B, dp(ws), dp(lh), dp(dih), dp(djh), None))
     assert abs(float(lh[0]) - float(lo[0])) < 2e-6 and abs(float(lh[0]) - float(g["loss"][0])) < 2e-6
     assert np.abs(dih.cpu().numpy() - dio).max() < 1e-6 and np.abs(djh.cpu().numpy() - djo).max() < 1e-6

@@ -85,7 +85,7 @@ def test_extraction_is_per_clip_at_the_timed_micro_batch(bf16_mode):
     ops.launch_counters(reset=True)
     z_all = fingerprint.extract_fingerprints(model, clips, 2048)
     cnt = ops.launch_counters()
-    assert cnt["gemm256"] > 0 and cnt["knn2_pair"] > 0 and cnt["ffn_fused"] == 10 and cnt["mrconv_fused"] == 10, cnt       # (C = 512: unfused)
+    assert cnt["gemm256"] > 0 and cnt["knn2_raw"] > 0 and cnt["ffn_fused"] == 10 and cnt["mrconv_fused"] == 10, cnt       # (C = 512: unfused)
     z_parts = fingerprint.extract_fingerprints(model, clips, 512)
     torch.cuda.synchronize()
     assert float((z_all.norm(dim=1) - 1).abs().max()) < 1e-5                               # F.normalize

@@ -214,7 +214,7 @@ def test_bf16_extraction_of_512_reference_clips_in_one_micro_batch(golden, resto
     z = fingerprint.extract_fingerprints(model, clips, 512)
     torch.cuda.synchronize()
     cnt = ops.launch_counters()
-    assert cnt["knn2_pair"] > 0 and cnt["ffn_fused"] > 0 and cnt["mrconv_fused"] > 0, cnt
+    assert cnt["knn2_raw"] > 0 and cnt["ffn_fused"] > 0 and cnt["mrconv_fused"] > 0, cnt
     assert ops.lib.nsid_gemm_g256_launches() > n256 and cnt["gemm256"] > 0, cnt
     ref = torch.cat([g.t("z_i_eval"), g.t("z_j_eval")])
     cos = torch.nn.functional.cosine_similarity(z.float().cpu(), ref, dim=1)
@@ -248,3 +248,38 @@ def test_knn_kernels_of_the_deep_plan_at_the_timed_batch(N, C, k, d, restore_mod
     same = (idx == order[:, :, :kd:d][:, :, :k]).all(dim=2)
     bad = int((clear & ~same).sum())
     assert bad == 0, f"{bad} clear rows differ from the fp64 ranking"
+
+
+@pytest.mark.parametrize("N,C,k,d", [(256, 64, 3, 1), (128, 128, 3, 1), (64, 256, 3, 1), (32, 512, 3, 1), (256, 64, 5, 1), (128, 128, 4, 2)])
+def test_knn_raw_bf16_pass_of_the_extraction_plan(N, C, k, d, restore_mode):
+    """forward-only extraction (config 5): stored bf16 features without an affine and >= 512 clips per launch take ONE bf16 MFMA pass on
+    the raw features with the normalisation as two fp32 factors per distance (csrc/knn.hip knn2_raw_kernel; torch_edge.py:270-284, 70-103).
+    Against an fp64 ranking of the same bf16 values: identical ids on every row whose first k*d + 1 distances are separated by more than
+    2e-6 -- the bound the two-part fp16 split is held to --, and the same ids as that split form outside such near-ties."""
+    from neuralsampleid_amd import ops
+    from synth import synth_randn
+    B = 512
+    r = (synth_randn(f"rawknn{N}{C}", B * N, C) * 1.7 + 0.3).to(DEV).to(torch.bfloat16)
+    r[5 * N + 3] = 0                                      # an all-zero node (F.normalize's eps branch): distance |y^_j|^2 to everybody
+    out = {}
+    for raw in (1, 0):
+        ops.set_tuning("knn_raw16", raw)
+        ops.launch_counters(reset=True)
+        out[raw] = ops.knn_graph(r, B, N, C, k, d, None).long().cpu()
+        cnt = ops.launch_counters()
+        assert cnt["knn2_raw"] == raw and cnt["knn2_pair"] == 1 - raw, cnt
+    ops.reset_tuning()
+    y = r.double().reshape(B, N, C).cpu()
+    y = y / y.norm(dim=2, keepdim=True).clamp_min(1e-12)
+    sq = (y * y).sum(2)
+    D = sq[:, :, None] - 2.0 * torch.bmm(y, y.transpose(1, 2)) + sq[:, None, :]
+    Ds, order = torch.sort(D, dim=2, stable=True)
+    kd = k * d
+    gaps = (Ds[:, :, 1:kd + 1] - Ds[:, :, :kd]).min(dim=2).values
+    clear = gaps > 2e-6
+    assert float(clear.float().mean()) > 0.9
+    want = order[:, :, :kd:d][:, :, :k]
+    for raw in (1, 0):
+        bad = int((clear & ~(out[raw] == want).all(dim=2)).sum())
+        assert bad == 0, f"raw={raw}: {bad} clear rows differ from the fp64 ranking"
+    assert (out[1][:, :, 0] == torch.arange(N)[None, :])[clear].all()                  # self first
