@@ -662,8 +662,9 @@ void knn2_pair_kernel(const T* __restrict__ r, long ldr, const float* __restrict
 }
 
 // the raw-feature form (stored bf16 features, no affine: forward-only extraction), two workgroups per CU
-template <int KD, int NT>
-__global__ __launch_bounds__(KNN2_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4)))
+// WPE waves per SIMD = WPE / 2 workgroups per CU (35 KB of LDS each): the register budget follows (4: 128, 6: 80, 8: 64 VGPRs)
+template <int KD, int NT, int WPE>
+__global__ __launch_bounds__(KNN2_THREADS) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
 void knn2_raw_kernel(const __bf16* __restrict__ r, long ldr, int N, int C, int k, int dilation, int32_t* __restrict__ idx) {
   knn2_body<__bf16, KD, NT, false, true>(r, ldr, nullptr, nullptr, N, C, k, dilation, idx);
 }
@@ -1102,16 +1103,24 @@ int launch_knn2_nt(const void* r, int ldr, const float* scale, const float* shif
     // features (knn2_raw_kernel); a training step (affine on the load, <= 256 clips) never takes it, so its arithmetic does not change
     if (scale == nullptr && nsid_tune(NSID_T_knn_raw16) != 0 && pair_min > 0 && B >= pair_min) {
       const size_t rbytes = (size_t)N * C * 2 + ((size_t)2 * N + 2 * 4 * 16 * KD) * sizeof(float);
-      static bool configured3 = false;
-      if (!configured3) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(knn2_raw_kernel<KD, NT>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                160 * 1024) != hipSuccess)
-          return NSID_ELAUNCH;
-        configured3 = true;
-      }
       nsid_count(NSID_C_knn2_raw);
-      NSID_LAUNCH((knn2_raw_kernel<KD, NT>), dim3(B), dim3(KNN2_THREADS), rbytes, s, static_cast<const __bf16*>(r), (long)ldr, N, C, k,
-                  dilation, idx);
+      const long wpe = nsid_tune(NSID_T_knn_raw_wpe);
+#define NSID_KNN_RAW_GO(W_)                                                                                                     \
+      do {                                                                                                                      \
+        static bool configured3 = false;                                                                                        \
+        if (!configured3) {                                                                                                     \
+          if (hipFuncSetAttribute(reinterpret_cast<const void*>(knn2_raw_kernel<KD, NT, W_>),                                   \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)                        \
+            return NSID_ELAUNCH;                                                                                                \
+          configured3 = true;                                                                                                   \
+        }                                                                                                                       \
+        NSID_LAUNCH((knn2_raw_kernel<KD, NT, W_>), dim3(B), dim3(KNN2_THREADS), rbytes, s, static_cast<const __bf16*>(r), (long)ldr, N, \
+                    C, k, dilation, idx);                                                                                       \
+      } while (0)
+      if (wpe >= 8) NSID_KNN_RAW_GO(8);
+      else if (wpe >= 6) NSID_KNN_RAW_GO(6);
+      else NSID_KNN_RAW_GO(4);
+#undef NSID_KNN_RAW_GO
       return nsid_launch_status();
     }
   }
