@@ -1117,9 +1117,14 @@ int launch_knn2_nt(const void* r, int ldr, const float* scale, const float* shif
         NSID_LAUNCH((knn2_raw_kernel<KD, NT, W_>), dim3(B), dim3(KNN2_THREADS), rbytes, s, static_cast<const __bf16*>(r), (long)ldr, N, \
                     C, k, dilation, idx);                                                                                       \
       } while (0)
-      if (wpe >= 8) NSID_KNN_RAW_GO(8);
-      else if (wpe >= 6) NSID_KNN_RAW_GO(6);
-      else NSID_KNN_RAW_GO(4);
+      bool done = false;
+      if constexpr (KD <= 5) {                 // (the 8-entry lists do not fit 64 registers: they would spill)
+        if (wpe >= 8) { NSID_KNN_RAW_GO(8); done = true; }
+      }
+      if (!done) {
+        if (wpe >= 6) NSID_KNN_RAW_GO(6);
+        else NSID_KNN_RAW_GO(4);
+      }
 #undef NSID_KNN_RAW_GO
       return nsid_launch_status();
     }
