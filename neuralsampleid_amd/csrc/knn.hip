@@ -662,7 +662,7 @@ void knn2_pair_kernel(const T* __restrict__ r, long ldr, const float* __restrict
 }
 
 // the raw-feature form (stored bf16 features, no affine: forward-only extraction), two workgroups per CU
-// WPE waves per SIMD = WPE / 2 workgroups per CU (35 KB of LDS each): the register budget follows (4: 128, 6: 80, 8: 64 VGPRs)
+// WPE waves per SIMD = WPE / 2 workgroups per CU (35 KB of LDS each): the register budget follows (4: 128, 6: 80 VGPRs)
 template <int KD, int NT, int WPE>
 __global__ __launch_bounds__(KNN2_THREADS) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
 void knn2_raw_kernel(const __bf16* __restrict__ r, long ldr, int N, int C, int k, int dilation, int32_t* __restrict__ idx) {
@@ -1117,14 +1117,8 @@ int launch_knn2_nt(const void* r, int ldr, const float* scale, const float* shif
         NSID_LAUNCH((knn2_raw_kernel<KD, NT, W_>), dim3(B), dim3(KNN2_THREADS), rbytes, s, static_cast<const __bf16*>(r), (long)ldr, N, \
                     C, k, dilation, idx);                                                                                       \
       } while (0)
-      bool done = false;
-      if constexpr (KD <= 5) {                 // (the 8-entry lists do not fit 64 registers: they would spill)
-        if (wpe >= 8) { NSID_KNN_RAW_GO(8); done = true; }
-      }
-      if (!done) {
-        if (wpe >= 6) NSID_KNN_RAW_GO(6);
-        else NSID_KNN_RAW_GO(4);
-      }
+      if (wpe >= 6) NSID_KNN_RAW_GO(6);       // (8 waves per SIMD = 64 registers spills 20-48 bytes per lane at N >= 128 and measured the same)
+      else NSID_KNN_RAW_GO(4);
 #undef NSID_KNN_RAW_GO
       return nsid_launch_status();
     }

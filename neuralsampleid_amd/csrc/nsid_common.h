@@ -159,7 +159,7 @@ static inline bool nsid_aligned16(const void* p) { return (reinterpret_cast<uint
   X(knn_strips, 0)             /* 1: always the general strip kernel (tests of the fallback) */                               \
   X(knn_pair_min, 512)         /* clips per launch from which knn2 runs as two 128-VGPR workgroups per CU; 0 = never */        \
   X(knn_raw16, 1)              /* forward-only launches (bf16 features, no affine, >= knn_pair_min clips): one bf16 MFMA pass on the raw features */ \
-  X(knn_raw_wpe, 6)            /* its waves per SIMD (4 / 6 / 8 = two / three / four workgroups per CU) */ \
+  X(knn_raw_wpe, 6)            /* its waves per SIMD (4 / 6 = two / three workgroups per CU) */ \
   X(knn_sel_min_n, 128)        /* graphs of at least this many nodes take the in-register threshold select for k*d > 8 */       \
   X(mr_grid_stride, 0)         /* 1: grid-stride aggregation instead of the LDS-staged per-clip kernel */                     \
   X(mr_split, 0)               /* channel split of the LDS-staged aggregation (0 = heuristic) */                              \
