@@ -120,12 +120,17 @@ void ffn256_fused_kernel(const F256Args p) {
 
   // ---- LDS-DMA addressing (gemm256.hip): lane l supplies row l >> 2 of a 16-row sub-block and the logical 16-byte chunk that lives at
   // physical chunk l & 3
-  const int grow = lane >> 2, lc = (lane & 3) ^ (((grow >> 3) & 1) << 1);
-  const unsigned voff1 = (unsigned)(grow * F_C + lc * 8) * 2u;          // W1: row stride 256 elements
-  // W2: row stride 1024 elements; sub-block c = 2 ks + half takes its row 4 q + e from output channel 32 ks + 8 q + 4 half + e, so
-  // that a lane's accumulators are the channels of its own x fragments (epilogue)
-  const unsigned voff2 = (unsigned)((8 * (grow >> 2) + (grow & 3)) * F_H + lc * 8) * 2u;
+  // W1: row stride F_C elements. W2: row stride F_H elements; sub-block c = 2 ks + half takes its row 4 q + e from output channel
+  // 32 ks + 8 q + 4 half + e, so that a lane's accumulators are the channels of its own x fragments (epilogue).
+  // The two lane offsets are RE-DERIVED from the lane index at every use (three vector instructions): as kernel-lifetime values the
+  // register allocator spilled them (and seven more) around the tile loop of the 256-register instantiation -- 40 bytes of scratch per
+  // lane, 7 stores + 7 loads per tile (round 4); the empty asm keeps the compiler from hoisting them back out.
   auto issue = [&](int u, int tile) {                                   // this wave's PW pieces of chunk u (of row tile `tile`)
+    int l_ = lane;
+    asm volatile("" : "+v"(l_));
+    const int grow = l_ >> 2, lc = (l_ & 3) ^ (((grow >> 3) & 1) << 1);
+    const unsigned voff1 = (unsigned)(grow * F_C + lc * 8) * 2u;
+    const unsigned voff2 = (unsigned)((8 * (grow >> 2) + (grow & 3)) * F_H + lc * 8) * 2u;
     const unsigned dst = lds0 + (u % F_NS) * F_SLOT;
     const int h0 = u * F_HC;
 #pragma unroll
@@ -146,8 +151,6 @@ void ffn256_fused_kernel(const F256Args p) {
   // the wave-private hidden sub-blocks use their own swizzle, chunk ^ (row >> 1 & 3): the 8-byte stores of a 16-lane group (one column
   // of 16 rows) then fall on 8 different 16-byte slots (2-way; 4-way with the weight images' swizzle, measured as 23 % of the
   // kernel's LDS cycles), and the 16-byte fragment reads stay conflict-free
-  const int hsw = (lr >> 1) & 3;
-  const int loh = lr * 64 + ((rq ^ hsw) << 4);
   // ---- persistent over the row tiles: workgroup g takes tiles g, g + grid, ... (one workgroup per CU: 148 KB of LDS)
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     char* const ot = reinterpret_cast<char*>(p.out + (long)tile * TR * F_C);
@@ -228,6 +231,11 @@ void ffn256_fused_kernel(const F256Args p) {
       if constexpr (g1) {
         // relu(acc + b1) -> bf16: four consecutive hidden values of one row per lane, into the wave's own sub-block of row tile b;
         // read back at once as the next iteration's B fragments (a wave's LDS operations execute in order: no barrier)
+        // (lane-derived LDS offsets re-derived here: see issue())
+        int l2 = lane;
+        asm volatile("" : "+v"(l2));
+        const int lr = l2 & 15, rq = l2 >> 4, hsw = (lr >> 1) & 3;
+        const int loh = lr * 64 + ((rq ^ hsw) << 4);
 #pragma unroll
         for (int a = 0; a < 2; ++a) {
           const f32x4 bj = *reinterpret_cast<const f32x4*>(b1s + ch * F_HC + 16 * a + 4 * rq);
@@ -252,10 +260,14 @@ void ffn256_fused_kernel(const F256Args p) {
     // from registers. GEMM 2's output-channel order was chosen for this (see issue()): accumulator tile c = 2 ks + half, element e of
     // lane (lr, rq) is channel 32 ks + 8 rq + 4 half + e of row 16 b + lr -- the very channels whose x the lane holds in xf[ks][b] --
     // so the residual needs no second read of x, no LDS staging and no barrier, and a lane stores 8 consecutive channels (16 bytes).
+    int l3 = lane;
+    asm volatile("" : "+v"(l3));
+    const int rq3 = l3 >> 4;
+    const unsigned xo3 = (unsigned)((wave * (16 * RT) + (l3 & 15)) * F_C + 8 * rq3) * 2u;
 #pragma unroll
     for (int ks = 0; ks < KS1; ++ks) {
-      const f32x4 bc0 = *reinterpret_cast<const f32x4*>(b2s + 32 * ks + 8 * rq);
-      const f32x4 bc1 = *reinterpret_cast<const f32x4*>(b2s + 32 * ks + 8 * rq + 4);
+      const f32x4 bc0 = *reinterpret_cast<const f32x4*>(b2s + 32 * ks + 8 * rq3);
+      const f32x4 bc1 = *reinterpret_cast<const f32x4*>(b2s + 32 * ks + 8 * rq3 + 4);
 #pragma unroll
       for (int b = 0; b < RT; ++b) {
         const f32x4 y0 = acc2[2 * ks][b] + bc0, y1 = acc2[2 * ks + 1][b] + bc1;
@@ -266,8 +278,8 @@ void ffn256_fused_kernel(const F256Args p) {
           o[e] = (__bf16)(y0[e] + (float)xr[e]);
           o[4 + e] = (__bf16)(y1[e] + (float)xr[4 + e]);
         }
-        *reinterpret_cast<bf16x8*>(ot + xo + b * (16 * F_C * 2) + ks * 64) = o;
-        if (more) xf[ks][b] = *reinterpret_cast<const bf16x8*>(xn + xo + b * (16 * F_C * 2) + ks * 64);
+        *reinterpret_cast<bf16x8*>(ot + xo3 + b * (16 * F_C * 2) + ks * 64) = o;
+        if (more) xf[ks][b] = *reinterpret_cast<const bf16x8*>(xn + xo3 + b * (16 * F_C * 2) + ks * 64);
       }
     }
   }  // tile
