@@ -110,7 +110,9 @@ def kernel_table(prof, elapsed_ms, precision):
         e = {"launches": d["launches"], "avg_us": round(1e3 * d["ms"] / d["launches"], 2), "tflops": round(tf, 2), "mfma_frac": None,
              "alg_GBps": round(gbs, 1), "hbm_frac": round(gbs / HBM_PEAK_GBPS, 4), "share_of_step": round(d["ms"] / elapsed_ms, 3)}
         if d["flops"] > 0:
-            if n.startswith("knn"):
+            if n.startswith("knn2_raw"):          # one bf16 MFMA pass on the stored features: executed = algorithmic
+                e["mfma_frac"] = round(tf / BF16_MFMA_PEAK_TFLOPS, 4)
+            elif n.startswith("knn"):
                 e["executed_flop_factor"] = KNN_EXECUTED_FLOP_FACTOR
                 e["mfma_frac"] = round(tf * KNN_EXECUTED_FLOP_FACTOR / BF16_MFMA_PEAK_TFLOPS, 4)
             elif n.startswith("ntxent"):
@@ -302,6 +304,15 @@ def measured_traffic(kernel, precision, tag=""):
             with open(path) as f:
                 ks = json.load(f)["kernels"]
         except (OSError, ValueError, KeyError):
+            continue
+        fam = {}
+        try:
+            with open(path) as f:
+                fam = json.load(f).get("family", {})
+        except (OSError, ValueError):
+            pass
+        if want in fam:                   # launch-weighted over the instantiations of a templated kernel (tools/hbm_traffic.py)
+            best = (int(fam[want]["hbm_bytes_per_launch"]), os.path.relpath(path, ROOT))
             continue
         for name, v in ks.items():
             n = norm(name)

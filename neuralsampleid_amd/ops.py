@@ -92,6 +92,11 @@ def _timed(name, flops, nbytes, fn, shape=()):
     PROFILE.records.append((name() if callable(name) else name, flops, nbytes, e0, e1, shape))
 
 
+def _cnt(key: str) -> int:
+    """a launch counter of the library (profiling only: which kernel a launcher that decides in C has just taken)"""
+    return int(lib.nsid_debug_counter(key.encode())) if PROFILE is not None else 0
+
+
 def _p(t: Optional[torch.Tensor]):
     return None if t is None else t.data_ptr()
 
@@ -290,8 +295,10 @@ def linear_fwd(x, w, bias, M, Nout, K, groups=1, in_scale=None, in_shift=None, a
     wop, wdt = _weight(w, dt, K)
     name_ = "gemm_kernel<128,%d,true,true>" % (64 if narrow else 128)
     n256 = lib.nsid_gemm_g256_launches() if PROFILE is not None else 0
-    # csrc/gemm.hip decides between the tile families; the launch counter of the 256x256-tile LDS-DMA kernel says which one ran
-    name = lambda: "gemm256_fwd_kernel" if lib.nsid_gemm_g256_launches() > n256 else name_
+    nws = _cnt("ws_fwd")
+    # csrc/gemm.hip decides between the kernel families; the launch counters say which one ran
+    name = lambda: ("ws_fwd_kernel" if _cnt("ws_fwd") > nws else
+                    ("gemm256_fwd_kernel" if lib.nsid_gemm_g256_launches() > n256 else name_))
     if in_scale is None and act_in != ACT_NONE:
         # activation on load without an affine: only ReLU on bf16 operands, bf16 weights and whole tiles (csrc/gemm.hip ARELU)
         bn_ = 64 if narrow else 128
@@ -382,7 +389,9 @@ def linear_bwd_data(dout, w, M, Nout, K, groups=1, addend=None, out=None, bn=Non
     narrow = (K <= 64 or (K <= 128 and Nout <= 256)) if half else K <= 64
     if half and row_tiles(M) * ((K + 127) // 128) * groups < 128:
         narrow = True
-    name = "gemm_kernel<128,%d,true,false>" % (64 if narrow else 128)
+    name_ = "gemm_kernel<128,%d,true,false>" % (64 if narrow else 128)
+    nws = _cnt("ws_bwd_data")
+    name = lambda: "ws_bwd_kernel" if _cnt("ws_bwd_data") > nws else name_
     esz = dout.element_size()
     wop, wdt = _weight(w, dt, K)
     want_pair = bn is not None            # bn=False: "return a pair, nothing to fuse"
@@ -709,7 +718,9 @@ def knn_graph(r, B, N, C, k, dilation=1, aff: Optional[BNAffine] = None) -> torc
     idx = torch.empty((B, N, k), device=r.device, dtype=torch.int32)
     kd = k * dilation
     sel = 8 < kd <= 64 and N >= get_tuning("knn_sel_min_n")      # csrc/knn.hip nsid_knn_graph
-    name = "knn2_kernel" if kd <= 8 else ("knn_sel_kernel" if sel else ("knn_rank_kernel" if N <= 128 else "knn_kernel"))
+    name_ = "knn2_kernel" if kd <= 8 else ("knn_sel_kernel" if sel else ("knn_rank_kernel" if N <= 128 else "knn_kernel"))
+    nraw = _cnt("knn2_raw")
+    name = lambda: "knn2_raw_kernel" if _cnt("knn2_raw") > nraw else name_      # (one bf16 MFMA pass: executed flops = algorithmic)
     # read the features once, write int32 ids; 2*N^2*C flop on the fp32 matrix pipe
     _timed(name, 2.0 * B * N * N * C, float(B) * (N * C * r.element_size() + N * k * 4), lambda: call(
         "nsid_knn_graph", _p(r), r.shape[-1], _p(aff.scale) if aff else None, _p(aff.shift) if aff else None,

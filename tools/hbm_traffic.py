@@ -52,6 +52,21 @@ def main():
         fk, wk = sum(f) / len(f), sum(w) / len(w)
         out["kernels"][k] = {"launches_profiled": max(len(f), len(w)), "FETCH_SIZE_KB_per_launch": round(fk, 1),
                              "WRITE_SIZE_KB_per_launch": round(wk, 1), "hbm_bytes_per_launch": int((2 * fk + wk) * 1024)}
+    # launch-weighted family entries for templated kernels other than gemm_kernel (ws_fwd_kernel, ws_bwd_kernel, knn2_raw_kernel, ...):
+    # bench.py looks a kernel up by its family name
+    fam = collections.defaultdict(lambda: [0.0, 0.0, 0])
+    for k, v in out["kernels"].items():
+        if "<" in k and not k.startswith("gemm_kernel<"):
+            a = fam[k.split("<")[0]]
+            a[0] += v["FETCH_SIZE_KB_per_launch"] * v["launches_profiled"]
+            a[1] += v["WRITE_SIZE_KB_per_launch"] * v["launches_profiled"]
+            a[2] += v["launches_profiled"]
+    tot_before = sum(v["hbm_bytes_per_launch"] * v["launches_profiled"] for v in out["kernels"].values())
+    for k, (f_, w_, n_) in fam.items():
+        if k not in out["kernels"] and n_ > 0:
+            out["family"] = out.get("family", {})
+            out["family"][k] = {"launches_profiled": n_, "FETCH_SIZE_KB_per_launch": round(f_ / n_, 1),
+                                "WRITE_SIZE_KB_per_launch": round(w_ / n_, 1), "hbm_bytes_per_launch": int((2 * f_ + w_) / n_ * 1024)}
     with open(sys.argv[3], "w") as fh:
         json.dump(out, fh, indent=1)
     tot = sum(v["hbm_bytes_per_launch"] * v["launches_profiled"] for v in out["kernels"].values())
