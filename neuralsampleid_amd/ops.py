@@ -66,6 +66,7 @@ class KernelProfile:
         torch.cuda.synchronize()
         out = {}
         for name, flops, nbytes, e0, e1, shape in self.records:
+            shape = tuple(shape)[:4] + (0,) * (4 - min(4, len(shape)))       # records without a GEMM shape: zeros
             d = out.setdefault((name,) + shape, [0, 0.0, flops, nbytes])
             d[0] += 1
             d[1] += self._ms(e0, e1)

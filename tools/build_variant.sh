@@ -2,6 +2,7 @@
 # Build an alternative kernel library with extra compiler flags for A/B experiments:
 #   tools/build_variant.sh alt -DNSID_RPAD=16     ->  neuralsampleid_amd/libnsid_hip_alt.so   (use with NSID_LIB=<path>)
 #   ONLY="gemm256" tools/build_variant.sh x -DFOO ->  recompiles only the named sources; the other objects come from the main build
+#   VARIANT_SRC=dir: a source that exists as dir/<name>.hip is compiled from there (timing experiments edit a COPY, never the product file)
 set -e
 name=$1; shift
 root=$(cd "$(dirname "$0")/.." && pwd)
@@ -13,7 +14,9 @@ for s in $all; do
     cp $root/neuralsampleid_amd/csrc/_obj/$s.o $obj/$s.o
     continue
   fi
-  /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -fPIC -std=c++17 -fno-gpu-rdc -I $root/include "$@" -c $root/neuralsampleid_amd/csrc/$s.hip -o $obj/$s.o &
+  src=$root/neuralsampleid_amd/csrc/$s.hip
+  [ -n "$VARIANT_SRC" ] && [ -f "$VARIANT_SRC/$s.hip" ] && src=$VARIANT_SRC/$s.hip       # an edited copy (tools/variants/...) of one source
+  /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -fPIC -std=c++17 -fno-gpu-rdc -I $root/include -I $root/neuralsampleid_amd/csrc "$@" -c $src -o $obj/$s.o &
 done
 wait
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $root/neuralsampleid_amd/libnsid_hip_$name.so $obj/*.o
