@@ -1,10 +1,10 @@
 #!/bin/bash
-# Gate of the streaming weight gradient (csrc/wgrad_stream.hip): its parity tests, then cold-operand timings against the staged forms
+# Gate of the streaming weight gradient (tools/variants/wgrad_stream.hip: hook it into the library first, see its header): its parity tests, then cold-operand timings against the staged forms
 # over the workgroup target. Run on the GPU box: tools/gpu_wgs_gate.sh [outdir]
 set -o pipefail
 OUT=${1:-gpurun_out/r05_wgs}
 mkdir -p $OUT
-timeout -k 10 600 python -m pytest tests/test_wgrad_stream_gpu.py -x -q > $OUT/pytest.log 2>&1
+timeout -k 10 600 python -m pytest tools/variants/wgrad_stream_test.py -x -q > $OUT/pytest.log 2>&1
 rc=$?
 echo "pytest rc=$rc" | tee -a $OUT/pytest.log
 tail -5 $OUT/pytest.log
