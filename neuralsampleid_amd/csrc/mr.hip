@@ -387,6 +387,175 @@ __global__ __launch_bounds__(MRB_THREADS) void mr_bwd_kernel(const T* __restrict
   }
 }
 
+// ---- backward with many neighbours (deep plan: k = 18), bf16 storage, N*C = 16 384, C a power of two.
+// The gather above costs a compare per incoming edge and element (~48 vector instructions per edge and 8 channels as the compiler
+// writes them) and a wave waits for the largest in-degree among the 1-8 nodes its lanes hold. This form
+//   * ranks the nodes of the clip by in-degree (N <= 256: every thread counts a slice of the others) and hands a wave nodes of
+//     NEIGHBOURING rank, the heaviest group together with the lightest one (two items per thread), so that the lanes of a wave run
+//     about the same number of iterations and the waves about the same total;
+//   * does the select in 20 instructions per edge and 8 channels: v_cmp_eq_u32_sdwa compares one arg-max BYTE with the edge's
+//     position, v_cndmask_b32_sdwa moves the selected bf16 HALF-WORD into the high half of a zero (= the fp32 value or 0), and the
+//     sums are packed fp32 adds;
+//   * keeps the one read of du and the LDS footprint of the form above (a clip's du_odd + arg-max bytes + the edge list, ~70 KB: a
+//     first version that parked the sums in 64 KB more of LDS was 6 us faster alone and 0.2 ms SLOWER in the deep step — it shut the
+//     other view's workgroups out of its CU): a thread requests the du chunks of ITS ranked node once the order is known and the
+//     loads fly while the edge list is filled; the own-row term seeds the sum in the same thread.
+// Sums are fp32: the own-row term, then the incoming edges in the order of the reversed edge list.
+constexpr int MRS_THREADS = 1024;
+
+// v[e] += (byte e of {a0, a1} == byte 0 of s2) ? fp32(bf16 e of o) : 0, e = 0 .. 7
+__device__ __forceinline__ void mrs_edge(f32x2 (&v)[4], const u32x4 o, const uint32_t a0, const uint32_t a1, const uint32_t s2,
+                                         const uint32_t zero) {
+  float t0, t1, t2, t3, t4, t5, t6, t7;
+  asm volatile(
+      "v_cmp_eq_u32_sdwa vcc, %[a0], %[s] src0_sel:BYTE_0 src1_sel:BYTE_0\n\t"
+      "v_cndmask_b32_sdwa %[t0], %[z], %[o0], vcc dst_sel:WORD_1 dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0\n\t"
+      "v_cmp_eq_u32_sdwa vcc, %[a0], %[s] src0_sel:BYTE_1 src1_sel:BYTE_0\n\t"
+      "v_cndmask_b32_sdwa %[t1], %[z], %[o0], vcc dst_sel:WORD_1 dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n\t"
+      "v_cmp_eq_u32_sdwa vcc, %[a0], %[s] src0_sel:BYTE_2 src1_sel:BYTE_0\n\t"
+      "v_cndmask_b32_sdwa %[t2], %[z], %[o1], vcc dst_sel:WORD_1 dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0\n\t"
+      "v_cmp_eq_u32_sdwa vcc, %[a0], %[s] src0_sel:BYTE_3 src1_sel:BYTE_0\n\t"
+      "v_cndmask_b32_sdwa %[t3], %[z], %[o1], vcc dst_sel:WORD_1 dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n\t"
+      "v_cmp_eq_u32_sdwa vcc, %[a1], %[s] src0_sel:BYTE_0 src1_sel:BYTE_0\n\t"
+      "v_cndmask_b32_sdwa %[t4], %[z], %[o2], vcc dst_sel:WORD_1 dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0\n\t"
+      "v_cmp_eq_u32_sdwa vcc, %[a1], %[s] src0_sel:BYTE_1 src1_sel:BYTE_0\n\t"
+      "v_cndmask_b32_sdwa %[t5], %[z], %[o2], vcc dst_sel:WORD_1 dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n\t"
+      "v_cmp_eq_u32_sdwa vcc, %[a1], %[s] src0_sel:BYTE_2 src1_sel:BYTE_0\n\t"
+      "v_cndmask_b32_sdwa %[t6], %[z], %[o3], vcc dst_sel:WORD_1 dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0\n\t"
+      "v_cmp_eq_u32_sdwa vcc, %[a1], %[s] src0_sel:BYTE_3 src1_sel:BYTE_0\n\t"
+      "v_cndmask_b32_sdwa %[t7], %[z], %[o3], vcc dst_sel:WORD_1 dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n\t"
+      "s_nop 0"       // gfx950: a VALU that wrote with dst_sel != DWORD needs one wait state before its result is read
+      : [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3), [t4] "=&v"(t4), [t5] "=&v"(t5), [t6] "=&v"(t6), [t7] "=&v"(t7)
+      : [a0] "v"(a0), [a1] "v"(a1), [s] "v"(s2), [z] "v"(zero), [o0] "v"(o[0]), [o1] "v"(o[1]), [o2] "v"(o[2]), [o3] "v"(o[3])
+      : "vcc");
+  v[0] += f32x2{t0, t1};
+  v[1] += f32x2{t2, t3};
+  v[2] += f32x2{t4, t5};
+  v[3] += f32x2{t6, t7};
+}
+
+__global__ __launch_bounds__(MRS_THREADS) void mr_bwd_sorted_kernel(const __bf16* __restrict__ du, const int32_t* __restrict__ idx,
+                                                                    const uint8_t* __restrict__ argmax, int N, int C, int cshift, int k,
+                                                                    __bf16* __restrict__ dy) {
+  extern __shared__ __attribute__((aligned(16))) char mrs_smem[];
+  constexpr int NC = 16384;                                          // elements of a clip (host-checked)
+  char* const odd = mrs_smem;                                        // [N][C] bf16
+  char* const am = mrs_smem + 2 * NC;                                // [N][C] arg-max bytes
+  int* const cnt = reinterpret_cast<int*>(mrs_smem + 3 * NC);        // [N] in-degree
+  int* const cur = cnt + N;                                          // [N] fill cursor
+  int* const rank = cur + N;                                         // [N] position in the order by (in-degree descending, node)
+  int* const perm = rank + N;                                        // [N] its inverse
+  int* const start = perm + N;                                       // [N + 1]
+  int* const src = start + N + 1;                                    // [N * k]: (source row * C) << 8 | neighbour position
+  const int b = blockIdx.x, t = threadIdx.x;
+  const long row0 = (long)b * N;
+  const int E = N * k;
+  const int32_t* nbb = idx + row0 * k;
+
+  for (int n = t; n < N; n += MRS_THREADS) { cnt[n] = 0; rank[n] = 0; }
+  __syncthreads();
+  for (int e = t; e < E; e += MRS_THREADS) atomicAdd(&cnt[min(max(nbb[e], 0), N - 1)], 1);
+  __syncthreads();
+  if (t < 64) {                                                      // exclusive scan of cnt[0..N) by one wave
+    const int per = (N + 63) / 64;
+    int loc = 0;
+    for (int i2 = 0; i2 < per; ++i2) { const int n = t * per + i2; if (n < N) loc += cnt[n]; }
+    int inc = loc;
+#pragma unroll
+    for (int o2 = 1; o2 < 64; o2 <<= 1) { const int v = __shfl_up(inc, o2, 64); if (t >= o2) inc += v; }
+    int run = inc - loc;
+    for (int i2 = 0; i2 < per; ++i2) {
+      const int n = t * per + i2;
+      if (n < N) { start[n] = run; cur[n] = run; run += cnt[n]; }
+    }
+    if (t == 63) start[N] = inc;
+  }
+  {                                                                  // rank: MRS_THREADS / N threads per node, a slice of the others each
+    const int parts = MRS_THREADS / N, n = t % N, part = t / N;
+    const int per = (N + parts - 1) / parts;
+    const int m0 = part * per, m1 = min(N, m0 + per);
+    const int dn = cnt[n];
+    int above = 0;
+    for (int m = m0; m < m1; ++m) { const int dm = cnt[m]; above += (dm > dn || (dm == dn && m < n)) ? 1 : 0; }
+    if (above) atomicAdd(&rank[n], above);
+  }
+  __syncthreads();
+  if (t < N) perm[rank[t]] = t;
+  __syncthreads();
+  // ---- items by rank: wave w takes the groups w and 31 - w of 64 / CV consecutive ranks; 8 dy channels = 16 du elements of one node.
+  // The loads fly while the reversed edge list is filled.
+  const int CV = C >> 3, w = t >> 6, l = t & 63;
+  const int spw = 64 / CV;                                           // nodes per wave item (CV <= 64: C <= 512)
+  int node[2];
+  u32x4 g[2][2];
+  uint32_t ab[2][2];
+  const int c = (l % CV) << 3;
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int gidx = it == 0 ? w : 31 - w;
+    const int n = perm[gidx * spw + l / CV];
+    node[it] = n;
+    const u32x4* gp = reinterpret_cast<const u32x4*>(du + (row0 + n) * 2 * C + 2 * c);
+    g[it][0] = gp[0];
+    g[it][1] = gp[1];
+    const uint2 a2 = *reinterpret_cast<const uint2*>(argmax + (row0 + n) * C + c);
+    ab[it][0] = a2.x; ab[it][1] = a2.y;
+  }
+  for (int e = t; e < E; e += MRS_THREADS) {
+    const int tg = min(max(nbb[e], 0), N - 1);
+    const int p = atomicAdd(&cur[tg], 1);
+    const int m = e / k;
+    src[p] = ((m << cshift) << 8) | (e - m * k);
+  }
+  // own-row term du_even - du_odd (registers), du_odd and the arg-max bytes (LDS)
+  float own[2][8];
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int mo = (node[it] << cshift) + c;
+    u32x4 od;
+#pragma unroll
+    for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+      for (int d = 0; d < 4; d += 2) {
+        const uint32_t w0 = g[it][h2][d], w1 = g[it][h2][d + 1];       // (even, odd) pairs of channels 4 h2 + d, + 1
+        own[it][4 * h2 + d] = __uint_as_float(w0 << 16) - __uint_as_float(w0 & 0xffff0000u);
+        own[it][4 * h2 + d + 1] = __uint_as_float(w1 << 16) - __uint_as_float(w1 & 0xffff0000u);
+        od[2 * h2 + d / 2] = (w0 >> 16) | (w1 & 0xffff0000u);
+      }
+    *reinterpret_cast<u32x4*>(odd + 2 * mo) = od;
+    *reinterpret_cast<uint2*>(am + mo) = uint2{ab[it][0], ab[it][1]};
+  }
+  __syncthreads();
+  const uint32_t zero = 0u;
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int n = node[it];
+    f32x2 v[4] = {f32x2{own[it][0], own[it][1]}, f32x2{own[it][2], own[it][3]}, f32x2{own[it][4], own[it][5]},
+                  f32x2{own[it][6], own[it][7]}};
+    const int p1 = start[n + 1];
+    int p = start[n];
+    for (; p + 1 < p1; p += 2) {                   // two edges per trip: both id -> row read chains in flight together
+      const uint32_t sa = (uint32_t)src[p], sb = (uint32_t)src[p + 1];
+      const uint32_t ma = (sa >> 8) + c, mb = (sb >> 8) + c;
+      const u32x4 oa = *reinterpret_cast<const u32x4*>(odd + 2 * ma);
+      const uint2 aa = *reinterpret_cast<const uint2*>(am + ma);
+      const u32x4 ob = *reinterpret_cast<const u32x4*>(odd + 2 * mb);
+      const uint2 a_b = *reinterpret_cast<const uint2*>(am + mb);
+      mrs_edge(v, oa, aa.x, aa.y, sa, zero);
+      mrs_edge(v, ob, a_b.x, a_b.y, sb, zero);
+    }
+    if (p < p1) {
+      const uint32_t s2 = (uint32_t)src[p];
+      const uint32_t mo = (s2 >> 8) + c;
+      const u32x4 o = *reinterpret_cast<const u32x4*>(odd + 2 * mo);
+      const uint2 a2 = *reinterpret_cast<const uint2*>(am + mo);
+      mrs_edge(v, o, a2.x, a2.y, s2, zero);
+    }
+    const float r8[8] = {v[0][0], v[0][1], v[1][0], v[1][1], v[2][0], v[2][1], v[3][0], v[3][1]};
+    Chunk<__bf16>::store(dy + (row0 + n) * C + c, r8);
+  }
+}
+
 // batched_index_select of the reference (torch_nn.py:79-98), in the reference's own layouts: x (B, C, N) fp32,
 // idx (B, N, k) clip-local -> out (B, C, N, k) contiguous, out[b,c,n,j] = x[b,c,idx[b,n,j]]. The hot path never
 // materialises this tensor (mr_fwd_kernel gathers while it aggregates); the symbol exists for drop-in callers.
@@ -495,6 +664,25 @@ extern "C" int nsid_mr_aggregate_bwd(const void* du, const int32_t* idx, const u
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
       return NSID_ELAUNCH;
     configured = true;
+  }
+  // many neighbours, bf16 storage, the encoder's clip size: degree-ranked gather (tuning key mr_bwd_sorted_min_k, 0 = never)
+  const long sorted_min = nsid_tune(NSID_T_mr_bwd_sorted_min_k);
+  const size_t sbytes = (size_t)3 * 16384 + ((size_t)5 * N + 1 + (size_t)N * k) * sizeof(int) + 16;
+  if (dtype == NSID_BF16 && sorted_min > 0 && k >= sorted_min && (long)N * C == 16384 && (C & (C - 1)) == 0 && C >= 64 && C <= 512 &&
+      sbytes <= 160 * 1024) {
+    static bool sconfigured = false;
+    if (!sconfigured) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(mr_bwd_sorted_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              160 * 1024) != hipSuccess)
+        return NSID_ELAUNCH;
+      sconfigured = true;
+    }
+    int cshift = 0;
+    while ((1 << cshift) < C) ++cshift;
+    nsid_count(NSID_C_mr_bwd_sorted);
+    NSID_LAUNCH(mr_bwd_sorted_kernel, dim3(B), dim3(MRS_THREADS), sbytes, static_cast<hipStream_t>(stream),
+                static_cast<const __bf16*>(du), idx, argmax, N, C, cshift, k, static_cast<__bf16*>(dy));
+    return nsid_launch_status();
   }
   NSID_DISPATCH_DTYPE(dtype, T, {
     NSID_LAUNCH((mr_bwd_kernel<T>), dim3(B), dim3(MRB_THREADS), bytes, static_cast<hipStream_t>(stream),

@@ -165,6 +165,7 @@ static inline bool nsid_aligned16(const void* p) { return (reinterpret_cast<uint
   X(mr_split, 0)               /* channel split of the LDS-staged aggregation (0 = heuristic) */                              \
   X(ffn_regs, 3)               /* eval FFN with the x tile in registers (ffn256_fused.hip) also at C = 64 (bit 0) / C = 128 (bit 1) */ \
   X(mr_key_min_k, 8)           /* bf16 aggregation with >= this many neighbours: integer-key search (mr_fwd_key_kernel); 0 = never */ \
+  X(mr_bwd_sorted_min_k, 3)    /* bf16 aggregation backward with >= this many neighbours: degree-ranked gather (mr_bwd_sorted_kernel); 0 = never */ \
   X(ffn_waves, 8)              /* waves per workgroup of the fused eval-mode FFN (4 or 8) */                                  \
   X(ffn256, 1)                 /* 1: the C = 256 stage's eval-mode FFN as one launch (ffn256_fused.hip); 0: two GEMM launches */ \
   X(mrconv_variant, 3)         /* fused eval-mode aggregation + grouped conv: bit 0 = 8 waves, bit 1 = direct 8-byte stores */ \
@@ -197,7 +198,7 @@ static inline long nsid_tune(NsidTuneKey k) { return g_nsid_tune[k]; }
   X(wgrad_rect) X(wgrad_square) X(wgrad3)                                                       \
   X(bn_bwd_apply) X(bn_bwd_apply_capped)                                                        \
   X(knn2) X(knn2_pair) X(knn2_raw) X(knn_rank) X(knn_sel) X(knn_strips)                                                  \
-  X(mr_fwd_lds) X(mr_fwd_grid) X(mr_fwd_key)                                                                  \
+  X(mr_fwd_lds) X(mr_fwd_grid) X(mr_fwd_key) X(mr_bwd_sorted)                                                                  \
   X(ffn_fused)            /* eval-mode FFN in one launch (ffn_fused.hip) */                     \
   X(mrconv_fused)         /* eval-mode max-relative aggregation + grouped conv in one launch (mrconv_fused.hip) */
 

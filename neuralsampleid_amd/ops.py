@@ -748,7 +748,8 @@ def mr_aggregate_bwd(du, idx, amax, B, N, C) -> torch.Tensor:
     dt = _act(du)
     dy = torch.empty((B * N, C), device=du.device, dtype=du.dtype)
     nbytes = float(B) * N * (3 * C * du.element_size() + idx.shape[-1] * 4 + C)
-    _timed("mr_bwd_kernel", 0.0, nbytes, lambda: call(
+    c0 = _cnt("mr_bwd_sorted")
+    _timed(lambda: "mr_bwd_sorted_kernel" if _cnt("mr_bwd_sorted") > c0 else "mr_bwd_kernel", 0.0, nbytes, lambda: call(
         "nsid_mr_aggregate_bwd", _p(du), _p(idx), _p(amax), B, N, C, idx.shape[-1], _p(dy), dt, _stream()),
         (B * N, C, 2 * C, 1))
     return dy

@@ -428,7 +428,7 @@ def test_integer_key_max_relative_equals_the_scalar_search(ops, N, C, k, case):
 
 
 @pytest.mark.parametrize("N,C,k,dt", [(256, 64, 18, "bf16"), (128, 128, 18, "bf16"), (64, 256, 3, "bf16"), (32, 512, 5, "bf16"),
-                                       (128, 128, 18, "fp32"), (256, 64, 3, "fp32")])
+                                       (64, 256, 18, "bf16"), (32, 512, 18, "bf16"), (128, 128, 18, "fp32"), (256, 64, 3, "fp32")])
 def test_max_relative_backward_with_hub_nodes(ops, N, C, k, dt):
     """csrc/mr.hip mr_bwd_kernel (CSR gather over the reversed graph) against a dense fp64 evaluation of torch_vertex.py:21-32's backward
     on graphs with hub nodes (a third of the ids point at node 0: in-degrees of hundreds) and repeated ids inside a list, arg-max
@@ -447,6 +447,49 @@ def test_max_relative_backward_with_hub_nodes(ops, N, C, k, dt):
     tgt = torch.gather(idx.long(), 2, amax.reshape(B, N, C).long())                       # (B, N, C): the row each element's gradient goes to
     ref = ref.scatter_add(1, tgt, d[..., 1].contiguous()).reshape(B * N, C)
     assert relerr(dy, ref) < (4e-3 if dt == "bf16" else 1e-6), relerr(dy, ref)      # the output is rounded to the storage type once
+
+
+@pytest.mark.parametrize("N,C", [(256, 64), (128, 128), (64, 256), (32, 512)])
+@pytest.mark.parametrize("k", [9, 18])
+@pytest.mark.parametrize("graph", ["uniform", "hub", "one_target", "out_of_range"])
+def test_degree_ranked_backward_equals_the_plain_gather(ops, N, C, k, graph):
+    """csrc/mr.hip mr_bwd_sorted_kernel (deep plan: nodes ranked by in-degree, SDWA select) against mr_bwd_kernel on the same inputs:
+    the same fp32 sums over the reversed edge list (its order comes from LDS atomics in both, so a sum may differ in its last fp32 bits
+    before the one rounding: at most one bf16 ulp apart), and against a dense fp64 evaluation of torch_vertex.py:21-32's backward"""
+    B = 24
+    g = torch.Generator().manual_seed(7 * N + C + k)
+    r = torch.randn(B * N, C, generator=g).to(BF).to(DEV)
+    idx = torch.randint(0, N, (B, N, k), generator=g)
+    if graph == "hub":
+        idx = torch.where(torch.rand(B, N, k, generator=g) < 0.4, torch.full_like(idx, 3), idx)
+    elif graph == "one_target":
+        idx = torch.full_like(idx, N - 1)                          # in-degree N * k at one node, 0 elsewhere
+    elif graph == "out_of_range":
+        idx = idx + torch.randint(-2, 3, idx.shape, generator=g) * N    # the kernels clamp ids, as the forward does
+    idx = idx.to(torch.int32).to(DEV)
+    du = torch.randn(B * N, 2 * C, generator=g).to(BF).to(DEV)
+    _, amax = ops.mr_aggregate_fwd(r, idx, B, N, C)
+    try:
+        ops.set_tuning("mr_bwd_sorted_min_k", 8)
+        ops.launch_counters(reset=True)
+        got = ops.mr_aggregate_bwd(du, idx, amax, B, N, C)
+        torch.cuda.synchronize()
+        assert ops.launch_counters()["mr_bwd_sorted"] == 1
+        ops.set_tuning("mr_bwd_sorted_min_k", 0)
+        ops.launch_counters(reset=True)
+        plain = ops.mr_aggregate_bwd(du, idx, amax, B, N, C)
+        torch.cuda.synchronize()
+        assert ops.launch_counters()["mr_bwd_sorted"] == 0
+    finally:
+        ops.reset_tuning()
+    a, b = got.float(), plain.float()
+    ulp = torch.maximum(a.abs(), b.abs()) * 2.0 ** -7 + 1e-30
+    assert bool(((a - b).abs() <= ulp).all())
+    assert (a != b).float().mean().item() < 0.02
+    d = du.double().reshape(B, N, C, 2)
+    tgt = torch.gather(idx.long().clamp(0, N - 1), 2, amax.reshape(B, N, C).long())
+    ref = (d[..., 0] - d[..., 1]).scatter_add(1, tgt, d[..., 1].contiguous()).reshape(B * N, C)
+    assert relerr(got, ref) < 4e-3, relerr(got, ref)
 
 
 def test_eval_ffn256_variants_agree(ops):

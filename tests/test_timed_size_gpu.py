@@ -175,6 +175,7 @@ def test_deep_config4_at_the_timed_batch(golden, restore_mode):
         F_.TAPE = None
     cnt = ops.launch_counters()
     assert cnt["knn_sel"] == 2 * 8 and cnt["knn_rank"] == 2 * 16 and cnt["wgrad3"] > 0 and cnt["wgrad_rect"] > 0, cnt
+    assert cnt["mr_bwd_sorted"] == 2 * 24, cnt                 # the degree-ranked aggregation backward of the deep plan (k = 18)
     assert cnt["gemm_full"] > 0 and cnt["gemm_bn_sums"] > 0 and cnt["mr_fwd_lds"] > 0, cnt
     opt.step()
     torch.cuda.synchronize()

@@ -4,13 +4,17 @@ import argparse, os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from neuralsampleid_amd import ops
-ap = argparse.ArgumentParser(); ap.add_argument("--B", type=int, default=256); ap.add_argument("--k", type=int, default=3)
+ap = argparse.ArgumentParser(); ap.add_argument("--B", type=int, default=256); ap.add_argument("--k", type=int, default=3); ap.add_argument("--tune", action="append", default=[]); ap.add_argument("--hub", type=float, default=0.0)
 a = ap.parse_args()
+for kv in a.tune:
+    k_, v_ = kv.split("="); ops.set_tuning(k_, int(v_))
 for N, C in ((256, 64), (128, 128), (64, 256), (32, 512)):
     for dt in (torch.bfloat16, torch.float32):
         g = torch.Generator(device="cuda").manual_seed(N)
         r = torch.randn(a.B * N, C, device="cuda", generator=g).to(dt)
         idx = torch.randint(0, N, (a.B, N, a.k), device="cuda", generator=g, dtype=torch.int32)
+        if a.hub > 0:
+            idx = torch.where(torch.rand(a.B, N, a.k, device="cuda", generator=g) < a.hub, torch.zeros_like(idx), idx)
         u, am = ops.mr_aggregate_fwd(r, idx, a.B, N, C, None, True)
         du = torch.randn(a.B * N, 2 * C, device="cuda", generator=g).to(dt)
         for _ in range(3):
