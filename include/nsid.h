@@ -174,7 +174,7 @@ int nsid_bn_apply(const void* r, const float* scale, const float* shift, int act
 /* backward, step 1: g = dout * act'(scale*r+shift); partial[2][tiles][C] = per-tile sums of g and g*xhat */
 int nsid_bn_bwd_reduce(const void* dout, const void* r, int M, int C, const float* scale, const float* shift,
                        const float* mean, const float* invstd, int act, float* partial, int dtype, void* stream);
-/* step 2: dgamma += sum g*xhat; dbeta += sum g; coef[2][C] = {sum g / M, sum g*xhat / M} */
+/* step 2: dgamma += sum g*xhat; dbeta += sum g; coef[2][C] = {sum g / M, sum g*xhat / M}; tiles = rows of partial sums (any count) */
 int nsid_bn_bwd_finalize(const float* partial, int tiles, int C, int M, float* dgamma, float* dbeta, float* coef,
                          void* stream);
 /* step 2 for a consumer that evaluates step 3 on its operand load (nsid_linear_bwd_data_bnapply): additionally
@@ -207,6 +207,13 @@ int nsid_mr_aggregate_fwd(const void* r, int ldr, const float* scale, const floa
                           int N, int C, int k, void* u, uint8_t* argmax, int dtype, void* stream);
 int nsid_mr_aggregate_bwd(const void* du, const int32_t* idx, const uint8_t* argmax, int B, int N, int C, int k,
                           void* dy, int dtype, void* stream);
+/* backward of the aggregation when its input was y = act(BN(r)) of a conv+BatchNorm layer (Grapher fc1, encoder/gcn_lib/torch_vertex.py:
+ * 183-195): dy as above, plus step 1 of that BatchNorm's backward over the clip's rows, partial[2][B][C] (one row per clip:
+ * nsid_bn_bwd_finalize[_fused] takes tiles = B), from the ROUNDED dy -- what nsid_bn_bwd_reduce would compute from the stored dy.
+ * bf16 storage, N*C = 16384, C a power of two in [64, 512] (the encoder's clip at every stage); NSID_EINVAL otherwise. */
+int nsid_mr_aggregate_bwd_bn(const void* du, const int32_t* idx, const uint8_t* argmax, int B, int N, int C, int k, void* dy,
+                             const void* bn_r, int bn_ldr, const float* bn_scale, const float* bn_shift, const float* bn_mean,
+                             const float* bn_invstd, int bn_act, float* partial, int dtype, void* stream);
 
 /* batched_index_select(x, idx) of the reference (encoder/gcn_lib/torch_nn.py:79-98) in the reference's own layouts:
  * x (B, C, N) fp32, idx (B, Nq, k) int32 clip-local -> out (B, C, Nq, k), out[b,c,n,j] = x[b,c,idx[b,n,j]].

@@ -34,6 +34,7 @@ SIGNATURES = {
     "nsid_knn_graph": "pippiiiiipis",
     "nsid_mr_aggregate_fwd": "pipppiiiippis",
     "nsid_mr_aggregate_bwd": "pppiiiipis",
+    "nsid_mr_aggregate_bwd_bn": "pppiiiippippppipis",
     "nsid_im2col3_fwd": "piiipis",
     "nsid_im2col3_bwd": "piiipis",
     "nsid_pack_ds_weight": "piips",

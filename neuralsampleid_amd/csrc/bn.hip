@@ -450,7 +450,7 @@ extern "C" int nsid_bn_bwd_reduce(const void* dout, const void* r, int M, int C,
 
 extern "C" int nsid_bn_bwd_finalize(const float* partial, int tiles, int C, int M, float* dgamma, float* dbeta,
                                     float* coef, void* stream) {
-  NSID_REQUIRE(partial && coef && C > 0 && M > 0 && tiles == nsid_row_tiles(M));
+  NSID_REQUIRE(partial && coef && C > 0 && M > 0 && tiles >= 1);      // rows of partial sums: nsid_row_tiles(M) from a GEMM epilogue / the reduce pass, or one per clip (nsid_mr_aggregate_bwd_bn)
   NSID_LAUNCH(bn_bwd_finalize_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_TG), 0,
               static_cast<hipStream_t>(stream), partial, tiles, C, M, dgamma, dbeta, coef, static_cast<const float*>(nullptr),
               static_cast<const float*>(nullptr), static_cast<const float*>(nullptr), static_cast<const float*>(nullptr),
@@ -461,7 +461,7 @@ extern "C" int nsid_bn_bwd_finalize(const float* partial, int tiles, int C, int 
 extern "C" int nsid_bn_bwd_finalize_fused(const float* partial, int tiles, int C, int M, float* dgamma, float* dbeta,
                                           float* coef, const float* scale, const float* shift, const float* mean,
                                           const float* invstd, float* coef4, void* stream) {
-  NSID_REQUIRE(partial && coef && coef4 && scale && shift && mean && invstd && C > 0 && M > 0 && tiles == nsid_row_tiles(M));
+  NSID_REQUIRE(partial && coef && coef4 && scale && shift && mean && invstd && C > 0 && M > 0 && tiles >= 1);
   NSID_LAUNCH(bn_bwd_finalize_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_TG), 0,
               static_cast<hipStream_t>(stream), partial, tiles, C, M, dgamma, dbeta, coef, scale, shift, mean, invstd, coef4);
   return nsid_launch_status();

@@ -434,9 +434,19 @@ __device__ __forceinline__ void mrs_edge(f32x2 (&v)[4], const u32x4 o, const uin
   v[3] += f32x2{t6, t7};
 }
 
-__global__ __launch_bounds__(MRS_THREADS) void mr_bwd_sorted_kernel(const __bf16* __restrict__ du, const int32_t* __restrict__ idx,
+// BNS: the aggregation's input was y = act(BN(r)) of a conv+BN layer (Grapher fc1): the launch also returns that BatchNorm's backward
+// column sums over the clip's rows, partial[0][b][c] = sum_n g, partial[1][b][c] = sum_n g * xhat with g = dy * act'(sc r + sh) taken from
+// the ROUNDED dy (what a separate reduce pass would read back): nsid_bn_bwd_finalize[_fused] with tiles = B consumes them.
+struct MrsBn {
+  const __bf16* r; long ldr;
+  const float* scale; const float* shift; const float* mean; const float* invstd; float slope;
+  float* partial; long plane;      // plane = B * C
+};
+
+template <bool BNS>
+__global__ __launch_bounds__(MRS_THREADS, 8) void mr_bwd_sorted_kernel(const __bf16* __restrict__ du, const int32_t* __restrict__ idx,
                                                                     const uint8_t* __restrict__ argmax, int N, int C, int cshift, int k,
-                                                                    __bf16* __restrict__ dy) {
+                                                                    __bf16* __restrict__ dy, const MrsBn bn) {
   extern __shared__ __attribute__((aligned(16))) char mrs_smem[];
   constexpr int NC = 16384;                                          // elements of a clip (host-checked)
   char* const odd = mrs_smem;                                        // [N][C] bf16
@@ -527,6 +537,8 @@ __global__ __launch_bounds__(MRS_THREADS) void mr_bwd_sorted_kernel(const __bf16
   }
   __syncthreads();
   const uint32_t zero = 0u;
+  bf16x8 o8s[BNS ? 2 : 1];                      // the rounded dy of both items: the column sums are taken after the gather, so that
+                                                // their per-channel constants are not live across it (60 -> 107 VGPRs = half the occupancy otherwise)
 #pragma unroll
   for (int it = 0; it < 2; ++it) {
     const int n = node[it];
@@ -552,7 +564,64 @@ __global__ __launch_bounds__(MRS_THREADS) void mr_bwd_sorted_kernel(const __bf16
       mrs_edge(v, o, a2.x, a2.y, s2, zero);
     }
     const float r8[8] = {v[0][0], v[0][1], v[1][0], v[1][1], v[2][0], v[2][1], v[3][0], v[3][1]};
-    Chunk<__bf16>::store(dy + (row0 + n) * C + c, r8);
+    bf16x8 o8;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o8[e] = (__bf16)r8[e];
+    *reinterpret_cast<bf16x8*>(dy + (row0 + n) * C + c) = o8;
+    if constexpr (BNS) o8s[it] = o8;
+  }
+  if constexpr (BNS) {
+    float sum0[8], sum1[8], bsc[8], bsh[8], bmu[8], bis[8];
+    const bool masked = bn.slope != 1.f;         // uniform: a BatchNorm without an activation behind it needs no mask
+    u32x4 rq[2];
+#pragma unroll
+    for (int it = 0; it < 2; ++it) rq[it] = *reinterpret_cast<const u32x4*>(bn.r + (row0 + node[it]) * bn.ldr + c);
+    load_channels<8>(bn.mean, c, bmu);
+    load_channels<8>(bn.invstd, c, bis);
+    if (masked) { load_channels<8>(bn.scale, c, bsc); load_channels<8>(bn.shift, c, bsh); }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { sum0[e] = 0.f; sum1[e] = 0.f; if (!masked) { bsc[e] = 1.f; bsh[e] = 0.f; } }
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const bf16x8 x8 = __builtin_bit_cast(bf16x8, rq[it]);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float dyv = (float)o8s[it][e], xx = (float)x8[e];
+        float gg = dyv;
+        if (masked) gg = (bsc[e] * xx + bsh[e]) > 0.f ? dyv : dyv * bn.slope;
+        sum0[e] += gg;
+        sum1[e] += gg * ((xx - bmu[e]) * bis[e]);
+      }
+    }
+    // lanes l, l + CV, ... hold the same 8 channels: butterfly over the lane bits above log2(CV), then one row per wave in LDS
+    // (aliased onto du_odd once every wave has left the gather), waves 8-15 add into the rows of waves 0-7, 2 C threads finish.
+    for (int o = CV; o < 64; o <<= 1) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        sum0[e] += __shfl_xor(sum0[e], o, 64);
+        sum1[e] += __shfl_xor(sum1[e], o, 64);
+      }
+    }
+    __syncthreads();
+    float* const red = reinterpret_cast<float*>(odd);                  // [8 rows][2][C]
+    float* const mine = red + ((w & 7) * 2) * C + c;
+    if (w < 8 && l < CV) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { mine[e] = sum0[e]; mine[C + e] = sum1[e]; }
+    }
+    __syncthreads();
+    if (w >= 8 && l < CV) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { mine[e] += sum0[e]; mine[C + e] += sum1[e]; }
+    }
+    __syncthreads();
+    if (t < 2 * C) {
+      const int which = t >= C ? 1 : 0, cc = t - which * C;
+      float a = 0.f;
+#pragma unroll
+      for (int r8 = 0; r8 < 8; ++r8) a += red[(r8 * 2 + which) * C + cc];
+      bn.partial[which * bn.plane + (long)b * C + cc] = a;
+    }
   }
 }
 
@@ -649,6 +718,35 @@ extern "C" int nsid_mr_aggregate_fwd(const void* r, int ldr, const float* scale,
   return nsid_launch_status();
 }
 
+// the degree-ranked gather where it applies (bf16 storage, the encoder's clip size, k >= tuning key mr_bwd_sorted_min_k); 1 otherwise
+static int mrs_launch(const void* du, const int32_t* idx, const uint8_t* argmax, int B, int N, int C, int k, void* dy, int dtype,
+                      const MrsBn* bn, void* stream) {
+  const long sorted_min = nsid_tune(NSID_T_mr_bwd_sorted_min_k);
+  const size_t sbytes = (size_t)3 * 16384 + ((size_t)5 * N + 1 + (size_t)N * k) * sizeof(int) + 16;
+  if (!(dtype == NSID_BF16 && sorted_min > 0 && k >= sorted_min && (long)N * C == 16384 && (C & (C - 1)) == 0 && C >= 64 && C <= 512 &&
+        sbytes <= 160 * 1024))
+    return 1;
+  static bool sconfigured = false;
+  if (!sconfigured) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(mr_bwd_sorted_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            160 * 1024) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(mr_bwd_sorted_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            160 * 1024) != hipSuccess)
+      return NSID_ELAUNCH;
+    sconfigured = true;
+  }
+  int cshift = 0;
+  while ((1 << cshift) < C) ++cshift;
+  nsid_count(NSID_C_mr_bwd_sorted);
+  if (bn != nullptr)
+    NSID_LAUNCH(mr_bwd_sorted_kernel<true>, dim3(B), dim3(MRS_THREADS), sbytes, static_cast<hipStream_t>(stream),
+                static_cast<const __bf16*>(du), idx, argmax, N, C, cshift, k, static_cast<__bf16*>(dy), *bn);
+  else
+    NSID_LAUNCH(mr_bwd_sorted_kernel<false>, dim3(B), dim3(MRS_THREADS), sbytes, static_cast<hipStream_t>(stream),
+                static_cast<const __bf16*>(du), idx, argmax, N, C, cshift, k, static_cast<__bf16*>(dy), MrsBn{});
+  return nsid_launch_status();
+}
+
 extern "C" int nsid_mr_aggregate_bwd(const void* du, const int32_t* idx, const uint8_t* argmax, int B, int N, int C,
                                      int k, void* dy, int dtype, void* stream) {
   NSID_REQUIRE(du && idx && argmax && dy && B > 0 && N > 0 && C > 0 && k > 0 && k <= 255 && NSID_DTYPE_OK(dtype));
@@ -665,28 +763,29 @@ extern "C" int nsid_mr_aggregate_bwd(const void* du, const int32_t* idx, const u
       return NSID_ELAUNCH;
     configured = true;
   }
-  // many neighbours, bf16 storage, the encoder's clip size: degree-ranked gather (tuning key mr_bwd_sorted_min_k, 0 = never)
-  const long sorted_min = nsid_tune(NSID_T_mr_bwd_sorted_min_k);
-  const size_t sbytes = (size_t)3 * 16384 + ((size_t)5 * N + 1 + (size_t)N * k) * sizeof(int) + 16;
-  if (dtype == NSID_BF16 && sorted_min > 0 && k >= sorted_min && (long)N * C == 16384 && (C & (C - 1)) == 0 && C >= 64 && C <= 512 &&
-      sbytes <= 160 * 1024) {
-    static bool sconfigured = false;
-    if (!sconfigured) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(mr_bwd_sorted_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              160 * 1024) != hipSuccess)
-        return NSID_ELAUNCH;
-      sconfigured = true;
-    }
-    int cshift = 0;
-    while ((1 << cshift) < C) ++cshift;
-    nsid_count(NSID_C_mr_bwd_sorted);
-    NSID_LAUNCH(mr_bwd_sorted_kernel, dim3(B), dim3(MRS_THREADS), sbytes, static_cast<hipStream_t>(stream),
-                static_cast<const __bf16*>(du), idx, argmax, N, C, cshift, k, static_cast<__bf16*>(dy));
-    return nsid_launch_status();
+  {
+    const int rc = mrs_launch(du, idx, argmax, B, N, C, k, dy, dtype, nullptr, stream);
+    if (rc != 1) return rc;
   }
   NSID_DISPATCH_DTYPE(dtype, T, {
     NSID_LAUNCH((mr_bwd_kernel<T>), dim3(B), dim3(MRB_THREADS), bytes, static_cast<hipStream_t>(stream),
                 static_cast<const T*>(du), idx, argmax, N, C, k, static_cast<T*>(dy));
   });
   return nsid_launch_status();
+}
+
+// nsid_mr_aggregate_bwd + the BatchNorm-backward column sums of the layer whose output the aggregation read (MrsBn above): one partial
+// row per clip. NSID_EINVAL outside the degree-ranked form (the caller then runs nsid_mr_aggregate_bwd and nsid_bn_bwd_reduce).
+extern "C" int nsid_mr_aggregate_bwd_bn(const void* du, const int32_t* idx, const uint8_t* argmax, int B, int N, int C, int k, void* dy,
+                                        const void* bn_r, int bn_ldr, const float* bn_scale, const float* bn_shift, const float* bn_mean,
+                                        const float* bn_invstd, int bn_act, float* partial, int dtype, void* stream) {
+  NSID_REQUIRE(du && idx && argmax && dy && bn_r && bn_scale && bn_shift && bn_mean && bn_invstd && partial && B > 0 && N > 0 && C > 0 &&
+               k > 0 && k <= 255 && dtype == NSID_BF16);
+  NSID_REQUIRE(C % 8 == 0 && bn_ldr % 8 == 0 && bn_ldr >= C && nsid_aligned16(du) && nsid_aligned16(dy) && nsid_aligned16(bn_r) &&
+               nsid_aligned16(bn_scale) && nsid_aligned16(bn_shift) && nsid_aligned16(bn_mean) && nsid_aligned16(bn_invstd));
+  NSID_REQUIRE(bn_act == NSID_ACT_NONE || bn_act == NSID_ACT_RELU || bn_act == NSID_ACT_LEAKY);
+  const float slope = bn_act == NSID_ACT_RELU ? 0.f : (bn_act == NSID_ACT_LEAKY ? 0.2f : 1.f);
+  MrsBn bn{static_cast<const __bf16*>(bn_r), bn_ldr, bn_scale, bn_shift, bn_mean, bn_invstd, slope, partial, (long)B * C};
+  const int rc = mrs_launch(du, idx, argmax, B, N, C, k, dy, dtype, &bn, stream);
+  return rc == 1 ? NSID_EINVAL : rc;
 }

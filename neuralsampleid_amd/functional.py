@@ -289,9 +289,10 @@ def grapher_backward(dx1: Tensor, P, S, G) -> Tensor:
     _bias_grad_before_bn(dr2, G[pre + "0.bias"])
     ops.linear_bwd_weight(dr2, u, ops.w2d(G[pre + "0.weight"]), M, C // 2, C // 2, 4)
     # max-relative aggregation: route to arg-max neighbour and centre; kNN itself carries no gradient
-    dy = ops.mr_aggregate_bwd(du, idx, amax, B, N, C)
+    # (bf16 storage: the launch also emits the backward column sums of fc1's BatchNorm, one row per clip — no reduce launch)
+    dy, part1 = ops.mr_aggregate_bwd(du, idx, amax, B, N, C, bn=(r1, a1, ACT_NONE))
     # fc1 (+BN), input = x0
-    dr1, dx0, part = ops.bn_backward_linear_bwd_data(dy, r1, a1, ACT_NONE, G["fc1.1.weight"], G["fc1.1.bias"], None,
+    dr1, dx0, part = ops.bn_backward_linear_bwd_data(dy, r1, a1, ACT_NONE, G["fc1.1.weight"], G["fc1.1.bias"], part1,
                                                      ops.w2d(P["fc1.0.weight"]), M, C, C, 1, addend=dx1, bn=_link_in(S) or False,
                                                      site=ops.SITE_FC1)
     _bias_grad_before_bn(dr1, G["fc1.0.bias"])

@@ -459,10 +459,11 @@ def bn_backward_linear_bwd_data(dy, r, aff: "BNAffine", act, dgamma, dbeta, part
         _tk("col_reduce_kernel", 2.0 * r.element_size() * M * C, lambda: call(
             "nsid_bn_bwd_reduce", _p(dy), _p(r), M, C, _p(aff.scale), _p(aff.shift), _p(aff.mean), _p(aff.invstd), act, _p(part_),
             dt, s), (M, C, 0, 1))
+    ptiles = partial.shape[1]                  # rows of THIS layer's partial sums (row tiles, or one per clip from mr_aggregate_bwd)
     coef = torch.empty((6, C), device=r.device, dtype=torch.float32)        # [0:2] = (c0, c1) for the unfused apply, [2:6] = coef4
     if not (DIAG_SKIP_FINALIZE & 2):
-        _tk("bn_bwd_finalize_kernel", 8.0 * tiles * C + 40.0 * C, lambda: call(
-            "nsid_bn_bwd_finalize_fused", _p(partial), tiles, C, M, _p(dgamma), _p(dbeta), _p(coef), _p(aff.scale), _p(aff.shift),
+        _tk("bn_bwd_finalize_kernel", 8.0 * ptiles * C + 40.0 * C, lambda: call(
+            "nsid_bn_bwd_finalize_fused", _p(partial), ptiles, C, M, _p(dgamma), _p(dbeta), _p(coef), _p(aff.scale), _p(aff.shift),
             _p(aff.mean), _p(aff.invstd), _p(coef[2]), s), (M, C, 0, 1))
     dr = torch.empty_like(dy)
     din = torch.empty((M, groups * K), device=dy.device, dtype=dy.dtype)
@@ -689,7 +690,7 @@ def bn_backward(dout, r, aff: BNAffine, act, dgamma, dbeta, inplace=False, parti
     partial: the column sums already produced by the GEMM that wrote dout (linear_bwd_data(bn=...)): skips the reduce."""
     dt = _act(dout, r)
     M, C = r.shape
-    tiles = row_tiles(M)
+    tiles = row_tiles(M) if partial is None else partial.shape[1]      # rows of partial sums (one per clip from mr_aggregate_bwd)
     s = _stream()
     coef = torch.empty((2, C), device=r.device, dtype=torch.float32)
     if partial is None:
@@ -744,15 +745,37 @@ def mr_aggregate_fwd(r, idx, B, N, C, aff: Optional[BNAffine] = None, want_argma
     return u, amax
 
 
-def mr_aggregate_bwd(du, idx, amax, B, N, C) -> torch.Tensor:
+def mr_bwd_sums_fused(du, N, C, k) -> bool:
+    """csrc/mr.hip mrs_launch: does the degree-ranked backward (the form that can also emit BatchNorm column sums) take this launch?"""
+    kmin = get_tuning("mr_bwd_sorted_min_k")
+    return bool(FUSE_MR_BWD_SUMS and du.dtype == torch.bfloat16 and kmin > 0 and k >= kmin and N * C == 16384 and C & (C - 1) == 0
+                and 64 <= C <= 512)
+
+
+FUSE_MR_BWD_SUMS = True      # the aggregation backward also emits the backward column sums of the BatchNorm in front of it (no reduce launch)
+
+
+def mr_aggregate_bwd(du, idx, amax, B, N, C, bn=None):
+    """dL/dy of the max-relative aggregation. bn = (r, aff, act): y was act(BN(r)) of a conv+BN layer (Grapher fc1); where the
+    degree-ranked kernel serves the launch the call returns (dy, partial) with partial[2][B][C] = that BatchNorm's backward column
+    sums per clip (bn_backward(partial=...) / bn_backward_linear_bwd_data(partial=...)), else (dy, None)."""
     dt = _act(du)
+    k = idx.shape[-1]
     dy = torch.empty((B * N, C), device=du.device, dtype=du.dtype)
-    nbytes = float(B) * N * (3 * C * du.element_size() + idx.shape[-1] * 4 + C)
+    nbytes = float(B) * N * (3 * C * du.element_size() + k * 4 + C)
+    if bn is not None and mr_bwd_sums_fused(du, N, C, k):
+        r, aff, act = bn
+        _chk(aff.scale, aff.shift, aff.mean, aff.invstd)
+        partial = torch.empty((2, B, C), device=du.device, dtype=torch.float32)
+        _timed("mr_bwd_sorted_kernel +bn_sums", 0.0, nbytes + float(B) * N * C * r.element_size(), lambda: call(
+            "nsid_mr_aggregate_bwd_bn", _p(du), _p(idx), _p(amax), B, N, C, k, _p(dy), _p(r), r.shape[-1], _p(aff.scale), _p(aff.shift),
+            _p(aff.mean), _p(aff.invstd), act, _p(partial), dt, _stream()), (B * N, C, 2 * C, 1))
+        return dy, partial
     c0 = _cnt("mr_bwd_sorted")
     _timed(lambda: "mr_bwd_sorted_kernel" if _cnt("mr_bwd_sorted") > c0 else "mr_bwd_kernel", 0.0, nbytes, lambda: call(
-        "nsid_mr_aggregate_bwd", _p(du), _p(idx), _p(amax), B, N, C, idx.shape[-1], _p(dy), dt, _stream()),
+        "nsid_mr_aggregate_bwd", _p(du), _p(idx), _p(amax), B, N, C, k, _p(dy), dt, _stream()),
         (B * N, C, 2 * C, 1))
-    return dy
+    return (dy, None) if bn is not None else dy
 
 
 # ------------------------------------------------------------------------------------------------ downsample

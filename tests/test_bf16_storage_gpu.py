@@ -492,6 +492,49 @@ def test_degree_ranked_backward_equals_the_plain_gather(ops, N, C, k, graph):
     assert relerr(got, ref) < 4e-3, relerr(got, ref)
 
 
+@pytest.mark.parametrize("N,C", [(256, 64), (128, 128), (64, 256), (32, 512)])
+@pytest.mark.parametrize("k,act", [(3, 0), (9, 1), (18, 2)])
+def test_aggregation_backward_emits_the_batchnorm_column_sums(ops, N, C, k, act):
+    """nsid_mr_aggregate_bwd_bn: the degree-ranked aggregation backward also returns step 1 of the backward of the BatchNorm in front
+    of the aggregation (Grapher fc1, torch_vertex.py:183-195), one row of sums per clip, taken from its own ROUNDED dy: the same dy bits
+    as the plain call, and sums equal to nsid_bn_bwd_reduce on that dy (fp64 evaluation: fp32 summation noise)"""
+    B = 16
+    g = torch.Generator().manual_seed(11 * N + C + k)
+    r = torch.randn(B * N, C, generator=g).to(BF).to(DEV)
+    idx = torch.randint(0, N, (B, N, k), generator=g)
+    idx = torch.where(torch.rand(B, N, k, generator=g) < 0.3, torch.full_like(idx, 1), idx).to(torch.int32).to(DEV)
+    du = torch.randn(B * N, 2 * C, generator=g).to(BF).to(DEV)
+    scale = 1 + 0.2 * torch.randn(C, generator=g)
+    scale[::3] = -scale[::3]
+    shift, mean, invstd = 0.3 * torch.randn(C, generator=g), 0.2 * torch.randn(C, generator=g), 0.5 + torch.rand(C, generator=g)
+    aff = ops.BNAffine(scale.to(DEV), shift.to(DEV), mean.to(DEV), invstd.to(DEV))
+    _, amax = ops.mr_aggregate_fwd(r, idx, B, N, C)
+    ops.launch_counters(reset=True)
+    dy, part = ops.mr_aggregate_bwd(du, idx, amax, B, N, C, bn=(r, aff, act))
+    torch.cuda.synchronize()
+    assert part is not None and tuple(part.shape) == (2, B, C) and ops.launch_counters()["mr_bwd_sorted"] == 1
+    plain = ops.mr_aggregate_bwd(du, idx, amax, B, N, C)
+    a, b_ = dy.float(), plain.float()
+    assert bool(((a - b_).abs() <= torch.maximum(a.abs(), b_.abs()) * 2.0 ** -7 + 1e-30).all())
+    d, x = dy.double().cpu().reshape(B, N, C), r.double().cpu().reshape(B, N, C)
+    slope = {0: 1.0, 1: 0.0, 2: 0.2}[act]
+    z = scale.double() * x + shift.double()
+    gg = torch.where(z > 0, d, d * slope) if act else d
+    xhat = (x - mean.double()) * invstd.double()
+    s0, s1 = gg.sum(1), (gg * xhat).sum(1)
+    a0, a1 = gg.abs().sum(1), (gg * xhat).abs().sum(1)
+    pc = part.double().cpu()
+    assert ((pc[0] - s0).abs() <= 4e-6 * a0 + 1e-5).all(), float((pc[0] - s0).abs().max())
+    assert ((pc[1] - s1).abs() <= 4e-6 * a1 + 1e-5).all(), float((pc[1] - s1).abs().max())
+    # and the whole layer: BatchNorm backward with these sums == with the reduce pass's
+    dgam = [torch.zeros(C, device=DEV) for _ in range(2)]
+    dbet = [torch.zeros(C, device=DEV) for _ in range(2)]
+    dr_a = ops.bn_backward(dy, r, aff, act, dgam[0], dbet[0], partial=part)
+    dr_b = ops.bn_backward(dy, r, aff, act, dgam[1], dbet[1])
+    assert relerr(dgam[0], dgam[1]) < 1e-5 and relerr(dbet[0], dbet[1]) < 1e-5
+    assert relerr(dr_a, dr_b) < 2e-3
+
+
 def test_eval_ffn256_variants_agree(ops):
     """csrc/ffn256_fused.hip under its tuning key: persistent over the row tiles (300 tiles on one workgroup per CU: some take two, the
     next tile's x fetched by the epilogue of the one before), one workgroup per tile, and the 4-wave form with the output accumulators
