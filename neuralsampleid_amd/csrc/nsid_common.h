@@ -140,7 +140,7 @@ static inline bool nsid_aligned16(const void* p) { return (reinterpret_cast<uint
   X(bn_bwd_apply_max_wg, 384)  /* BatchNorm-backward apply pass: 1.5 workgroups per CU leave room for the other view */      \
   X(gemm_deep_ks, 2)           /* 32-deep MFMA sub-steps per LDS stage for launches of <= gemm_deep_max_wg workgroups */      \
   X(gemm_deep_pd, 2)           /* register sets (= stages in flight) of those launches: 2 or 4 */                             \
-  X(gemm_deep_max_wg, 512)                                                                                                    \
+  X(gemm_deep_max_wg, 1024)    /* round 5 re-sweep (weight-stationary kernels in): 512 -> 1024 = -0.8 % of the step (x3), deep plan neutral */ \
   X(gemm_deep_ec, 0)           /* early commit (three LDS stage buffers): wins alone, loses in the two-stream step */         \
   X(gemm_deep_kinds, 5)        /* which GEMM kinds take the deep form: bit 0 forward, bit 1 backward-data, bit 2 weight gradient */ \
   X(fwd_narrow, -1)            /* -1: shape heuristic; 0 / 1 force 128- / 64-wide forward tiles */                             \
