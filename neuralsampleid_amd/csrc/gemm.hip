@@ -1354,6 +1354,23 @@ static int linear_bwd_data_impl(const void* dout, int ldd, const void* w, int w_
     p.abn_dr = abn->dr; p.abn_lddr = (long)groups * Nout;
     if (K % (narrow ? 64 : 128) != 0 || M % 128 != 0 || Nout % 64 != 0) return 1;
   }
+  // A handful of tiles with a long reduction (the projector head: M = batch rows, Nout = 4096 -> K = 1024 was 32 workgroups of 64 stages
+  // each, 61 us on the turnaround between forward and backward where nothing else runs): split the reduction over up to 256
+  // workgroups, fp32 atomics into the zeroed output. fp32 storage, plain epilogue only (tuning key bwd_split_max_tiles, 0 = never).
+  if (act_dtype == NSID_F32 && addend == nullptr && bn_r == nullptr && abn == nullptr && groups == 1 && Nout >= 1024 && ldi == K) {
+    const long tiles = (long)nsid_row_tiles(M) * ((K + (narrow ? 63 : 127)) / (narrow ? 64 : 128));
+    const long maxt = nsid_tune(NSID_T_bwd_split_max_tiles);
+    const long S = maxt > 0 && tiles <= maxt ? std::min<long>(256 / tiles, Nout / 256) : 1;
+    if (S > 1) {
+      // (the library's own fill kernel: a memset node did not replay with the captured step)
+      const int rcz = nsid_fill_zero(din, (size_t)M * K * 4, stream);
+      if (rcz != NSID_OK) return rcz;
+      p.rsplit = (int)S;
+      p.rchunk = (int)((Nout + S - 1) / S);
+      p.atomic_out = 1;
+      nsid_count(NSID_C_gemm_bwd_split);
+    }
+  }
   if (narrow) return launch<128, 64, true, false>(p, groups, s, act_dtype, wb);
   return launch<128, 128, true, false>(p, groups, s, act_dtype, wb);
 }

@@ -143,6 +143,7 @@ static inline bool nsid_aligned16(const void* p) { return (reinterpret_cast<uint
   X(gemm_deep_max_wg, 1024)    /* round 5 re-sweep (weight-stationary kernels in): 512 -> 1024 = -0.8 % of the step (x3), deep plan neutral */ \
   X(gemm_deep_ec, 0)           /* early commit (three LDS stage buffers): wins alone, loses in the two-stream step */         \
   X(gemm_deep_kinds, 5)        /* which GEMM kinds take the deep form: bit 0 forward, bit 1 backward-data, bit 2 weight gradient */ \
+  X(bwd_split_max_tiles, 64)   /* fp32-storage backward-data launches of at most this many tiles and Nout >= 1024 split their reduction (atomics); 0 = never */ \
   X(fwd_narrow, -1)            /* -1: shape heuristic; 0 / 1 force 128- / 64-wide forward tiles */                             \
   X(bwd_narrow, -1)                                                                                                           \
   X(g256_min, 512)             /* >= this many 256x256 tiles: gemm256.hip (LDS-DMA staging); 0 = never */                     \
@@ -188,6 +189,7 @@ static inline long nsid_tune(NsidTuneKey k) { return g_nsid_tune[k]; }
   X(gemm_full)            /* predication-free full-tile instantiation */                        \
   X(gemm_ks2)             /* 64-deep LDS stages */                                              \
   X(gemm_pd4) X(gemm_ec)                                                \
+  X(gemm_bwd_split)       /* backward-data with a split reduction (the projector head) */   \
   X(gemm_split_major)     /* split index fastest in the grid (a split stays on one XCD) */      \
   X(gemm_affine_load)     /* producer BatchNorm + activation applied on the operand load */     \
   X(gemm_relu_load)                                                                             \

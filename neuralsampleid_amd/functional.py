@@ -415,12 +415,16 @@ def downsample_backward(dout: Tensor, P, S, G) -> Tensor:
 
 
 # ------------------------------------------------------------------------------------------------ proj + node mean
+HEAD_KSPLIT = True      # split the 512-deep reduction of the B-row projection GEMM (one-box A/B: docs/experiments.md, round 5)
+
+
 def proj_mean_forward(x: Tensor, P, S: Optional[dict], B: int, N: int) -> Tensor:
     """mean over nodes commutes with the 1x1 projection: h = W mean_n(x) + b (32x fewer FLOPs than proj-then-mean)"""
     M, C = x.shape
     E = P["weight"].shape[0]
     xm = ops.node_mean_fwd(x, B, N, C)
-    h, _ = ops.linear_fwd(xm, ops.w2d(P["weight"]), P["bias"], B, E, C)
+    # B rows: a handful of tiles with a 512-deep reduction — split it (fp32 atomics into the zeroed output), as the projector's fc2
+    h, _ = ops.linear_fwd(xm, ops.w2d(P["weight"]), P["bias"], B, E, C, ksplit=4 if (HEAD_KSPLIT and C >= 512 and B <= 512) else 1)
     if S is not None:
         S.update(xm=xm, B=B, N=N, C=C, xdtype=x.dtype)
     return h

@@ -90,6 +90,29 @@ def test_linear_bwd_data(ops, M, Nout, K, groups, add):
     close(got, ref, what="din")
 
 
+@pytest.mark.parametrize("M,Nout,K", [(256, 4096, 1024), (256, 1024, 512), (200, 2048, 192), (8, 4096, 1024)])
+def test_linear_bwd_data_split_reduction(ops, M, Nout, K):
+    """the projector head's backward-data (simclr/simclr.py:25-28 backward; B rows, Nout up to 4096): a handful of tiles with a long
+    reduction is split over up to 256 workgroups (fp32 atomics into the output, which the launch zeroes itself), against fp64 and against the unsplit launch"""
+    dout = rnd(f"sd{M}{Nout}", M, Nout)
+    w = rnd(f"sw{Nout}{K}", Nout, K) * Nout ** -0.5
+    ref = dout.double() @ w.double()
+    out = torch.full((M, K), 7.0, device=DEV)                 # stale contents: the launch must not rely on a zeroed buffer
+    ops.launch_counters(reset=True)
+    got = ops.linear_bwd_data(dout.to(DEV), w.to(DEV), M, Nout, K, 1, out=out)
+    torch.cuda.synchronize()
+    assert ops.launch_counters()["gemm_bwd_split"] == 1
+    close(got, ref, what="din (split)")
+    try:
+        ops.set_tuning("bwd_split_max_tiles", 0)
+        ops.launch_counters(reset=True)
+        plain = ops.linear_bwd_data(dout.to(DEV), w.to(DEV), M, Nout, K, 1)
+        assert ops.launch_counters()["gemm_bwd_split"] == 0
+    finally:
+        ops.reset_tuning()
+    close(got, plain, tol=2e-5, what="split vs unsplit")
+
+
 @pytest.mark.parametrize("M,Nout,K,groups,affine,act", [(1024, 64, 64, 1, False, 0), (700, 256, 64, 1, True, 1),
                                                         (512, 32, 32, 4, False, 0), (4096, 128, 512, 1, True, 1),
                                                         (256, 4096, 1024, 1, False, 0), (2048, 64, 8, 1, False, 0)])
