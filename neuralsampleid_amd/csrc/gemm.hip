@@ -1195,7 +1195,7 @@ static int linear_fwd_impl(const void* x, int ldx, const void* w, int w_dtype, c
   NSID_REQUIRE((ldx >= groups * K || (groups == 1 && ldx > 0)) && ldo >= groups * Nout);
   NSID_REQUIRE(Nout % 4 == 0 && ldo % 4 == 0 && nsid_aligned16(out) && (bias == nullptr || nsid_aligned16(bias)));
   NSID_REQUIRE((in_scale == nullptr) == (in_shift == nullptr));
-  NSID_REQUIRE(ksplit == 1 || (stat == nullptr && act_out == NSID_ACT_NONE));
+  NSID_REQUIRE(ksplit == 1 || (stat == nullptr && (act_out == NSID_ACT_NONE || (act_out == NSID_ACT_ELU && act_dtype == NSID_F32))));   // ELU is a separate pass over the finished sums (below)
   NSID_REQUIRE(act_in != NSID_ACT_ELU && (act_out == NSID_ACT_NONE || act_out == NSID_ACT_ELU || act_out == NSID_ACT_RELU));
   // an activation on load WITHOUT an affine exists as ReLU on bf16 operands with bf16 weights (full tiles; eval path)
   NSID_REQUIRE(in_scale != nullptr || act_in == NSID_ACT_NONE ||

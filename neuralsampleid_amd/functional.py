@@ -415,6 +415,7 @@ def downsample_backward(dout: Tensor, P, S, G) -> Tensor:
 
 
 # ------------------------------------------------------------------------------------------------ proj + node mean
+HEAD_FC1_KSPLIT = 1     # reduction split of the projector's first linear: measured 2 / 4 against 1: 7.787 / 7.787 against 7.773 ms (x3): off
 HEAD_KSPLIT = True      # split the 512-deep reduction of the B-row projection GEMM (one-box A/B: docs/experiments.md, round 5)
 
 
@@ -443,7 +444,8 @@ def proj_mean_backward(dh: Tensor, P, S, G) -> Tensor:
 def projector_forward(h: Tensor, P, S: Optional[dict], eps: float = 1e-10) -> Tensor:
     B, Hin = h.shape
     Hid, D = P["0.weight"].shape[0], P["2.weight"].shape[0]
-    a1, _ = ops.linear_fwd(h, P["0.weight"], P["0.bias"], B, Hid, Hin, act_out=ACT_ELU)
+    a1, _ = ops.linear_fwd(h, P["0.weight"], P["0.bias"], B, Hid, Hin, act_out=ACT_ELU,
+                           ksplit=HEAD_FC1_KSPLIT if (Hin >= 1024 and B <= 512 and h.dtype == torch.float32) else 1)
     ks = 8 if Hid >= 2048 else 1
     p, _ = ops.linear_fwd(a1, P["2.weight"], P["2.bias"], B, D, Hid, ksplit=ks)
     z, norm = ops.l2norm_fwd(p, eps)

@@ -73,6 +73,12 @@ def test_linear_fwd_ksplit(ops):
     x, w, b = rnd("ksx", M, K), rnd("ksw", Nout, K) * K ** -0.5, rnd("ksb", Nout)
     out, _ = ops.linear_fwd(x.to(DEV), w.to(DEV), b.to(DEV), M, Nout, K, ksplit=8)
     close(out, x.double() @ w.double().t() + b.double(), what="ksplit")
+    # with the ELU of the projector's first linear (simclr/simclr.py:25-28): its own pass over the finished sums
+    M, Nout, K = 256, 4096, 1024
+    x, w, b = rnd("ksx2", M, K), rnd("ksw2", Nout, K) * K ** -0.5, rnd("ksb2", Nout)
+    for ks in (1, 2, 4):
+        out, _ = ops.linear_fwd(x.to(DEV), w.to(DEV), b.to(DEV), M, Nout, K, act_out=3, ksplit=ks)
+        close(out, torch.nn.functional.elu(x.double() @ w.double().t() + b.double()), what=f"ksplit {ks} + ELU")
 
 
 @pytest.mark.parametrize("M,Nout,K,groups,add", [(512, 64, 64, 1, True), (200, 256, 64, 1, False),
