@@ -261,6 +261,10 @@ int nsid_peak_patchify_fwd(const float* spec, const float* w, const float* bias,
 int nsid_peak_patchify_bwd(const float* spec, const float* minmax, const void* out, const void* dout, int ldo,
                            int B, int H, int W, int pb, int pf, int F, float* dw /* += */, float* dbias /* += */,
                            int out_dtype, void* stream);
+/* the same with a workspace of B * 776 floats for GraFP's patch (pb = 4, pf = 8, F = 8, 64 x 128 clips; NSID_EINVAL otherwise):
+ * per-clip partial sums by plain stores + one reduce launch instead of B * 776 atomics onto 776 addresses */
+int nsid_peak_patchify_bwd_ws(const float* spec, const float* minmax, const void* out, const void* dout, int ldo, int B, int H,
+                              int W, int pb, int pf, int F, float* dw, float* dbias, float* ws, int out_dtype, void* stream);
 
 /* ---- node mean (encoder/graph_encoder.py:211), ELU', L2 normalise (simclr/simclr.py:38,44) --------------*/
 int nsid_node_mean_fwd(const void* x, int B, int N, int C, float* out, int x_dtype, void* stream);

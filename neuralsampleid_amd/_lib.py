@@ -46,6 +46,7 @@ SIGNATURES = {
     "nsid_ds_prepack": "ipppppps",
     "nsid_peak_patchify_fwd": "pppiiiiiipipis",
     "nsid_peak_patchify_bwd": "ppppiiiiiiippis",
+    "nsid_peak_patchify_bwd_ws": "ppppiiiiiiipppis",
     "nsid_node_mean_fwd": "piiipis",
     "nsid_node_mean_bwd": "piiipis",
     "nsid_elu_bwd": "pplps",

@@ -363,6 +363,96 @@ __global__ __launch_bounds__(256) void patchify_bwd_kernel(const float* __restri
   if (t < F) atomicAdd(dbias + t, bacc);
 }
 
+// ---- GraFP's patch (4 x 8, 8 filters, 64 x 128 clips) with a workspace: the form above spends most of its 44 us in its last lines —
+// 512 workgroups (two views) adding 776 values each into the SAME 776 addresses (memory-side atomics on one 3 KB row run 14x below
+// their rate) — and executes its three plane branches one after the other in every wave. Here a workgroup writes its clip's 776
+// partial sums to ws[b][776] with plain stores and a second launch adds them up (one atomic per output and view); the 768 outputs
+// are laid over the 256 threads as (filter, position in the patch) so that every thread computes all three planes without branches.
+constexpr int PB2_OUT = 8 * 3 * 32 + 8;           // 768 weight gradients + 8 bias gradients per clip
+
+template <typename T>
+__global__ __launch_bounds__(256) void patchify_bwd2_kernel(const float* __restrict__ spec, const float* __restrict__ minmax,
+                                                            const T* __restrict__ out, const T* __restrict__ dout, int ldo,
+                                                            float* __restrict__ ws) {
+  constexpr int H = 64, W = 128, PBk = 4, PFk = 8, F = 8, Hp = 16, Wp = 16, NP = 256, LDW = W + PATCH_PAD;
+  __shared__ __attribute__((aligned(16))) float g[NP * F];          // g[p][f] = dout where out > 0
+  __shared__ __attribute__((aligned(16))) float xs[H * LDW];        // the normalised clip
+  __shared__ float red[(Wp + Hp) * F];                              // column sums [pw][f], then row sums [ph][f]
+  const int t = threadIdx.x, b = blockIdx.x;
+  const float* x = spec + (long)b * H * W;
+  const float lo = minmax[2 * b], range = minmax[2 * b + 1] - lo;
+  {
+    const long o = ((long)b * NP + t) * ldo;                         // patch t: F = 8 values = one chunk (bf16) or two (fp32)
+    float ov[8], dv[8];
+    if constexpr (Chunk<T>::N == 8) {
+      Chunk<T>::load(out + o, ov);
+      Chunk<T>::load(dout + o, dv);
+    } else {
+      Chunk<T>::load(out + o, ov); Chunk<T>::load(out + o + 4, ov + 4);
+      Chunk<T>::load(dout + o, dv); Chunk<T>::load(dout + o + 4, dv + 4);
+    }
+    f32x4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f32x4*>(x + 4 * (t + 256 * u));
+#pragma unroll
+    for (int e = 0; e < 8; ++e) g[t * F + e] = ov[e] > 0.f ? dv[e] : 0.f;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i4 = 4 * (t + 256 * u), hh = i4 / W, ww = i4 % W;
+      *reinterpret_cast<f32x4*>(xs + hh * LDW + ww) =
+          f32x4{(v[u][0] - lo) / range, (v[u][1] - lo) / range, (v[u][2] - lo) / range, (v[u][3] - lo) / range};
+    }
+  }
+  __syncthreads();
+  {
+    const int f = t % F, k2 = t / F;                                 // 32 x 8 sums: one per thread
+    float a = 0.f;
+    if (k2 < Wp) { for (int ph = 0; ph < Hp; ++ph) a += g[(ph * Wp + k2) * F + f]; }
+    else { for (int pw = 0; pw < Wp; ++pw) a += g[((k2 - Wp) * Wp + pw) * F + f]; }
+    red[t] = a;
+  }
+  __syncthreads();
+  const int f = t >> 5, ij = t & 31, i = ij >> 3, j = ij & 7;
+  float a_t = 0.f, a_f = 0.f;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    a_t += red[q * F + f] * linspace01(q * PFk + j, W);
+    a_f += red[(Wp + q) * F + f] * linspace01(q * PBk + i, H);
+  }
+  float part[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int ph = 0; ph < Hp; ++ph) {
+    const float* srow = g + (ph * Wp) * F + f;
+    const float* xrow = xs + (ph * PBk + i) * LDW + j;
+#pragma unroll
+    for (int pw = 0; pw < Wp; ++pw) part[pw & 3] += srow[pw * F] * xrow[pw * PFk];
+  }
+  float* wsb = ws + (long)b * PB2_OUT;
+  wsb[f * 96 + ij] = a_t;
+  wsb[f * 96 + 32 + ij] = a_f;
+  wsb[f * 96 + 64 + ij] = (part[0] + part[1]) + (part[2] + part[3]);
+  if (t < F) {
+    float a = 0.f;
+    for (int pw = 0; pw < Wp; ++pw) a += red[pw * F + t];
+    wsb[768 + t] = a;
+  }
+}
+
+// dw[q] += sum_b ws[b][q] (q < 768), dbias[f] += sum_b ws[b][768 + f]: 64 outputs x 4 clip slices per workgroup
+__global__ __launch_bounds__(256) void patchify_bwd2_reduce_kernel(const float* __restrict__ ws, int B, float* __restrict__ dw,
+                                                                   float* __restrict__ dbias) {
+  __shared__ float part[256];
+  const int t = threadIdx.x, q = blockIdx.x * 64 + (t & 63), sl = t >> 6;
+  float a = 0.f;
+  if (q < PB2_OUT)
+    for (int b = sl; b < B; b += 4) a += ws[(long)b * PB2_OUT + q];
+  part[t] = a;
+  __syncthreads();
+  if (sl == 0 && q < PB2_OUT) {
+    a = (part[t] + part[t + 64]) + (part[t + 128] + part[t + 192]);
+    atomicAdd(q < 768 ? dw + q : dbias + (q - 768), a);
+  }
+}
+
 // ------------------------------------------------------------------ node mean
 template <typename T>
 __global__ __launch_bounds__(256) void node_mean_fwd_kernel(const T* __restrict__ x, int N, int C,
@@ -628,6 +718,23 @@ extern "C" int nsid_peak_patchify_bwd(const float* spec, const float* minmax, co
     NSID_LAUNCH((patchify_bwd_kernel<T>), dim3(B < 256 ? B : 256), dim3(256), bytes, static_cast<hipStream_t>(stream),
                 spec, minmax, static_cast<const T*>(out), static_cast<const T*>(dout), ldo, B, H, W, pb, pf, F, dw, dbias);
   });
+  return nsid_launch_status();
+}
+
+// the same with a caller-provided workspace of B * 776 floats (GraFP's patch: pb = 4, pf = 8, F = 8, 64 x 128 clips): partial sums per
+// clip by plain stores + one reduce launch instead of B * 776 atomics on 776 addresses. Other shapes: nsid_peak_patchify_bwd.
+extern "C" int nsid_peak_patchify_bwd_ws(const float* spec, const float* minmax, const void* out, const void* dout, int ldo, int B,
+                                         int H, int W, int pb, int pf, int F, float* dw, float* dbias, float* ws, int out_dtype,
+                                         void* stream) {
+  NSID_REQUIRE(spec && minmax && out && dout && dw && dbias && ws && B > 0 && ldo >= F && NSID_DTYPE_OK(out_dtype));
+  NSID_REQUIRE(H == 64 && W == 128 && pb == 4 && pf == 8 && F == 8 && ldo % (out_dtype == NSID_BF16 ? 8 : 4) == 0);
+  NSID_REQUIRE(nsid_aligned16(spec) && nsid_aligned16(out) && nsid_aligned16(dout));
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  NSID_DISPATCH_DTYPE(out_dtype, T, {
+    NSID_LAUNCH((patchify_bwd2_kernel<T>), dim3(B), dim3(256), 0, s, spec, minmax, static_cast<const T*>(out),
+                static_cast<const T*>(dout), ldo, ws);
+  });
+  NSID_LAUNCH(patchify_bwd2_reduce_kernel, dim3((PB2_OUT + 63) / 64), dim3(256), 0, s, ws, B, dw, dbias);
   return nsid_launch_status();
 }
 

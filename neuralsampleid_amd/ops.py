@@ -966,10 +966,21 @@ def peak_patchify_fwd(spec, w, bias, pb, pf, out_dtype=torch.float32):
     return out, minmax
 
 
+PATCHIFY_BWD_WS = True      # GraFP's patch: per-clip partial sums + one reduce launch (csrc/misc.hip patchify_bwd2_kernel)
+
+
 def peak_patchify_bwd(spec, minmax, out, dout, pb, pf, dw, dbias) -> None:
     _chk(spec, minmax, dw, dbias)
     B, H, W = spec.shape
-    _tk("patchify_bwd_kernel", 4.0 * B * H * W + 2.0 * out.element_size() * out.numel(), lambda: call(
+    F = out.shape[-1]
+    nbytes = 4.0 * B * H * W + 2.0 * out.element_size() * out.numel()
+    if PATCHIFY_BWD_WS and (H, W, pb, pf, F) == (64, 128, 4, 8, 8) and out.is_contiguous() and dout.is_contiguous():
+        ws = torch.empty((B, 776), device=spec.device, dtype=torch.float32)
+        _tk("patchify_bwd2_kernel", nbytes + 8.0 * ws.numel(), lambda: call(
+            "nsid_peak_patchify_bwd_ws", _p(spec), _p(minmax), _p(out), _p(dout), F, B, H, W, pb, pf, F, _p(dw), _p(dbias), _p(ws),
+            _act(out, dout), _stream()), (out.shape[0], out.shape[1], pb * pf * 3, 1))
+        return
+    _tk("patchify_bwd_kernel", nbytes, lambda: call(
         "nsid_peak_patchify_bwd", _p(spec), _p(minmax), _p(out), _p(dout), out.shape[-1], B, H, W, pb, pf,
         out.shape[-1], _p(dw), _p(dbias), _act(out, dout), _stream()), (out.shape[0], out.shape[1], pb * pf * 3, 1))
 

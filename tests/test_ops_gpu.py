@@ -486,9 +486,39 @@ def test_peak_patchify_golden(ops, golden):
     close(out.reshape(B, 256, 8).transpose(1, 2), g.t("y"), tol=1e-5, what="patchify")
     dw, db = torch.zeros(8, 3, 4, 8, device=DEV), torch.zeros(8, device=DEV)
     dout = g.t("gout").transpose(1, 2).reshape(B * 256, 8).contiguous().to(DEV)
-    ops.peak_patchify_bwd(spec, minmax, out, dout, 4, 8, dw, db)
-    close(dw, g.t("dweight"), tol=1e-4, what="dweight")
-    close(db, g.t("dbias"), tol=1e-4, what="dbias")
+    for ws in (True, False):        # the workspace form (per-clip partial sums + a reduce launch) and the atomics form
+        dw.zero_(); db.zero_()
+        ops.PATCHIFY_BWD_WS = ws
+        try:
+            ops.peak_patchify_bwd(spec, minmax, out, dout, 4, 8, dw, db)
+        finally:
+            ops.PATCHIFY_BWD_WS = True
+        close(dw, g.t("dweight"), tol=1e-4, what=f"dweight (ws={ws})")
+        close(db, g.t("dbias"), tol=1e-4, what=f"dbias (ws={ws})")
+
+
+@pytest.mark.parametrize("dt", ["bf16", "fp32"])
+def test_peak_patchify_backward_workspace_form_at_the_timed_batch(ops, dt):
+    """peak_extractor.py:45-70 backward at B = 256 in both storage types: the workspace form accumulates on top of what dw / dbias hold
+    (the second view adds to the first) and equals the atomics form to fp32 summation noise"""
+    B = 256
+    tdt = torch.bfloat16 if dt == "bf16" else torch.float32
+    w, b = rnd("ppw", 8, 3, 4, 8).to(DEV), rnd("ppb", 8).to(DEV)
+    spec = (rnd("pps", B, 64, 128) * 20 - 40).to(DEV)
+    out, minmax = ops.peak_patchify_fwd(spec, w, b, 4, 8, tdt)
+    dout = rnd("ppd", B * 256, 8).to(tdt).to(DEV)
+    res = {}
+    for ws in (True, False):
+        dw, db = torch.ones(8, 3, 4, 8, device=DEV), torch.full((8,), 2.0, device=DEV)
+        ops.PATCHIFY_BWD_WS = ws
+        try:
+            ops.peak_patchify_bwd(spec, minmax, out, dout, 4, 8, dw, db)
+        finally:
+            ops.PATCHIFY_BWD_WS = True
+        res[ws] = (dw.cpu().double(), db.cpu().double())
+    scale = max(1.0, float(res[False][0].abs().max()))
+    assert float((res[True][0] - res[False][0]).abs().max()) <= 2e-5 * scale
+    assert float((res[True][1] - res[False][1]).abs().max()) <= 2e-5 * max(1.0, float(res[False][1].abs().max()))
 
 
 def test_head_pieces(ops):
