@@ -758,7 +758,8 @@ def main():
         # forward-only extraction of 100 000 clips; each entry is a complete bench line of its own (roofline, traffic, cpu_baseline)
         import copy
         others = {}
-        for name, changes in (("config4_deep_step", {"deep": True}),
+        for name, changes in (("config2_k5_step", {"k": 5, "no_cpu_baseline": True}),            # train.py:46 trains with --k 5
+                              ("config4_deep_step", {"deep": True}),
                               ("config5_fingerprint_100k", {"mode": "infer", "clips": 100000})):
             a2 = copy.copy(args)
             for k_, v_ in changes.items():
@@ -774,6 +775,7 @@ def main():
         # the same two numbers as scalars, at the top level AND inside `config` (the driver's record keeps `config`, `roofline` and
         # `cpu_baseline` whole and only the NAMES of other top-level keys: VERDICT r4)
         c4, c5 = others.get("config4_deep_step", {}), others.get("config5_fingerprint_100k", {})
+        out["config2_k5_ms_per_step"] = out["config"]["config2_k5_ms_per_step"] = others.get("config2_k5_step", {}).get("ms_per_step")
         out["config4_ms_per_step"] = out["config"]["config4_ms_per_step"] = c4.get("ms_per_step")
         out["config5_clips_per_s"] = out["config"]["config5_clips_per_s"] = c5.get("value")
     if rank == 0:

@@ -146,6 +146,22 @@ int nsid_linear_bwd_data_bnapply(const void* dy, const void* r, const float* coe
 int nsid_linear_bwd_weight(const void* dout, int ldd, const void* x, int ldx, float* dw, int M, int Nout, int K,
                            int groups, const float* in_scale, const float* in_shift, int act_in,
                            int act_dtype /* dout and x */, void* stream);
+/* Many weight gradients in ONE launch per tile class: the deferred weight-gradient phase of a training step (nothing reads a weight
+ * gradient before train.py:73-75's clip + step, so the conv layers of encoder/gcn_lib/torch_vertex.py:152-162,
+ * encoder/graph_encoder.py:74-77 and gcn_lib/torch_nn.py:56 record their problem during backward and issue all of them here).
+ * Problem i: dw += sum over its row segments v of dout[v]^T f_v(x[v]) with f_v = act_in(in_scale[v] * x + in_shift[v]) (in_scale[v] NULL:
+ * identity; both segments with or without). The two segments are the two views of a contrastive step: the same layer, M rows each,
+ * the same leading dimensions; dout[1] = x[1] = NULL: one segment. bf16 activations only (NSID_EINVAL otherwise). The problem table is
+ * copied into the kernel arguments: the array may be freed as soon as the call returns, the launch is capturable. */
+typedef struct nsid_wgrad_problem {
+  const void* dout[2];
+  const void* x[2];
+  const float* in_scale[2];
+  const float* in_shift[2];
+  float* dw;
+  int ldd, ldx, M, Nout, K, groups, act_in, reserved;
+} nsid_wgrad_problem;
+int nsid_linear_bwd_weight_grouped(const nsid_wgrad_problem* problems, int n, int act_dtype, void* stream);
 /* out[c] += sum_m x[m, c]  (bias gradients) */
 int nsid_colsum_acc(const void* x, int ldx, int M, int C, float* out, int dtype, void* stream);
 

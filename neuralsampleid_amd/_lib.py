@@ -21,6 +21,7 @@ SIGNATURES = {
     "nsid_linear_bwd_data": "pipipipiiiiiis",
     "nsid_linear_bwd_data_bn": "pipipipiiiiiipppppips",
     "nsid_linear_bwd_weight": "pipipiiiippiis",
+    "nsid_linear_bwd_weight_grouped": "piis",
     "nsid_colsum_acc": "piiipis",
     "nsid_bn_finalize": "piiipppppffpppps",
     "nsid_bn_finalize_deferred": "piiippfppppps",
@@ -66,6 +67,14 @@ SIGNATURES = {
     "nsid_fill_zero": "pzs",
     "nsid_scale_f32": "pplps",
 }
+
+class WgradProblem(ctypes.Structure):
+    """include/nsid.h nsid_wgrad_problem: one layer's weight gradient over up to two row segments (the two views)"""
+    _fields_ = [("dout", ctypes.c_void_p * 2), ("x", ctypes.c_void_p * 2), ("in_scale", ctypes.c_void_p * 2),
+                ("in_shift", ctypes.c_void_p * 2), ("dw", ctypes.c_void_p), ("ldd", ctypes.c_int), ("ldx", ctypes.c_int),
+                ("M", ctypes.c_int), ("Nout", ctypes.c_int), ("K", ctypes.c_int), ("groups", ctypes.c_int), ("act_in", ctypes.c_int),
+                ("reserved", ctypes.c_int)]
+
 
 _CT = {"p": ctypes.c_void_p, "i": ctypes.c_int, "l": ctypes.c_long, "f": ctypes.c_float, "s": ctypes.c_void_p,
        "z": ctypes.c_size_t}

@@ -343,10 +343,11 @@ __device__ unsigned long long* g_gemm_trace = nullptr;
 // NW: waves per workgroup, laid out (NW/2) x 2 over the tile. NW = 8 on 256x128 tiles gives every wave the 64x64 sub-tile
 // of the 4-wave 128x128 kernel while a stage moves a quarter fewer operand bytes per flop, at two workgroups = 16 waves
 // per CU (the 4-wave 256x128 form needs 201 registers: 8 waves per CU).
+// The body is a device function of (arguments, tile index, split index, group): gemm_kernel derives the three from its own grid,
+// wgrad_grouped_kernel (below) from a table of many weight-gradient problems served by ONE launch.
 template <int BM, int BN, bool A_RMAJOR, bool B_RMAJOR, bool H, bool ST, bool AAFF, bool WB = false, bool FULL = false,
           bool ARELU = false, int KS = 1, int PD = 0, bool EC = false, int PADX = 0, int NW = 4, bool ABN = false>
-__global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : ((KS > 1 || PD > 2) ? 1 : ((FULL && WB && BM == 128 && BN == 128 && !AAFF && !ABN) ? 3 : 2)))   // waves per SIMD
-void gemm_kernel(const GemmArgs p) {
+__device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid, const int split, const int g) {
   unsigned long long* const trace = g_gemm_trace;
   unsigned long long t_start = 0, t_loop = 0;
   if (trace) t_start = __builtin_amdgcn_s_memrealtime();
@@ -380,17 +381,8 @@ void gemm_kernel(const GemmArgs p) {
 
   const int tiles_j = (p.J + BN - 1) / BN;
   const int tiles_i = (p.I + BM - 1) / BM;
-  int bid = p.split_major ? blockIdx.y : blockIdx.x;
-  const int split = p.split_major ? blockIdx.x : blockIdx.y;
-  if (!p.split_major) {
-    // XCD-aware remap (blocks b and b+8 share an L2): give each XCD a contiguous run of tiles so the
-    // column tiles that re-read one A row-panel hit the same L2. Bijective only when the grid divides by 8.
-    const int nwg = gridDim.x;
-    if ((nwg & 7) == 0) bid = (bid & 7) * (nwg >> 3) + (bid >> 3);
-  }
   const int ti = bid / tiles_j, tj = bid % tiles_j;
   if (ti >= tiles_i) return;
-  const int g = blockIdx.z;
   const int i0 = ti * BM, j0 = tj * BN;
   const int rbeg = split * p.rchunk;
   const int rend = min(p.R, rbeg + p.rchunk);
@@ -871,6 +863,84 @@ void gemm_kernel(const GemmArgs p) {
     trace[4 * lin + 2] = __builtin_amdgcn_s_memrealtime();
     trace[4 * lin + 3] = ((unsigned long long)xcc << 32) | hw;
   }
+}
+
+template <int BM, int BN, bool A_RMAJOR, bool B_RMAJOR, bool H, bool ST, bool AAFF, bool WB = false, bool FULL = false,
+          bool ARELU = false, int KS = 1, int PD = 0, bool EC = false, int PADX = 0, int NW = 4, bool ABN = false>
+__global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : ((KS > 1 || PD > 2) ? 1 : ((FULL && WB && BM == 128 && BN == 128 && !AAFF && !ABN) ? 3 : 2)))   // waves per SIMD
+void gemm_kernel(const GemmArgs p) {
+  int bid = p.split_major ? blockIdx.y : blockIdx.x;
+  const int split = p.split_major ? blockIdx.x : blockIdx.y;
+  if (!p.split_major) {
+    // XCD-aware remap (blocks b and b+8 share an L2): give each XCD a contiguous run of tiles so the
+    // column tiles that re-read one A row-panel hit the same L2. Bijective only when the grid divides by 8.
+    const int nwg = gridDim.x;
+    if ((nwg & 7) == 0) bid = (bid & 7) * (nwg >> 3) + (bid >> 3);
+  }
+  gemm_body<BM, BN, A_RMAJOR, B_RMAJOR, H, ST, AAFF, WB, FULL, ARELU, KS, PD, EC, PADX, NW, ABN>(p, bid, split, blockIdx.z);
+}
+
+// ---- many weight-gradient problems in ONE launch (the deferred phase of a training step: nsid_linear_bwd_weight_grouped) ----------
+// A weight gradient hangs off the dependent chain — nothing reads it before the optimiser — but as a launch of its own it fills 256 CUs
+// only by splitting its row reduction 8-16 ways (fp32 atomics: workgroups x tile bytes) and pays launch latency, first-operand latency
+// and a tail once per layer and view. Here the problems of many layers form one grid: a workgroup looks its problem up in a table that
+// travels in the kernel arguments (nothing is retained, the launch is capturable), both views of a layer are two row SEGMENTS of one
+// problem (a split lies in one segment: the body's loop is untouched), and because the union of the problems fills the chip each
+// problem needs only rows / wgg_rows splits: a quarter of the atomic bytes of the per-layer launches.
+constexpr int WGG_MAXP = 28;           // 8 + 116 + 28 x 120 bytes of explicit arguments + 256 hidden: under the 4 KB of a kernel-argument segment
+struct WgProb {                 // 120 bytes
+  const void* A[2];             // dout of the two row segments (views); [1] unused when seg_splits == nsplit
+  const void* B[2];             // x
+  const float* bsc[2];          // producer affine of x per segment (or null)
+  const float* bsh[2];
+  float* C;                     // dw [groups][I][J]
+  int lda, ldb, I, J, R;        // R = rows of ONE segment
+  int groups, rchunk;           // rows per split
+  int seg_splits, nsplit;       // splits of segment 0, splits in all
+  int tiles, nwg;               // output tiles per group; workgroups of this problem (the next problem starts at a multiple of 8)
+  float slope;
+};
+struct WgGroupArgs {
+  int n, pad;
+  int wg0[WGG_MAXP + 1];
+  WgProb prob[WGG_MAXP];
+};
+static_assert(sizeof(WgProb) == 120 && sizeof(WgGroupArgs) <= 4096, "the problem table travels in the kernel arguments");
+
+template <int BM, int BN, bool FULL>
+__global__ __launch_bounds__(256, FULL ? 1 : 2) void wgrad_grouped_kernel(const WgGroupArgs ga) {
+  const int w = blockIdx.x;
+  int pi = 0;
+  for (int i = 1; i < ga.n; ++i) pi += (w >= ga.wg0[i]) ? 1 : 0;          // uniform: scalar loads and compares
+  pi = __builtin_amdgcn_readfirstlane(pi);
+  const WgProb& q = ga.prob[pi];
+  const int l = w - ga.wg0[pi];
+  if (l >= q.nwg) return;
+  // workgroup -> (split, tile): the tiles of one split read the same rows of both operands, so they go to ONE XCD (workgroup w is
+  // dispatched to XCD w % 8, and every problem starts at a multiple of 8)
+  const int S = q.nsplit;
+  int split, rest;
+  if (S < 8 && (8 % S) == 0) {
+    const int x = l & 7, per = 8 / S;
+    split = x % S;
+    rest = (l >> 3) * per + x / S;
+  } else {
+    split = l % S;
+    rest = l / S;
+  }
+  if (rest >= q.tiles * q.groups) return;
+  const int g = rest / q.tiles, bid = rest % q.tiles;
+  const int seg = split >= q.seg_splits ? 1 : 0;
+  GemmArgs p{};
+  p.A = q.A[seg]; p.lda = q.lda; p.a_goff = q.I;
+  p.B = q.B[seg]; p.ldb = q.ldb; p.b_goff = q.J;
+  p.C = q.C; p.ldc = q.J; p.c_goff = (long)q.I * q.J;
+  p.I = q.I; p.J = q.J; p.R = q.R;
+  p.b_scale = q.bsc[seg]; p.b_shift = q.bsh[seg]; p.b_slope = q.slope; p.b_aff_goff = q.J;
+  p.a_slope = 1.f; p.bn_slope = 1.f;
+  p.atomic_out = 1;
+  p.rchunk = q.rchunk; p.rsplit = q.nsplit;
+  gemm_body<BM, BN, false, false, true, true, false, false, FULL, false, FULL ? 2 : 1, FULL ? 2 : 0>(p, bid, split - seg * q.seg_splits, g);
 }
 
 // ELU of the projector (simclr/simclr.py:26) runs as its own in-place pass: expm1f inlined into the fully unrolled
@@ -1440,4 +1510,78 @@ extern "C" int nsid_linear_bwd_weight(const void* dout, int ldd, const void* x, 
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (small) return launch<64, 64, false, false>(p, groups, s, act_dtype);
   return launch<128, 128, false, false>(p, groups, s, act_dtype);
+}
+
+// Many weight gradients in one launch per tile class (see wgrad_grouped_kernel). problems[i].dout[1] / x[1] NULL: one row segment.
+extern "C" int nsid_linear_bwd_weight_grouped(const nsid_wgrad_problem* problems, int n, int act_dtype, void* stream) {
+  NSID_REQUIRE(problems && n > 0 && act_dtype == NSID_BF16);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const long rows_target = std::max<long>(128, nsid_tune(NSID_T_wgg_rows));
+  // three classes: 0 = 128x64 full tiles (64-deep stages), 1 = 64x64 full tiles, 2 = 64x64 predicated (any shape)
+  WgGroupArgs ga[3];
+  long wgs[3] = {0, 0, 0};
+  for (int c = 0; c < 3; ++c) ga[c].n = 0;
+  auto flush = [&](int c) -> int {
+    if (ga[c].n == 0) return NSID_OK;
+    ga[c].wg0[ga[c].n] = (int)wgs[c];
+    const dim3 grid((unsigned)wgs[c]), block(256);
+    if (c == 0) NSID_LAUNCH((wgrad_grouped_kernel<128, 64, true>), grid, block, 0, s, ga[c]);
+    else if (c == 1) NSID_LAUNCH((wgrad_grouped_kernel<64, 64, true>), grid, block, 0, s, ga[c]);
+    else NSID_LAUNCH((wgrad_grouped_kernel<64, 64, false>), grid, block, 0, s, ga[c]);
+    nsid_count(NSID_C_wgrad_grouped);
+    ga[c].n = 0;
+    wgs[c] = 0;
+    return nsid_launch_status();
+  };
+  for (int i = 0; i < n; ++i) {
+    const nsid_wgrad_problem& q = problems[i];
+    const int nseg = q.dout[1] != nullptr ? 2 : 1;
+    NSID_REQUIRE(q.dout[0] && q.x[0] && q.dw && q.M > 0 && q.Nout > 0 && q.K > 0 && q.groups > 0);
+    NSID_REQUIRE((q.dout[1] == nullptr) == (q.x[1] == nullptr));
+    NSID_REQUIRE(q.Nout % 8 == 0 && q.K % 8 == 0 && q.ldd % 8 == 0 && q.ldx % 8 == 0);
+    for (int v = 0; v < nseg; ++v) {
+      NSID_REQUIRE(nsid_aligned16(q.dout[v]) && nsid_aligned16(q.x[v]));
+      NSID_REQUIRE((q.in_scale[v] == nullptr) == (q.in_shift[v] == nullptr));
+      NSID_REQUIRE((q.in_scale[v] == nullptr) == (q.in_scale[0] == nullptr));       // both segments with or without the affine
+      NSID_REQUIRE(q.in_scale[v] == nullptr || (nsid_aligned16(q.in_scale[v]) && nsid_aligned16(q.in_shift[v])));
+    }
+    const bool rows_ok = q.M % 128 == 0;
+    const int cls = (rows_ok && q.Nout % 128 == 0 && q.K % 64 == 0) ? 0 : ((rows_ok && q.Nout % 64 == 0 && q.K % 64 == 0) ? 1 : 2);
+    const int bm = cls == 0 ? 128 : 64;
+    WgProb w{};
+    for (int v = 0; v < 2; ++v) {
+      w.A[v] = q.dout[v]; w.B[v] = q.x[v]; w.bsc[v] = q.in_scale[v]; w.bsh[v] = q.in_shift[v];
+    }
+    w.C = q.dw; w.lda = q.ldd; w.ldb = q.ldx; w.I = q.Nout; w.J = q.K; w.R = q.M; w.groups = q.groups;
+    w.slope = act_slope(q.act_in);
+    long S = 1;                                  // splits per segment: rows / wgg_rows, whole 128-row multiples each
+    if (cls < 2) {
+      while (q.M % (2 * S) == 0 && (q.M / (2 * S)) % 128 == 0 && q.M / (2 * S) >= rows_target) S *= 2;
+      w.rchunk = (int)(q.M / S);
+    } else {
+      S = std::max<long>(1, (q.M + rows_target - 1) / rows_target);
+      w.rchunk = (int)(((q.M + S - 1) / S + 31) / 32 * 32);
+      S = (q.M + w.rchunk - 1) / w.rchunk;
+    }
+    w.seg_splits = (int)S;
+    w.nsplit = (int)S * nseg;
+    w.tiles = ((q.Nout + bm - 1) / bm) * ((q.K + 63) / 64);
+    const long tg = (long)w.tiles * q.groups;
+    long nwg = tg * w.nsplit;
+    if (w.nsplit < 8 && 8 % w.nsplit == 0) nwg = (tg + 8 / w.nsplit - 1) / (8 / w.nsplit) * 8;
+    w.nwg = (int)nwg;
+    NSID_REQUIRE(nwg < (1L << 30));
+    if (ga[cls].n == WGG_MAXP || wgs[cls] + nwg > (1L << 30)) {
+      const int rc = flush(cls);
+      if (rc != NSID_OK) return rc;
+    }
+    ga[cls].wg0[ga[cls].n] = (int)wgs[cls];
+    ga[cls].prob[ga[cls].n++] = w;
+    wgs[cls] += (nwg + 7) / 8 * 8;
+  }
+  for (int c = 0; c < 3; ++c) {
+    const int rc = flush(c);
+    if (rc != NSID_OK) return rc;
+  }
+  return NSID_OK;
 }

@@ -170,6 +170,7 @@ static inline bool nsid_aligned16(const void* p) { return (reinterpret_cast<uint
   X(ffn_waves, 8)              /* waves per workgroup of the fused eval-mode FFN (4 or 8) */                                  \
   X(ffn256, 1)                 /* 1: the C = 256 stage's eval-mode FFN as one launch (ffn256_fused.hip); 0: two GEMM launches */ \
   X(mrconv_variant, 3)         /* fused eval-mode aggregation + grouped conv: bit 0 = 8 waves, bit 1 = direct 8-byte stores */ \
+  X(wgg_rows, 8192)            /* rows per workgroup of the grouped (deferred) weight gradients: splits per view = M / wgg_rows */ \
   X(ws_gemm, 7)                /* weight-stationary streaming GEMMs (wsgemm.hip) for the small-K layers: bit 0 forward, bit 1 backward-data, bit 2 backward-data with the BatchNorm backward on its operand load */
 
 enum NsidTuneKey {
@@ -197,7 +198,7 @@ static inline long nsid_tune(NsidTuneKey k) { return g_nsid_tune[k]; }
   X(gemm_bn_apply_load)   /* backward-data applies a BatchNorm backward on its operand load */  \
   X(gemm256)              /* gemm256.hip */                                                     \
   X(ws_fwd) X(ws_bwd_data) X(ws_bwd_bnapply) /* wsgemm.hip: weight-stationary streaming forms */                   \
-  X(wgrad_rect) X(wgrad_square) X(wgrad3)                                                       \
+  X(wgrad_rect) X(wgrad_square) X(wgrad3) X(wgrad_grouped)                                                       \
   X(bn_bwd_apply) X(bn_bwd_apply_capped)                                                        \
   X(knn2) X(knn2_pair) X(knn2_raw) X(knn_rank) X(knn_sel) X(knn_strips)                                                  \
   X(mr_fwd_lds) X(mr_fwd_grid) X(mr_fwd_key) X(mr_bwd_sorted)                                                                  \

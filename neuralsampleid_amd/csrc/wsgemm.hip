@@ -468,8 +468,14 @@ template <int K, int NOUT, int GI>
 int ws_launch(const WsArgs& p, int gy, bool aff, bool stat, hipStream_t s) {
   const dim3 grid(p.M / 128, gy), block(256);
   if (aff) {
-    if (stat) NSID_LAUNCH((ws_fwd_kernel<K, NOUT, GI, true, true>), grid, block, 0, s, p);
-    else NSID_LAUNCH((ws_fwd_kernel<K, NOUT, GI, true, false>), grid, block, 0, s, p);
+    // several groups per workgroup hold GI * K / 16 operand fragments per lane; with the affine's constants beside them the K = 64
+    // form spilled 18-24 registers. No layer of the encoder feeds a grouped conv through a pending BatchNorm (its input is
+    // the aggregation's output): those launches keep gemm.hip's tile kernel.
+    if constexpr (GI > 1) return 1;
+    else {
+      if (stat) NSID_LAUNCH((ws_fwd_kernel<K, NOUT, GI, true, true>), grid, block, 0, s, p);
+      else NSID_LAUNCH((ws_fwd_kernel<K, NOUT, GI, true, false>), grid, block, 0, s, p);
+    }
   } else {
     if (stat) NSID_LAUNCH((ws_fwd_kernel<K, NOUT, GI, false, true>), grid, block, 0, s, p);
     else NSID_LAUNCH((ws_fwd_kernel<K, NOUT, GI, false, false>), grid, block, 0, s, p);

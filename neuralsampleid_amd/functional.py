@@ -147,6 +147,62 @@ def _store_partial(S, part):
 GRAD_READY_HOOK = None
 
 
+# ------------------------------------------------------------------------------------------------ deferred weight gradients
+# Nothing waits for a weight gradient until the optimiser (or the gradient all-reduce), yet launched in stream order it sits on its
+# view's dependent chain: the next backward-data GEMM starts behind it. With DEFER_WGRAD the conv layers of the Grapher / FFN blocks and
+# the stem only RECORD their weight-gradient problem (dr, the saved GEMM input and its pending affine stay alive); when autograd has
+# run the whole backward pass (engine callback) the two view streams are joined ONCE and the recorded problems are issued together
+# (ops.linear_bwd_weight_batch: both views of a layer as one problem over 2M rows, layers grouped into a few launches).
+# References: the backward of every conv at encoder/gcn_lib/torch_vertex.py:152-162, encoder/graph_encoder.py:74-77,
+# encoder/gcn_lib/torch_nn.py:56; train.py:70-75.
+DEFER_WGRAD = 0
+
+
+class DeferredWgrads:
+    def __init__(self):
+        self.items, self.hooks, self.armed = [], [], False
+        self.verify = None      # tests: a list that receives (dw, the same sum through the per-layer launches) for every layer of a flush
+
+    def add(self, dout, x, dw, M, Nout, K, groups, in_scale, in_shift, act_in):
+        self.items.append((dout, x, dw, M, Nout, K, groups, in_scale, in_shift, act_in))
+        if not self.armed:
+            self.armed = True
+            torch.autograd.Variable._execution_engine.queue_callback(self.flush)
+
+    def flush(self):
+        """runs on the thread that called backward(), once every backward node has been enqueued"""
+        self.armed = False
+        items, hooks, self.items, self.hooks = self.items, self.hooks, [], []
+        if not items:
+            return
+        join_side_streams()
+        ops.linear_bwd_weight_batch(items)
+        if self.verify is not None:     # tests: the same problems through the per-layer launches, from the tensors as they are NOW
+            tmp = {}
+            for it in items:
+                t = tmp.setdefault(it[2].data_ptr(), (it[2], torch.zeros_like(it[2])))[1]
+                ops.linear_bwd_weight(it[0], it[1], t, *it[3:])
+            self.verify.extend((dw, t) for dw, t in tmp.values())
+        if GRAD_READY_HOOK is not None:
+            for params in hooks:
+                GRAD_READY_HOOK(params)
+
+
+DEFERRED = DeferredWgrads()
+
+
+def _wgrad(dout, x, dw, M, Nout, K, groups=1, in_scale=None, in_shift=None, act_in=ACT_NONE):
+    """dw += dout^T f(x): now, or recorded for the deferred phase (only inside a backward pass that accumulates straight into p.grad:
+    an autograd-returned gradient tensor must be complete when its node returns)"""
+    if DEFER_WGRAD and DIRECT_GRADS and _IN_DIRECT_BACKWARD and dout.dtype == torch.bfloat16:
+        DEFERRED.add(dout, x, dw, M, Nout, K, groups, in_scale, in_shift, act_in)
+    else:
+        ops.linear_bwd_weight(dout, x, dw, M, Nout, K, groups, in_scale, in_shift, act_in)
+
+
+_IN_DIRECT_BACKWARD = False     # set by _BlockFn.backward while a block accumulates into p.grad
+
+
 def _bias_grad_before_bn(dr, g):
     if EXACT_BIAS_GRAD:
         ops.colsum_acc(dr, g)
@@ -229,7 +285,7 @@ def stem_backward(dx0: Tensor, P, S, G, need_input_grad: bool = True) -> Optiona
     M, K = nodes.shape
     C = r.shape[1]
     dr = ops.bn_backward(dx0, r, aff, ACT_LEAKY, G["1.weight"], G["1.bias"], partial=_link_partial(S))
-    ops.linear_bwd_weight(dr, nodes, ops.w2d(G["0.weight"]), M, C, K)
+    _wgrad(dr, nodes, ops.w2d(G["0.weight"]), M, C, K)
     return ops.linear_bwd_data(dr, ops.w2d(P["0.weight"]), M, C, K) if need_input_grad else None
 
 
@@ -281,13 +337,13 @@ def grapher_backward(dx1: Tensor, P, S, G) -> Tensor:
                                                      ops.w2d(P["fc2.0.weight"]), M, C, 2 * C, 1, bn=(r2, a2, ACT_RELU),
                                                      site=ops.SITE_FC2, inplace=False)
     _bias_grad_before_bn(dr3, G["fc2.0.bias"])
-    ops.linear_bwd_weight(dr3, r2, ops.w2d(G["fc2.0.weight"]), M, C, 2 * C, 1, a2.scale, a2.shift, ACT_RELU)
+    _wgrad(dr3, r2, ops.w2d(G["fc2.0.weight"]), M, C, 2 * C, 1, a2.scale, a2.shift, ACT_RELU)
     # grouped conv (+BN+ReLU), input = u
     # (the BatchNorm-backward apply is evaluated on the backward-data GEMM's operand load where the shape allows: ops.py)
     dr2, du, _ = ops.bn_backward_linear_bwd_data(dv, r2, a2, ACT_RELU, G[pre + "1.weight"], G[pre + "1.bias"], part2,
                                                  ops.w2d(P[pre + "0.weight"]), M, C // 2, C // 2, 4, site=ops.SITE_GCONV)
     _bias_grad_before_bn(dr2, G[pre + "0.bias"])
-    ops.linear_bwd_weight(dr2, u, ops.w2d(G[pre + "0.weight"]), M, C // 2, C // 2, 4)
+    _wgrad(dr2, u, ops.w2d(G[pre + "0.weight"]), M, C // 2, C // 2, 4)
     # max-relative aggregation: route to arg-max neighbour and centre; kNN itself carries no gradient
     # (bf16 storage: the launch also emits the backward column sums of fc1's BatchNorm, one row per clip — no reduce launch)
     dy, part1 = ops.mr_aggregate_bwd(du, idx, amax, B, N, C, bn=(r1, a1, ACT_NONE))
@@ -296,7 +352,7 @@ def grapher_backward(dx1: Tensor, P, S, G) -> Tensor:
                                                      ops.w2d(P["fc1.0.weight"]), M, C, C, 1, addend=dx1, bn=_link_in(S) or False,
                                                      site=ops.SITE_FC1)
     _bias_grad_before_bn(dr1, G["fc1.0.bias"])
-    ops.linear_bwd_weight(dr1, x0, ops.w2d(G["fc1.0.weight"]), M, C, C)
+    _wgrad(dr1, x0, ops.w2d(G["fc1.0.weight"]), M, C, C)
     _store_partial(S, part)
     return dx0
 
@@ -335,10 +391,10 @@ def ffn_backward(dx2: Tensor, P, S, G) -> Tensor:
     dr5, dh, part4 = ops.bn_backward_linear_bwd_data(dx2, r5, a5, ACT_NONE, G["fc2.1.weight"], G["fc2.1.bias"], _link_partial(S),
                                                      ops.w2d(P["fc2.0.weight"]), M, C, H, 1, bn=(r4, a4, ACT_RELU), site=ops.SITE_FFN2,
                                                      inplace=False)
-    ops.linear_bwd_weight(dr5, r4, ops.w2d(G["fc2.0.weight"]), M, C, H, 1, a4.scale, a4.shift, ACT_RELU)
+    _wgrad(dr5, r4, ops.w2d(G["fc2.0.weight"]), M, C, H, 1, a4.scale, a4.shift, ACT_RELU)
     dr4, dx1, part = ops.bn_backward_linear_bwd_data(dh, r4, a4, ACT_RELU, G["fc1.1.weight"], G["fc1.1.bias"], part4,
                                                      ops.w2d(P["fc1.0.weight"]), M, H, C, 1, addend=dx2, bn=_link_in(S) or False)
-    ops.linear_bwd_weight(dr4, x1, ops.w2d(G["fc1.0.weight"]), M, H, C)
+    _wgrad(dr4, x1, ops.w2d(G["fc1.0.weight"]), M, H, C)
     _store_partial(S, part)
     return dx1
 
@@ -503,10 +559,19 @@ class _BlockFn(torch.autograd.Function):
         P, S, names = ctx.P, ctx.S, ctx.names
         direct = DIRECT_GRADS and all(P[n].grad is not None and P[n].grad.is_contiguous() for n in names)
         G = {n: (P[n].grad if direct else ops.zeros(P[n].shape, P[n].device)) for n in names}
-        dx = ctx.bwd(dout.contiguous(), P, S, G)
+        global _IN_DIRECT_BACKWARD
+        n_def = len(DEFERRED.items)
+        _IN_DIRECT_BACKWARD = direct
+        try:
+            dx = ctx.bwd(dout.contiguous(), P, S, G)
+        finally:
+            _IN_DIRECT_BACKWARD = False
         ctx.S = None
         if direct and GRAD_READY_HOOK is not None:
-            GRAD_READY_HOOK([P[n] for n in names])
+            if len(DEFERRED.items) > n_def:      # this block's gradients are complete only after the deferred phase
+                DEFERRED.hooks.append([P[n] for n in names])
+            else:
+                GRAD_READY_HOOK([P[n] for n in names])
         head = (None, None, None, None, None, None, dx if ctx.x_needs else None)
         return head + tuple(None if direct else G[n] for n in names)
 

@@ -516,6 +516,45 @@ def linear_bwd_weight(dout, x, dw, M, Nout, K, groups=1, in_scale=None, in_shift
         _p(in_scale), _p(in_shift), act_in, dt, _stream()), (M, Nout, K, groups))
 
 
+WGRAD_GROUPED = 1        # 0: the deferred phase issues one nsid_linear_bwd_weight per recorded problem (the gate of round 6: 8.68 ms)
+
+
+def linear_bwd_weight_batch(items) -> None:
+    """the deferred weight-gradient phase (functional.DeferredWgrads): items = [(dout, x, dw, M, Nout, K, groups, in_scale, in_shift,
+    act_in)] in backward order, both views of a layer sharing the same dw. dw += dout^T f(x) for every item.
+    bf16 storage: ONE call of nsid_linear_bwd_weight_grouped — the items that share dw and shape become the two row segments of one
+    problem, the problems of all layers one launch per tile class (csrc/gemm.hip wgrad_grouped_kernel)."""
+    if not items:
+        return
+    from ._lib import WgradProblem
+    import ctypes
+    if not WGRAD_GROUPED or any(it[0].dtype != torch.bfloat16 or it[1].dtype != torch.bfloat16 for it in items):
+        for it in items:
+            linear_bwd_weight(*it)
+        return
+    probs, open_ = [], {}           # open_: (dw pointer, shape) -> a problem that still has a free second segment
+    flops = nbytes = 0.0
+    for dout, x, dw, M, Nout, K, groups, in_scale, in_shift, act_in in items:
+        _chk(dw, in_scale, in_shift)
+        _act(dout, x)
+        flops += 2.0 * M * Nout * K * groups
+        nbytes += groups * 2.0 * M * (Nout + K)
+        key = (dw.data_ptr(), M, Nout, K, groups, dout.shape[-1], x.shape[-1], act_in, in_scale is None)
+        q = open_.pop(key, None)
+        if q is None:
+            q = WgradProblem()
+            q.dout[0], q.x[0], q.in_scale[0], q.in_shift[0] = _p(dout), _p(x), _p(in_scale), _p(in_shift)
+            q.dw, q.ldd, q.ldx, q.M, q.Nout, q.K, q.groups, q.act_in = _p(dw), dout.shape[-1], x.shape[-1], M, Nout, K, groups, act_in
+            probs.append(q)
+            open_[key] = q
+            nbytes += 4.0 * groups * Nout * K
+        else:
+            q.dout[1], q.x[1], q.in_scale[1], q.in_shift[1] = _p(dout), _p(x), _p(in_scale), _p(in_shift)
+    arr = (WgradProblem * len(probs))(*probs)
+    _timed("wgrad_grouped_kernel", flops, nbytes, lambda: call(
+        "nsid_linear_bwd_weight_grouped", ctypes.addressof(arr), len(probs), BF16, _stream()), (len(items), len(probs), 0, 1))
+
+
 def colsum_acc(x, out) -> None:
     _chk(out)
     _tk("colsum_atomic_kernel", float(x.element_size()) * x.numel(), lambda: call(

@@ -224,6 +224,33 @@ def test_bf16_extraction_of_512_reference_clips_in_one_micro_batch(golden, resto
     assert float(cos.min()) >= 0.999
 
 
+@pytest.mark.parametrize("N,C", [(256, 64), (128, 128), (64, 256), (32, 512)])
+def test_knn_kernels_of_the_k5_training_default_at_the_timed_batch(N, C, restore_mode):
+    """train.py:46 trains with --k 5 (bench.py times it as config2_k5_ms_per_step): the search kernel of
+    every stage at B = 256, bf16 features as stored WITH the pending BatchNorm affine of Grapher.fc1 (the training-mode call,
+    functional.grapher_forward), against an fp64 ranking of the same normalised values (torch_edge.py:70-103, 270-284)"""
+    from neuralsampleid_amd import ops
+    from synth import synth_randn
+    B, k = 256, 5
+    r = synth_randn(f"k5knn{N}{C}", B * N, C).to(DEV).to(torch.bfloat16)
+    scale = (1.0 + 0.25 * synth_randn(f"k5sc{C}", C)).abs().to(DEV).contiguous()
+    shift = (0.3 * synth_randn(f"k5sh{C}", C)).to(DEV).contiguous()
+    ops.launch_counters(reset=True)
+    idx = ops.knn_graph(r, B, N, C, k, 1, ops.BNAffine(scale, shift)).long().cpu()
+    cnt = ops.launch_counters()
+    assert cnt["knn2"] == 1 and cnt["knn2_raw"] == 0, cnt
+    y = (r.double() * scale.double() + shift.double()).reshape(B, N, C).cpu()
+    y = y / y.norm(dim=2, keepdim=True).clamp_min(1e-12)
+    sq = (y * y).sum(2)
+    D = sq[:, :, None] - 2.0 * torch.bmm(y, y.transpose(1, 2)) + sq[:, None, :]
+    Ds, order = torch.sort(D, dim=2, stable=True)
+    gaps = (Ds[:, :, 1:k + 1] - Ds[:, :, :k]).min(dim=2).values
+    clear = gaps > 2e-6
+    assert float(clear.float().mean()) > 0.9
+    bad = int((clear & ~(idx == order[:, :, :k]).all(dim=2)).sum())
+    assert bad == 0, f"{bad} clear rows differ from the fp64 ranking"
+
+
 @pytest.mark.parametrize("N,C,k,d", [(256, 64, 18, 1), (128, 128, 18, 2), (64, 256, 18, 3), (32, 512, 18, 1), (256, 64, 3, 1), (128, 128, 3, 1)])
 def test_knn_kernels_of_the_deep_plan_at_the_timed_batch(N, C, k, d, restore_mode):
     """the search kernels bench.py --deep (and the default step) launch, at B = 256, bf16 features as stored: on every row whose first
