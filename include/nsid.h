@@ -161,7 +161,10 @@ typedef struct nsid_wgrad_problem {
   float* dw;
   int ldd, ldx, M, Nout, K, groups, act_in, reserved;
 } nsid_wgrad_problem;
-int nsid_linear_bwd_weight_grouped(const nsid_wgrad_problem* problems, int n, int act_dtype, void* stream);
+int nsid_linear_bwd_weight_grouped(const nsid_wgrad_problem* problems, int n, int act_dtype,
+                                   int max_workgroups /* 0: one workgroup per work item; > 0: at most this many, each walking several
+                                                         items: a launch that runs beside other kernels of the step */,
+                                   void* stream);
 /* out[c] += sum_m x[m, c]  (bias gradients) */
 int nsid_colsum_acc(const void* x, int ldx, int M, int C, float* out, int dtype, void* stream);
 

@@ -21,7 +21,7 @@ SIGNATURES = {
     "nsid_linear_bwd_data": "pipipipiiiiiis",
     "nsid_linear_bwd_data_bn": "pipipipiiiiiipppppips",
     "nsid_linear_bwd_weight": "pipipiiiippiis",
-    "nsid_linear_bwd_weight_grouped": "piis",
+    "nsid_linear_bwd_weight_grouped": "piiis",
     "nsid_colsum_acc": "piiipis",
     "nsid_bn_finalize": "piiipppppffpppps",
     "nsid_bn_finalize_deferred": "piiippfppppps",

@@ -887,50 +887,23 @@ void gemm_kernel(const GemmArgs p) {
 // travels in the kernel arguments (nothing is retained, the launch is capturable), both views of a layer are two row SEGMENTS of one
 // problem (a split lies in one segment: the body's loop is untouched), and because the union of the problems fills the chip each
 // problem needs only rows / wgg_rows splits: a quarter of the atomic bytes of the per-layer launches.
-constexpr int WGG_MAXP = 28;           // 8 + 116 + 28 x 120 bytes of explicit arguments + 256 hidden: under the 4 KB of a kernel-argument segment
-struct WgProb {                 // 120 bytes
-  const void* A[2];             // dout of the two row segments (views); [1] unused when seg_splits == nsplit
-  const void* B[2];             // x
-  const float* bsc[2];          // producer affine of x per segment (or null)
-  const float* bsh[2];
-  float* C;                     // dw [groups][I][J]
-  int lda, ldb, I, J, R;        // R = rows of ONE segment
-  int groups, rchunk;           // rows per split
-  int seg_splits, nsplit;       // splits of segment 0, splits in all
-  int tiles, nwg;               // output tiles per group; workgroups of this problem (the next problem starts at a multiple of 8)
-  float slope;
-};
-struct WgGroupArgs {
-  int n, pad;
-  int wg0[WGG_MAXP + 1];
-  WgProb prob[WGG_MAXP];
-};
-static_assert(sizeof(WgProb) == 120 && sizeof(WgGroupArgs) <= 4096, "the problem table travels in the kernel arguments");
+template <int BM, int BN, bool FULL>
+__device__ __forceinline__ void wgrad_grouped_item(const WgGroupArgs& ga, const int w);
 
+// The grid is min(workgroups of all problems, cap): with a cap a workgroup walks the items b, b + grid, b + 2 grid, ... (a static
+// schedule: no counter, every workgroup reaches its exit). A capped launch runs BESIDE the two backward chains of a step (one
+// workgroup per CU leaves the other view's kernels their LDS and wave slots); the final, uncapped one has the chip to itself.
 template <int BM, int BN, bool FULL>
 __global__ __launch_bounds__(256, FULL ? 1 : 2) void wgrad_grouped_kernel(const WgGroupArgs ga) {
-  const int w = blockIdx.x;
-  int pi = 0;
-  for (int i = 1; i < ga.n; ++i) pi += (w >= ga.wg0[i]) ? 1 : 0;          // uniform: scalar loads and compares
-  pi = __builtin_amdgcn_readfirstlane(pi);
+  const int total = ga.wg0[ga.n];
+  for (int w = blockIdx.x; w < total; w += gridDim.x) wgrad_grouped_item<BM, BN, FULL>(ga, w);
+}
+
+template <int BM, int BN, bool FULL>
+__device__ __forceinline__ void wgrad_grouped_item(const WgGroupArgs& ga, const int w) {
+  int pi, split, bid, g, seg;
+  if (!wgg_decode(ga, w, pi, split, bid, g, seg)) return;
   const WgProb& q = ga.prob[pi];
-  const int l = w - ga.wg0[pi];
-  if (l >= q.nwg) return;
-  // workgroup -> (split, tile): the tiles of one split read the same rows of both operands, so they go to ONE XCD (workgroup w is
-  // dispatched to XCD w % 8, and every problem starts at a multiple of 8)
-  const int S = q.nsplit;
-  int split, rest;
-  if (S < 8 && (8 % S) == 0) {
-    const int x = l & 7, per = 8 / S;
-    split = x % S;
-    rest = (l >> 3) * per + x / S;
-  } else {
-    split = l % S;
-    rest = l / S;
-  }
-  if (rest >= q.tiles * q.groups) return;
-  const int g = rest / q.tiles, bid = rest % q.tiles;
-  const int seg = split >= q.seg_splits ? 1 : 0;
   GemmArgs p{};
   p.A = q.A[seg]; p.lda = q.lda; p.a_goff = q.I;
   p.B = q.B[seg]; p.ldb = q.ldb; p.b_goff = q.J;
@@ -940,7 +913,9 @@ __global__ __launch_bounds__(256, FULL ? 1 : 2) void wgrad_grouped_kernel(const 
   p.a_slope = 1.f; p.bn_slope = 1.f;
   p.atomic_out = 1;
   p.rchunk = q.rchunk; p.rsplit = q.nsplit;
-  gemm_body<BM, BN, false, false, true, true, false, false, FULL, false, FULL ? 2 : 1, FULL ? 2 : 0>(p, bid, split - seg * q.seg_splits, g);
+  gemm_body<BM, BN, false, false, true, true, false, false, FULL, false, FULL ? 2 : 1, FULL ? 2 : 0>(p, bid, split, g);
+  // (the body's reduction loop ends with a workgroup barrier behind the last fragment reads and its atomic epilogue does not touch
+  // LDS: the next item of a capped launch may stage its first operands right away)
 }
 
 // ELU of the projector (simclr/simclr.py:26) runs as its own in-place pass: expm1f inlined into the fully unrolled
@@ -1513,18 +1488,33 @@ extern "C" int nsid_linear_bwd_weight(const void* dout, int ldd, const void* x, 
 }
 
 // Many weight gradients in one launch per tile class (see wgrad_grouped_kernel). problems[i].dout[1] / x[1] NULL: one row segment.
-extern "C" int nsid_linear_bwd_weight_grouped(const nsid_wgrad_problem* problems, int n, int act_dtype, void* stream) {
-  NSID_REQUIRE(problems && n > 0 && act_dtype == NSID_BF16);
+extern "C" int nsid_linear_bwd_weight_grouped(const nsid_wgrad_problem* problems, int n, int act_dtype, int max_workgroups,
+                                              void* stream) {
+  NSID_REQUIRE(problems && n > 0 && act_dtype == NSID_BF16 && max_workgroups >= 0);
   hipStream_t s = static_cast<hipStream_t>(stream);
   const long rows_target = std::max<long>(128, nsid_tune(NSID_T_wgg_rows));
-  // three classes: 0 = 128x64 full tiles (64-deep stages), 1 = 64x64 full tiles, 2 = 64x64 predicated (any shape)
-  WgGroupArgs ga[3];
-  long wgs[3] = {0, 0, 0};
-  for (int c = 0; c < 3; ++c) ga[c].n = 0;
+  const long rows_sq = std::max<long>(128, nsid_tune(NSID_T_wgg_rows_sq)), rows_gen = std::max<long>(32, nsid_tune(NSID_T_wgg_rows_gen));
+  const bool use_w3 = nsid_tune(NSID_T_wgg_w3) != 0;
+  // classes: 0 = 128x64 full tiles (64-deep stages), 1 = 64x64 full tiles, 2 = 64x64 predicated (any shape),
+  //          3 / 4 = 128x128 tiles, 8 waves (wgrad.hip), without / with the producer affine on x
+  constexpr int NCLS = 5;
+  WgGroupArgs ga[NCLS];
+  long wgs[NCLS] = {0, 0, 0, 0, 0};
+  for (int c = 0; c < NCLS; ++c) ga[c].n = 0;
   auto flush = [&](int c) -> int {
     if (ga[c].n == 0) return NSID_OK;
     ga[c].wg0[ga[c].n] = (int)wgs[c];
-    const dim3 grid((unsigned)wgs[c]), block(256);
+    long gsz = wgs[c];
+    if (max_workgroups > 0 && gsz > max_workgroups) gsz = std::max(8, max_workgroups / 8 * 8);     // (a multiple of 8: item w stays on XCD w % 8)
+    const dim3 grid((unsigned)gsz), block(256);
+    if (c >= 3) {
+      nsid_count(NSID_C_wgrad_grouped);
+      nsid_count(NSID_C_wgrad_grouped_w3);
+      const int rc3 = nsid_wgrad3_grouped_launch(ga[c], (int)gsz, c == 4, s);
+      ga[c].n = 0;
+      wgs[c] = 0;
+      return rc3;
+    }
     if (c == 0) NSID_LAUNCH((wgrad_grouped_kernel<128, 64, true>), grid, block, 0, s, ga[c]);
     else if (c == 1) NSID_LAUNCH((wgrad_grouped_kernel<64, 64, true>), grid, block, 0, s, ga[c]);
     else NSID_LAUNCH((wgrad_grouped_kernel<64, 64, false>), grid, block, 0, s, ga[c]);
@@ -1546,8 +1536,10 @@ extern "C" int nsid_linear_bwd_weight_grouped(const nsid_wgrad_problem* problems
       NSID_REQUIRE(q.in_scale[v] == nullptr || (nsid_aligned16(q.in_scale[v]) && nsid_aligned16(q.in_shift[v])));
     }
     const bool rows_ok = q.M % 128 == 0;
-    const int cls = (rows_ok && q.Nout % 128 == 0 && q.K % 64 == 0) ? 0 : ((rows_ok && q.Nout % 64 == 0 && q.K % 64 == 0) ? 1 : 2);
-    const int bm = cls == 0 ? 128 : 64;
+    int cls = (rows_ok && q.Nout % 128 == 0 && q.K % 64 == 0) ? 0 : ((rows_ok && q.Nout % 64 == 0 && q.K % 64 == 0) ? 1 : 2);
+    if (cls == 0 && use_w3 && q.K % 128 == 0) cls = q.in_scale[0] != nullptr ? 4 : 3;
+    const int bm = cls == 1 || cls == 2 ? 64 : 128, bn = cls >= 3 ? 128 : 64;
+    const long rows_cls = cls == 1 ? rows_sq : (cls == 2 ? rows_gen : rows_target);
     WgProb w{};
     for (int v = 0; v < 2; ++v) {
       w.A[v] = q.dout[v]; w.B[v] = q.x[v]; w.bsc[v] = q.in_scale[v]; w.bsh[v] = q.in_shift[v];
@@ -1555,17 +1547,17 @@ extern "C" int nsid_linear_bwd_weight_grouped(const nsid_wgrad_problem* problems
     w.C = q.dw; w.lda = q.ldd; w.ldb = q.ldx; w.I = q.Nout; w.J = q.K; w.R = q.M; w.groups = q.groups;
     w.slope = act_slope(q.act_in);
     long S = 1;                                  // splits per segment: rows / wgg_rows, whole 128-row multiples each
-    if (cls < 2) {
-      while (q.M % (2 * S) == 0 && (q.M / (2 * S)) % 128 == 0 && q.M / (2 * S) >= rows_target) S *= 2;
+    if (cls != 2) {
+      while (q.M % (2 * S) == 0 && (q.M / (2 * S)) % 128 == 0 && q.M / (2 * S) >= rows_cls) S *= 2;
       w.rchunk = (int)(q.M / S);
     } else {
-      S = std::max<long>(1, (q.M + rows_target - 1) / rows_target);
+      S = std::max<long>(1, (q.M + rows_cls - 1) / rows_cls);
       w.rchunk = (int)(((q.M + S - 1) / S + 31) / 32 * 32);
       S = (q.M + w.rchunk - 1) / w.rchunk;
     }
     w.seg_splits = (int)S;
     w.nsplit = (int)S * nseg;
-    w.tiles = ((q.Nout + bm - 1) / bm) * ((q.K + 63) / 64);
+    w.tiles = ((q.Nout + bm - 1) / bm) * ((q.K + bn - 1) / bn);
     const long tg = (long)w.tiles * q.groups;
     long nwg = tg * w.nsplit;
     if (w.nsplit < 8 && 8 % w.nsplit == 0) nwg = (tg + 8 / w.nsplit - 1) / (8 / w.nsplit) * 8;
@@ -1579,7 +1571,7 @@ extern "C" int nsid_linear_bwd_weight_grouped(const nsid_wgrad_problem* problems
     ga[cls].prob[ga[cls].n++] = w;
     wgs[cls] += (nwg + 7) / 8 * 8;
   }
-  for (int c = 0; c < 3; ++c) {
+  for (int c = 0; c < NCLS; ++c) {
     const int rc = flush(c);
     if (rc != NSID_OK) return rc;
   }

@@ -170,7 +170,10 @@ static inline bool nsid_aligned16(const void* p) { return (reinterpret_cast<uint
   X(ffn_waves, 8)              /* waves per workgroup of the fused eval-mode FFN (4 or 8) */                                  \
   X(ffn256, 1)                 /* 1: the C = 256 stage's eval-mode FFN as one launch (ffn256_fused.hip); 0: two GEMM launches */ \
   X(mrconv_variant, 3)         /* fused eval-mode aggregation + grouped conv: bit 0 = 8 waves, bit 1 = direct 8-byte stores */ \
-  X(wgg_rows, 8192)            /* rows per workgroup of the grouped (deferred) weight gradients: splits per view = M / wgg_rows */ \
+  X(wgg_rows, 4096)            /* rows per workgroup of the grouped (deferred) weight gradients: splits per view = M / wgg_rows (one-box A/B: 1024 / 2048 / 4096 / 8192 / 16384 rows: 7.67 / 7.47 / 7.42 / 7.56 / 7.88 ms) */ \
+  X(wgg_rows_sq, 1024)         /* the same for its 64x64-tile class (the C = 64 layers: few tiles, long row loops) */ \
+  X(wgg_rows_gen, 512)         /* and for its predicated class (stem, the 32-channel grouped conv) */ \
+  X(wgg_w3, 1)                 /* grouped problems with Nout % 128 == 0 and K % 128 == 0 on 128x128 tiles, 8 waves (wgrad.hip) */ \
   X(ws_gemm, 7)                /* weight-stationary streaming GEMMs (wsgemm.hip) for the small-K layers: bit 0 forward, bit 1 backward-data, bit 2 backward-data with the BatchNorm backward on its operand load */
 
 enum NsidTuneKey {
@@ -198,7 +201,7 @@ static inline long nsid_tune(NsidTuneKey k) { return g_nsid_tune[k]; }
   X(gemm_bn_apply_load)   /* backward-data applies a BatchNorm backward on its operand load */  \
   X(gemm256)              /* gemm256.hip */                                                     \
   X(ws_fwd) X(ws_bwd_data) X(ws_bwd_bnapply) /* wsgemm.hip: weight-stationary streaming forms */                   \
-  X(wgrad_rect) X(wgrad_square) X(wgrad3) X(wgrad_grouped)                                                       \
+  X(wgrad_rect) X(wgrad_square) X(wgrad3) X(wgrad_grouped) X(wgrad_grouped_w3)                                                       \
   X(bn_bwd_apply) X(bn_bwd_apply_capped)                                                        \
   X(knn2) X(knn2_pair) X(knn2_raw) X(knn_rank) X(knn_sel) X(knn_strips)                                                  \
   X(mr_fwd_lds) X(mr_fwd_grid) X(mr_fwd_key) X(mr_bwd_sorted)                                                                  \
@@ -213,6 +216,59 @@ enum NsidCounterKey {
 };
 extern long g_nsid_counter[NSID_C_COUNT];
 static inline void nsid_count(NsidCounterKey k) { ++g_nsid_counter[k]; }
+
+// ---- grouped weight gradients (gemm.hip wgrad_grouped_kernel, wgrad.hip wgrad3_grouped_kernel): the table of problems one launch
+// serves, carried in the kernel arguments
+constexpr int WGG_MAXP = 28;           // 8 + 116 + 28 x 120 bytes of explicit arguments + 256 hidden: under the 4 KB of a kernel-argument segment
+struct WgProb {                 // 120 bytes
+  const void* A[2];             // dout of the two row segments (views); [1] unused when seg_splits == nsplit
+  const void* B[2];             // x
+  const float* bsc[2];          // producer affine of x per segment (or null)
+  const float* bsh[2];
+  float* C;                     // dw [groups][I][J]
+  int lda, ldb, I, J, R;        // R = rows of ONE segment
+  int groups, rchunk;           // rows per split
+  int seg_splits, nsplit;       // splits of segment 0, splits in all
+  int tiles, nwg;               // output tiles per group; workgroups of this problem (the next problem starts at a multiple of 8)
+  float slope;
+};
+struct WgGroupArgs {
+  int n, pad;
+  int wg0[WGG_MAXP + 1];
+  WgProb prob[WGG_MAXP];
+};
+static_assert(sizeof(WgProb) == 120 && sizeof(WgGroupArgs) <= 4096, "the problem table travels in the kernel arguments");
+
+
+// workgroup item w of a grouped launch -> problem pi, split (inside its row segment seg), output tile bid, group g; false: padding.
+// The tiles of one split read the same rows of both operands, so they go to ONE XCD (item w runs on XCD w % 8 and every problem
+// starts at a multiple of 8).
+__device__ __forceinline__ bool wgg_decode(const WgGroupArgs& ga, const int w, int& pi, int& split, int& bid, int& g, int& seg) {
+  pi = 0;
+  for (int i = 1; i < ga.n; ++i) pi += (w >= ga.wg0[i]) ? 1 : 0;          // uniform: scalar loads and compares
+  pi = __builtin_amdgcn_readfirstlane(pi);
+  const WgProb& q = ga.prob[pi];
+  const int l = w - ga.wg0[pi];
+  if (l >= q.nwg) return false;
+  const int S = q.nsplit;
+  int rest;
+  if (S < 8 && (8 % S) == 0) {
+    const int x = l & 7, per = 8 / S;
+    split = x % S;
+    rest = (l >> 3) * per + x / S;
+  } else {
+    split = l % S;
+    rest = l / S;
+  }
+  if (rest >= q.tiles * q.groups) return false;
+  g = rest / q.tiles;
+  bid = rest % q.tiles;
+  seg = split >= q.seg_splits ? 1 : 0;
+  split -= seg * q.seg_splits;
+  return true;
+}
+// wgrad.hip: the 8-wave 128x128-tile form of a grouped launch (Nout % 128 == 0, K % 128 == 0, whole 128-row chunks)
+int nsid_wgrad3_grouped_launch(const WgGroupArgs& ga, int grid, bool affine, hipStream_t stream);
 
 // wgrad.hip: 128x128-tile form of the bf16 weight-gradient GEMM; returns 1 when the shape is outside its preconditions
 int nsid_wgrad2_launch(const void* dout, int ldd, const void* x, int ldx, float* dw, int M, int Nout, int K, int groups,

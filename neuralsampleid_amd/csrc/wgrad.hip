@@ -87,15 +87,13 @@ __device__ __forceinline__ bf16x8 w3_frag(const char* lds, int row0, int col0, i
 }
 
 template <bool BAFF>
-__global__ __launch_bounds__(W3_THREADS, 2) void wgrad3_kernel(const WgArgs p) {
+__device__ __forceinline__ void wgrad3_body(const WgArgs& p, const int split, const int tile, const int g) {
   __shared__ __attribute__((aligned(16))) char lds_raw[W3_LDS];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int lr = lane & 15, rq = lane >> 4;
   const int quad = wave & 3, half = wave >> 2;
   const int wm0 = (quad >> 1) * 64, wn0 = (quad & 1) * 64;
-  const int split = blockIdx.x;
-  const int ti = blockIdx.y / p.tiles_j, tj = blockIdx.y % p.tiles_j;
-  const int g = blockIdx.z;
+  const int ti = tile / p.tiles_j, tj = tile % p.tiles_j;
   const int i0 = ti * W3_T, j0 = tj * W3_T;
   const char* A = reinterpret_cast<const char*>(p.A + g * p.a_goff + i0);
   const char* B = reinterpret_cast<const char*>(p.B + g * p.b_goff + j0);
@@ -174,7 +172,40 @@ __global__ __launch_bounds__(W3_THREADS, 2) void wgrad3_kernel(const WgArgs p) {
   }
 }
 
+template <bool BAFF>
+__global__ __launch_bounds__(W3_THREADS, 2) void wgrad3_kernel(const WgArgs p) {
+  wgrad3_body<BAFF>(p, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// many problems in one launch (nsid_linear_bwd_weight_grouped, see gemm.hip wgrad_grouped_kernel): the same body, its problem from the
+// table in the kernel arguments. In the deferred phase of a step nothing else runs, so the 8-wave workgroup with 78 KB of LDS -- which
+// loses inside the two-stream chains because it owns its CU -- is the form to use: a third fewer L2 -> LDS bytes per flop than 128x64.
+template <bool BAFF>
+__global__ __launch_bounds__(W3_THREADS, 2) void wgrad3_grouped_kernel(const WgGroupArgs ga) {
+  const int total = ga.wg0[ga.n];
+  for (int w = blockIdx.x; w < total; w += gridDim.x) {
+    int pi, split, bid, g, seg;
+    if (wgg_decode(ga, w, pi, split, bid, g, seg)) {
+      const WgProb& q = ga.prob[pi];
+      WgArgs p;
+      p.A = static_cast<const __bf16*>(q.A[seg]); p.lda = q.lda; p.a_goff = q.I;
+      p.B = static_cast<const __bf16*>(q.B[seg]); p.ldb = q.ldb; p.b_goff = q.J;
+      p.C = q.C; p.ldc = q.J; p.c_goff = (long)q.I * q.J;
+      p.R = q.R; p.rchunk = q.rchunk; p.tiles_j = q.J / W3_T;
+      p.b_scale = q.bsc[seg]; p.b_shift = q.bsh[seg]; p.b_slope = q.slope; p.b_aff_goff = q.J;
+      wgrad3_body<BAFF>(p, split, bid, g);
+    }
+    if (gridDim.x < total) __syncthreads();       // a capped launch: the epilogue's LDS scratch is read before the next item stages
+  }
+}
+
 }  // namespace
+
+int nsid_wgrad3_grouped_launch(const WgGroupArgs& ga, int grid, bool affine, hipStream_t stream) {
+  if (affine) NSID_LAUNCH((wgrad3_grouped_kernel<true>), dim3(grid), dim3(W3_THREADS), 0, stream, ga);
+  else NSID_LAUNCH((wgrad3_grouped_kernel<false>), dim3(grid), dim3(W3_THREADS), 0, stream, ga);
+  return nsid_launch_status();
+}
 
 // returns NSID_OK when launched, 1 when the shape is outside this kernel's preconditions (the caller then runs the
 // first form), or an error code

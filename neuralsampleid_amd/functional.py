@@ -156,33 +156,85 @@ GRAD_READY_HOOK = None
 # References: the backward of every conv at encoder/gcn_lib/torch_vertex.py:152-162, encoder/graph_encoder.py:74-77,
 # encoder/gcn_lib/torch_nn.py:56; train.py:70-75.
 DEFER_WGRAD = 0
+# Two-stream steps only: which stage boundaries of backward (1 = behind the last Downsample's backward, i.e. stage 4 done in that view,
+# 2 = stages 4-3, 3 = stages 4-2) FORK the problems recorded so far onto an auxiliary stream as soon as BOTH views have passed them: the
+# grouped launch then runs beside the remaining backward of the two views instead of behind it. Capped at DEFER_FORK_WGS workgroups (one
+# per CU: the chains keep their LDS and wave slots). Three live streams (+ the communicator's under data parallelism): inside the four
+# hardware queues (docs/experiments.md, round 3).
+# DEFER_FORK_AT: the boundaries as decimal digits (2, 12, 123; 0 = no fork).
+DEFER_FORK_AT = 2
+DEFER_FORK_WGS = 256
 
 
 class DeferredWgrads:
     def __init__(self):
         self.items, self.hooks, self.armed = [], [], False
         self.verify = None      # tests: a list that receives (dw, the same sum through the per-layer launches) for every layer of a flush
+        self.crossed, self.events, self.aux = {}, {}, None
 
     def add(self, dout, x, dw, M, Nout, K, groups, in_scale, in_shift, act_in):
-        self.items.append((dout, x, dw, M, Nout, K, groups, in_scale, in_shift, act_in))
+        stage = self.crossed.get(torch.cuda.current_stream().cuda_stream, 0)      # boundaries this view's backward has passed
+        self.items.append((stage, (dout, x, dw, M, Nout, K, groups, in_scale, in_shift, act_in)))
         if not self.armed:
             self.armed = True
             torch.autograd.Variable._execution_engine.queue_callback(self.flush)
 
-    def flush(self):
-        """runs on the thread that called backward(), once every backward node has been enqueued"""
-        self.armed = False
-        items, hooks, self.items, self.hooks = self.items, self.hooks, [], []
+    def note_hook(self, params):
+        self.hooks.append((self.crossed.get(torch.cuda.current_stream().cuda_stream, 0), params))
+
+    def boundary(self):
+        """end of a Downsample's backward on the current stream (= in this view)"""
+        if not self.armed:
+            return
+        st = torch.cuda.current_stream()
+        c = self.crossed[st.cuda_stream] = self.crossed.get(st.cuda_stream, 0) + 1
+        if str(c) not in str(int(DEFER_FORK_AT)) or not SIDE_STREAMS:
+            return
+        ev = torch.cuda.Event()
+        ev.record(st)
+        evs = self.events.setdefault(c, {})
+        evs[st.cuda_stream] = ev
+        if len(evs) < 2:
+            return
+        # both views are past boundary c: everything recorded in front of it goes out now, beside the rest of backward
+        if self.aux is None:
+            self.aux = torch.cuda.Stream(device=st.device)
+            SIDE_STREAMS.append(self.aux)
+        for e in evs.values():
+            self.aux.wait_event(e)
+        ready = [it for stage, it in self.items if stage < c]
+        self.items = [(stage, it) for stage, it in self.items if stage >= c]
+        hooks = [h for stage, h in self.hooks if stage < c]
+        self.hooks = [(stage, h) for stage, h in self.hooks if stage >= c]
+        with torch.cuda.stream(self.aux):
+            self._issue(ready, DEFER_FORK_WGS)
+            if GRAD_READY_HOOK is not None:
+                for params in hooks:
+                    GRAD_READY_HOOK(params)
+
+    def _issue(self, items, max_wgs):
         if not items:
             return
-        join_side_streams()
-        ops.linear_bwd_weight_batch(items)
+        for it in items:                   # the launch reads tensors that were produced on the view streams
+            it[0].record_stream(torch.cuda.current_stream())
+            it[1].record_stream(torch.cuda.current_stream())
+        ops.linear_bwd_weight_batch(items, max_wgs)
         if self.verify is not None:     # tests: the same problems through the per-layer launches, from the tensors as they are NOW
             tmp = {}
             for it in items:
                 t = tmp.setdefault(it[2].data_ptr(), (it[2], torch.zeros_like(it[2])))[1]
                 ops.linear_bwd_weight(it[0], it[1], t, *it[3:])
             self.verify.extend((dw, t) for dw, t in tmp.values())
+
+    def flush(self):
+        """runs on the thread that called backward(), once every backward node has been enqueued"""
+        self.armed = False
+        items, hooks, self.items, self.hooks = [it for _, it in self.items], [h for _, h in self.hooks], [], []
+        self.crossed, self.events = {}, {}
+        if not items and not hooks:
+            return
+        join_side_streams()
+        self._issue(items, 0)
         if GRAD_READY_HOOK is not None:
             for params in hooks:
                 GRAD_READY_HOOK(params)
@@ -447,6 +499,12 @@ def downsample_forward(x: Tensor, P, S: Optional[dict], B: int, N: int, training
 
 
 def downsample_backward(dout: Tensor, P, S, G) -> Tensor:
+    dx = _downsample_backward(dout, P, S, G)
+    DEFERRED.boundary()                 # a stage of this view's backward is complete
+    return dx
+
+
+def _downsample_backward(dout: Tensor, P, S, G) -> Tensor:
     col, x, wp, r, aff, B, N, C = (S[k_] for k_ in ("col", "x", "wp", "r", "aff", "B", "N", "C"))
     Mo, Co = r.shape
     dr = ops.bn_backward(dout, r, aff, ACT_NONE, G["conv.1.weight"], G["conv.1.bias"], partial=_link_partial(S))
@@ -569,7 +627,7 @@ class _BlockFn(torch.autograd.Function):
         ctx.S = None
         if direct and GRAD_READY_HOOK is not None:
             if len(DEFERRED.items) > n_def:      # this block's gradients are complete only after the deferred phase
-                DEFERRED.hooks.append([P[n] for n in names])
+                DEFERRED.note_hook([P[n] for n in names])
             else:
                 GRAD_READY_HOOK([P[n] for n in names])
         head = (None, None, None, None, None, None, dx if ctx.x_needs else None)

@@ -519,11 +519,12 @@ def linear_bwd_weight(dout, x, dw, M, Nout, K, groups=1, in_scale=None, in_shift
 WGRAD_GROUPED = 1        # 0: the deferred phase issues one nsid_linear_bwd_weight per recorded problem (the gate of round 6: 8.68 ms)
 
 
-def linear_bwd_weight_batch(items) -> None:
+def linear_bwd_weight_batch(items, max_workgroups: int = 0) -> None:
     """the deferred weight-gradient phase (functional.DeferredWgrads): items = [(dout, x, dw, M, Nout, K, groups, in_scale, in_shift,
     act_in)] in backward order, both views of a layer sharing the same dw. dw += dout^T f(x) for every item.
     bf16 storage: ONE call of nsid_linear_bwd_weight_grouped — the items that share dw and shape become the two row segments of one
-    problem, the problems of all layers one launch per tile class (csrc/gemm.hip wgrad_grouped_kernel)."""
+    problem, the problems of all layers one launch per tile class (csrc/gemm.hip wgrad_grouped_kernel).
+    max_workgroups > 0: a launch that runs beside the backward chains (at most that many workgroups, each walking several items)."""
     if not items:
         return
     from ._lib import WgradProblem
@@ -552,7 +553,8 @@ def linear_bwd_weight_batch(items) -> None:
             q.dout[1], q.x[1], q.in_scale[1], q.in_shift[1] = _p(dout), _p(x), _p(in_scale), _p(in_shift)
     arr = (WgradProblem * len(probs))(*probs)
     _timed("wgrad_grouped_kernel", flops, nbytes, lambda: call(
-        "nsid_linear_bwd_weight_grouped", ctypes.addressof(arr), len(probs), BF16, _stream()), (len(items), len(probs), 0, 1))
+        "nsid_linear_bwd_weight_grouped", ctypes.addressof(arr), len(probs), BF16, int(max_workgroups), _stream()),
+        (len(items), len(probs), 0, 1))
 
 
 def colsum_acc(x, out) -> None:
