@@ -151,7 +151,8 @@ int nsid_linear_bwd_weight(const void* dout, int ldd, const void* x, int ldx, fl
  * encoder/graph_encoder.py:74-77 and gcn_lib/torch_nn.py:56 record their problem during backward and issue all of them here).
  * Problem i: dw += sum over its row segments v of dout[v]^T f_v(x[v]) with f_v = act_in(in_scale[v] * x + in_shift[v]) (in_scale[v] NULL:
  * identity; both segments with or without). The two segments are the two views of a contrastive step: the same layer, M rows each,
- * the same leading dimensions; dout[1] = x[1] = NULL: one segment. bf16 activations only (NSID_EINVAL otherwise). The problem table is
+ * the same leading dimensions; dout[1] = x[1] = NULL: one segment. act_dtype: the storage of every dout / x of the call (fp32: the
+ * projector head's tensors; the tile classes with 64-deep stages exist for bf16 only). The problem table is
  * copied into the kernel arguments: the array may be freed as soon as the call returns, the launch is capturable. */
 typedef struct nsid_wgrad_problem {
   const void* dout[2];
@@ -159,7 +160,11 @@ typedef struct nsid_wgrad_problem {
   const float* in_scale[2];
   const float* in_shift[2];
   float* dw;
-  int ldd, ldx, M, Nout, K, groups, act_in, reserved;
+  int ldd, ldx, M, Nout, K, groups, act_in;
+  int ds_out_nodes;   /* 0: a plain row GEMM. > 0: the packed weight gradient of a Downsample (Conv2d 3x3 s2 p1 on a width-1 map,
+                         encoder/graph_encoder.py:44): x[v] is its (B*N, K/3) input, read as the zero-padded 3-tap view of
+                         nsid_downsample3_bwd_weight, dout[v] its (M = B*N/2, Nout) output gradient, dw the packed (Nout, K) gradient,
+                         ds_out_nodes = N/2; ldx = K/3, groups = 1, no affine */
 } nsid_wgrad_problem;
 int nsid_linear_bwd_weight_grouped(const nsid_wgrad_problem* problems, int n, int act_dtype,
                                    int max_workgroups /* 0: one workgroup per work item; > 0: at most this many, each walking several

@@ -73,7 +73,7 @@ class WgradProblem(ctypes.Structure):
     _fields_ = [("dout", ctypes.c_void_p * 2), ("x", ctypes.c_void_p * 2), ("in_scale", ctypes.c_void_p * 2),
                 ("in_shift", ctypes.c_void_p * 2), ("dw", ctypes.c_void_p), ("ldd", ctypes.c_int), ("ldx", ctypes.c_int),
                 ("M", ctypes.c_int), ("Nout", ctypes.c_int), ("K", ctypes.c_int), ("groups", ctypes.c_int), ("act_in", ctypes.c_int),
-                ("reserved", ctypes.c_int)]
+                ("ds_out_nodes", ctypes.c_int)]
 
 
 _CT = {"p": ctypes.c_void_p, "i": ctypes.c_int, "l": ctypes.c_long, "f": ctypes.c_float, "s": ctypes.c_void_p,

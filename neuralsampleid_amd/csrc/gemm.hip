@@ -887,19 +887,21 @@ void gemm_kernel(const GemmArgs p) {
 // travels in the kernel arguments (nothing is retained, the launch is capturable), both views of a layer are two row SEGMENTS of one
 // problem (a split lies in one segment: the body's loop is untouched), and because the union of the problems fills the chip each
 // problem needs only rows / wgg_rows splits: a quarter of the atomic bytes of the per-layer launches.
-template <int BM, int BN, bool FULL>
+template <int BM, int BN, bool FULL, bool H = true, bool ST = true, int PADX = 0>
 __device__ __forceinline__ void wgrad_grouped_item(const WgGroupArgs& ga, const int w);
 
 // The grid is min(workgroups of all problems, cap): with a cap a workgroup walks the items b, b + grid, b + 2 grid, ... (a static
 // schedule: no counter, every workgroup reaches its exit). A capped launch runs BESIDE the two backward chains of a step (one
 // workgroup per CU leaves the other view's kernels their LDS and wave slots); the final, uncapped one has the chip to itself.
-template <int BM, int BN, bool FULL>
+// H / ST: bf16 MFMA operands / bf16 storage (the projector head keeps fp32 tensors: ST = false; strict fp32 arithmetic: H = false);
+// PADX = 2: x is a Downsample input read as the zero-padded 3-tap view.
+template <int BM, int BN, bool FULL, bool H = true, bool ST = true, int PADX = 0>
 __global__ __launch_bounds__(256, FULL ? 1 : 2) void wgrad_grouped_kernel(const WgGroupArgs ga) {
   const int total = ga.wg0[ga.n];
-  for (int w = blockIdx.x; w < total; w += gridDim.x) wgrad_grouped_item<BM, BN, FULL>(ga, w);
+  for (int w = blockIdx.x; w < total; w += gridDim.x) wgrad_grouped_item<BM, BN, FULL, H, ST, PADX>(ga, w);
 }
 
-template <int BM, int BN, bool FULL>
+template <int BM, int BN, bool FULL, bool H, bool ST, int PADX>
 __device__ __forceinline__ void wgrad_grouped_item(const WgGroupArgs& ga, const int w) {
   int pi, split, bid, g, seg;
   if (!wgg_decode(ga, w, pi, split, bid, g, seg)) return;
@@ -913,7 +915,10 @@ __device__ __forceinline__ void wgrad_grouped_item(const WgGroupArgs& ga, const 
   p.a_slope = 1.f; p.bn_slope = 1.f;
   p.atomic_out = 1;
   p.rchunk = q.rchunk; p.rsplit = q.nsplit;
-  gemm_body<BM, BN, false, false, true, true, false, false, FULL, false, FULL ? 2 : 1, FULL ? 2 : 0>(p, bid, split, g);
+  if constexpr (PADX == 2) {
+    p.pad_period = q.pad_period; p.pad_phase = 0; p.pad_c0 = 0; p.pad_c1 = q.pad_c1; p.pad_safe = q.pad_c1;
+  }
+  gemm_body<BM, BN, false, false, H, ST, false, false, FULL, false, FULL ? 2 : 1, FULL ? 2 : 0, false, PADX>(p, bid, split, g);
   // (the body's reduction loop ends with a workgroup barrier behind the last fragment reads and its atomic epilogue does not touch
   // LDS: the next item of a capped launch may stage its first operands right away)
 }
@@ -1490,16 +1495,20 @@ extern "C" int nsid_linear_bwd_weight(const void* dout, int ldd, const void* x, 
 // Many weight gradients in one launch per tile class (see wgrad_grouped_kernel). problems[i].dout[1] / x[1] NULL: one row segment.
 extern "C" int nsid_linear_bwd_weight_grouped(const nsid_wgrad_problem* problems, int n, int act_dtype, int max_workgroups,
                                               void* stream) {
-  NSID_REQUIRE(problems && n > 0 && act_dtype == NSID_BF16 && max_workgroups >= 0);
+  NSID_REQUIRE(problems && n > 0 && NSID_DTYPE_OK(act_dtype) && max_workgroups >= 0);
+  const bool st16 = act_dtype == NSID_BF16;
+  const int ch = st16 ? 8 : 4;
   hipStream_t s = static_cast<hipStream_t>(stream);
   const long rows_target = std::max<long>(128, nsid_tune(NSID_T_wgg_rows));
   const long rows_sq = std::max<long>(128, nsid_tune(NSID_T_wgg_rows_sq)), rows_gen = std::max<long>(32, nsid_tune(NSID_T_wgg_rows_gen));
   const bool use_w3 = nsid_tune(NSID_T_wgg_w3) != 0;
   // classes: 0 = 128x64 full tiles (64-deep stages), 1 = 64x64 full tiles, 2 = 64x64 predicated (any shape),
-  //          3 / 4 = 128x128 tiles, 8 waves (wgrad.hip), without / with the producer affine on x
-  constexpr int NCLS = 5;
+  //          3 / 4 = 128x128 tiles, 8 waves (wgrad.hip), without / with the producer affine on x,
+  //          5 = Downsample (64x64 predicated over the padded 3-tap view of x), 6 = fp32 storage (64x64 predicated; the projector head)
+  constexpr int NCLS = 7;
   WgGroupArgs ga[NCLS];
-  long wgs[NCLS] = {0, 0, 0, 0, 0};
+  long wgs[NCLS] = {0, 0, 0, 0, 0, 0, 0};
+  const bool half = g_gemm_precision == NSID_GEMM_BF16 || st16;
   for (int c = 0; c < NCLS; ++c) ga[c].n = 0;
   auto flush = [&](int c) -> int {
     if (ga[c].n == 0) return NSID_OK;
@@ -1507,7 +1516,7 @@ extern "C" int nsid_linear_bwd_weight_grouped(const nsid_wgrad_problem* problems
     long gsz = wgs[c];
     if (max_workgroups > 0 && gsz > max_workgroups) gsz = std::max(8, max_workgroups / 8 * 8);     // (a multiple of 8: item w stays on XCD w % 8)
     const dim3 grid((unsigned)gsz), block(256);
-    if (c >= 3) {
+    if (c == 3 || c == 4) {
       nsid_count(NSID_C_wgrad_grouped);
       nsid_count(NSID_C_wgrad_grouped_w3);
       const int rc3 = nsid_wgrad3_grouped_launch(ga[c], (int)gsz, c == 4, s);
@@ -1517,7 +1526,10 @@ extern "C" int nsid_linear_bwd_weight_grouped(const nsid_wgrad_problem* problems
     }
     if (c == 0) NSID_LAUNCH((wgrad_grouped_kernel<128, 64, true>), grid, block, 0, s, ga[c]);
     else if (c == 1) NSID_LAUNCH((wgrad_grouped_kernel<64, 64, true>), grid, block, 0, s, ga[c]);
-    else NSID_LAUNCH((wgrad_grouped_kernel<64, 64, false>), grid, block, 0, s, ga[c]);
+    else if (c == 2) NSID_LAUNCH((wgrad_grouped_kernel<64, 64, false>), grid, block, 0, s, ga[c]);
+    else if (c == 5) NSID_LAUNCH((wgrad_grouped_kernel<64, 64, false, true, true, 2>), grid, block, 0, s, ga[c]);
+    else if (half) NSID_LAUNCH((wgrad_grouped_kernel<64, 64, false, true, false>), grid, block, 0, s, ga[c]);
+    else NSID_LAUNCH((wgrad_grouped_kernel<64, 64, false, false, false>), grid, block, 0, s, ga[c]);
     nsid_count(NSID_C_wgrad_grouped);
     ga[c].n = 0;
     wgs[c] = 0;
@@ -1528,7 +1540,10 @@ extern "C" int nsid_linear_bwd_weight_grouped(const nsid_wgrad_problem* problems
     const int nseg = q.dout[1] != nullptr ? 2 : 1;
     NSID_REQUIRE(q.dout[0] && q.x[0] && q.dw && q.M > 0 && q.Nout > 0 && q.K > 0 && q.groups > 0);
     NSID_REQUIRE((q.dout[1] == nullptr) == (q.x[1] == nullptr));
-    NSID_REQUIRE(q.Nout % 8 == 0 && q.K % 8 == 0 && q.ldd % 8 == 0 && q.ldx % 8 == 0);
+    NSID_REQUIRE(q.Nout % ch == 0 && q.K % ch == 0 && q.ldd % ch == 0 && q.ldx % ch == 0 && q.ds_out_nodes >= 0);
+    const bool ds = q.ds_out_nodes > 0;       // x[v]: the (B * 2 * ds_out_nodes, K / 3) input of a Downsample; dw: its packed (Nout, K) gradient
+    NSID_REQUIRE(!ds || (st16 && q.groups == 1 && q.K % 3 == 0 && (q.K / 3) % 8 == 0 && q.M % q.ds_out_nodes == 0 && q.in_scale[0] == nullptr &&
+                         q.ldx == q.K / 3));
     for (int v = 0; v < nseg; ++v) {
       NSID_REQUIRE(nsid_aligned16(q.dout[v]) && nsid_aligned16(q.x[v]));
       NSID_REQUIRE((q.in_scale[v] == nullptr) == (q.in_shift[v] == nullptr));
@@ -1538,16 +1553,23 @@ extern "C" int nsid_linear_bwd_weight_grouped(const nsid_wgrad_problem* problems
     const bool rows_ok = q.M % 128 == 0;
     int cls = (rows_ok && q.Nout % 128 == 0 && q.K % 64 == 0) ? 0 : ((rows_ok && q.Nout % 64 == 0 && q.K % 64 == 0) ? 1 : 2);
     if (cls == 0 && use_w3 && q.K % 128 == 0) cls = q.in_scale[0] != nullptr ? 4 : 3;
-    const int bm = cls == 1 || cls == 2 ? 64 : 128, bn = cls >= 3 ? 128 : 64;
-    const long rows_cls = cls == 1 ? rows_sq : (cls == 2 ? rows_gen : rows_target);
+    if (ds) cls = 5;
+    if (!st16) cls = 6;
+    const int bm = (cls == 0 || cls == 3 || cls == 4) ? 128 : 64, bn = (cls == 3 || cls == 4) ? 128 : 64;
+    const long rows_cls = (cls == 1 || cls == 5) ? rows_sq : ((cls == 2 || cls == 6) ? rows_gen : rows_target);
     WgProb w{};
     for (int v = 0; v < 2; ++v) {
       w.A[v] = q.dout[v]; w.B[v] = q.x[v]; w.bsc[v] = q.in_scale[v]; w.bsh[v] = q.in_shift[v];
     }
     w.C = q.dw; w.lda = q.ldd; w.ldb = q.ldx; w.I = q.Nout; w.J = q.K; w.R = q.M; w.groups = q.groups;
+    if (ds) {       // the im2col matrix as a view of x: col[m][kk] = xflat[(2m - 1) * C + kk] (nsid_downsample3_bwd_weight)
+      const int C = q.K / 3;
+      for (int v = 0; v < nseg; ++v) w.B[v] = static_cast<const char*>(q.x[v]) - (long)C * 2;
+      w.ldb = 2 * C; w.pad_period = q.ds_out_nodes; w.pad_c1 = C;
+    }
     w.slope = act_slope(q.act_in);
     long S = 1;                                  // splits per segment: rows / wgg_rows, whole 128-row multiples each
-    if (cls != 2) {
+    if (cls != 2 && cls != 5 && cls != 6) {
       while (q.M % (2 * S) == 0 && (q.M / (2 * S)) % 128 == 0 && q.M / (2 * S) >= rows_cls) S *= 2;
       w.rchunk = (int)(q.M / S);
     } else {

@@ -219,8 +219,8 @@ static inline void nsid_count(NsidCounterKey k) { ++g_nsid_counter[k]; }
 
 // ---- grouped weight gradients (gemm.hip wgrad_grouped_kernel, wgrad.hip wgrad3_grouped_kernel): the table of problems one launch
 // serves, carried in the kernel arguments
-constexpr int WGG_MAXP = 28;           // 8 + 116 + 28 x 120 bytes of explicit arguments + 256 hidden: under the 4 KB of a kernel-argument segment
-struct WgProb {                 // 120 bytes
+constexpr int WGG_MAXP = 28;           // 8 + 116 + 28 x 128 bytes of explicit arguments + 256 hidden: under the 4 KB of a kernel-argument segment
+struct WgProb {                 // 128 bytes
   const void* A[2];             // dout of the two row segments (views); [1] unused when seg_splits == nsplit
   const void* B[2];             // x
   const float* bsc[2];          // producer affine of x per segment (or null)
@@ -231,13 +231,14 @@ struct WgProb {                 // 120 bytes
   int seg_splits, nsplit;       // splits of segment 0, splits in all
   int tiles, nwg;               // output tiles per group; workgroups of this problem (the next problem starts at a multiple of 8)
   float slope;
+  int pad_period, pad_c1;       // Downsample problems (x read as the zero-padded 3-tap view, see nsid_downsample3_bwd_weight): output nodes per clip, C
 };
 struct WgGroupArgs {
   int n, pad;
   int wg0[WGG_MAXP + 1];
   WgProb prob[WGG_MAXP];
 };
-static_assert(sizeof(WgProb) == 120 && sizeof(WgGroupArgs) <= 4096, "the problem table travels in the kernel arguments");
+static_assert(sizeof(WgProb) == 128 && sizeof(WgGroupArgs) + 256 <= 4096, "the problem table travels in the kernel arguments");
 
 
 // workgroup item w of a grouped launch -> problem pi, split (inside its row segment seg), output tile bid, group g; false: padding.

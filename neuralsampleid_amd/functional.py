@@ -155,14 +155,16 @@ GRAD_READY_HOOK = None
 # (ops.linear_bwd_weight_batch: both views of a layer as one problem over 2M rows, layers grouped into a few launches).
 # References: the backward of every conv at encoder/gcn_lib/torch_vertex.py:152-162, encoder/graph_encoder.py:74-77,
 # encoder/gcn_lib/torch_nn.py:56; train.py:70-75.
-DEFER_WGRAD = 0
+DEFER_WGRAD = 1      # one-box A/B of the whole step (round 6, x2): 7.73 in-chain -> 8.68 deferred as per-layer launches -> 7.36 ms grouped
 # Two-stream steps only: which stage boundaries of backward (1 = behind the last Downsample's backward, i.e. stage 4 done in that view,
 # 2 = stages 4-3, 3 = stages 4-2) FORK the problems recorded so far onto an auxiliary stream as soon as BOTH views have passed them: the
 # grouped launch then runs beside the remaining backward of the two views instead of behind it. Capped at DEFER_FORK_WGS workgroups (one
 # per CU: the chains keep their LDS and wave slots). Three live streams (+ the communicator's under data parallelism): inside the four
 # hardware queues (docs/experiments.md, round 3).
-# DEFER_FORK_AT: the boundaries as decimal digits (2, 12, 123; 0 = no fork).
-DEFER_FORK_AT = 2
+# DEFER_FORK_AT: the boundaries as decimal digits (2, 12, 123; 0 = no fork). MEASURED (round 6, one box, x2; no fork 7.50 ms):
+# fork at 2 with 256 / 512 / 1024 / all workgroups 8.02 / 7.81 / 7.78 / 7.72; at 1: 7.68; at 3: 7.67; at 1,2: 7.96; at 1,2,3: 8.09 --
+# whatever runs beside the two chains slows them by more than it hides (the finding of rounds 2-5 for every fat kernel). Off.
+DEFER_FORK_AT = 0
 DEFER_FORK_WGS = 256
 
 
@@ -172,9 +174,9 @@ class DeferredWgrads:
         self.verify = None      # tests: a list that receives (dw, the same sum through the per-layer launches) for every layer of a flush
         self.crossed, self.events, self.aux = {}, {}, None
 
-    def add(self, dout, x, dw, M, Nout, K, groups, in_scale, in_shift, act_in):
+    def add(self, dout, x, dw, M, Nout, K, groups, in_scale, in_shift, act_in, extra=None):
         stage = self.crossed.get(torch.cuda.current_stream().cuda_stream, 0)      # boundaries this view's backward has passed
-        self.items.append((stage, (dout, x, dw, M, Nout, K, groups, in_scale, in_shift, act_in)))
+        self.items.append((stage, (dout, x, dw, M, Nout, K, groups, in_scale, in_shift, act_in, extra)))
         if not self.armed:
             self.armed = True
             torch.autograd.Variable._execution_engine.queue_callback(self.flush)
@@ -223,7 +225,7 @@ class DeferredWgrads:
             tmp = {}
             for it in items:
                 t = tmp.setdefault(it[2].data_ptr(), (it[2], torch.zeros_like(it[2])))[1]
-                ops.linear_bwd_weight(it[0], it[1], t, *it[3:])
+                ops.wgrad_item(it[:2] + (t,) + it[3:])
             self.verify.extend((dw, t) for dw, t in tmp.values())
 
     def flush(self):
@@ -246,13 +248,22 @@ DEFERRED = DeferredWgrads()
 def _wgrad(dout, x, dw, M, Nout, K, groups=1, in_scale=None, in_shift=None, act_in=ACT_NONE):
     """dw += dout^T f(x): now, or recorded for the deferred phase (only inside a backward pass that accumulates straight into p.grad:
     an autograd-returned gradient tensor must be complete when its node returns)"""
-    if DEFER_WGRAD and DIRECT_GRADS and _IN_DIRECT_BACKWARD and dout.dtype == torch.bfloat16:
+    if _deferring() and (DEFER_HEAD or dout.dtype == torch.bfloat16):
         DEFERRED.add(dout, x, dw, M, Nout, K, groups, in_scale, in_shift, act_in)
     else:
         ops.linear_bwd_weight(dout, x, dw, M, Nout, K, groups, in_scale, in_shift, act_in)
 
 
 _IN_DIRECT_BACKWARD = False     # set by _BlockFn.backward while a block accumulates into p.grad
+
+
+DEFER_DS = 1        # the Downsample layers' packed weight gradients join the deferred phase
+DEFER_HEAD = 1      # so do the fp32 problems of the projection / projector head (256 rows each: tile-count bound launches at the turnaround)
+
+
+def _deferring() -> bool:
+    """bf16 storage only (the projector head's fp32 tensors included): the strict-fp32 path keeps its in-chain launches"""
+    return bool(DEFER_WGRAD and DIRECT_GRADS and _IN_DIRECT_BACKWARD and ACT_DTYPE == torch.bfloat16)
 
 
 def _bias_grad_before_bn(dr, g):
@@ -514,8 +525,14 @@ def _downsample_backward(dout: Tensor, P, S, G) -> Tensor:
         dwp = S.get("dwp_slot")                       # zeroed by the step's prepack launch; None: both slots were taken
         if dwp is None:
             dwp = ops.zeros(prep["dwp"].shape[1:], prep["dwp"].device)
-        ops.downsample3_bwd_weight(dr, x, dwp, B, N, C, Co)
-        ops.unpack_ds_wgrad(dwp, G["conv.0.weight"])
+        if _deferring() and DEFER_DS and dr.dtype == torch.bfloat16:
+            # both views add into the layer's FIRST packed buffer (one problem with two row segments), unpacked once after the grouped launch
+            if S.get("dwp_slot") is not None:
+                dwp = prep["dwp"][0]
+            DEFERRED.add(dr, x, dwp, Mo, Co, 3 * C, 1, None, None, ACT_NONE, ("ds", B, N, C, G["conv.0.weight"]))
+        else:
+            ops.downsample3_bwd_weight(dr, x, dwp, B, N, C, Co)
+            ops.unpack_ds_wgrad(dwp, G["conv.0.weight"])
         return ops.downsample3_bwd_data(dr, None, None, B, N, C, Co, w16=(prep["wp16"], prep["wb16"]))
     dwp = ops.zeros(wp.shape, wp.device)
     if col is None:                                  # strided-view form: x is the operand
@@ -548,7 +565,7 @@ def proj_mean_forward(x: Tensor, P, S: Optional[dict], B: int, N: int) -> Tensor
 def proj_mean_backward(dh: Tensor, P, S, G) -> Tensor:
     xm, B, N, C = S["xm"], S["B"], S["N"], S["C"]
     E = dh.shape[1]
-    ops.linear_bwd_weight(dh, xm, ops.w2d(G["weight"]), B, E, C)
+    _wgrad(dh, xm, ops.w2d(G["weight"]), B, E, C)
     ops.colsum_acc(dh, G["bias"])
     dxm = ops.linear_bwd_data(dh, ops.w2d(P["weight"]), B, E, C)
     return ops.node_mean_bwd(dxm, B, N, C, S["xdtype"])
@@ -573,11 +590,11 @@ def projector_backward(dz: Tensor, P, S, G) -> Tensor:
     B, Hin = h.shape
     Hid, D = a1.shape[1], z.shape[1]
     dp = ops.l2norm_bwd(dz, z, norm, eps)
-    ops.linear_bwd_weight(dp, a1, G["2.weight"], B, D, Hid)
+    _wgrad(dp, a1, G["2.weight"], B, D, Hid)
     ops.colsum_acc(dp, G["2.bias"])
     da1 = ops.linear_bwd_data(dp, P["2.weight"], B, D, Hid)
     dpre = ops.elu_bwd(da1, a1)
-    ops.linear_bwd_weight(dpre, h, G["0.weight"], B, Hid, Hin)
+    _wgrad(dpre, h, G["0.weight"], B, Hid, Hin)
     ops.colsum_acc(dpre, G["0.bias"])
     return ops.linear_bwd_data(dpre, P["0.weight"], B, Hid, Hin)
 

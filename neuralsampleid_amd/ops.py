@@ -519,42 +519,71 @@ def linear_bwd_weight(dout, x, dw, M, Nout, K, groups=1, in_scale=None, in_shift
 WGRAD_GROUPED = 1        # 0: the deferred phase issues one nsid_linear_bwd_weight per recorded problem (the gate of round 6: 8.68 ms)
 
 
+def wgrad_item(it) -> None:
+    """one recorded weight-gradient problem through the per-layer launch (the grouped phase's fallback and its test reference)"""
+    extra = it[10] if len(it) > 10 else None
+    if extra is None:
+        linear_bwd_weight(*it[:10])
+    else:                                      # ("ds", B, N, C): the packed gradient of a Downsample (unpacked by the caller)
+        _, B, N, C = extra[:4]
+        downsample3_bwd_weight(it[0], it[1], it[2], B, N, C, it[4])
+
+
 def linear_bwd_weight_batch(items, max_workgroups: int = 0) -> None:
     """the deferred weight-gradient phase (functional.DeferredWgrads): items = [(dout, x, dw, M, Nout, K, groups, in_scale, in_shift,
-    act_in)] in backward order, both views of a layer sharing the same dw. dw += dout^T f(x) for every item.
-    bf16 storage: ONE call of nsid_linear_bwd_weight_grouped — the items that share dw and shape become the two row segments of one
+    act_in[, extra])] in backward order, both views of a layer sharing the same dw. dw += dout^T f(x) for every item.
+    extra = ("ds", B, N, C, weight_grad): a Downsample — x is its input, dw its packed gradient, unpacked into weight_grad afterwards.
+    ONE call of nsid_linear_bwd_weight_grouped per storage type: the items that share dw and shape become the two row segments of one
     problem, the problems of all layers one launch per tile class (csrc/gemm.hip wgrad_grouped_kernel).
     max_workgroups > 0: a launch that runs beside the backward chains (at most that many workgroups, each walking several items)."""
     if not items:
         return
     from ._lib import WgradProblem
     import ctypes
-    if not WGRAD_GROUPED or any(it[0].dtype != torch.bfloat16 or it[1].dtype != torch.bfloat16 for it in items):
+    unpack = {}
+    for it in items:
+        if len(it) > 10 and it[10] is not None:
+            unpack[it[2].data_ptr()] = (it[2], it[10][4])
+    if not WGRAD_GROUPED:
         for it in items:
-            linear_bwd_weight(*it)
-        return
-    probs, open_ = [], {}           # open_: (dw pointer, shape) -> a problem that still has a free second segment
-    flops = nbytes = 0.0
-    for dout, x, dw, M, Nout, K, groups, in_scale, in_shift, act_in in items:
-        _chk(dw, in_scale, in_shift)
-        _act(dout, x)
-        flops += 2.0 * M * Nout * K * groups
-        nbytes += groups * 2.0 * M * (Nout + K)
-        key = (dw.data_ptr(), M, Nout, K, groups, dout.shape[-1], x.shape[-1], act_in, in_scale is None)
-        q = open_.pop(key, None)
-        if q is None:
-            q = WgradProblem()
-            q.dout[0], q.x[0], q.in_scale[0], q.in_shift[0] = _p(dout), _p(x), _p(in_scale), _p(in_shift)
-            q.dw, q.ldd, q.ldx, q.M, q.Nout, q.K, q.groups, q.act_in = _p(dw), dout.shape[-1], x.shape[-1], M, Nout, K, groups, act_in
-            probs.append(q)
-            open_[key] = q
-            nbytes += 4.0 * groups * Nout * K
-        else:
-            q.dout[1], q.x[1], q.in_scale[1], q.in_shift[1] = _p(dout), _p(x), _p(in_scale), _p(in_shift)
-    arr = (WgradProblem * len(probs))(*probs)
-    _timed("wgrad_grouped_kernel", flops, nbytes, lambda: call(
-        "nsid_linear_bwd_weight_grouped", ctypes.addressof(arr), len(probs), BF16, int(max_workgroups), _stream()),
-        (len(items), len(probs), 0, 1))
+            wgrad_item(it)
+    else:
+        for dtype, code in ((torch.bfloat16, BF16), (torch.float32, F32)):
+            probs, open_ = [], {}           # open_: (dw pointer, shape) -> a problem that still has a free second segment
+            flops = nbytes = 0.0
+            n_items = 0
+            for it in items:
+                dout, x, dw, M, Nout, K, groups, in_scale, in_shift, act_in = it[:10]
+                if dout.dtype != dtype:
+                    continue
+                extra = it[10] if len(it) > 10 else None
+                _chk(dw, in_scale, in_shift)
+                if _act(dout, x) != code:
+                    raise RuntimeError("a weight-gradient problem with mixed storage types")
+                n_items += 1
+                flops += 2.0 * M * Nout * K * groups
+                nbytes += groups * float(dout.element_size()) * M * (Nout + K)
+                ldx = x.shape[-1]
+                key = (dw.data_ptr(), M, Nout, K, groups, dout.shape[-1], ldx, act_in, in_scale is None, extra is None)
+                q = open_.pop(key, None)
+                if q is None:
+                    q = WgradProblem()
+                    q.dout[0], q.x[0], q.in_scale[0], q.in_shift[0] = _p(dout), _p(x), _p(in_scale), _p(in_shift)
+                    q.dw, q.ldd, q.ldx, q.M, q.Nout, q.K, q.groups, q.act_in = _p(dw), dout.shape[-1], ldx, M, Nout, K, groups, act_in
+                    q.ds_out_nodes = 0 if extra is None else extra[2] // 2
+                    probs.append(q)
+                    open_[key] = q
+                    nbytes += 4.0 * groups * Nout * K
+                else:
+                    q.dout[1], q.x[1], q.in_scale[1], q.in_shift[1] = _p(dout), _p(x), _p(in_scale), _p(in_shift)
+            if not probs:
+                continue
+            arr = (WgradProblem * len(probs))(*probs)
+            _timed("wgrad_grouped_kernel", flops, nbytes, lambda: call(
+                "nsid_linear_bwd_weight_grouped", ctypes.addressof(arr), len(probs), code, int(max_workgroups), _stream()),
+                (n_items, len(probs), 0, 1))
+    for dwp, wgrad in unpack.values():
+        unpack_ds_wgrad(dwp, wgrad)
 
 
 def colsum_acc(x, out) -> None:

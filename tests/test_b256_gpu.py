@@ -231,8 +231,8 @@ def test_bf16_hip_vs_emulation_at_b256_and_timed_variants_ran(golden, restore_mo
     note("bf16_vs_emulation", {"vs_emulation": a, "hip_vs_golden": b_hip, "emulation_vs_golden": b_em, "counters": cnt})
     print("measured", json.dumps({"vs_emulation": a, "hip_vs_golden": b_hip, "emulation_vs_golden": b_em, "counters": cnt}, indent=1))
     # (c) the variants of the timed step
-    for key in ("gemm_full", "gemm_ks2", "gemm_split_major", "gemm_affine_load", "gemm_bn_sums", "wgrad_rect", "wgrad_square",
-                "wgrad3", "bn_bwd_apply_capped", "knn2", "mr_fwd_lds"):
+    for key in ("gemm_full", "gemm_ks2", "gemm_split_major", "gemm_affine_load", "gemm_bn_sums", "wgrad_grouped", "wgrad_grouped_w3",
+                "bn_bwd_apply_capped", "knn2", "mr_fwd_lds"):       # (the weight gradients: the deferred grouped phase, functional.DEFER_WGRAD)
         assert cnt[key] > 0, (key, cnt)
     assert cnt["gemm256"] == 0 and cnt["knn_strips"] == 0, cnt     # default tuning: not in the training step
     # (a) same rounding points on both sides

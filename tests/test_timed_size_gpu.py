@@ -8,7 +8,7 @@
                ranking at this batch in test_knn_kernels_of_the_deep_plan_at_the_timed_batch.)
       eval, step 0 : both sides on synth.fixed_graph (the reference's ids would be a 22 MB fixture) -> embeddings, per-clip checksums,
                losses, all per-parameter gradient norms, six full gradients, running statistics; then the same step in bf16 storage.
-               Launch counters prove that knn_sel, knn_rank, the 8-wave weight gradient (wgrad3) and the rectangular one ran.
+               Launch counters prove that knn_sel, knn_rank, the grouped weight-gradient phase (8-wave 128x128 class included) ran.
 (b) BASELINE config 5 as timed — bf16 storage, ONE 512-clip micro-batch through fingerprint.extract_fingerprints: the 512 clips whose
     reference embeddings b256_seed42_k3.npz already holds (z_i_eval, z_j_eval). Counters: knn2_pair (two workgroups per CU from 512
     clips), the 256x256-tile LDS-DMA GEMM, the fused eval-mode FFN and aggregation + grouped conv all ran inside that forward."""
@@ -174,7 +174,7 @@ def test_deep_config4_at_the_timed_batch(golden, restore_mode):
     finally:
         F_.TAPE = None
     cnt = ops.launch_counters()
-    assert cnt["knn_sel"] == 2 * 8 and cnt["knn_rank"] == 2 * 16 and cnt["wgrad3"] > 0 and cnt["wgrad_rect"] > 0, cnt
+    assert cnt["knn_sel"] == 2 * 8 and cnt["knn_rank"] == 2 * 16 and cnt["wgrad_grouped_w3"] > 0 and cnt["wgrad_grouped"] > 0, cnt
     assert cnt["mr_bwd_sorted"] == 2 * 24, cnt                 # the degree-ranked aggregation backward of the deep plan (k = 18)
     assert cnt["gemm_full"] > 0 and cnt["gemm_bn_sums"] > 0 and cnt["mr_fwd_lds"] > 0, cnt
     opt.step()

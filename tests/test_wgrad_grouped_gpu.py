@@ -117,7 +117,43 @@ def test_grouped_weight_gradients_at_the_timed_batch(bf16_mode):
             assert e < (2e-4 if li == 1 else 3e-5), (rows, li, e)
 
 
-def test_grouped_entry_refuses_fp32_storage_and_bad_pointers(bf16_mode):
+def test_grouped_downsample_and_fp32_head_problems(bf16_mode):
+    """the two other members of the deferred phase: a Downsample's packed weight gradient (x read as the zero-padded 3-tap view,
+    encoder/graph_encoder.py:44-50) and the projector head's fp32 tensors (simclr/simclr.py:23-28), each with both views as segments,
+    against the per-layer launches"""
+    from neuralsampleid_amd import ops
+    g = torch.Generator().manual_seed(5)
+    items, refs = [], []
+    for (B, N, C, Co) in ((8, 256, 64, 128), (8, 64, 256, 512)):
+        Mo = B * N // 2
+        dwp, ref = torch.zeros(Co, 3 * C, device=DEV), torch.zeros(Co, 3 * C, device=DEV)
+        grad, grad_ref = torch.zeros(Co, C, 3, 3, device=DEV), torch.zeros(Co, C, 3, 3, device=DEV)
+        for v in range(2):
+            dr = (0.5 * torch.randn(Mo, Co, generator=g)).to(torch.bfloat16).to(DEV)
+            x = torch.randn(B * N, C, generator=g).to(torch.bfloat16).to(DEV)
+            items.append((dr, x, dwp, Mo, Co, 3 * C, 1, None, None, ops.ACT_NONE, ("ds", B, N, C, grad)))
+            ops.downsample3_bwd_weight(dr, x, ref, B, N, C, Co)
+        ops.unpack_ds_wgrad(ref, grad_ref)
+        refs.append((grad, grad_ref))
+    for (M, N, K) in ((256, 1024, 512), (256, 128, 4096)):
+        dw, ref = torch.zeros(N, K, device=DEV), torch.zeros(N, K, device=DEV)
+        for v in range(2):
+            d = (0.5 * torch.randn(M, N, generator=g)).to(DEV)
+            x = torch.randn(M, K, generator=g).to(DEV)
+            items.append((d, x, dw, M, N, K, 1, None, None, ops.ACT_NONE, None))
+            ops.linear_bwd_weight(d, x, ref, M, N, K)
+        refs.append((dw, ref))
+    ops.launch_counters(reset=True)
+    ops.linear_bwd_weight_batch(items)
+    torch.cuda.synchronize()
+    cnt = ops.launch_counters()
+    assert cnt["wgrad_grouped"] == 2 and cnt["gemm_bwd_weight"] == 0, cnt
+    for out, ref in refs:
+        scale = float(ref.abs().max())
+        assert scale > 0 and float((out - ref).abs().max()) / scale < 1e-5, (tuple(out.shape), float((out - ref).abs().max()), scale)
+
+
+def test_grouped_entry_refuses_bad_arguments(bf16_mode):
     import ctypes
     from neuralsampleid_amd import ops
     from neuralsampleid_amd._lib import WgradProblem, lib
@@ -127,7 +163,7 @@ def test_grouped_entry_refuses_fp32_storage_and_bad_pointers(bf16_mode):
     q.dout[0], q.x[0], q.dw, q.ldd, q.ldx, q.M, q.Nout, q.K, q.groups = d.data_ptr(), d.data_ptr(), dw.data_ptr(), 64, 64, 128, 64, 64, 1
     arr = (WgradProblem * 1)(q)
     s = torch.cuda.current_stream().cuda_stream
-    assert lib.nsid_linear_bwd_weight_grouped(ctypes.addressof(arr), 1, ops.F32, 0, s) == -1
+    assert lib.nsid_linear_bwd_weight_grouped(ctypes.addressof(arr), 1, 7, 0, s) == -1            # no such storage type
     assert lib.nsid_linear_bwd_weight_grouped(ctypes.addressof(arr), 0, ops.BF16, 0, s) == -1
     arr[0].x[0] = None
     assert lib.nsid_linear_bwd_weight_grouped(ctypes.addressof(arr), 1, ops.BF16, 0, s) == -1
@@ -159,7 +195,7 @@ def test_deferred_phase_gives_the_gradients_of_the_in_chain_launches(bf16_mode):
         model.load_state_dict(synth_state(model.state_dict()))
         model.to(DEV).train()
         opt = FusedClipAdam(model.parameters(), lr=GRAFP_CFG["lr"], max_norm=1.0)
-        F_.DEFER_WGRAD = defer
+        defer_keep, F_.DEFER_WGRAD = F_.DEFER_WGRAD, defer
         fork_keep, F_.DEFER_FORK_AT = F_.DEFER_FORK_AT, fork
         F_.DEFERRED.verify = [] if defer else None
         F_.TAPE = F_.KnnTape(replay=tape)
@@ -173,7 +209,7 @@ def test_deferred_phase_gives_the_gradients_of_the_in_chain_launches(bf16_mode):
             checks = F_.DEFERRED.verify
         finally:
             F_.TAPE = None
-            F_.DEFER_WGRAD = 0
+            F_.DEFER_WGRAD = defer_keep
             F_.DEFER_FORK_AT = fork_keep
             F_.DEFERRED.verify = None
         cnt = ops.launch_counters()
@@ -183,7 +219,7 @@ def test_deferred_phase_gives_the_gradients_of_the_in_chain_launches(bf16_mode):
         assert not F_.DEFERRED.items and not F_.DEFERRED.armed
         torch.cuda.synchronize()
         if defer:
-            assert len(checks) == 61, len(checks)           # 12 blocks x 5 conv layers + the stem
+            assert len(checks) == 67, len(checks)           # 12 blocks x 5 conv layers + the stem + 3 Downsamples + proj + projector
             for dw, t in checks:
                 scale = max(float(t.abs().max()), 1e-6)
                 assert float((dw - t).abs().max()) / scale < 2e-5, (tuple(dw.shape), float((dw - t).abs().max()), scale)
