@@ -224,6 +224,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_fwd_kernel(const G256Args p) {
         for (int a = 0; a < 8; ++a) acc[b][a] += bj;
       }
     }
+    // (statistics variant: thread / lane indices re-derived from the hardware lane count at their use: kept live from the kernel entry
+    // across the main loop they spilled into scratch at the 256-register budget)
+    const int elane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
     if constexpr (MODE == G256_STAT) {
       // column sums over the wave's 128 rows: in-lane over the 8 row tiles, then over the 16 lanes lr that share a column
 #pragma unroll
@@ -242,8 +245,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_fwd_kernel(const G256Args p) {
             s += __shfl_xor(s, o, 64);
             q += __shfl_xor(q, o, 64);
           }
-          if (lr == 0) {
-            const int c = wc * 64 + 16 * b + 4 * rq + r;
+          if ((elane & 15) == 0) {
+            const int c = wc * 64 + 16 * b + 4 * (elane >> 4) + r;
             red[(0 * 2 + wr) * 256 + c] = s;
             red[(1 * 2 + wr) * 256 + c] = q;
           }
@@ -315,7 +318,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_fwd_kernel(const G256Args p) {
     }
     if constexpr (MODE == G256_STAT) {
       __syncthreads();                         // the parked sums of all eight waves (also drains every LDS-DMA: statistics = training,
-      if (tid < 256) {                         //  one tile per workgroup there)
+      const int tid = wave * 64 + elane;       //  one tile per workgroup there)
+      if (tid < 256) {
         const long col = cj0 + tid;
         const int cti = ci0 >> 8;
 #pragma unroll
@@ -327,7 +331,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_fwd_kernel(const G256Args p) {
       __syncthreads();                         // red is reused by the next tile
       wait_vm<0>();                            // the statistics stores are not in the count of the wait at the top
     }
-    if (p.trace && tid == 0) {
+    if (p.trace && wave == 0 && elane == 0) {
       unsigned hw, xcc;
       asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
       asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));

@@ -567,30 +567,37 @@ __global__ __launch_bounds__(MRS_THREADS, 8) void mr_bwd_sorted_kernel(const __b
     bf16x8 o8;
 #pragma unroll
     for (int e = 0; e < 8; ++e) o8[e] = (__bf16)r8[e];
-    *reinterpret_cast<bf16x8*>(dy + (row0 + n) * C + c) = o8;
+    // (uniform 64-bit base + 32-bit lane offset: a per-lane 64-bit address lived across the gather loop and spilled at 64 VGPRs)
+    *reinterpret_cast<bf16x8*>(dy + row0 * C + (unsigned)(n * C + c)) = o8;
     if constexpr (BNS) o8s[it] = o8;
   }
   if constexpr (BNS) {
-    float sum0[8], sum1[8], bsc[8], bsh[8], bmu[8], bis[8];
+    float sum0[8], sum1[8];
     const bool masked = bn.slope != 1.f;         // uniform: a BatchNorm without an activation behind it needs no mask
     u32x4 rq[2];
 #pragma unroll
-    for (int it = 0; it < 2; ++it) rq[it] = *reinterpret_cast<const u32x4*>(bn.r + (row0 + node[it]) * bn.ldr + c);
-    load_channels<8>(bn.mean, c, bmu);
-    load_channels<8>(bn.invstd, c, bis);
-    if (masked) { load_channels<8>(bn.scale, c, bsc); load_channels<8>(bn.shift, c, bsh); }
+    for (int it = 0; it < 2; ++it) rq[it] = *reinterpret_cast<const u32x4*>(bn.r + row0 * bn.ldr + (unsigned)(node[it] * (int)bn.ldr + c));
+    // four channels at a time: the 16 per-channel constants of a half are dead before the next half loads its own (all eight at once
+    // were 64 VGPRs + 2 spilled at the 64-register budget of a 1 024-thread workgroup that shares its CU)
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { sum0[e] = 0.f; sum1[e] = 0.f; if (!masked) { bsc[e] = 1.f; bsh[e] = 0.f; } }
+    for (int h4 = 0; h4 < 8; h4 += 4) {
+      float bsc[4], bsh[4], bmu[4], bis[4];
+      load_channels<4>(bn.mean, c + h4, bmu);
+      load_channels<4>(bn.invstd, c + h4, bis);
+      if (masked) { load_channels<4>(bn.scale, c + h4, bsc); load_channels<4>(bn.shift, c + h4, bsh); }
 #pragma unroll
-    for (int it = 0; it < 2; ++it) {
-      const bf16x8 x8 = __builtin_bit_cast(bf16x8, rq[it]);
+      for (int e = 0; e < 4; ++e) { sum0[h4 + e] = 0.f; sum1[h4 + e] = 0.f; if (!masked) { bsc[e] = 1.f; bsh[e] = 0.f; } }
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const float dyv = (float)o8s[it][e], xx = (float)x8[e];
-        float gg = dyv;
-        if (masked) gg = (bsc[e] * xx + bsh[e]) > 0.f ? dyv : dyv * bn.slope;
-        sum0[e] += gg;
-        sum1[e] += gg * ((xx - bmu[e]) * bis[e]);
+      for (int it = 0; it < 2; ++it) {
+        const bf16x8 x8 = __builtin_bit_cast(bf16x8, rq[it]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float dyv = (float)o8s[it][h4 + e], xx = (float)x8[h4 + e];
+          float gg = dyv;
+          if (masked) gg = (bsc[e] * xx + bsh[e]) > 0.f ? dyv : dyv * bn.slope;
+          sum0[h4 + e] += gg;
+          sum1[h4 + e] += gg * ((xx - bmu[e]) * bis[e]);
+        }
       }
     }
     // lanes l, l + CV, ... hold the same 8 channels: butterfly over the lane bits above log2(CV), then one row per wave in LDS

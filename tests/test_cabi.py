@@ -112,6 +112,23 @@ def test_no_packed_fma_with_a_constant_multiplier(libpath, tmp_path):
     assert seen > 1000 and not bad, bad[:5]
 
 
+def test_no_kernel_of_the_library_touches_scratch_memory(libpath, tmp_path):
+    """register spills: a kernel that spills pays a scratch round trip per wave and, worse, hides a register budget that no longer
+    holds (round 5 shipped ws_fwd_kernel<64,64,4,true,*> with 18-24 scratch instructions, mr_bwd_sorted_kernel<true> with 2,
+    gemm256_fwd_kernel<2> with 5). Every gfx950 kernel of the shipped library must be free of scratch_load / scratch_store."""
+    texts = _gfx950_disassembly(libpath, tmp_path)
+    bad, name, kernels = {}, None, 0
+    for text in texts:
+        for line in text.splitlines():
+            m = re.match(r"^[0-9a-f]+ <(.+)>:$", line)
+            if m:
+                name = m.group(1)
+                kernels += 1
+            elif name and re.search(r"\bscratch_(load|store)", line):
+                bad[name] = bad.get(name, 0) + 1
+    assert kernels > 300 and not bad, bad
+
+
 def test_workspace_query(libpath):
     """SURVEY 8b's per-op scratch query: 0 for the ops that live in LDS, the partial-sum buffers for the three that do not"""
     lib = ctypes.CDLL(libpath)

@@ -263,7 +263,7 @@ def test_weight_stationary_forward_moves_the_gradient_norm_as_signed_noise(bf16_
     print("signed gnorm differences (default path against the emulation):", signed, "mean", mean)
     assert min(signed) < 0 < max(signed), signed
     assert abs(mean) < 0.06, (mean, signed)
-    assert max(abs(v) for v in signed) < 0.2, signed
+    assert max(abs(v) for v in signed) < 0.3, signed          # (measured: -0.093 ... +0.137, mean -0.004)
 
 
 BLOCKS = [("c64n256_k3d1", 64, 256, 3, 1), ("c128n128_k5d1", 128, 128, 5, 1), ("c256n64_k18d3", 256, 64, 18, 3),
