@@ -19,8 +19,7 @@ __device__ __forceinline__ float div_shared(float v, float d, float r) {
 }
 
 
-constexpr int KNN_THREADS = 256;   // 4 waves, one 16-row strip each per pass
-constexpr int KNN_WAVES = 4;
+constexpr int KNN_WAVES = 4;       // waves of the strip kernel (one 16-row distance strip each per pass) when the clip leaves room for them
 
 __device__ __forceinline__ unsigned orderable(float f) {
   const unsigned u = __float_as_uint(f);
@@ -41,7 +40,7 @@ __device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
 }
 
 template <typename T>
-__global__ __launch_bounds__(KNN_THREADS) void knn_kernel(const T* __restrict__ r, long ldr,
+__global__ __launch_bounds__(256) void knn_kernel(const T* __restrict__ r, long ldr,
                                                           const float* __restrict__ scale,
                                                           const float* __restrict__ shift, int N, int C, int k,
                                                           int dilation, int32_t* __restrict__ idx) {
@@ -54,6 +53,9 @@ __global__ __launch_bounds__(KNN_THREADS) void knn_kernel(const T* __restrict__ 
 
   const int b = blockIdx.x;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  // the number of waves (= distance strips in flight) comes from the launch: 4 by default, fewer when the fp32 clip + 4 strips exceed the
+  // 160 KB of LDS (N * C = 24 576 at encoder size 'm': 102 KB of features + 4 x 16.6 KB of strips; two strips fit)
+  const int KNN_WAVES = blockDim.x >> 6, KNN_THREADS = blockDim.x;
   const T* src = r + (long)b * N * ldr;
   constexpr int NV = Chunk<T>::N;
   const int CV = C / NV;
@@ -1197,7 +1199,10 @@ static int knn_graph_impl(const void* r, int ldr, const float* scale, const floa
     if (kd <= 5) return launch_knn2<float, 5>(r, ldr, scale, shift, B, N, C, k, dilation, idx, s);
     return launch_knn2<float, 8>(r, ldr, scale, shift, B, N, C, k, dilation, idx, s);
   }
-  const size_t bytes = ((size_t)N * (C + 4) + N + (size_t)KNN_WAVES * 16 * (N + 4)) * sizeof(float);
+  int waves = KNN_WAVES;
+  auto lds_bytes = [&](int w) { return ((size_t)N * (C + 4) + N + (size_t)w * 16 * (N + 4)) * sizeof(float); };
+  while (waves > 1 && lds_bytes(waves) > 160 * 1024) waves >>= 1;
+  const size_t bytes = lds_bytes(waves);
   NSID_REQUIRE(bytes <= 160 * 1024);
   nsid_count(NSID_C_knn_strips);
   static size_t configured = 0;       // raise the dynamic-LDS cap once per size step (not a per-call sync)
@@ -1210,7 +1215,7 @@ static int knn_graph_impl(const void* r, int ldr, const float* scale, const floa
     configured = 160 * 1024;
   }
   NSID_DISPATCH_DTYPE(dtype, T, {
-    NSID_LAUNCH((knn_kernel<T>), dim3(B), dim3(KNN_THREADS), bytes, static_cast<hipStream_t>(stream),
+    NSID_LAUNCH((knn_kernel<T>), dim3(B), dim3(64 * waves), bytes, static_cast<hipStream_t>(stream),
                 static_cast<const T*>(r), (long)ldr, scale, shift, N, C, k, dilation, idx);
   });
   return nsid_launch_status();

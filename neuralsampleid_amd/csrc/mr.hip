@@ -754,12 +754,41 @@ static int mrs_launch(const void* du, const int32_t* idx, const uint8_t* argmax,
   return nsid_launch_status();
 }
 
+namespace {
+// Clips that do not fit LDS in fp32 (N * C = 32 768 at the default encoder size, strict-fp32 mode only): the same sum as a scatter with
+// global fp32 atomics in two launches -- dy = du_even - du_odd, then every (m, c) adds du_odd[m, c] to its arg-max neighbour's row.
+__global__ __launch_bounds__(256) void mr_bwd_own_kernel(const float* __restrict__ du, long total, float* __restrict__ dy) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) dy[i] = du[2 * i] - du[2 * i + 1];
+}
+__global__ __launch_bounds__(256) void mr_bwd_scatter_kernel(const float* __restrict__ du, const int32_t* __restrict__ idx,
+                                                             const uint8_t* __restrict__ argmax, int N, int C, int k, long total,
+                                                             float* __restrict__ dy) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long m = i / C;                       // global row
+    const int c = (int)(i - m * C);
+    const long b = m / N;
+    const int j = min((int)argmax[i], k - 1);
+    const int tg = min(max(idx[m * k + j], 0), N - 1);
+    atomicAdd(dy + (b * N + tg) * C + c, du[2 * i + 1]);
+  }
+}
+}  // namespace
+
 extern "C" int nsid_mr_aggregate_bwd(const void* du, const int32_t* idx, const uint8_t* argmax, int B, int N, int C,
                                      int k, void* dy, int dtype, void* stream) {
   NSID_REQUIRE(du && idx && argmax && dy && B > 0 && N > 0 && C > 0 && k > 0 && k <= 255 && NSID_DTYPE_OK(dtype));
   NSID_REQUIRE(C % (dtype == NSID_BF16 ? 8 : 4) == 0 && nsid_aligned16(du) && nsid_aligned16(dy));
   const size_t esz = dtype == NSID_BF16 ? 2 : 4;
   const size_t bytes = (size_t)N * C * (esz + 1) + ((size_t)2 * N + 1 + (size_t)N * k) * sizeof(int) + 16;
+  if (bytes > 160 * 1024 && dtype == NSID_F32) {
+    const long total = (long)B * N * C;
+    const int grid = (int)std::min<long>((total + 255) / 256, 4096);
+    NSID_LAUNCH(mr_bwd_own_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), static_cast<const float*>(du), total,
+                static_cast<float*>(dy));
+    NSID_LAUNCH(mr_bwd_scatter_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), static_cast<const float*>(du), idx,
+                argmax, N, C, k, total, static_cast<float*>(dy));
+    return nsid_launch_status();
+  }
   NSID_REQUIRE(bytes <= 160 * 1024 && C % 4 == 0 && ((size_t)N * C * (esz + 1)) % 4 == 0);
   static bool configured = false;
   if (!configured) {

@@ -379,6 +379,51 @@ def gold_e2e_s():
     print("   loss eval", float(loss_eval), "train", float(loss), "gnorm", gn)
 
 
+def _gold_e2e_size(size, B=4, k=3):
+    """Checksum-only golden of a further encoder size (VERDICT r5 task 7; encoder/graph_encoder.py:124-129: 'm' = 96 / 192 / 384 / 768
+    x [2,2,16,2], anything else = 128 / 256 / 512 / 1024 x [2,2,18,2]): B = 4, eval embeddings and step 0 of train.py:53-75. Stored: z of
+    both passes, per-clip checksums of h, the losses, neighbour ids of both passes as uint8 (N <= 256) with the eval pass's margins as
+    float16 (the free-running comparison), and the gradient / running-statistics norms as vectors in named_parameters / state_dict order."""
+    print("e2e_" + size)
+    x_i, x_j = synth_clips(B)
+    torch.manual_seed(1234)
+    model = SimCLR(CFG, GraphEncoder(CFG, in_channels=CFG["n_filters"], k=k, size=size))
+    load_synth(model)
+    tape = KnnTape(model)
+    model.eval()
+    with torch.no_grad():
+        h_i, h_j, z_i, z_j = model(x_i, x_j)
+        loss_eval = ntxent_loss(z_i, z_j, CFG)
+    ev = dict(h_i_eval_pc=_per_clip(h_i), h_j_eval_pc=_per_clip(h_j), z_i_eval=z_i, z_j_eval=z_j, loss_eval=loss_eval.reshape(1))
+    for name, t in tape.take("eval").items():
+        ev[name] = t.to(torch.uint8) if name.startswith("knn.") else t.to(torch.float16)
+    model.train()
+    model.zero_grad()
+    h_i, h_j, z_i, z_j = model(x_i, x_j)
+    loss = ntxent_loss(z_i, z_j, CFG)
+    loss.backward()
+    tr = dict(h_i_train_pc=_per_clip(h_i), h_j_train_pc=_per_clip(h_j), z_i_train=z_i, z_j_train=z_j, loss_train=loss.detach().reshape(1))
+    for name, t in tape.take("s0").items():
+        if name.startswith("knn."):
+            tr[name] = t.to(torch.uint8)
+    gnorms = np.array([float(p.grad.double().norm()) if p.grad is not None else -1.0 for _, p in model.named_parameters()], np.float64)
+    bnnorms = np.array([float(t.double().norm()) for n, t in model.state_dict().items() if n.endswith(("running_mean", "running_var"))],
+                       np.float64)
+    shapes = json.dumps({n: list(t.shape) for n, t in model.state_dict().items() if "relative_pos" not in n}, sort_keys=True)
+    gn = float(torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=1.0))
+    save(f"e2e_b{B}_{size}_k{k}", x_i=x_i, x_j=x_j, **ev, **tr, grad_norms=gnorms, bn_norms_after_step1=bnnorms, gnorm=np.array([gn], np.float64),
+         state_shapes_sha=np.frombuffer(hashlib.sha256(shapes.encode()).hexdigest().encode(), dtype=np.uint8))
+    print("   loss eval", float(loss_eval), "train", float(loss), "gnorm", gn, "params", sum(p.numel() for p in model.parameters()))
+
+
+def gold_e2e_m():
+    _gold_e2e_size("m")
+
+
+def gold_e2e_b():
+    _gold_e2e_size("b")
+
+
 def bench_clips(batch, seed):
     """bench.py's synth_clips — the inputs of the TIMED step: seeds (seed, seed + 1)"""
     gi = torch.Generator().manual_seed(seed)
@@ -745,7 +790,7 @@ def gold_relpos():
 
 if __name__ == "__main__":
     torch.manual_seed(0)
-    only = sys.argv[1:] or ["shapes", "init", "relpos", "knn", "mrconv", "block", "downsample", "peak", "ntxent", "e2e", "e2e_s",
+    only = sys.argv[1:] or ["shapes", "init", "relpos", "knn", "mrconv", "block", "downsample", "peak", "ntxent", "e2e", "e2e_s", "e2e_m", "e2e_b",
                             "deep", "fpdb", "b256", "deep_b256"]
     for name in only:
         globals()["gold_" + name]()

@@ -703,6 +703,114 @@ def test_simclr_e2e_size_s(golden):
     assert abs(gn - float(g["gnorm"][0])) / float(g["gnorm"][0]) < 5e-3
 
 
+@pytest.mark.parametrize("size", ["m", "b"])
+def test_simclr_e2e_sizes_m_and_default(golden, size):
+    """The remaining encoder sizes of encoder/graph_encoder.py:124-129 end to end (VERDICT r5 task 7): 'm' = 96 / 192 / 384 / 768 channels x
+    [2,2,16,2] blocks, the default ('b') = 128 / 256 / 512 / 1024 x [2,2,18,2]; B = 4, k = 3, strict fp32. Against the reference's own
+    outputs (make_golden.py::gold_e2e_m / gold_e2e_b, checksum-only fixtures): eval embeddings with the HIP kNN's own neighbour sets
+    checked, then step 0 of train.py:53-75 with the reference's neighbour ids forced."""
+    import hashlib
+    from neuralsampleid_amd import functional as F_
+    from neuralsampleid_amd.encoder.graph_encoder import GraphEncoder
+    from neuralsampleid_amd.simclr.ntxent import ntxent_loss
+    from neuralsampleid_amd.simclr.simclr import SimCLR
+    g = golden(f"e2e_b4_{size}_k3")
+    model = SimCLR(GRAFP_CFG, GraphEncoder(GRAFP_CFG, in_channels=GRAFP_CFG["n_filters"], k=3, size=size))
+    shapes = json.dumps({k_: list(v.shape) for k_, v in model.state_dict().items() if "relative_pos" not in k_}, sort_keys=True)
+    assert hashlib.sha256(shapes.encode()).hexdigest() == bytes(g["state_shapes_sha"]).decode()      # the reference's key set and shapes
+    model = load_synth(model).to(DEV)
+    x_i, x_j = g.t("x_i").to(DEV), g.t("x_j").to(DEV)
+    pc = lambda t: torch.stack([t.detach().double().sum(1), t.detach().double().norm(dim=1)], 1).cpu()
+    n_calls = len([k_ for k_ in g if k_.startswith("knn.eval.")])
+    gold_idx = [g.t(f"knn.eval.{c}").to(torch.int32) for c in range(n_calls)]
+    gaps = [np.asarray(g[f"gap.eval.{c}"], dtype=np.float32) for c in range(n_calls)]
+    model.eval()
+    F_.TAPE = F_.KnnTape(replay=gold_idx)
+    with torch.no_grad():
+        h_i, h_j, z_i, z_j = model(x_i, x_j)
+        loss = ntxent_loss(z_i, z_j, GRAFP_CFG)
+    rec = F_.TAPE.recorded
+    F_.TAPE = None
+    assert len(rec) == n_calls == 2 * sum(model.encoder.blocks)
+    hard, soft, rows = check_tape(rec, gold_idx, gaps)
+    assert hard == 0 and soft <= rows * 3e-3, (hard, soft, rows)        # (margins are stored as fp16: the near-tie band is as wide as before)
+    # per-clip [sum, norm] of h: the embeddings of these sizes reach |h| ~ 5e4 per clip: 5e-5 of the norm (measured 1.4e-5 on the sums)
+    tol_pc = 5e-5 * float(g.t("h_i_eval_pc")[:, 1].max())
+    assert (pc(h_i) - g.t("h_i_eval_pc")).abs().max() < tol_pc and (pc(h_j) - g.t("h_j_eval_pc")).abs().max() < tol_pc
+    assert maxerr(z_i, g.t("z_i_eval")) < 1e-5 and maxerr(z_j, g.t("z_j_eval")) < 1e-5
+    assert abs(float(loss.detach()) - float(g["loss_eval"][0])) < 1e-5
+    # step 0
+    model.train()
+    model.zero_grad()
+    F_.TAPE = F_.KnnTape(replay=[g.t(f"knn.s0.{c}").to(torch.int32) for c in range(n_calls)])
+    h_i, h_j, z_i, z_j = model(x_i, x_j)
+    loss = ntxent_loss(z_i, z_j, GRAFP_CFG)
+    loss.backward()
+    F_.TAPE = None
+    assert maxerr(z_i, g.t("z_i_train")) < 2e-5 and abs(float(loss.detach()) - float(g["loss_train"][0])) < 5e-5
+    assert (pc(h_i) - g.t("h_i_train_pc")).abs().max() < 5e-5 * float(g.t("h_i_train_pc")[:, 1].max())
+    gn_ref = np.asarray(g["grad_norms"])
+    params = list(model.named_parameters())
+    assert len(params) == len(gn_ref)
+    worst = max((abs(float(p.grad.double().norm()) - nrm) / nrm, n) for (n, p), nrm in zip(params, gn_ref) if nrm > 1e-3)
+    assert worst[0] < 2e-2, worst
+    bn_ref = np.asarray(g["bn_norms_after_step1"])
+    bn = [float(t.double().norm()) for n, t in model.state_dict().items() if n.endswith(("running_mean", "running_var"))]
+    assert len(bn) == len(bn_ref) and max(abs(a - b) / max(b, 1.0) for a, b in zip(bn, bn_ref)) <= 1e-4
+    gn = float(torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=1.0))
+    assert abs(gn - float(g["gnorm"][0])) / float(g["gnorm"][0]) < 5e-3
+
+
+@pytest.mark.parametrize("size", ["m", "b"])
+def test_sizes_m_and_default_in_the_timed_arithmetic(golden, size):
+    """the same two models with bf16 storage: the channel counts 96 / 192 / 384 / 768 / 1024 are outside every shape table of the
+    weight-stationary and fused kernels, which must decline (launch counters) and leave the generic tile kernels to run; eval
+    embeddings within cos 0.999 of the reference's fp32 ones, a training step with deferred grouped weight gradients runs"""
+    from neuralsampleid_amd import functional as F_
+    from neuralsampleid_amd import ops
+    from neuralsampleid_amd.encoder.graph_encoder import GraphEncoder
+    from neuralsampleid_amd.optim import FusedClipAdam
+    from neuralsampleid_amd.simclr.ntxent import ntxent_loss
+    from neuralsampleid_amd.simclr.simclr import SimCLR
+    g = golden(f"e2e_b4_{size}_k3")
+    model = load_synth(SimCLR(GRAFP_CFG, GraphEncoder(GRAFP_CFG, in_channels=GRAFP_CFG["n_filters"], k=3, size=size))).to(DEV)
+    x_i, x_j = g.t("x_i").to(DEV), g.t("x_j").to(DEV)
+    n_calls = len([k_ for k_ in g if k_.startswith("knn.eval.")])
+    ops.set_gemm_precision("bf16")
+    F_.set_activation_dtype("bf16")
+    try:
+        model.eval()
+        F_.TAPE = F_.KnnTape(replay=[g.t(f"knn.eval.{c}").to(torch.int32) for c in range(n_calls)])
+        with torch.no_grad():
+            _, _, z_i, z_j = model(x_i, x_j)
+        F_.TAPE = None
+        cos = torch.nn.functional.cosine_similarity(torch.cat([z_i, z_j]).float().cpu(), torch.cat([g.t("z_i_eval"), g.t("z_j_eval")]), dim=1)
+        assert float(cos.min()) > 0.999, float(cos.min())
+        model.train()
+        opt = FusedClipAdam(model.parameters(), lr=GRAFP_CFG["lr"], max_norm=1.0)
+        ops.launch_counters(reset=True)
+        F_.TAPE = F_.KnnTape(replay=[g.t(f"knn.s0.{c}").to(torch.int32) for c in range(n_calls)])
+        opt.zero_grad()
+        _, _, z_i, z_j = model(x_i, x_j)
+        loss = ntxent_loss(z_i, z_j, GRAFP_CFG)
+        loss.backward()
+        F_.TAPE = None
+        cnt = ops.launch_counters()
+        opt.step()
+        torch.cuda.synchronize()
+        assert cnt["wgrad_grouped"] > 0 and cnt["gemm_fwd"] > 0, cnt
+        if size == "m":          # 96 / 192 / 384 / 768: no layer matches a weight-stationary shape
+            assert cnt["ws_fwd"] == 0 and cnt["ws_bwd_data"] == 0, cnt
+        # (4 clips under 44-48 train-mode BatchNorms: the bf16 step is far from the fp32 one -- measured |dloss| 0.61 at size 'b';
+        #  the statement here is that every kernel family accepts these channel counts, not parity: that is the fp32 test above)
+        assert math.isfinite(float(loss.detach())) and abs(float(loss.detach()) - float(g["loss_train"][0])) < 1.0 and float(opt.grad_norm) > 0
+        assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in model.parameters() if p.requires_grad)
+    finally:
+        F_.TAPE = None
+        ops.set_gemm_precision("fp32")
+        F_.set_activation_dtype("fp32")
+
+
 def test_size_s_bf16_storage_runs_the_generic_kernels(golden):
     """the same model in the timed arithmetic (bf16 storage): eval embeddings stay within cos 0.999 of the reference's fp32 ones and a
     training step runs (finite loss, every parameter receives a gradient) -- the C = 80 / 160 / 400 / 640 shapes on the generic bf16 paths"""
