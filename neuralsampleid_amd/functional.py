@@ -166,6 +166,7 @@ DEFER_WGRAD = 1      # one-box A/B of the whole step (round 6, x2): 7.73 in-chai
 # whatever runs beside the two chains slows them by more than it hides (the finding of rounds 2-5 for every fat kernel). Off.
 DEFER_FORK_AT = 0
 DEFER_FORK_WGS = 256
+DEFER_CHUNKS = 1     # pieces of the deferred phase when a gradient-ready hook is installed (parallel.GradReducer.install sets 3 under data parallelism)
 
 
 class DeferredWgrads:
@@ -181,8 +182,10 @@ class DeferredWgrads:
             self.armed = True
             torch.autograd.Variable._execution_engine.queue_callback(self.flush)
 
-    def note_hook(self, params):
-        self.hooks.append((self.crossed.get(torch.cuda.current_stream().cuda_stream, 0), params))
+    def note_hook(self, params, n_before=0):
+        """the block whose backward has just recorded the items [n_before:] reports its parameters when all of those have been issued"""
+        stage = self.crossed.get(torch.cuda.current_stream().cuda_stream, 0)
+        self.hooks.append((stage, params, {it[2].data_ptr() for _, it in self.items[n_before:]}))
 
     def boundary(self):
         """end of a Downsample's backward on the current stream (= in this view)"""
@@ -206,8 +209,8 @@ class DeferredWgrads:
             self.aux.wait_event(e)
         ready = [it for stage, it in self.items if stage < c]
         self.items = [(stage, it) for stage, it in self.items if stage >= c]
-        hooks = [h for stage, h in self.hooks if stage < c]
-        self.hooks = [(stage, h) for stage, h in self.hooks if stage >= c]
+        hooks = [h for stage, h, _ in self.hooks if stage < c]
+        self.hooks = [h3 for h3 in self.hooks if h3[0] >= c]
         with torch.cuda.stream(self.aux):
             self._issue(ready, DEFER_FORK_WGS)
             if GRAD_READY_HOOK is not None:
@@ -231,15 +234,38 @@ class DeferredWgrads:
     def flush(self):
         """runs on the thread that called backward(), once every backward node has been enqueued"""
         self.armed = False
-        items, hooks, self.items, self.hooks = [it for _, it in self.items], [h for _, h in self.hooks], [], []
+        items, hooks, self.items, self.hooks = [it for _, it in self.items], [(h, ptrs) for _, h, ptrs in self.hooks], [], []
         self.crossed, self.events = {}, {}
         if not items and not hooks:
             return
         join_side_streams()
-        self._issue(items, 0)
-        if GRAD_READY_HOOK is not None:
-            for params in hooks:
-                GRAD_READY_HOOK(params)
+        chunks = max(1, int(DEFER_CHUNKS)) if GRAD_READY_HOOK is not None else 1
+        if chunks == 1:
+            self._issue(items, 0)
+            if GRAD_READY_HOOK is not None:
+                for params, _ in hooks:
+                    GRAD_READY_HOOK(params)
+            return
+        # Data parallelism: the phase goes out in `chunks` pieces of about equal gradient size, in backward order (late layers first:
+        # the order the reducer cuts its buckets in), and every block reports its parameters as soon as its piece has been issued -- the
+        # bucketed all-reduce of piece c runs on the communicator's stream beside the launches of piece c + 1.
+        order, size = [], {}
+        for it in items:
+            ptr = it[2].data_ptr()
+            if ptr not in size:
+                order.append(ptr)
+                size[ptr] = it[2].numel()
+        total, acc, piece_of = float(sum(size.values())), 0.0, {}
+        for ptr in order:
+            piece_of[ptr] = min(chunks - 1, int(acc * chunks / total))
+            acc += size[ptr]
+        fired = [False] * len(hooks)
+        for c in range(chunks):
+            self._issue([it for it in items if piece_of[it[2].data_ptr()] == c], 0)
+            for i, (params, ptrs) in enumerate(hooks):
+                if not fired[i] and all(piece_of.get(p_, 0) <= c for p_ in ptrs):
+                    fired[i] = True
+                    GRAD_READY_HOOK(params)
 
 
 DEFERRED = DeferredWgrads()
@@ -644,7 +670,7 @@ class _BlockFn(torch.autograd.Function):
         ctx.S = None
         if direct and GRAD_READY_HOOK is not None:
             if len(DEFERRED.items) > n_def:      # this block's gradients are complete only after the deferred phase
-                DEFERRED.note_hook([P[n] for n in names])
+                DEFERRED.note_hook([P[n] for n in names], n_def)
             else:
                 GRAD_READY_HOOK([P[n] for n in names])
         head = (None, None, None, None, None, None, dx if ctx.x_needs else None)

@@ -252,6 +252,10 @@ class GradReducer:
     def install(self):
         from . import functional
         functional.GRAD_READY_HOOK = self.block_done
+        if _distributed(self.group):
+            # the deferred weight-gradient phase (functional.DeferredWgrads) goes out in three pieces, late layers first, so that the
+            # all-reduce of a piece's buckets overlaps the launches of the next one
+            functional.DEFER_CHUNKS = 3
         return self
 
 
