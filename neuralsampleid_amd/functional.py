@@ -166,6 +166,8 @@ DEFER_WGRAD = 1      # one-box A/B of the whole step (round 6, x2): 7.73 in-chai
 # whatever runs beside the two chains slows them by more than it hides (the finding of rounds 2-5 for every fat kernel). Off.
 DEFER_FORK_AT = 0
 DEFER_FORK_WGS = 256
+DEFER_TWO_LANES = 1  # the short launches of the phase on the second view stream beside the two big ones: 7.40 -> 7.29 ms (x3); moving
+#                      half of the wide problems over as well: equal (7.284 / 7.275)
 DEFER_CHUNKS = 1     # pieces of the deferred phase when a gradient-ready hook is installed (parallel.GradReducer.install sets 3 under data parallelism)
 
 
@@ -231,6 +233,25 @@ class DeferredWgrads:
                 ops.wgrad_item(it[:2] + (t,) + it[3:])
             self.verify.extend((dw, t) for dw, t in tmp.values())
 
+    def _issue_two_lanes(self, items):
+        """The wide layers' problems (the 8-wave 128x128 classes: ~90 % of the flops, two launches, HBM-bound) on the current stream and
+        everything else (five short launches that fill the chip badly: the C = 64 / 128 layers, Downsample, stem, the fp32 head — 0.35 ms
+        of the 1.37 ms phase in an eager trace) on the idle view stream BESIDE them: no dependency chain on either side, so unlike a
+        launch beside backward the co-resident kernels only fill each other's gaps. One fork edge, one join edge."""
+        side = next((st for st in SIDE_STREAMS if st is not self.aux), None)
+        heavy = [it for it in items if it[0].dtype == torch.bfloat16 and (len(it) <= 10 or it[10] is None) and it[3] % 128 == 0 and
+                 it[4] % 128 == 0 and it[5] % 128 == 0]
+        if not DEFER_TWO_LANES or side is None or not heavy or len(heavy) == len(items):
+            self._issue(items, 0)
+            return
+        light = [it for it in items if not any(it is h for h in heavy)]
+        main = torch.cuda.current_stream()
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            self._issue(light, 0)
+        self._issue(heavy, 0)
+        main.wait_stream(side)
+
     def flush(self):
         """runs on the thread that called backward(), once every backward node has been enqueued"""
         self.armed = False
@@ -241,7 +262,7 @@ class DeferredWgrads:
         join_side_streams()
         chunks = max(1, int(DEFER_CHUNKS)) if GRAD_READY_HOOK is not None else 1
         if chunks == 1:
-            self._issue(items, 0)
+            self._issue_two_lanes(items)
             if GRAD_READY_HOOK is not None:
                 for params, _ in hooks:
                     GRAD_READY_HOOK(params)
