@@ -55,3 +55,42 @@ def test_step_traffic_comes_from_the_committed_pmc_passes():
     assert abs(d["step_traffic_GB"] - tot / d["steps_profiled"] / 1e9) < 1e-2       # the figure is the sum of its own table
     mb = bench.measured_step_traffic("_infer", key="microbatch_traffic_GB")
     assert mb is not None and 5.0 < mb[0] < 40.0
+
+
+def test_rocprof_family_maps_kernel_names_onto_the_launch_families():
+    f = bench.rocprof_family
+    g = ("void (anonymous namespace)::gemm_kernel<128, 128, true, false, true, true, false, true, true, false, 1, 0, false, 0, 4, %s>"
+         "((anonymous namespace)::GemmArgs)")
+    assert f(g % "false") == "gemm_kernel<128,128,true,false>" and f(g % "true") == "gemm_kernel<128,128,true,false> +bn_apply_load"
+    assert f("void (anonymous namespace)::ws_bwd_kernel<64, 256, 1, false, true, true>((anonymous namespace)::WsBwdArgs)") == "ws_bwd_kernel +bn_apply_load"
+    assert f("void (anonymous namespace)::ws_fwd_kernel<128, 128, 1, false, true>((anonymous namespace)::WsArgs)") == "ws_fwd_kernel"
+    assert f("_ZN12_GLOBAL__N_120mr_bwd_sorted_kernelILb1EEEvPKDF16bPKiPKhiiiiPDF16bNS_5MrsBnE") == "mr_bwd_sorted_kernel +bn_sums"
+    assert f("_ZN12_GLOBAL__N_117mr_fwd_lds_kernelIDF16bEEvPKT_lPKfS5_PKiiiiPS1_Phi") == "mr_fwd_kernel"
+    assert f("void (anonymous namespace)::wgrad3_grouped_kernel<true>((anonymous namespace)::WgGroupArgs)") == "wgrad_grouped_kernel"
+    assert f("void (anonymous namespace)::wgrad_grouped_kernel<64, 64, false, true, true, 2>((anonymous namespace)::WgGroupArgs)") == "wgrad_grouped_kernel"
+    assert f("(anonymous namespace)::ntxent_lse_kernel(float const*, float const*, int, int, float, int, float*, float*, float*)") == "ntxent_kernels"
+    assert f("(anonymous namespace)::bn_finalize_kernel(float const*, int, int)") == "bn_finalize_kernel"
+
+
+def test_the_committed_bench_line_agrees_with_the_committed_rocprof_trace():
+    """VERDICT r5 task 5: the kernel table of round 5 summed to 9.1 ms where the rocprofv3 trace of the same tree had 11.4 ms (event
+    pairs under-timed short kernels). The round-6 line takes its durations from a live rocprofv3 child run: for the committed pair
+    profiles/r06a/bench.json + kernel_stats.csv (two separate runs of one tree on one box) the table's sum over its families must lie
+    within 0.90 ... 1.05 of the trace's sum over the same families, family by family within 25 % for everything above 100 us per step."""
+    import csv
+    with open(os.path.join(ROOT, "profiles", "r06a", "bench.json")) as fh:
+        line = json.loads(fh.read().strip().splitlines()[-1])
+    assert line["kernel_timing"].startswith("rocprofv3") and line["step_traffic_kind"] == "live" and line["roofline"]["traffic_kind"] == "live"
+    table = {k: v["avg_us"] * v["launches"] for k, v in line["kernels"].items()}
+    rows = list(csv.DictReader(open(os.path.join(ROOT, "profiles", "r06a", "kernel_stats.csv"))))
+    steps = max(int(r["Calls"]) for r in rows if "adam_kernel" in r["Name"])
+    trace = {}
+    for r in rows:
+        fam = bench.rocprof_family(r["Name"])
+        trace[fam] = trace.get(fam, 0.0) + float(r["TotalDurationNs"]) / 1e3 / steps
+    s_table, s_trace = sum(table.values()), sum(v for k, v in trace.items() if k in table)
+    assert 0.90 * s_trace <= s_table <= 1.05 * s_trace, (s_table, s_trace)
+    for k, us in table.items():
+        if us > 100.0:
+            assert abs(us - trace[k]) <= 0.25 * trace[k], (k, us, trace[k])
+    assert line["config"]["workload"].startswith("B=256 bf16 k=3 hipGraph 2-stream")      # the distinguishing facts survive a truncation
