@@ -176,6 +176,7 @@ class DeferredWgrads:
         self.items, self.hooks, self.armed = [], [], False
         self.verify = None      # tests: a list that receives (dw, the same sum through the per-layer launches) for every layer of a flush
         self.crossed, self.events, self.aux = {}, {}, None
+        self.calls = []
 
     def add(self, dout, x, dw, M, Nout, K, groups, in_scale, in_shift, act_in, extra=None):
         stage = self.crossed.get(torch.cuda.current_stream().cuda_stream, 0)      # boundaries this view's backward has passed
@@ -183,6 +184,20 @@ class DeferredWgrads:
         if not self.armed:
             self.armed = True
             torch.autograd.Variable._execution_engine.queue_callback(self.flush)
+
+    def add_call(self, fn, tensors):
+        """other work that only produces parameter gradients (the peak extractor's backward): runs on the phase's second lane"""
+        self.calls.append((fn, tensors))
+        if not self.armed:
+            self.armed = True
+            torch.autograd.Variable._execution_engine.queue_callback(self.flush)
+
+    def _run_calls(self):
+        calls, self.calls = self.calls, []
+        for fn, tensors in calls:
+            for t in tensors:
+                t.record_stream(torch.cuda.current_stream())
+            fn()
 
     def note_hook(self, params, n_before=0):
         """the block whose backward has just recorded the items [n_before:] reports its parameters when all of those have been issued"""
@@ -241,14 +256,16 @@ class DeferredWgrads:
         side = next((st for st in SIDE_STREAMS if st is not self.aux), None)
         heavy = [it for it in items if it[0].dtype == torch.bfloat16 and (len(it) <= 10 or it[10] is None) and it[3] % 128 == 0 and
                  it[4] % 128 == 0 and it[5] % 128 == 0]
-        if not DEFER_TWO_LANES or side is None or not heavy or len(heavy) == len(items):
+        if not DEFER_TWO_LANES or side is None or not heavy or (len(heavy) == len(items) and not self.calls):
             self._issue(items, 0)
+            self._run_calls()
             return
         light = [it for it in items if not any(it is h for h in heavy)]
         main = torch.cuda.current_stream()
         side.wait_stream(main)
         with torch.cuda.stream(side):
             self._issue(light, 0)
+            self._run_calls()
         self._issue(heavy, 0)
         main.wait_stream(side)
 
@@ -257,7 +274,7 @@ class DeferredWgrads:
         self.armed = False
         items, hooks, self.items, self.hooks = [it for _, it in self.items], [(h, ptrs) for _, h, ptrs in self.hooks], [], []
         self.crossed, self.events = {}, {}
-        if not items and not hooks:
+        if not items and not hooks and not self.calls:
             return
         join_side_streams()
         chunks = max(1, int(DEFER_CHUNKS)) if GRAD_READY_HOOK is not None else 1
@@ -282,6 +299,8 @@ class DeferredWgrads:
             acc += size[ptr]
         fired = [False] * len(hooks)
         for c in range(chunks):
+            if c == 0:
+                self._run_calls()          # (before any hook fires: a hook without recorded problems reports at the first piece)
             self._issue([it for it in items if piece_of[it[2].data_ptr()] == c], 0)
             for i, (params, ptrs) in enumerate(hooks):
                 if not fired[i] and all(piece_of.get(p_, 0) <= c for p_ in ptrs):
@@ -654,9 +673,16 @@ def patchify_forward(spec: Tensor, P, S: Optional[dict], pb: int, pf: int) -> Te
     return out
 
 
+DEFER_PATCHIFY = 1      # the peak extractor's backward (parameter gradients only; the last launches of a view's chain, fully exposed: 27 us)
+#                         joins the deferred phase's second lane
+
+
 def patchify_backward(dout: Tensor, P, S, G) -> None:
-    ops.peak_patchify_bwd(S["spec"], S["minmax"], S["out"], dout, S["pb"], S["pf"], G["convs.0.weight"],
-                          G["convs.0.bias"])
+    args = (S["spec"], S["minmax"], S["out"], dout, S["pb"], S["pf"], G["convs.0.weight"], G["convs.0.bias"])
+    if _deferring() and DEFER_PATCHIFY:
+        DEFERRED.add_call(lambda: ops.peak_patchify_bwd(*args), args[:4])
+    else:
+        ops.peak_patchify_bwd(*args)
 
 
 # ================================================================================================ autograd

@@ -23,11 +23,19 @@ class _PatchifyFn(torch.autograd.Function):
     def backward(ctx, dout):
         direct = F_.DIRECT_GRADS and all(v.grad is not None for v in ctx.P.values())
         G = {k: (v.grad if direct else F_.ops.zeros(v.shape, v.device)) for k, v in ctx.P.items()}
-        F_.patchify_backward(dout.contiguous(), ctx.P, ctx.S, G)
+        n_calls = len(F_.DEFERRED.calls)
+        F_._IN_DIRECT_BACKWARD = direct
+        try:
+            F_.patchify_backward(dout.contiguous(), ctx.P, ctx.S, G)
+        finally:
+            F_._IN_DIRECT_BACKWARD = False
         ctx.S = None
         if direct:
             if F_.GRAD_READY_HOOK is not None:
-                F_.GRAD_READY_HOOK(list(ctx.P.values()))
+                if len(F_.DEFERRED.calls) > n_calls:        # the launches run in the deferred phase (functional.DEFER_PATCHIFY)
+                    F_.DEFERRED.note_hook(list(ctx.P.values()), len(F_.DEFERRED.items))
+                else:
+                    F_.GRAD_READY_HOOK(list(ctx.P.values()))
             return None, None, None, None, None, None
         return None, G["convs.0.weight"], G["convs.0.bias"], None, None, None
 
