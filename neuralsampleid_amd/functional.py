@@ -332,6 +332,15 @@ def _deferring() -> bool:
     return bool(DEFER_WGRAD and DIRECT_GRADS and _IN_DIRECT_BACKWARD and ACT_DTYPE == torch.bfloat16)
 
 
+def _bias_grad(dout, g):
+    """g += column sums of dout (a Linear's bias gradient): with the deferred phase a recorded call on its second lane (three 5 us
+    launches per view at the turnaround between forward and backward, where nothing else runs)"""
+    if _deferring() and DEFER_HEAD:
+        DEFERRED.add_call(lambda: ops.colsum_acc(dout, g), (dout,))
+    else:
+        ops.colsum_acc(dout, g)
+
+
 def _bias_grad_before_bn(dr, g):
     if EXACT_BIAS_GRAD:
         ops.colsum_acc(dr, g)
@@ -632,7 +641,7 @@ def proj_mean_backward(dh: Tensor, P, S, G) -> Tensor:
     xm, B, N, C = S["xm"], S["B"], S["N"], S["C"]
     E = dh.shape[1]
     _wgrad(dh, xm, ops.w2d(G["weight"]), B, E, C)
-    ops.colsum_acc(dh, G["bias"])
+    _bias_grad(dh, G["bias"])
     dxm = ops.linear_bwd_data(dh, ops.w2d(P["weight"]), B, E, C)
     return ops.node_mean_bwd(dxm, B, N, C, S["xdtype"])
 
@@ -657,11 +666,11 @@ def projector_backward(dz: Tensor, P, S, G) -> Tensor:
     Hid, D = a1.shape[1], z.shape[1]
     dp = ops.l2norm_bwd(dz, z, norm, eps)
     _wgrad(dp, a1, G["2.weight"], B, D, Hid)
-    ops.colsum_acc(dp, G["2.bias"])
+    _bias_grad(dp, G["2.bias"])
     da1 = ops.linear_bwd_data(dp, P["2.weight"], B, D, Hid)
     dpre = ops.elu_bwd(da1, a1)
     _wgrad(dpre, h, G["0.weight"], B, Hid, Hin)
-    ops.colsum_acc(dpre, G["0.bias"])
+    _bias_grad(dpre, G["0.bias"])
     return ops.linear_bwd_data(dpre, P["0.weight"], B, Hid, Hin)
 
 
