@@ -35,7 +35,6 @@ SIGNATURES = {
     "nsid_knn_graph": "pippiiiiipis",
     "nsid_mr_aggregate_fwd": "pipppiiiippis",
     "nsid_mr_aggregate_bwd": "pppiiiipis",
-    "nsid_mr_aggregate_bwd_bn": "pppiiiippippppipis",
     "nsid_im2col3_fwd": "piiipis",
     "nsid_im2col3_bwd": "piiipis",
     "nsid_pack_ds_weight": "piips",
@@ -124,6 +123,8 @@ def _load():
     # returns 1 (nothing launched) for shapes outside the fused form: bound directly, not through call()
     lib.nsid_linear_bwd_data_bnapply.argtypes = [_CT[c] for c in "pppippipipiiiiiipppppips"]
     lib.nsid_linear_bwd_data_bnapply.restype = ctypes.c_int
+    lib.nsid_mr_aggregate_bwd_bn.argtypes = [_CT[c] for c in "pppiiiippippppipis"]     # declines with NSID_EINVAL outside its form: the caller falls back
+    lib.nsid_mr_aggregate_bwd_bn.restype = ctypes.c_int
     lib.nsid_ffn_fused_fwd.argtypes = [_CT[c] for c in "ppppppiiis"]
     lib.nsid_ffn_fused_fwd.restype = ctypes.c_int
     lib.nsid_mrconv_fused_fwd.argtypes = [_CT[c] for c in "ppiiiippps"]
@@ -138,7 +139,7 @@ def _load():
 
 
 lib = _load()
-EXPORTS = list(SIGNATURES) + ["nsid_version", "nsid_debug_gemm_trace", "nsid_debug_knn_trace", "nsid_get_gemm_precision", "nsid_gemm_g256_launches", "nsid_linear_bwd_data_bnapply", "nsid_ffn_fused_fwd", "nsid_mrconv_fused_fwd", "nsid_debug_counter", "nsid_debug_counters_reset", "nsid_debug_counter_count", "nsid_debug_counter_key", "nsid_set_tuning", "nsid_get_tuning", "nsid_reset_tuning", "nsid_tuning_count", "nsid_tuning_key", "nsid_row_tiles", "nsid_sumsq_blocks", "nsid_ntxent_ws_floats", "nsid_workspace_bytes"]
+EXPORTS = list(SIGNATURES) + ["nsid_version", "nsid_debug_gemm_trace", "nsid_debug_knn_trace", "nsid_get_gemm_precision", "nsid_gemm_g256_launches", "nsid_linear_bwd_data_bnapply", "nsid_mr_aggregate_bwd_bn", "nsid_ffn_fused_fwd", "nsid_mrconv_fused_fwd", "nsid_debug_counter", "nsid_debug_counters_reset", "nsid_debug_counter_count", "nsid_debug_counter_key", "nsid_set_tuning", "nsid_get_tuning", "nsid_reset_tuning", "nsid_tuning_count", "nsid_tuning_key", "nsid_row_tiles", "nsid_sumsq_blocks", "nsid_ntxent_ws_floats", "nsid_workspace_bytes"]
 
 _ERR = {-1: "NSID_EINVAL (unsupported shape, misaligned pointer or bad argument)",
         -2: "NSID_ELAUNCH (HIP runtime refused the launch)"}

@@ -42,6 +42,10 @@ struct WsArgs {
   int M;
 };
 
+// vmcnt(0) through the builtin (the compiler's own wait-count bookkeeping stays consistent): simm16 on gfx9 = vmcnt [3:0] + [15:14],
+// expcnt [6:4], lgkmcnt [11:8]; the other counters are left at their maximum
+__device__ __forceinline__ void ws_wait_vm0() { __builtin_amdgcn_s_waitcnt((7 << 4) | (0xF << 8)); }
+
 constexpr int WS_TP = 72;               // bytes per channel row of a wave's transpose buffer: 32 rows of bf16 + 8 (conflict-free ds_write_b64)
 constexpr int WS_TB = 32 * WS_TP;       // one 32 x 32 tile
 
@@ -111,7 +115,8 @@ __global__ __launch_bounds__(256, (GI * NOUT * K * 2 > 60 * 1024) ? 1 : 2) void 
       reinterpret_cast<f32x4*>(affs + GI * K)[i] = reinterpret_cast<const f32x4*>(p.in_shift + (long)gy * GI * K)[i];
     }
   }
-  __syncthreads();          // (waits for this wave's LDS-DMA and LDS stores, then the barrier: the image is complete)
+  ws_wait_vm0();            // this wave's LDS-DMA pieces have landed (explicit: gfx950's s_barrier does not wait for VMEM)
+  __syncthreads();          // ... and its LDS stores; behind the barrier the image is complete for every wave
 
   if constexpr (AFF) {
     // producer BatchNorm + activation on the fragments, in place: v = sc * x + sh; act(v) = max(v, slope * v) (slope in [0, 1]; NaN stays)
@@ -314,6 +319,7 @@ __global__ __launch_bounds__(256, (GI * N * K * 2 > 56 * 1024) ? 1 : 2) void ws_
     }
   };
   if constexpr (ADD || BNR) side_load(0, 0);
+  ws_wait_vm0();            // (the weight image's LDS-DMA; the side tiles just requested are waited for with it: once per workgroup)
   __syncthreads();
 
   if constexpr (ABN) {

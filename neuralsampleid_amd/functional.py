@@ -631,7 +631,9 @@ def proj_mean_forward(x: Tensor, P, S: Optional[dict], B: int, N: int) -> Tensor
     E = P["weight"].shape[0]
     xm = ops.node_mean_fwd(x, B, N, C)
     # B rows: a handful of tiles with a 512-deep reduction — split it (fp32 atomics into the zeroed output), as the projector's fc2
-    h, _ = ops.linear_fwd(xm, ops.w2d(P["weight"]), P["bias"], B, E, C, ksplit=4 if (HEAD_KSPLIT and C >= 512 and B <= 512) else 1)
+    # (training only: S is None in inference, whose embeddings then do not depend on atomics order or on the launch size -- ADVICE r5)
+    h, _ = ops.linear_fwd(xm, ops.w2d(P["weight"]), P["bias"], B, E, C,
+                          ksplit=4 if (HEAD_KSPLIT and S is not None and C >= 512 and B <= 512) else 1)
     if S is not None:
         S.update(xm=xm, B=B, N=N, C=C, xdtype=x.dtype)
     return h
@@ -652,7 +654,7 @@ def projector_forward(h: Tensor, P, S: Optional[dict], eps: float = 1e-10) -> Te
     Hid, D = P["0.weight"].shape[0], P["2.weight"].shape[0]
     a1, _ = ops.linear_fwd(h, P["0.weight"], P["0.bias"], B, Hid, Hin, act_out=ACT_ELU,
                            ksplit=HEAD_FC1_KSPLIT if (Hin >= 1024 and B <= 512 and h.dtype == torch.float32) else 1)
-    ks = 8 if Hid >= 2048 else 1
+    ks = 8 if (Hid >= 2048 and S is not None) else 1        # split reductions (fp32 atomics) in training only
     p, _ = ops.linear_fwd(a1, P["2.weight"], P["2.bias"], B, D, Hid, ksplit=ks)
     z, norm = ops.l2norm_fwd(p, eps)
     if S is not None:

@@ -837,10 +837,17 @@ def mr_aggregate_bwd(du, idx, amax, B, N, C, bn=None):
         r, aff, act = bn
         _chk(aff.scale, aff.shift, aff.mean, aff.invstd)
         partial = torch.empty((2, B, C), device=du.device, dtype=torch.float32)
-        _timed("mr_bwd_sorted_kernel +bn_sums", 0.0, nbytes + float(B) * N * C * r.element_size(), lambda: call(
-            "nsid_mr_aggregate_bwd_bn", _p(du), _p(idx), _p(amax), B, N, C, k, _p(dy), _p(r), r.shape[-1], _p(aff.scale), _p(aff.shift),
-            _p(aff.mean), _p(aff.invstd), act, _p(partial), dt, _stream()), (B * N, C, 2 * C, 1))
-        return dy, partial
+        rc = [0]
+
+        def launch():
+            rc[0] = lib.nsid_mr_aggregate_bwd_bn(_p(du), _p(idx), _p(amax), B, N, C, k, _p(dy), _p(r), r.shape[-1], _p(aff.scale),
+                                                 _p(aff.shift), _p(aff.mean), _p(aff.invstd), act, _p(partial), dt, _stream())
+        _timed("mr_bwd_sorted_kernel +bn_sums", 0.0, nbytes + float(B) * N * C * r.element_size(), launch, (B * N, C, 2 * C, 1))
+        if rc[0] == 0:
+            return dy, partial
+        # the C side declined (its own LDS / k bounds, which this predicate does not restate): the plain launch + a reduce by the caller
+        if PROFILE is not None:
+            PROFILE.records.pop()
     c0 = _cnt("mr_bwd_sorted")
     _timed(lambda: "mr_bwd_sorted_kernel" if _cnt("mr_bwd_sorted") > c0 else "mr_bwd_kernel", 0.0, nbytes, lambda: call(
         "nsid_mr_aggregate_bwd", _p(du), _p(idx), _p(amax), B, N, C, k, _p(dy), dt, _stream()),
@@ -940,6 +947,12 @@ class DsPrep:
         """the prepared entry of `w` if it was refreshed for the weight's current contents, else None (callers pack per call)"""
         e = self.entries.get(w.data_ptr())
         if not DS_PREP_ENABLED or e is None or e["key"] != (w._version, WEIGHT_EPOCH):
+            return None
+        owner = e["wref"]()
+        # the entry is keyed by address and holds only a weak reference: a NEW weight at the address of a freed one must not inherit
+        # its packed copies (ADVICE r5). `.data` / detach aliases of the registered parameter share its storage and are accepted.
+        if owner is None or (owner is not w and (owner.data_ptr() != w.data_ptr() or owner.shape != w.shape or
+                                                 owner.untyped_storage().data_ptr() != w.untyped_storage().data_ptr())):
             return None
         return e
 
