@@ -387,7 +387,7 @@ def rocprof_family(name):
     return alias.get(base, base)
 
 
-def live_profile(argv, timeout_s=240):
+def live_profile(argv, timeout_s=120):
     """Run THIS bench configuration as a child process under `rocprofv3 --kernel-trace --stats` (eager, one stream, 3 steps) and, in two
     more child runs, under `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes, --kernel-trace only beside them). Returns
     {"per_step_us": {family: us}, "launches": {family: n per step}, "steps": n, "traffic": {...} or None} or None when rocprofv3 is

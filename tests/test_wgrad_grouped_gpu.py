@@ -236,3 +236,50 @@ def test_deferred_phase_gives_the_gradients_of_the_in_chain_launches(bf16_mode):
             assert float((gr - ref).norm()) / max(float(ref.norm()), 1e-9) < 0.08, (tag, n)
         gn = lambda d: float(torch.sqrt(sum(v.double().pow(2).sum() for v in d.values())))
         assert abs(gn(grads[tag]) - gn(grads["base"])) / gn(grads["base"]) < 0.02, tag
+
+
+def test_the_phase_in_pieces_reports_every_block_after_its_gradients(bf16_mode):
+    """data parallelism (functional.DEFER_CHUNKS = 3, parallel.GradReducer.install): the deferred phase goes out in pieces, late layers
+    first, and a block reports its parameters (GRAD_READY_HOOK: the reducer fires the bucket's all-reduce there) only when the piece that
+    holds its last gradient has been issued. A fake hook snapshots the reported gradients AT the report (stream order = what an
+    all-reduce enqueued there would read): they must equal the final ones, every trainable parameter reports once per view, and the
+    first report comes from the late layers."""
+    from neuralsampleid_amd import functional as F_
+    from neuralsampleid_amd.encoder.graph_encoder import GraphEncoder
+    from neuralsampleid_amd.optim import FusedClipAdam
+    from neuralsampleid_amd.simclr.ntxent import ntxent_loss
+    from neuralsampleid_amd.simclr.simclr import SimCLR
+    from synth import GRAFP_CFG, synth_clips, synth_state
+    x_i, x_j = synth_clips(8)
+    model = SimCLR(GRAFP_CFG, GraphEncoder(GRAFP_CFG, in_channels=GRAFP_CFG["n_filters"], k=3, size="t"), overlap_views=True)
+    model.load_state_dict(synth_state(model.state_dict()))
+    model.to(DEV).train()
+    opt = FusedClipAdam(model.parameters(), lr=GRAFP_CFG["lr"], max_norm=1.0)
+    names = {id(p): n for n, p in model.named_parameters()}
+    reports, snaps = [], []
+
+    def hook(params):
+        F_.join_side_streams()                  # what the reducer's comm stream does: wait for every producer stream
+        for p in params:
+            reports.append(names[id(p)])
+            snaps.append((names[id(p)], p.grad.detach().clone()))
+    keep = (F_.GRAD_READY_HOOK, F_.DEFER_CHUNKS)
+    F_.GRAD_READY_HOOK, F_.DEFER_CHUNKS = hook, 3
+    try:
+        opt.zero_grad()
+        _, _, z_i, z_j = model(x_i.to(DEV), x_j.to(DEV))
+        ntxent_loss(z_i, z_j, GRAFP_CFG).backward()
+    finally:
+        F_.GRAD_READY_HOOK, F_.DEFER_CHUNKS = keep
+    torch.cuda.synchronize()
+    final = {n: p.grad.detach() for n, p in model.named_parameters() if p.requires_grad}
+    count = {}
+    for n in reports:
+        count[n] = count.get(n, 0) + 1
+    assert set(count) == set(final) and set(count.values()) == {2}, {n: c for n, c in count.items() if c != 2}
+    assert reports[0].startswith(("projector", "encoder.proj", "encoder.backbone.14")), reports[0]
+    last = {}
+    for n, g in snaps:                            # the SECOND report of a parameter (both views in) carries its complete gradient
+        last[n] = g
+    for n, g in last.items():
+        assert torch.equal(g, final[n]), n
