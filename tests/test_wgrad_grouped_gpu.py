@@ -81,6 +81,13 @@ def test_grouped_weight_gradients_match_fp64_and_the_per_layer_launches(bf16_mod
     torch.cuda.synchronize()
     cnt = ops.launch_counters()
     assert 1 <= cnt["wgrad_grouped"] <= 6 and cnt["wgrad_grouped_w3"] >= 1 and cnt["gemm_bwd_weight"] == 0, cnt
+    # a capped launch (max_workgroups: every workgroup walks several items with a static stride) adds the same sums once more
+    first = [dw.clone() for dw in outs]
+    ops.linear_bwd_weight_batch([items[i] for i in order], max_workgroups=64)
+    torch.cuda.synchronize()
+    for dw, f0 in zip(outs, first):
+        assert float((dw - 2 * f0).abs().max()) <= 2e-5 * float(f0.abs().max()) + 1e-6
+        dw.copy_(f0)
     for (M, N, K, G, aff), dw, dw1, ref in zip(LAYERS, outs, singles, refs):
         scale = float(ref.abs().max())
         e = float((dw.double().cpu() - ref).abs().max()) / scale
@@ -189,14 +196,14 @@ def test_deferred_phase_gives_the_gradients_of_the_in_chain_launches(bf16_mode):
     from synth import GRAFP_CFG, synth_clips, synth_state
     x_i, x_j = synth_clips(8)
     grads, tape = {}, None
-    for tag, defer, overlap, fork in (("base", 0, False, 0), ("base2", 0, False, 0), ("defer", 1, False, 0), ("defer2s", 1, True, 0),
-                                      ("fork2", 1, True, 2), ("fork123", 1, True, 123)):
+    for tag, defer, overlap, lanes in (("base", 0, False, 1), ("base2", 0, False, 1), ("defer", 1, False, 1), ("defer2s", 1, True, 1),
+                                       ("defer2s_one_lane", 1, True, 0)):
         model = SimCLR(GRAFP_CFG, GraphEncoder(GRAFP_CFG, in_channels=GRAFP_CFG["n_filters"], k=3, size="t"), overlap_views=overlap)
         model.load_state_dict(synth_state(model.state_dict()))
         model.to(DEV).train()
         opt = FusedClipAdam(model.parameters(), lr=GRAFP_CFG["lr"], max_norm=1.0)
         defer_keep, F_.DEFER_WGRAD = F_.DEFER_WGRAD, defer
-        fork_keep, F_.DEFER_FORK_AT = F_.DEFER_FORK_AT, fork
+        lanes_keep, F_.DEFER_TWO_LANES = F_.DEFER_TWO_LANES, lanes
         F_.DEFERRED.verify = [] if defer else None
         F_.TAPE = F_.KnnTape(replay=tape)
         ops.launch_counters(reset=True)
@@ -210,12 +217,10 @@ def test_deferred_phase_gives_the_gradients_of_the_in_chain_launches(bf16_mode):
         finally:
             F_.TAPE = None
             F_.DEFER_WGRAD = defer_keep
-            F_.DEFER_FORK_AT = fork_keep
+            F_.DEFER_TWO_LANES = lanes_keep
             F_.DEFERRED.verify = None
         cnt = ops.launch_counters()
         assert (cnt["wgrad_grouped"] > 0) == bool(defer), cnt
-        if fork:            # the forked launches ran on the auxiliary stream, beside the rest of backward
-            assert F_.DEFERRED.aux is not None and cnt["wgrad_grouped"] >= 4, cnt
         assert not F_.DEFERRED.items and not F_.DEFERRED.armed
         torch.cuda.synchronize()
         if defer:
@@ -228,7 +233,7 @@ def test_deferred_phase_gives_the_gradients_of_the_in_chain_launches(bf16_mode):
     # train-mode BatchNorm at batch 8 spreads over every earlier layer: measured 0 ... 0.021 relative L2 on the stem weight between two
     # UNDEFERRED runs (tools/deferred_debug2.py). The exact statement is the flush-time check above; here: no conv weight further than
     # 0.08 from the undeferred step, the global norm within 2 %
-    for tag in ("defer", "defer2s", "fork2", "fork123"):
+    for tag in ("defer", "defer2s", "defer2s_one_lane"):
         for n, gr in grads[tag].items():
             if not n.endswith("0.weight") or "projector" in n:
                 continue
