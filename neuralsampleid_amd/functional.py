@@ -169,6 +169,10 @@ class DeferredWgrads:
         self.items, self.hooks, self.calls, self.armed = [], [], [], False
         self.verify = None      # tests: a list that receives (dw, the same sum through the per-layer launches) for every layer of a flush
 
+    def reset(self):
+        """drop whatever an interrupted backward pass left behind (optim.FusedClipAdam.zero_grad calls it at the start of every step)"""
+        self.items, self.hooks, self.calls, self.armed = [], [], [], False
+
     def _arm(self):
         if not self.armed:
             self.armed = True

@@ -53,6 +53,7 @@ class FusedClipAdam:
 
     def zero_grad(self, set_to_none: bool = False):
         from . import functional
+        functional.DEFERRED.reset()          # (a backward pass that raised may have left recorded weight-gradient problems behind)
         functional.join_side_streams()
         ops.fill_zero(self.flat_g)
         if functional.ACT_DTYPE == torch.bfloat16:
