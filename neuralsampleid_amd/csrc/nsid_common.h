@@ -169,7 +169,8 @@ static inline bool nsid_aligned16(const void* p) { return (reinterpret_cast<uint
   X(mr_bwd_sorted_min_k, 3)    /* bf16 aggregation backward with >= this many neighbours: degree-ranked gather (mr_bwd_sorted_kernel); 0 = never */ \
   X(ffn_waves, 8)              /* waves per workgroup of the fused eval-mode FFN (4 or 8) */                                  \
   X(ffn256, 1)                 /* 1: the C = 256 stage's eval-mode FFN as one launch (ffn256_fused.hip); 0: two GEMM launches */ \
-  X(mrconv_variant, 3)         /* fused eval-mode aggregation + grouped conv: bit 0 = 8 waves, bit 1 = direct 8-byte stores */ \
+  X(mrconv_variant, 7)         /* fused eval-mode aggregation + grouped conv: bit 0 = 8 waves, bit 1 = direct 8-byte stores, bit 2 = one group per workgroup over a range of clips at C = 256 (bit 3: at every width) */ \
+  X(mrconv_pg_wgs, 768)        /* workgroups of that form */ \
   X(wgg_rows, 4096)            /* rows per workgroup of the grouped (deferred) weight gradients: splits per view = M / wgg_rows (one-box A/B: 1024 / 2048 / 4096 / 8192 / 16384 rows: 7.67 / 7.47 / 7.42 / 7.56 / 7.88 ms) */ \
   X(wgg_rows_sq, 1024)         /* the same for its 64x64-tile class (the C = 64 layers: few tiles, long row loops) */ \
   X(wgg_rows_gen, 512)         /* and for its predicated class (stem, the 32-channel grouped conv) */ \

@@ -316,7 +316,7 @@ def test_bn_backward_on_the_backward_data_operand_load(ops, M, Nout, K, groups, 
     assert relerr(din1, din_ref) < 6e-3, relerr(din1, din_ref)
 
 
-@pytest.mark.parametrize("B,C,k", [(5, 64, 3), (3, 128, 5), (4, 256, 3), (2, 256, 18), (64, 64, 3)])
+@pytest.mark.parametrize("B,C,k", [(5, 64, 3), (3, 128, 5), (4, 256, 3), (2, 256, 18), (64, 64, 3), (301, 128, 3), (1030, 256, 5)])
 def test_eval_mrconv_in_one_launch(ops, B, C, k):
     """csrc/mrconv_fused.hip: max-relative aggregation + grouped conv (+ folded BatchNorm + ReLU) in one launch per clip, the
     interleaved (B*N, 2C) tensor never formed: against the two-launch form (nsid_mr_aggregate_fwd + grouped nsid_linear_fwd with the
@@ -334,7 +334,8 @@ def test_eval_mrconv_in_one_launch(ops, B, C, k):
     u, _ = ops.mr_aggregate_fwd(y, idx, B, N, C, None, want_argmax=False)
     two, _ = ops.linear_fwd(u, w, b, B * N, C // 2, C // 2, groups=4, act_out=ops.ACT_RELU)
     try:
-        for variant in (0, 1, 2, 3):              # 4 / 8 waves x staged / direct stores (tuning key mrconv_variant; default 3)
+        # 4 / 8 waves x staged / direct stores, and (bit 2, round 6) one group per workgroup over a range of clips (k <= 8; else the per-clip form)
+        for variant in (0, 1, 2, 3, 7, 15):
             ops.set_tuning("mrconv_variant", variant)
             launch_counters(reset=True)
             out = ops.mrconv_fused_fwd(y, idx, B, N, C, w, b)
