@@ -376,6 +376,8 @@ extern "C" int nsid_mrconv_fused_fwd(const void* y, const int32_t* idx, int B, i
   NSID_REQUIRE(nsid_aligned16(y) && nsid_aligned16(w) && nsid_aligned16(bias) && nsid_aligned16(out));
   MrcArgs p{static_cast<const __bf16*>(y), idx, static_cast<const __bf16*>(w), bias, static_cast<__bf16*>(out), k};
   hipStream_t s = static_cast<hipStream_t>(stream);
+  // (C = 512, 139 KB of weights per group = one workgroup per CU, was tried in the weights-resident form: 166 us per launch against
+  //  119 us for the aggregation + grouped GEMM pair: not taken)
   const int rc = C == 64 ? mrc_launch<64>(p, B, s) : (C == 128 ? mrc_launch<128>(p, B, s) : mrc_launch<256>(p, B, s));
   if (rc == NSID_OK) nsid_count(NSID_C_mrconv_fused);
   return rc;
