@@ -699,6 +699,72 @@ __global__ __launch_bounds__(KNN2_THREADS) void knn_rank_kernel(const T* __restr
   const int lr = lane & 15, rq = lane >> 4;
   const int NS = N >> 4;
   const int kd = k * dilation;
+  if (2 * NS <= KNN2_WAVES) {
+    // Few strips (N <= 64: the 64- and 32-node graphs of the deep plan, 4 / 2 strips for 8 waves): TWO waves per strip instead of idle
+    // ones -- each takes half of the strip's column tiles in the distance pass and half of its (row, j) pairs in the rank-counting pass,
+    // one workgroup barrier between the passes (round 6: the kernel is one clip per CU, i.e. pure latency; 33.5 us per launch at
+    // B = 256, N = 64 with four of eight waves working).
+    const int s = wave % NS, h = wave / NS;            // waves >= 2 NS stay idle (N = 32)
+    const bool act = wave < 2 * NS;                    // wave-uniform
+    float* strip2 = strips + s * 16 * SLD;
+    if (act) {
+      const int t0 = h * (NS / 2), t1 = t0 + NS / 2;   // NT divides NS / 2 (host: NT = NS / 2)
+      for (int tn = t0; tn < t1; tn += NT) {
+        f32x4 lead[NT], corr[NT];
+#pragma unroll
+        for (int u = 0; u < NT; ++u) lead[u] = corr[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+        KnnFrag fa = knn_frag(img, rq, 16 * s + lr, KC, N), fb[NT];
+#pragma unroll
+        for (int u = 0; u < NT; ++u) fb[u] = knn_frag(img, rq, 16 * (tn + u) + lr, KC, N);
+        for (int kc = 0; kc < KC; kc += 4) {
+          const int kn = (kc + 4 < KC ? kc + 4 : kc) + rq;
+          const KnnFrag na = knn_frag(img, kn, 16 * s + lr, KC, N);
+          KnnFrag nb[NT];
+#pragma unroll
+          for (int u = 0; u < NT; ++u) nb[u] = knn_frag(img, kn, 16 * (tn + u) + lr, KC, N);
+#pragma unroll
+          for (int u = 0; u < NT; ++u) knn_mfma3(fa, fb[u], lead[u], corr[u]);
+          fa = na;
+#pragma unroll
+          for (int u = 0; u < NT; ++u) fb[u] = nb[u];
+        }
+#pragma unroll
+        for (int u = 0; u < NT; ++u) {
+          const float sj = sq[16 * (tn + u) + lr];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float si = sq[16 * s + 4 * rq + e];
+            strip2[(4 * rq + e) * SLD + 16 * (tn + u) + lr] = (si + (-2.f * (lead[u][e] + corr[u][e]))) + sj;      // the same expression as below
+          }
+        }
+      }
+    }
+    __syncthreads();
+    if (act) {
+      for (int p = lane + 64 * h; p < 16 * N; p += 128) {        // the two waves of a strip interleave its (row, j) pairs
+        const int row = p / N, j = p % N;
+        const float* drow = strip2 + row * SLD;
+        const float dj = drow[j];
+        int rank = 0, same = 0;
+        for (int m = 0; m < N; m += 4) {
+          const f32x4 dm = *reinterpret_cast<const f32x4*>(drow + m);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { rank += dm[e] < dj ? 1 : 0; same += dm[e] == dj ? 1 : 0; }
+        }
+        if (__any(same > 1)) {                           // wave-uniform
+          if (same > 1)
+            for (int m = 0; m < j; ++m) rank += drow[m] == dj ? 1 : 0;
+        }
+        int32_t* out = idx + ((long)b * N + 16 * s + row) * k;
+        if (dj != dj) {                                  // NaN distances: every entry ranks 0 — emit valid ids anyway
+          if (j < k) out[j] = j;
+        } else if (rank < kd && rank % dilation == 0) {
+          out[rank / dilation] = j;
+        }
+      }
+    }
+    return;
+  }
   float* strip = strips + wave * 16 * SLD;
   for (int s = wave; s < NS; s += KNN2_WAVES) {      // no workgroup barrier below: a wave owns its strip buffer
     for (int tn = 0; tn < NS; tn += NT) {
@@ -1084,8 +1150,13 @@ int launch_knn_rank_nt(const void* r, int ldr, const float* scale, const float* 
 template <typename T>
 int launch_knn_rank(const void* r, int ldr, const float* scale, const float* shift, int B, int N, int C, int k,
                     int dilation, int32_t* idx, hipStream_t s) {
-  return (N >> 4) >= 4 ? launch_knn_rank_nt<T, 4>(r, ldr, scale, shift, B, N, C, k, dilation, idx, s)
-                       : launch_knn_rank_nt<T, 2>(r, ldr, scale, shift, B, N, C, k, dilation, idx, s);
+  // column tiles per MFMA pass: 4 where a wave owns a whole strip (N = 128); N <= 64 runs two waves per strip, each with half of its
+  // column tiles: 2 (N = 64) or 1 (N = 32)
+  const int NS = N >> 4;
+  if (2 * NS <= KNN2_WAVES)
+    return NS >= 4 ? launch_knn_rank_nt<T, 2>(r, ldr, scale, shift, B, N, C, k, dilation, idx, s)
+                   : launch_knn_rank_nt<T, 1>(r, ldr, scale, shift, B, N, C, k, dilation, idx, s);
+  return launch_knn_rank_nt<T, 4>(r, ldr, scale, shift, B, N, C, k, dilation, idx, s);
 }
 
 template <typename T, int KD, int NT>
