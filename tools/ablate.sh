@@ -17,6 +17,6 @@ run "no aggregation bwd" "nsid_mr_aggregate_bwd,nsid_mr_aggregate_bwd_bn"
 run "no col_reduce (bn_bwd_reduce)" "nsid_bn_bwd_reduce"
 run "no NT-Xent" "nsid_ntxent_fwd_bwd"
 run "no patchify" "nsid_peak_patchify_fwd,nsid_peak_patchify_bwd,nsid_peak_patchify_bwd_ws"
-run "no node mean / l2norm / elu" "nsid_node_mean_fwd,nsid_node_mean_bwd,nsid_l2norm_fwd,nsid_l2norm_bwd,nsid_elu_bwd"
+run "no node mean, l2norm, elu" "nsid_node_mean_fwd,nsid_node_mean_bwd,nsid_l2norm_fwd,nsid_l2norm_bwd,nsid_elu_bwd"
 run "no optimiser" "nsid_adam_step,nsid_sumsq_partial,nsid_fill_zero,nsid_f32_to_bf16,nsid_ds_prepack"
 run "baseline again" "nsid_version"
