@@ -10,11 +10,17 @@ namespace {
 
 // 1024 threads = 16 tile groups x 64 channels: lanes run along channels (coalesced 256-B rows of the partial
 // matrix), tile groups stride over the row tiles; partial sums are combined in fp64 in a fixed order (deterministic).
-constexpr int FIN_CH = 64, FIN_TG = 16;
+// Round 6: a workgroup that covers 64 channels pulls tiles x 64 x 2 floats through ONE CU (262 KB for the 512 row tiles of the C = 64
+// layers at B = 256: 2-3 us at what a CU draws from L2, on a dependent chain where a microsecond per finalize launch is 0.3 ms of the
+// step). With many row tiles the same 1024 threads cover 16 channels x 64 tile groups instead: four times the workgroups (CUs), a quarter
+// of the bytes each. FIN_CH is a template parameter of the two finalize kernels; bn_fin_ch() chooses.
+constexpr int FIN_THREADS = 1024;
 
+template <int FIN_CH>
 __device__ __forceinline__ void tile_sums(const float* __restrict__ p0, const float* __restrict__ p1, int tiles,
                                           int C, int c, int tg, bool ok, double* red0, double* red1, double& sum,
                                           double& sq) {
+  constexpr int FIN_TG = FIN_THREADS / FIN_CH;
   double a = 0.0, b = 0.0;
   if (ok) {
     // all loads of a batch are issued before the first add (the fp64 chain would otherwise serialise one L2 round trip
@@ -56,15 +62,16 @@ __device__ __forceinline__ float running_blend(float old, float stat, float m) {
   return a + b;
 }
 
-__global__ __launch_bounds__(FIN_CH * FIN_TG) void bn_finalize_kernel(
+template <int FIN_CH>
+__global__ __launch_bounds__(FIN_THREADS) void bn_finalize_kernel(
     const float* __restrict__ stat, int tiles, int C, int M, const float* gamma, const float* beta,
     float* running_mean, float* running_var, int64_t* nbt, float momentum, float eps, float* scale, float* shift,
     float* mean_out, float* invstd_out, float* uvar_out) {
-  __shared__ double red0[FIN_CH * FIN_TG], red1[FIN_CH * FIN_TG];
+  __shared__ double red0[FIN_THREADS], red1[FIN_THREADS];
   const int c = blockIdx.x * FIN_CH + (threadIdx.x & (FIN_CH - 1)), tg = threadIdx.x / FIN_CH;
   if (blockIdx.x == 0 && threadIdx.x == 0 && nbt != nullptr) *nbt += 1;
   double sum, sq;
-  tile_sums(stat, stat + (long)tiles * C, tiles, C, c, tg, c < C, red0, red1, sum, sq);
+  tile_sums<FIN_CH>(stat, stat + (long)tiles * C, tiles, C, c, tg, c < C, red0, red1, sum, sq);
   if (tg != 0 || c >= C) return;
   const double mean = sum / M;
   double var = sq / M - mean * mean;
@@ -194,7 +201,8 @@ __global__ __launch_bounds__(256) void col_reduce_kernel(const T* __restrict__ d
 // coef4 (optional): the BatchNorm backward as ONE affine of its two sources for a consumer that evaluates it on its operand load
 // (gemm.hip ABN): dr = sc*(g - c0 - xhat*c1) = sc*g + P*r + Q with P = -sc*c1*invstd, Q = sc*(c1*invstd*mean - c0);
 // coef4[4][C] = {sc, sh, P, Q} (sc, sh: the forward affine, needed for the activation mask g = dy * act'(sc*r + sh)).
-__global__ __launch_bounds__(FIN_CH * FIN_TG) void bn_bwd_finalize_kernel(const float* __restrict__ partial,
+template <int FIN_CH>
+__global__ __launch_bounds__(FIN_THREADS) void bn_bwd_finalize_kernel(const float* __restrict__ partial,
                                                                            int tiles, int C, int M, float* dgamma,
                                                                            float* dbeta, float* coef,
                                                                            const float* __restrict__ scale,
@@ -202,10 +210,10 @@ __global__ __launch_bounds__(FIN_CH * FIN_TG) void bn_bwd_finalize_kernel(const 
                                                                            const float* __restrict__ mean,
                                                                            const float* __restrict__ invstd,
                                                                            float* __restrict__ coef4) {
-  __shared__ double red0[FIN_CH * FIN_TG], red1[FIN_CH * FIN_TG];
+  __shared__ double red0[FIN_THREADS], red1[FIN_THREADS];
   const int c = blockIdx.x * FIN_CH + (threadIdx.x & (FIN_CH - 1)), tg = threadIdx.x / FIN_CH;
   double sg, sgx;
-  tile_sums(partial, partial + (long)tiles * C, tiles, C, c, tg, c < C, red0, red1, sg, sgx);
+  tile_sums<FIN_CH>(partial, partial + (long)tiles * C, tiles, C, c, tg, c < C, red0, red1, sg, sgx);
   if (tg != 0 || c >= C) return;
   // atomic: the two views of a step may run this concurrently on different streams for the same layer
   if (dbeta) atomicAdd(dbeta + c, (float)sg);
@@ -327,6 +335,19 @@ inline long chunk_keeping_grid(long nchunks, int CV, int U, long max_wg, bool* c
   return (want + g0 - 1) / g0 * g0;
 }
 
+// Channel width of a finalize workgroup: 16 once there are many row tiles (tuning key bn_fin_tiles, 0 = always 64).
+inline int bn_fin_ch(int tiles) {
+  const int t = (int)nsid_tune(NSID_T_bn_fin_tiles);
+  return (t > 0 && tiles >= t) ? 16 : 64;
+}
+#define NSID_FIN_LAUNCH(kernel, tiles, C, stream, ...)                                                                      \
+  do {                                                                                                                       \
+    if (bn_fin_ch(tiles) == 16)                                                                                              \
+      NSID_LAUNCH(kernel<16>, dim3(((C) + 15) / 16), dim3(FIN_THREADS), 0, static_cast<hipStream_t>(stream), __VA_ARGS__);   \
+    else                                                                                                                     \
+      NSID_LAUNCH(kernel<64>, dim3(((C) + 63) / 64), dim3(FIN_THREADS), 0, static_cast<hipStream_t>(stream), __VA_ARGS__);   \
+  } while (0)
+
 }  // namespace
 
 extern "C" int nsid_bn_finalize(const float* stat, int tiles, int C, int M, const float* gamma, const float* beta,
@@ -335,8 +356,7 @@ extern "C" int nsid_bn_finalize(const float* stat, int tiles, int C, int M, cons
   NSID_REQUIRE(stat && gamma && beta && scale && shift && mean && invstd && C > 0 && M > 0);
   NSID_REQUIRE(tiles == nsid_row_tiles(M));
   NSID_REQUIRE((running_mean == nullptr) == (running_var == nullptr));
-  NSID_LAUNCH(bn_finalize_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_TG), 0,
-              static_cast<hipStream_t>(stream), stat, tiles, C, M, gamma, beta, running_mean, running_var, nbt,
+  NSID_FIN_LAUNCH(bn_finalize_kernel, tiles, C, stream, stat, tiles, C, M, gamma, beta, running_mean, running_var, nbt,
               momentum, eps, scale, shift, mean, invstd, static_cast<float*>(nullptr));
   return nsid_launch_status();
 }
@@ -351,8 +371,7 @@ extern "C" int nsid_bn_finalize_deferred(const float* stat, int tiles, int C, in
                                          float* invstd, float* uvar, void* stream) {
   NSID_REQUIRE(stat && gamma && beta && scale && shift && mean && invstd && uvar && C > 0 && M > 0);
   NSID_REQUIRE(tiles == nsid_row_tiles(M));
-  NSID_LAUNCH(bn_finalize_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_TG), 0,
-              static_cast<hipStream_t>(stream), stat, tiles, C, M, gamma, beta, static_cast<float*>(nullptr),
+  NSID_FIN_LAUNCH(bn_finalize_kernel, tiles, C, stream, stat, tiles, C, M, gamma, beta, static_cast<float*>(nullptr),
               static_cast<float*>(nullptr), static_cast<int64_t*>(nullptr), 0.f, eps, scale, shift, mean, invstd, uvar);
   return nsid_launch_status();
 }
@@ -451,8 +470,7 @@ extern "C" int nsid_bn_bwd_reduce(const void* dout, const void* r, int M, int C,
 extern "C" int nsid_bn_bwd_finalize(const float* partial, int tiles, int C, int M, float* dgamma, float* dbeta,
                                     float* coef, void* stream) {
   NSID_REQUIRE(partial && coef && C > 0 && M > 0 && tiles >= 1);      // rows of partial sums: nsid_row_tiles(M) from a GEMM epilogue / the reduce pass, or one per clip (nsid_mr_aggregate_bwd_bn)
-  NSID_LAUNCH(bn_bwd_finalize_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_TG), 0,
-              static_cast<hipStream_t>(stream), partial, tiles, C, M, dgamma, dbeta, coef, static_cast<const float*>(nullptr),
+  NSID_FIN_LAUNCH(bn_bwd_finalize_kernel, tiles, C, stream, partial, tiles, C, M, dgamma, dbeta, coef, static_cast<const float*>(nullptr),
               static_cast<const float*>(nullptr), static_cast<const float*>(nullptr), static_cast<const float*>(nullptr),
               static_cast<float*>(nullptr));
   return nsid_launch_status();
@@ -462,8 +480,7 @@ extern "C" int nsid_bn_bwd_finalize_fused(const float* partial, int tiles, int C
                                           float* coef, const float* scale, const float* shift, const float* mean,
                                           const float* invstd, float* coef4, void* stream) {
   NSID_REQUIRE(partial && coef && coef4 && scale && shift && mean && invstd && C > 0 && M > 0 && tiles >= 1);
-  NSID_LAUNCH(bn_bwd_finalize_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_TG), 0,
-              static_cast<hipStream_t>(stream), partial, tiles, C, M, dgamma, dbeta, coef, scale, shift, mean, invstd, coef4);
+  NSID_FIN_LAUNCH(bn_bwd_finalize_kernel, tiles, C, stream, partial, tiles, C, M, dgamma, dbeta, coef, scale, shift, mean, invstd, coef4);
   return nsid_launch_status();
 }
 

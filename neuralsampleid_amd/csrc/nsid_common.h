@@ -174,6 +174,7 @@ static inline bool nsid_aligned16(const void* p) { return (reinterpret_cast<uint
   X(wgg_rows, 4096)            /* rows per workgroup of the grouped (deferred) weight gradients: splits per view = M / wgg_rows (one-box A/B: 1024 / 2048 / 4096 / 8192 / 16384 rows: 7.67 / 7.47 / 7.42 / 7.56 / 7.88 ms) */ \
   X(wgg_rows_sq, 1024)         /* the same for its 64x64-tile class (the C = 64 layers: few tiles, long row loops) */ \
   X(wgg_rows_gen, 512)         /* and for its predicated class (stem, the 32-channel grouped conv) */ \
+  X(bn_fin_tiles, 0)           /* BatchNorm finalize kernels: from this many row tiles on a workgroup covers 16 channels x 64 tile groups instead of 64 x 16 (0: never; 256 measured equal within noise, docs/experiments.md round 6) */ \
   X(wgg_w3, 1)                 /* grouped problems with Nout % 128 == 0 and K % 128 == 0 on 128x128 tiles, 8 waves (wgrad.hip) */ \
   X(ws_gemm, 7)                /* weight-stationary streaming GEMMs (wsgemm.hip) for the small-K layers: bit 0 forward, bit 1 backward-data, bit 2 backward-data with the BatchNorm backward on its operand load */
 
