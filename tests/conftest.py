@@ -5,6 +5,9 @@ import numpy as np
 import pytest
 import torch
 
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from compare import SampledRef  # noqa: E402
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 for p in (ROOT, GOLDEN):
@@ -27,7 +30,9 @@ def pytest_collection_modifyitems(config, items):
 
 class Golden(dict):
     def t(self, key):
-        return torch.from_numpy(np.asarray(self[key]))
+        """the stored tensor; a tests/compare.py::SampledRef for a tensor stored in compact form (maxerr / relerr take either)"""
+        v = self[key]
+        return v if isinstance(v, SampledRef) else torch.from_numpy(np.asarray(v))
 
 
 def _by_rule(rule, args):
@@ -50,6 +55,13 @@ def load_golden(name):
     import json
     with np.load(os.path.join(GOLDEN, name + ".npz")) as z:
         data = {k: z[k] for k in z.files}
+    for key in [k[:-2] for k in data if k.endswith("@m")]:          # compact form -> one SampledRef under the tensor's own key
+        data[key] = SampledRef(key, data.pop(key + "@s"), data.pop(key + "@c"), data.pop(key + "@m"))
+    if data.pop("__gapbits__", None) is not None:                   # margins stored as one bit per row ("< 1e-4"): gap.* as 0 / 1
+        for key in [k for k in data if k.startswith("near.")]:
+            rows = data["knn." + key[5:]].shape[:-1]
+            near = np.unpackbits(data[key])[: int(np.prod(rows))].reshape(rows).astype(bool)
+            data["gap." + key[5:]] = np.where(near, np.float32(0.0), np.float32(1.0))
     rules = data.pop("__synth__", None)
     if rules is not None:
         digests = _synth_digests()

@@ -110,6 +110,8 @@ def save(name, **arrays):
         merged = json.load(open(dpath)) if os.path.exists(dpath) else {}
         merged.update(_DIGESTS)
         json.dump(merged, open(dpath, "w"), indent=0, sort_keys=True)
+    from compact import compact_fixture          # large reference tensors -> sample + checksums, margins -> bits (tests/golden/compact.py)
+    out = compact_fixture(name, out)
     path = os.path.join(HERE, name + ".npz")
     np.savez_compressed(path, **out)
     print(f"  {name}.npz  {os.path.getsize(path) / 1024:.0f} KB" + (f"  (by rule: {sorted(synth)})" if synth else ""))

@@ -19,6 +19,7 @@ import torch
 
 from b256_common import B, N_CALLS, bench_clips, chaos, check_tape, checksums, per_clip, tape_of
 from conftest import ROOT
+from compare import maxerr, relerr
 from synth import GRAFP_CFG
 
 pytestmark = pytest.mark.gpu
@@ -35,15 +36,6 @@ def note(key, value):
             json.dump(MEASURED, f, indent=1, sort_keys=True)
     except OSError:
         pass
-
-
-def relerr(a, b):
-    a, b = a.detach().cpu().double(), b.detach().cpu().double()
-    return float((a - b).norm() / b.norm().clamp_min(1e-30))
-
-
-def maxerr(a, b):
-    return float((a.detach().cpu().double() - b.detach().cpu().double()).abs().max())
 
 
 def build(overlap=False):

@@ -10,6 +10,7 @@ import numpy as np
 import pytest
 import torch
 
+from compare import relerr
 from synth import GRAFP_CFG, synth_randn, synth_state
 
 pytestmark = pytest.mark.gpu
@@ -26,11 +27,6 @@ def ops():
 
 def bf(x):
     return x.to(torch.bfloat16).double()
-
-
-def relerr(a, b):
-    a, b = a.detach().cpu().double(), b.detach().cpu().double()
-    return float((a - b).norm() / b.norm().clamp_min(1e-30))
 
 
 def act_ref(x, act):

@@ -7,6 +7,7 @@ import pytest
 
 import torch
 
+from compare import relerr
 from synth import GRAFP_CFG, synth_randn, synth_state
 
 pytestmark = pytest.mark.gpu
@@ -23,11 +24,6 @@ def ops():
     o.reset_tuning()
     o.set_gemm_precision("fp32")
     F_.set_activation_dtype("fp32")
-
-
-def relerr(a, b):
-    a, b = a.detach().cpu().double(), b.detach().cpu().double()
-    return float((a - b).norm() / b.norm().clamp_min(1e-30))
 
 
 def act_ref(x, act):

@@ -16,6 +16,7 @@ import torch.nn as nn
 
 from conftest import GOLDEN, from_rows, to_rows
 from oracle import ref_torch as R
+from compare import absmax, maxerr, relerr
 from synth import GRAFP_CFG, synth_clips, synth_state, synth_tensor
 
 pytestmark = pytest.mark.gpu
@@ -28,15 +29,6 @@ def _reset_tape():
     from neuralsampleid_amd import functional as F_
     F_.TAPE = None
     R.TAPE = None
-
-
-def relerr(a, b):
-    a, b = a.detach().cpu().double(), b.detach().cpu().double()
-    return float((a - b).norm() / b.norm().clamp_min(1e-30))
-
-
-def maxerr(a, b):
-    return float((a.detach().cpu().double() - b.detach().cpu().double()).abs().max())
 
 
 def load_synth(module, prefix=""):
@@ -171,7 +163,7 @@ def test_block_modules(golden, tag, C, N, k, d):
         y_eval = blk(x.to(DEV))
     own = F_.TAPE.recorded[0]
     F_.TAPE = None
-    assert maxerr(y_eval, g.t("y_eval")) < 1e-4 * max(1.0, float(g.t("y_eval").abs().max()))
+    assert maxerr(y_eval, g.t("y_eval")) < 1e-4 * max(1.0, absmax(g.t("y_eval")))
     same = (np.sort(own.cpu().numpy(), -1) == np.sort(idx_eval.numpy(), -1)).all(-1)
     assert same.mean() > 0.99                                  # own kNN agrees with the oracle's up to near-ties
 
@@ -181,12 +173,12 @@ def test_block_modules(golden, tag, C, N, k, d):
     y = blk(xg)
     y.backward(g.t("gout").to(DEV))
     F_.TAPE = None
-    assert maxerr(y, g.t("y_train")) < 1e-4 * max(1.0, float(g.t("y_train").abs().max()))
+    assert maxerr(y, g.t("y_train")) < 1e-4 * max(1.0, absmax(g.t("y_train")))
     assert relerr(xg.grad, g.t("dx")) < 1e-3
     for name, p in blk.named_parameters():
         if "grad." + name in g:
             ref = g.t("grad." + name)
-            if float(ref.abs().max()) < 1e-3:
+            if absmax(ref) < 1e-3:
                 # analytically zero (a bias or BN beta whose shift the next BatchNorm removes): roundoff on both sides
                 assert float(p.grad.abs().max()) < 1e-3, name
             else:

@@ -5,6 +5,7 @@ import numpy as np
 import pytest
 import torch
 
+from compare import absmax, maxerr
 from conftest import from_rows, to_rows
 from oracle import ref_torch as R
 from synth import GRAFP_CFG, synth_randn, synth_tensor
@@ -24,10 +25,9 @@ def rnd(tag, *shape):
 
 
 def close(a, b, tol=2e-4, what=""):
-    a = a.detach().cpu().double()
-    b = b.detach().cpu().double()
-    scale = max(1.0, float(b.abs().max()))
-    err = float((a - b).abs().max())
+    """b: the reference (a tensor, or a golden tensor in compact form: tests/compare.py)"""
+    scale = max(1.0, absmax(b))
+    err = maxerr(a, b)
     assert err <= tol * scale, f"{what}: max err {err:.3e} (scale {scale:.3e})"
 
 

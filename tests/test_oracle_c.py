@@ -9,6 +9,7 @@ import numpy as np
 import pytest
 import torch
 
+from compare import allclose
 from conftest import from_rows, to_rows
 from oracle import ref_torch as R
 from synth import GRAFP_CFG, synth_tensor
@@ -79,7 +80,7 @@ def test_mr_aggregate(C, golden):
     gu = f32(to_rows(g.t("gu")))
     dy = np.zeros((B * N, Cc), np.float32)
     assert C.oracle_mr_aggregate_bwd(p(gu), p(idx, IP), p(am, UP), B, N, Cc, k, p(dy)) == 0
-    assert torch.allclose(from_rows(torch.from_numpy(dy).reshape(B, N, Cc)), g.t("dx"), atol=1e-6)
+    assert allclose(from_rows(torch.from_numpy(dy).reshape(B, N, Cc)), g.t("dx"), atol=1e-6)
 
 
 def test_downsample_and_batchnorm(C, golden):
@@ -98,7 +99,7 @@ def test_downsample_and_batchnorm(C, golden):
         out = np.zeros_like(conv)
         assert C.oracle_bn_fwd(p(conv), B * No, 2 * Cc, p(f32(P["conv.1.weight"])), p(f32(P["conv.1.bias"])), p(rm), p(rv), training,
                                p(out)) == 0
-        assert torch.allclose(from_rows(torch.from_numpy(out).reshape(B, No, 2 * Cc)), g.t(key), atol=2e-5)
+        assert allclose(from_rows(torch.from_numpy(out).reshape(B, No, 2 * Cc)), g.t(key), atol=2e-5)
         if training:
             assert torch.allclose(torch.from_numpy(rm), g.t("post.conv.1.running_mean"), atol=1e-6)
             assert torch.allclose(torch.from_numpy(rv), g.t("post.conv.1.running_var"), atol=1e-6)
@@ -112,7 +113,7 @@ def test_peak_patchify(C, golden):
     B, H, W = x.shape
     out = np.zeros((B * 256, 8), np.float32)
     assert C.oracle_peak_patchify_fwd(p(x), p(w), p(b), B, H, W, 4, 8, 8, p(out)) == 0
-    assert torch.allclose(torch.from_numpy(out).reshape(B, 256, 8).transpose(1, 2), g.t("y"), atol=1e-5)
+    assert allclose(torch.from_numpy(out).reshape(B, 256, 8).transpose(1, 2), g.t("y"), atol=1e-5)
 
 
 @pytest.mark.parametrize("B", [2, 8, 256])
@@ -124,8 +125,8 @@ def test_ntxent(C, golden, B):
     dzi, dzj = np.zeros_like(zi), np.zeros_like(zj)
     assert C.oracle_ntxent(p(zi), p(zj), B, zi.shape[1], float(g["tau"]), p(loss), p(dzi), p(dzj)) == 0
     assert abs(float(loss[0]) - float(g["loss"][0])) < 2e-6
-    assert torch.allclose(torch.from_numpy(dzi), g.t("dz_i"), atol=1e-6)
-    assert torch.allclose(torch.from_numpy(dzj), g.t("dz_j"), atol=1e-6)
+    assert allclose(torch.from_numpy(dzi), g.t("dz_i"), atol=1e-6)
+    assert allclose(torch.from_numpy(dzj), g.t("dz_j"), atol=1e-6)
 
 
 def test_grouped_linear_and_block_against_the_torch_oracle(C):

@@ -15,20 +15,12 @@ import pytest
 import torch
 
 from conftest import GOLDEN, ROOT
+from compare import maxerr, relerr
 from synth import GRAFP_CFG, synth_state
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
 MEASURED = {}
-
-
-def relerr(a, b):
-    a, b = a.detach().cpu().double(), b.detach().cpu().double()
-    return float((a - b).norm() / b.norm().clamp_min(1e-30))
-
-
-def maxerr(a, b):
-    return float((a.detach().cpu().double() - b.detach().cpu().double()).abs().max())
 
 
 def note(key, value):

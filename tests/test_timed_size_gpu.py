@@ -21,6 +21,7 @@ import torch
 
 from b256_common import bench_clips, per_clip
 from conftest import GOLDEN, ROOT
+from compare import maxerr, relerr
 from synth import GRAFP_CFG, fixed_graph, row_set_hash, synth_state
 
 pytestmark = pytest.mark.gpu
@@ -36,15 +37,6 @@ def note(key, value):
             json.dump(MEASURED, f, indent=1, sort_keys=True)
     except OSError:
         pass
-
-
-def relerr(a, b):
-    a, b = a.detach().cpu().double(), b.detach().cpu().double()
-    return float((a - b).norm() / b.norm().clamp_min(1e-30))
-
-
-def maxerr(a, b):
-    return float((a.detach().cpu().double() - b.detach().cpu().double()).abs().max())
 
 
 @pytest.fixture()
