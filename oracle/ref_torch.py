@@ -119,10 +119,14 @@ class KnnTape:
     reaches every clip through the BN batch statistics), so end-to-end parity is checked in two halves:
     indices agree outside near-ties, and outputs agree when the indices are forced to the reference's."""
 
-    def __init__(self, replay: Optional[List[Tensor]] = None):
+    def __init__(self, replay: Optional[List[Tensor]] = None, patch=None):
+        """patch: per call (flat row numbers, ids for those rows): the search's own result except on those rows (a fixture that holds
+        the reference's ids only on its near-tie rows); the graphs actually used are collected in .patched"""
         self.replay = list(replay) if replay is not None else None
         self.recorded: List[Tensor] = []
         self.pos = 0
+        self.patch = list(patch) if patch is not None else None
+        self.patched: List[Tensor] = []
 
 
 TAPE: Optional[KnnTape] = None
@@ -137,6 +141,13 @@ def knn_graph(y: Tensor, k: int, dilation: int = 1) -> Tensor:
         if TAPE.replay is not None:
             idx = TAPE.replay[TAPE.pos].long()
             TAPE.pos += 1
+        elif TAPE.patch is not None:
+            rows, ids = TAPE.patch[TAPE.pos]
+            TAPE.pos += 1
+            idx = idx.clone()
+            if len(rows):
+                idx.view(-1, idx.shape[-1])[torch.as_tensor(rows, dtype=torch.long)] = torch.as_tensor(ids).long()
+            TAPE.patched.append(idx)
     return idx
 
 

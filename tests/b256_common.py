@@ -6,6 +6,7 @@ import os
 import numpy as np
 import torch
 
+import tapes
 from conftest import GOLDEN
 from synth import GRAFP_CFG
 
@@ -32,22 +33,14 @@ def chaos():
         return json.load(f)
 
 
-def tape_of(g, tag="s0"):
-    return [g.t(f"knn.{tag}.{c}").to(torch.int64) for c in range(N_CALLS)]
+def patches_of(g, tag="s0"):
+    return tapes.patches_of(g, tag)
 
 
-def check_tape(recorded, g, tag="s0"):
-    """own neighbour SETS against the reference's: (hard mismatches, mismatches on recorded near-tie rows, rows)"""
-    hard = soft = rows = 0
-    for c, own in enumerate(recorded):
-        ref = g[f"knn.{tag}.{c}"].astype(np.int64)
-        own = own.detach().cpu().numpy().astype(np.int64)
-        near = np.unpackbits(g[f"near.{tag}.{c}"])[: ref.shape[0] * ref.shape[1]].reshape(ref.shape[:2]).astype(bool)
-        diff = (np.sort(own, -1) != np.sort(ref, -1)).any(-1)
-        hard += int((diff & ~near).sum())
-        soft += int((diff & near).sum())
-        rows += diff.size
-    return hard, soft, rows
+def check_tape(tape, g, tag="s0"):
+    """(hard, soft, rows) of a KnnTape that ran in patch mode: tests/tapes.py::check_patched"""
+    assert tapes.n_calls(g, tag) == N_CALLS
+    return tapes.check_patched(tape, g, tag)
 
 
 def per_clip(t):

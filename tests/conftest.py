@@ -42,6 +42,9 @@ def _by_rule(rule, args):
         return synth_randn(args[0], *args[1])
     if rule in ("clips_i", "clips_j"):
         return synth_clips(args[0])[0 if rule == "clips_i" else 1]
+    if rule in ("unit_i", "unit_j"):
+        from synth import synth_unit_pair
+        return synth_unit_pair(args[0])[0 if rule == "unit_i" else 1]
     if rule in ("bench_i", "bench_j"):          # bench.py's synth_clips
         gi, gj = torch.Generator().manual_seed(args[1]), torch.Generator().manual_seed(args[1] + 1)
         x_i = torch.randn(args[0], GRAFP_CFG["n_mels"], GRAFP_CFG["n_frames"], generator=gi) * 20.0 - 40.0
@@ -59,7 +62,7 @@ def load_golden(name):
         data[key] = SampledRef(key, data.pop(key + "@s"), data.pop(key + "@c"), data.pop(key + "@m"))
     if data.pop("__gapbits__", None) is not None:                   # margins stored as one bit per row ("< 1e-4"): gap.* as 0 / 1
         for key in [k for k in data if k.startswith("near.")]:
-            rows = data["knn." + key[5:]].shape[:-1]
+            rows = tuple(data["knnshape." + key[5:]][:-1]) if "knnshape." + key[5:] in data else data["knn." + key[5:]].shape[:-1]
             near = np.unpackbits(data[key])[: int(np.prod(rows))].reshape(rows).astype(bool)
             data["gap." + key[5:]] = np.where(near, np.float32(0.0), np.float32(1.0))
     rules = data.pop("__synth__", None)

@@ -23,7 +23,7 @@ import torch.nn as nn
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
-from synth import GRAFP_CFG, fixed_graph, row_set_hash, synth_clips, synth_randn, synth_state  # noqa: E402
+from synth import GRAFP_CFG, fixed_graph, row_set_hash, synth_clips, synth_randn, synth_state, synth_unit_pair  # noqa: E402
 
 REF = os.environ.get("NSID_REFERENCE", "/root/reference")
 
@@ -255,9 +255,9 @@ def gold_peak():
 def gold_ntxent():
     print("ntxent")
     for B in (2, 8, 256):
-        zi = torch.nn.functional.normalize(synth_randn(f"ntx_i{B}", B, 128), dim=1).requires_grad_(True)
-        zj = torch.nn.functional.normalize(
-            zi.detach() + 0.5 * synth_randn(f"ntx_j{B}", B, 128), dim=1).requires_grad_(True)
+        zi, zj = synth_unit_pair(B)                       # (a rule: the fixture stores the outputs only)
+        _RULE_MADE.extend([("unit_i", [B], zi.clone()), ("unit_j", [B], zj.clone())])
+        zi, zj = zi.requires_grad_(True), zj.requires_grad_(True)
         loss = ntxent_loss(zi, zj, CFG)
         loss.backward()
         save(f"ntxent_b{B}", z_i=zi, z_j=zj, loss=loss.detach().reshape(1), dz_i=zi.grad, dz_j=zj.grad,

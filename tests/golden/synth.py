@@ -78,8 +78,31 @@ def fixed_graph(batch: int, nodes: int, k: int, call: int) -> torch.Tensor:
     return (n + 1 + 7 * j + 3 * b + 5 * call) % nodes
 
 
+def clip_graph_hash(idx) -> np.ndarray:
+    """64-bit hash per clip of a whole graph build (B, N, k): every row's neighbour SET (ids sorted, so the search's output order does
+    not matter) mixed with the row number, summed over the rows in wrapping uint64. A fixture that stores the reference's ids only on
+    its near-tie rows (tests/golden/compact.py::sparse_tape) proves with it that every OTHER row of a rebuilt graph is the reference's."""
+    a = np.sort(np.asarray(idx.cpu() if isinstance(idx, torch.Tensor) else idx).astype(np.uint64), axis=-1)
+    with np.errstate(over="ignore"):
+        code = np.zeros(a.shape[:-1], np.uint64)
+        for j in range(a.shape[-1]):
+            code = code * np.uint64(257) + a[..., j] + np.uint64(1)
+        x = (code + np.arange(a.shape[1], dtype=np.uint64)[None, :] * np.uint64(0x9E3779B97F4A7C15)) * np.uint64(0xBF58476D1CE4E5B9)
+        x ^= x >> np.uint64(30)
+        x *= np.uint64(0x94D049BB133111EB)
+        x ^= x >> np.uint64(31)
+        return x.sum(axis=1, dtype=np.uint64)
+
+
 def row_set_hash(idx: torch.Tensor) -> torch.Tensor:
     """order-independent 8-bit hash of every row's neighbour SET: sum_j (id_j + 1)^2 mod 251 (uint8). Pins which nodes a search
     selected at a size where the ids themselves are too many to store."""
     v = idx.to(torch.int64) + 1
     return ((v * v).sum(-1) % 251).to(torch.uint8)
+
+
+def synth_unit_pair(B: int, dim: int = 128):
+    """the NT-Xent fixtures' inputs: unit rows z_i, and z_j = unit(z_i + 0.5 noise) (make_golden.py::gold_ntxent)"""
+    zi = torch.nn.functional.normalize(synth_randn(f"ntx_i{B}", B, dim), dim=1)
+    zj = torch.nn.functional.normalize(zi + 0.5 * synth_randn(f"ntx_j{B}", B, dim), dim=1)
+    return zi, zj

@@ -4,7 +4,7 @@ change of one view's input moves its loss by 2e-2 and its gradients by 30 %, so 
 with the reference's neighbour ids teacher-forced; eval mode (no cross-clip coupling) runs the oracle's own neighbour search."""
 import torch
 
-from b256_common import N_CALLS, bench_clips, chaos, check_tape, checksums, per_clip, tape_of
+from b256_common import N_CALLS, bench_clips, chaos, check_tape, checksums, patches_of, per_clip
 from oracle import ref_torch as R
 from synth import GRAFP_CFG
 
@@ -47,17 +47,18 @@ def test_oracle_b256_eval_and_train_step0(golden):
     keys = R.trainable_keys(P)
     for k_ in keys:
         P[k_].requires_grad_(True)
-    R.TAPE = R.KnnTape(replay=tape_of(g))
+    # the reference's graphs: own search, the reference's ids on its 1 121 near-tie rows; the per-clip hashes prove the rest
+    R.TAPE = R.KnnTape(patch=patches_of(g))
     try:
         st = R.BNState()
         h_i, h_j, z_i, z_j = R.simclr_forward(x_i, x_j, P, GRAFP_CFG, plan, True, st)
         loss = R.ntxent(z_i, z_j, GRAFP_CFG["tau"])
         loss.backward()
-        rec = R.TAPE.recorded
+        tape = R.TAPE
     finally:
         R.TAPE = None
-    assert len(rec) == N_CALLS
-    hard, soft, rows = check_tape(rec, g)
+    assert len(tape.recorded) == N_CALLS
+    hard, soft, rows = check_tape(tape, g)
     print("kNN: hard", hard, "soft", soft, "of", rows)
     assert hard == 0 and soft <= 1500, (hard, soft)          # 1 121 recorded near-tie rows in the reference's own graphs
     # measured (teacher-forced): |dloss| 1.4e-6, gnorm 7.5e-5 relative, max |dz| 6.6e-6

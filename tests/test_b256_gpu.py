@@ -17,7 +17,7 @@ import os
 import pytest
 import torch
 
-from b256_common import B, N_CALLS, bench_clips, chaos, check_tape, checksums, per_clip, tape_of
+from b256_common import B, N_CALLS, bench_clips, chaos, check_tape, checksums, patches_of, per_clip
 from conftest import ROOT
 from compare import maxerr, relerr
 from synth import GRAFP_CFG
@@ -60,14 +60,16 @@ def restore_mode():
     set_mode("fp32")
 
 
-def hip_step0(x_i, x_j, tape, overlap=False):
-    """step 0 of train.py:53-75 with FusedClipAdam(direct_grads) — the optimiser the bench uses; tape: neighbour ids to force"""
+def hip_step0(x_i, x_j, tape, overlap=False, patch=None):
+    """step 0 of train.py:53-75 with FusedClipAdam(direct_grads) — the optimiser the bench uses; tape: neighbour ids to force;
+    patch: instead, the reference's ids on its near-tie rows only (b256_common.patches_of) — the returned "knn_tape" then holds the
+    own search's graphs (.recorded) and the ones used (.patched) for b256_common.check_tape"""
     from neuralsampleid_amd import functional as F_
     from neuralsampleid_amd.optim import FusedClipAdam
     from neuralsampleid_amd.simclr.ntxent import ntxent_loss
     model = build(overlap).to(DEV).train()
     opt = FusedClipAdam(model.parameters(), lr=GRAFP_CFG["lr"], max_norm=1.0)
-    F_.TAPE = F_.KnnTape(replay=tape)
+    F_.TAPE = knn_tape = F_.KnnTape(replay=tape, patch=patch)
     try:
         opt.zero_grad()
         h_i, h_j, z_i, z_j = model(x_i, x_j)
@@ -80,7 +82,29 @@ def hip_step0(x_i, x_j, tape, overlap=False):
     opt.step()
     torch.cuda.synchronize()
     return dict(model=model, h_i=h_i.detach(), h_j=h_j.detach(), z_i=z_i.detach(), z_j=z_j.detach(), loss=float(loss.detach()),
-                gnorm=float(opt.grad_norm), grads=grads, tape=rec)
+                gnorm=float(opt.grad_norm), grads=grads, tape=rec, knn_tape=knn_tape)
+
+
+_REFERENCE_TAPE = []
+
+
+def reference_tape(g, x_i, x_j):
+    """the reference's 24 step-0 graphs, rebuilt once per session in strict fp32: own search + the fixture's near-tie rows, every clip
+    of every build proven by its hash (b256_common.check_tape). Leaves the arithmetic mode at fp32."""
+    if not _REFERENCE_TAPE:
+        from neuralsampleid_amd import functional as F_
+        set_mode("fp32")
+        model = build().to(DEV).train()
+        F_.TAPE = tape = F_.KnnTape(patch=patches_of(g))
+        try:
+            with torch.no_grad():
+                model(x_i, x_j)
+        finally:
+            F_.TAPE = None
+        hard, soft, rows = check_tape(tape, g)
+        assert hard == 0, (hard, soft, rows)
+        _REFERENCE_TAPE.extend(t.clone() for t in tape.patched)
+    return list(_REFERENCE_TAPE)
 
 
 LATE = ("encoder.backbone.14", "encoder.proj", "projector")
@@ -117,8 +141,9 @@ def test_fp32_hip_vs_reference_at_b256(golden, restore_mode):
          "eval_h_clip_norm_rel": float(((per_clip(h_i)[:, 1] - g.t("h_i_eval_clip")[:, 1]).abs() / g.t("h_i_eval_clip")[:, 1]).max()),
          "eval_h_head_max": maxerr(h_i[:8], g.t("h_i_eval_head"))}
     del model
-    r = hip_step0(x_i, x_j, tape_of(g))
-    hard, soft, rows = check_tape(r["tape"], g)
+    r = hip_step0(x_i, x_j, None, patch=patches_of(g))
+    hard, soft, rows = check_tape(r["knn_tape"], g)
+    ref_tape = [t.clone() for t in r["knn_tape"].patched]              # hard == 0 (asserted below): these ARE the reference's graphs
     full, norms = grad_report(r["grads"], g, chk)
     sd = r["model"].state_dict()
     bn = max(abs(float(sd[n].double().norm()) - nrm) / max(nrm, 1.0) for n, (s_, nrm) in chk["bn_after_step1"].items())
@@ -131,7 +156,7 @@ def test_fp32_hip_vs_reference_at_b256(golden, restore_mode):
     # free-running: own neighbour search in every block, nothing forced
     f = hip_step0(x_i, x_j, None)
     same = [float((torch.sort(a.long(), -1).values == torch.sort(b.to(DEV).long(), -1).values).all(-1).float().mean())
-            for a, b in zip(f["tape"], tape_of(g))]
+            for a, b in zip(f["tape"], ref_tape)]
     m["free"] = {"dloss": abs(f["loss"] - float(g["loss_train"][0])), "gnorm_rel": abs(f["gnorm"] - float(g["gnorm"][0])) / float(g["gnorm"][0]),
                  "max_dz": max(maxerr(f["z_i"], g.t("z_i_train")), maxerr(f["z_j"], g.t("z_j_train"))),
                  "rows_with_equal_sets_per_graph_build": same}
@@ -188,10 +213,11 @@ def test_bf16_hip_vs_emulation_at_b256_and_timed_variants_ran(golden, restore_mo
     g = golden("b256_seed42_k3")
     chk = checksums()
     em, em_chk = emulation_fixture(golden)
-    set_mode("bf16")
     x_i, x_j = (t.to(DEV) for t in bench_clips())
+    ref_tape = reference_tape(g, x_i, x_j)
+    set_mode("bf16")
     launch_counters(reset=True)
-    r = hip_step0(x_i, x_j, tape_of(g))
+    r = hip_step0(x_i, x_j, ref_tape)
     cnt = launch_counters()
     cos = lambda a, b: float(torch.nn.functional.cosine_similarity(a.detach().cpu().float(), b.float(), dim=1).min())
     # fully stored gradients: relative L2; all parameters: relative difference of the gradient NORMS

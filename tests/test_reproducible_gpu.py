@@ -10,8 +10,9 @@ import os
 import pytest
 import torch
 
+import tapes
 from synth import GRAFP_CFG
-from test_e2e_gpu import build_model, load_synth, tape_of
+from test_e2e_gpu import build_model, load_synth
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
@@ -69,7 +70,15 @@ def test_deep_configuration_knn_kernels_repeat_bitwise(golden, mode):
     model = load_synth(SimCLR(GRAFP_CFG, GraphEncoder(GRAFP_CFG, in_channels=GRAFP_CFG["n_filters"], k=18, size="t",
                                                       blocks=[4, 4, 12, 4], use_dilation=True))).train()
     x_i, x_j = g.t("x_i").to(DEV), g.t("x_j").to(DEV)
-    gold_idx, _ = tape_of(g, "s0")
+    # the reference's step-0 graphs: one strict-fp32 forward, own search + the fixture's near-tie rows (tests/tapes.py)
+    F_.set_activation_dtype("fp32")
+    F_.TAPE = tape = F_.KnnTape(patch=tapes.patches_of(g, "s0"))
+    with torch.no_grad():
+        model(x_i, x_j)
+    F_.TAPE = None
+    assert tapes.check_patched(tape, g, "s0")[0] == 0
+    gold_idx = [t.clone() for t in tape.patched]
+    F_.set_activation_dtype(mode)
 
     def run():
         F_.TAPE = F_.KnnTape(replay=gold_idx)
