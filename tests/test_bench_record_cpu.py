@@ -75,14 +75,14 @@ def test_rocprof_family_maps_kernel_names_onto_the_launch_families():
 def test_the_committed_bench_line_agrees_with_the_committed_rocprof_trace():
     """VERDICT r5 task 5: the kernel table of round 5 summed to 9.1 ms where the rocprofv3 trace of the same tree had 11.4 ms (event
     pairs under-timed short kernels). The round-6 line takes its durations from a live rocprofv3 child run: for the committed pair
-    profiles/r06b/bench.json + kernel_stats.csv (two separate runs of one tree on one box) the table's sum over its families must lie
+    profiles/r06c/bench.json + kernel_stats.csv (two separate runs of one tree on one box) the table's sum over its families must lie
     within 0.90 ... 1.05 of the trace's sum over the same families, family by family within 25 % for everything above 100 us per step."""
     import csv
-    with open(os.path.join(ROOT, "profiles", "r06b", "bench.json")) as fh:
+    with open(os.path.join(ROOT, "profiles", "r06c", "bench.json")) as fh:
         line = json.loads(fh.read().strip().splitlines()[-1])
     assert line["kernel_timing"].startswith("rocprofv3") and line["step_traffic_kind"] == "live" and line["roofline"]["traffic_kind"] == "live"
     table = {k: v["avg_us"] * v["launches"] for k, v in line["kernels"].items()}
-    rows = list(csv.DictReader(open(os.path.join(ROOT, "profiles", "r06b", "kernel_stats.csv"))))
+    rows = list(csv.DictReader(open(os.path.join(ROOT, "profiles", "r06c", "kernel_stats.csv"))))
     steps = max(int(r["Calls"]) for r in rows if "adam_kernel" in r["Name"])
     trace = {}
     for r in rows:
