@@ -217,8 +217,11 @@ int nsid_bn_bwd_apply(const void* dout, const void* r, int M, int C, const float
  * L2-normalised over channels, D = |a|^2 - 2ab + |b|^2 is formed per clip in LDS (never written to HBM),
  * the k*dilation nearest are selected in ascending distance (ties: lower index first) and every dilation-th is
  * kept.  idx[(b*N+n)*k + j] is clip-local (0..N-1), int32; the reference's edge_index[1] (centre) is implicit.
- * Limits (checked, NSID_EINVAL otherwise): N % 32 == 0, N <= 256, C % 16 == 0, ldr >= C, k*dilation <= N, r 16-byte
- * aligned; ldr % 4 == 0 (fp32) / % 8 == 0 (bf16). */
+ * Limits (checked, NSID_EINVAL otherwise): N % 32 == 0, C % 16 == 0, ldr >= C, k*dilation <= N, r 16-byte
+ * aligned; ldr % 4 == 0 (fp32) / % 8 == 0 (bf16). Graphs of more than 256 nodes, or clips of more than 32 768 features
+ * (encoder/graph_encoder.py:144 with a cfg beyond grafp.yaml's 64 x 128 input), take a form with one workgroup per
+ * 16-row strip (same arithmetic, features re-read from L2): 16 (C + 4) + 19 N + 64 floats of LDS must fit 160 KB
+ * (N <= ~2 000). */
 int nsid_knn_graph(const void* r, int ldr, const float* scale, const float* shift, int B, int N, int C, int k,
                    int dilation, int32_t* idx, int dtype, void* stream);
 
@@ -279,7 +282,9 @@ int nsid_unpack_ds_wgrad(const float* dwp, int Cout, int Cin, float* dw /* += */
 /* ---- GPUPeakExtractorv2 (peak_extractor.py:45-70) ------------------------------------------------------
  * per-clip min-max normalise, [time ramp, freq ramp, spec] -> Conv2d(3->F, kernel=stride=(pb,pf)) + ReLU.
  * out is node-major [B*(H/pb)*(W/pf)][ldo] (columns >= F untouched); minmax[B][2] is kept for backward.
- * backward gives the conv weight/bias gradients only (the spectrogram is data). */
+ * backward gives the conv weight/bias gradients only (the spectrogram is data).
+ * A clip is staged whole in LDS by the forward (H (W + 8) floats <= ~155 KB: 64 x 128 and 256 x 128 inputs both fit); the backward walks a
+ * clip that exceeds 64 KB in bands of patch rows. */
 int nsid_peak_patchify_fwd(const float* spec, const float* w, const float* bias, int B, int H, int W, int pb, int pf,
                            int F, void* out, int ldo, float* minmax, int out_dtype, void* stream);
 int nsid_peak_patchify_bwd(const float* spec, const float* minmax, const void* out, const void* dout, int ldo,

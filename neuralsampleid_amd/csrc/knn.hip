@@ -173,6 +173,101 @@ __global__ __launch_bounds__(256) void knn_kernel(const T* __restrict__ r, long 
 
 
 // ------------------------------------------------------------------------------------------------------------------
+// Graphs beyond 256 nodes (a cfg with more patches than grafp.yaml's 64 x 128 / (4 x 8): e.g. the literal 256-mel input, 1 024 / 512
+// nodes at the first two stages — encoder/graph_encoder.py:144 takes any N). A clip's fp32 features no longer fit the LDS beside a
+// distance strip, so a workgroup takes ONE 16-row strip of one clip and reads the column nodes' features from L2 as it goes:
+//   phase 0  every node's norm, reciprocal and |y^|^2 (the same expressions and summation order as knn_kernel: lane = channel mod 64,
+//            wave_sum) — each strip's workgroup repeats this for the whole clip (N / 16 times redundant, one clip read each: a
+//            correctness path for configurations the timed ones never reach, not a tuned one);
+//   phase 1  the strip's own 16 rows normalised into LDS;
+//   phase 2  D[16][N] by the exact-fp32 MFMA of knn_kernel, the column operand normalised on its way from global memory
+//            (div_shared with the node's norm from phase 0), the four waves taking column-tile pairs in turn;
+//   phase 3  k * dilation rounds of arg-min per row straight on the LDS strip (ties -> the lower node id, as knn_kernel), four rows
+//            per wave. Ids and distances are those of knn_kernel on the same input (tests/test_ops_gpu.py compares them where both run).
+// LDS: 16 (C + 4) + 3 N + 16 (N + 4) floats (82 KB at N = 1 024, C = 64).
+template <typename T>
+__global__ __launch_bounds__(256) void knn_big_kernel(const T* __restrict__ r, long ldr, const float* __restrict__ scale,
+                                                      const float* __restrict__ shift, int N, int C, int k, int dilation,
+                                                      int32_t* __restrict__ idx) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int LD = C + 4, SLD = N + 4;
+  float* arows = smem;                 // [16][LD]
+  float* den = arows + 16 * LD;        // [N] max(|y|, 1e-12)
+  float* rdn = den + N;                // [N] 1 / den
+  float* sq = rdn + N;                 // [N] |y^|^2
+  float* strip = sq + N;               // [16][SLD]
+  const int s = blockIdx.x, b = blockIdx.y;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int lr = lane & 15, rq = lane >> 4;
+  const T* src = r + (long)b * N * ldr;
+  auto feat = [&](int n, int c) -> float {
+    float v = (float)src[(long)n * ldr + c];
+    if (scale != nullptr) v = scale[c] * v + shift[c];
+    return v;
+  };
+
+  for (int n = wave; n < N; n += 4) {
+    float ss = 0.f;
+    for (int c = lane; c < C; c += 64) { const float v = feat(n, c); ss += v * v; }
+    ss = wave_sum(ss);
+    const float denom = fmaxf(sqrtf(ss), 1e-12f), rden = 1.f / denom;
+    float s2 = 0.f;
+    for (int c = lane; c < C; c += 64) { const float v = div_shared(feat(n, c), denom, rden); s2 += v * v; }
+    s2 = wave_sum(s2);
+    if (lane == 0) { den[n] = denom; rdn[n] = rden; sq[n] = s2; }
+  }
+  __syncthreads();
+  for (int q = t; q < 16 * C; q += 256) {
+    const int i = q / C, c = q - i * C, n = 16 * s + i;
+    arows[i * LD + c] = div_shared(feat(n, c), den[n], rdn[n]);
+  }
+  __syncthreads();
+
+  const int NS = N >> 4;
+  const float* arow = arows + lr * LD + 4 * rq;
+  for (int tn = 2 * wave; tn < NS; tn += 8) {
+    const int n0 = 16 * tn + lr, n1 = n0 + 16;
+    const float d0 = den[n0], r0 = rdn[n0], d1 = den[n1], r1 = rdn[n1];
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    for (int ch = 0; ch < C; ch += 16) {
+      const f32x4 fa = *reinterpret_cast<const f32x4*>(arow + ch);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int c = ch + 4 * rq + e;
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[e], div_shared(feat(n0, c), d0, r0), acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[e], div_shared(feat(n1, c), d1, r1), acc1, 0, 0, 0);
+      }
+    }
+    const float sj0 = sq[n0], sj1 = sq[n1];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float si = sq[16 * s + 4 * rq + e];
+      strip[(4 * rq + e) * SLD + 16 * tn + lr] = (si + (-2.f * acc0[e])) + sj0;
+      strip[(4 * rq + e) * SLD + 16 * tn + 16 + lr] = (si + (-2.f * acc1[e])) + sj1;
+    }
+  }
+  __syncthreads();
+
+  const int kd = k * dilation;
+  for (int i = wave; i < 16; i += 4) {
+    float* row = strip + i * SLD;
+    int32_t* out = idx + ((long)b * N + 16 * s + i) * k;
+    for (int round = 0; round < kd; ++round) {
+      unsigned loc = 0xFFFFFFFFu;
+      int at = 0x7FFFFFFF;
+      for (int j = lane; j < N; j += 64) {                 // the lane's columns in increasing order: strict < keeps the lower id
+        const unsigned key = orderable(row[j]);
+        if (key < loc) { loc = key; at = j; }
+      }
+      const unsigned m = wave_min_u32(loc);
+      const int j = (int)wave_min_u32(loc == m ? (unsigned)at : 0x7FFFFFFFu);
+      if (j < N && (j & 63) == lane) row[j] = __builtin_nanf("");          // retired: a NaN's key is above every finite distance and +inf
+      if (lane == 0 && (round % dilation) == 0) out[round / dilation] = j < N ? j : N - 1;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // Fast path (k*dilation <= 8, C a multiple of 64): 8 waves per clip, no distance strips in LDS, no wave-wide reductions.
 // The MFMA is issued with the operands swapped (A = the COLUMN nodes' rows, B = the ROW nodes' rows), so the C/D layout
 // hands lane (lr, rq) the distances D[i = i0+lr][j = j0 + 4*rq + e]: every row of the 16-row tile is spread over the 4
@@ -1232,9 +1327,30 @@ static int knn_graph_impl(const void* r, int ldr, const float* scale, const floa
                           int k, int dilation, int32_t* idx, int dtype, void* stream) {
   NSID_REQUIRE(r && idx && B > 0 && k > 0 && dilation > 0 && NSID_DTYPE_OK(dtype));
   NSID_REQUIRE(ldr % (dtype == NSID_BF16 ? 8 : 4) == 0);
-  NSID_REQUIRE(N % 32 == 0 && N <= 256 && C % 16 == 0 && ldr % 4 == 0 && ldr >= C && nsid_aligned16(r));
+  NSID_REQUIRE(N % 32 == 0 && C % 16 == 0 && ldr % 4 == 0 && ldr >= C && nsid_aligned16(r));
   NSID_REQUIRE(k * dilation <= N);
   NSID_REQUIRE((scale == nullptr) == (shift == nullptr));
+  // beyond grafp.yaml's graphs (more than 256 nodes, or a clip of more than 32 768 features — the kernels below keep a clip in LDS;
+  // 16 384 in every timed configuration, up to 32 768 at the encoder sizes 'm' / default): one workgroup per 16-row strip
+  if (N > 256 || (long)N * C > 32768) {
+    const size_t bytes = ((size_t)16 * (C + 4) + 3 * (size_t)N + (size_t)16 * (N + 4)) * sizeof(float);
+    NSID_REQUIRE(bytes <= 160 * 1024 && B <= 65535);
+    nsid_count(NSID_C_knn_big);
+    static bool configured = false;
+    if (!configured) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(knn_big_kernel<float>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+          hipFuncSetAttribute(reinterpret_cast<const void*>(knn_big_kernel<__bf16>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+        return NSID_ELAUNCH;
+      configured = true;
+    }
+    NSID_DISPATCH_DTYPE(dtype, T, {
+      NSID_LAUNCH((knn_big_kernel<T>), dim3(N / 16, B), dim3(256), bytes, static_cast<hipStream_t>(stream),
+                  static_cast<const T*>(r), (long)ldr, scale, shift, N, C, k, dilation, idx);
+    });
+    return nsid_launch_status();
+  }
   const int kd = k * dilation;
   const bool use_fast = nsid_tune(NSID_T_knn_strips) == 0;
   const bool pow2 = C >= 64 && C <= 512 && (C & (C - 1)) == 0 && N >= 32 && (N & (N - 1)) == 0;

@@ -257,9 +257,13 @@ __global__ __launch_bounds__(256) void patchify_bwd_kernel(const float* __restri
                                                            const T* __restrict__ out,
                                                            const T* __restrict__ dout, int ldo, int B, int H,
                                                            int W, int pb, int pf, int F, float* __restrict__ dw,
-                                                           float* __restrict__ dbias) {
+                                                           float* __restrict__ dbias, int bands) {
   extern __shared__ __attribute__((aligned(16))) float sm[];   // g [NP][F], then the normalised clip [H][W+pad]
   const int t = threadIdx.x;
+  // bands > 1 (a clip beyond the LDS, e.g. 256 mel bins): a clip is walked as `bands` bands of patch rows — the sums over patches are
+  // sums over bands, only the frequency ramp needs the band's offset. H / Hp / NP below are ONE BAND's; Hall is the clip's height.
+  const int Hall = H;
+  H /= bands;
   const int Hp = H / pb, Wp = W / pf, NP = Hp * Wp;
   const int per_f = 3 * pb * pf, LDW = W + PATCH_PAD;
   float* xs = sm + NP * F;
@@ -269,8 +273,9 @@ __global__ __launch_bounds__(256) void patchify_bwd_kernel(const float* __restri
   float wacc[MAXQ] = {0.f, 0.f, 0.f, 0.f}, bacc = 0.f;
   constexpr int NV = Chunk<T>::N;
   const bool vec = (F % NV == 0) && (ldo % NV == 0);          // 16-byte rows of out / dout (F = 8 bf16: one chunk a patch)
-  for (int b = blockIdx.x; b < B; b += gridDim.x) {
-    const float* x = spec + (long)b * H * W;
+  for (int vb = blockIdx.x; vb < B * bands; vb += gridDim.x) {
+    const int b = vb / bands, band = vb - b * bands;
+    const float* x = spec + ((long)b * bands + band) * H * W;
     const float lo = minmax[2 * b], range = minmax[2 * b + 1] - lo;
     __syncthreads();                                           // previous clip's readers are done with sm
     // staging: every global load of a batch is issued before its first use (these loops were serial round trips)
@@ -278,7 +283,7 @@ __global__ __launch_bounds__(256) void patchify_bwd_kernel(const float* __restri
       const int FC = F / NV;
       for (int q = t; q < NP * FC; q += blockDim.x) {
         const int p = q / FC, f = (q % FC) * NV;
-        const long o = ((long)b * NP + p) * ldo + f;
+        const long o = ((long)vb * NP + p) * ldo + f;
         float ov[NV], dv[NV];
         Chunk<T>::load(out + o, ov);
         Chunk<T>::load(dout + o, dv);
@@ -288,7 +293,7 @@ __global__ __launch_bounds__(256) void patchify_bwd_kernel(const float* __restri
     } else {
       for (int q = t; q < NP * F; q += blockDim.x) {
         const int p = q / F, f = q % F;
-        const long o = ((long)b * NP + p) * ldo + f;
+        const long o = ((long)vb * NP + p) * ldo + f;
         sm[q] = (float)out[o] > 0.f ? (float)dout[o] : 0.f;
       }
     }
@@ -331,7 +336,7 @@ __global__ __launch_bounds__(256) void patchify_bwd_kernel(const float* __restri
         if (c == 0) {
           for (int pw = 0; pw < Wp; ++pw) acc += red[pw * F + f] * linspace01(pw * pf + j, W);
         } else if (c == 1) {
-          for (int ph = 0; ph < Hp; ++ph) acc += red[(Wp + ph) * F + f] * linspace01(ph * pb + i, H);
+          for (int ph = 0; ph < Hp; ++ph) acc += red[(Wp + ph) * F + f] * linspace01((band * Hp + ph) * pb + i, Hall);
         } else {
           constexpr int UB = 4;                                // independent LDS chains, no division in the loops
           float part[UB] = {0.f, 0.f, 0.f, 0.f};
@@ -692,18 +697,31 @@ extern "C" int nsid_peak_patchify_fwd(const float* spec, const float* w, const f
   NSID_REQUIRE(spec && w && bias && out && B > 0 && H > 1 && W > 1 && pb > 0 && pf > 0 && F > 0);
   NSID_REQUIRE(H % pb == 0 && W % pf == 0 && ldo >= F && NSID_DTYPE_OK(out_dtype));
   const size_t bytes = ((size_t)F * 3 * pb * pf + 8 + (size_t)H * (W + 8)) * sizeof(float);
-  NSID_REQUIRE(bytes <= 64 * 1024 && W % 4 == 0 && (F * 3 * pb * pf) % 4 == 0 && nsid_aligned16(spec) && pb * pf <= 64);
+  // the clip is staged whole (its min / max come first): 35 KB for grafp.yaml's 64 x 128, 139 KB for a 256-mel input
+  NSID_REQUIRE(bytes <= 160 * 1024 && W % 4 == 0 && (F * 3 * pb * pf) % 4 == 0 && nsid_aligned16(spec) && pb * pf <= 64);
+  bool attr_ok = true;
+  auto big_lds = [&](const void* fn) {          // beyond the default 64 KB of dynamic LDS: raise the kernel's cap (idempotent)
+    if (bytes > 64 * 1024 && hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) attr_ok = false;
+  };
   NSID_DISPATCH_DTYPE(out_dtype, T, {
-    if (pb == 4 && pf == 8)
-      NSID_LAUNCH((patchify_fwd_kernel<T, 32, 4, 8>), dim3(B), dim3(256), bytes, static_cast<hipStream_t>(stream), spec, w,
-                  bias, H, W, pb, pf, F, static_cast<T*>(out), ldo, minmax);
-    else if (pb * pf == 32)
-      NSID_LAUNCH((patchify_fwd_kernel<T, 32>), dim3(B), dim3(256), bytes, static_cast<hipStream_t>(stream), spec, w,
-                  bias, H, W, pb, pf, F, static_cast<T*>(out), ldo, minmax);
-    else
-      NSID_LAUNCH((patchify_fwd_kernel<T, 64>), dim3(B), dim3(256), bytes, static_cast<hipStream_t>(stream), spec, w,
-                  bias, H, W, pb, pf, F, static_cast<T*>(out), ldo, minmax);
+    if (pb == 4 && pf == 8) {
+      big_lds(reinterpret_cast<const void*>(patchify_fwd_kernel<T, 32, 4, 8>));
+      if (attr_ok)
+        NSID_LAUNCH((patchify_fwd_kernel<T, 32, 4, 8>), dim3(B), dim3(256), bytes, static_cast<hipStream_t>(stream), spec, w,
+                    bias, H, W, pb, pf, F, static_cast<T*>(out), ldo, minmax);
+    } else if (pb * pf == 32) {
+      big_lds(reinterpret_cast<const void*>(patchify_fwd_kernel<T, 32>));
+      if (attr_ok)
+        NSID_LAUNCH((patchify_fwd_kernel<T, 32>), dim3(B), dim3(256), bytes, static_cast<hipStream_t>(stream), spec, w,
+                    bias, H, W, pb, pf, F, static_cast<T*>(out), ldo, minmax);
+    } else {
+      big_lds(reinterpret_cast<const void*>(patchify_fwd_kernel<T, 64>));
+      if (attr_ok)
+        NSID_LAUNCH((patchify_fwd_kernel<T, 64>), dim3(B), dim3(256), bytes, static_cast<hipStream_t>(stream), spec, w,
+                    bias, H, W, pb, pf, F, static_cast<T*>(out), ldo, minmax);
+    }
   });
+  if (!attr_ok) return NSID_ELAUNCH;
   return nsid_launch_status();
 }
 extern "C" int nsid_peak_patchify_bwd(const float* spec, const float* minmax, const void* out, const void* dout,
@@ -711,12 +729,19 @@ extern "C" int nsid_peak_patchify_bwd(const float* spec, const float* minmax, co
                                       int out_dtype, void* stream) {
   NSID_REQUIRE(spec && minmax && out && dout && dw && dbias && B > 0 && H % pb == 0 && W % pf == 0 && ldo >= F);
   NSID_REQUIRE(NSID_DTYPE_OK(out_dtype));
-  const size_t bytes = ((size_t)(H / pb) * (W / pf) * F + (size_t)H * (W + 8) + (size_t)(H / pb + W / pf) * F) * sizeof(float);
+  // a clip beyond 64 KB of LDS (256 mel bins: 172 KB) goes through in bands of patch rows, the fewest that fit
+  int bands = 1;
+  auto lds_bytes = [&](int nb) {
+    const int Hb = H / nb;
+    return ((size_t)(Hb / pb) * (W / pf) * F + (size_t)Hb * (W + 8) + (size_t)(Hb / pb + W / pf) * F) * sizeof(float);
+  };
+  while (lds_bytes(bands) > 64 * 1024 && (H / pb) % (2 * bands) == 0) bands *= 2;
+  const size_t bytes = lds_bytes(bands);
   NSID_REQUIRE(bytes <= 64 * 1024 && (long)F * 3 * pb * pf <= 4 * 256 && F <= 256 && W % 4 == 0 && nsid_aligned16(spec));
-  NSID_REQUIRE(((H / pb) * (W / pf) * F) % 4 == 0);
+  NSID_REQUIRE(((H / bands / pb) * (W / pf) * F) % 4 == 0 && (long)B * bands < (1L << 30));
   NSID_DISPATCH_DTYPE(out_dtype, T, {
-    NSID_LAUNCH((patchify_bwd_kernel<T>), dim3(B < 256 ? B : 256), dim3(256), bytes, static_cast<hipStream_t>(stream),
-                spec, minmax, static_cast<const T*>(out), static_cast<const T*>(dout), ldo, B, H, W, pb, pf, F, dw, dbias);
+    NSID_LAUNCH((patchify_bwd_kernel<T>), dim3(B * bands < 256 ? B * bands : 256), dim3(256), bytes, static_cast<hipStream_t>(stream),
+                spec, minmax, static_cast<const T*>(out), static_cast<const T*>(dout), ldo, B, H, W, pb, pf, F, dw, dbias, bands);
   });
   return nsid_launch_status();
 }

@@ -757,6 +757,81 @@ static int mrs_launch(const void* du, const int32_t* idx, const uint8_t* argmax,
 namespace {
 // Clips that do not fit LDS in fp32 (N * C = 32 768 at the default encoder size, strict-fp32 mode only): the same sum as a scatter with
 // global fp32 atomics in two launches -- dy = du_even - du_odd, then every (m, c) adds du_odd[m, c] to its arg-max neighbour's row.
+// ---- clips beyond the LDS in bf16 storage (N * C > ~50 000: a cfg with more than 256 nodes): the same reversed-graph gather as
+// mr_bwd_kernel with only the edge list in LDS; du_odd and the arg-max bytes of the source rows come from L2. One read of du for the
+// own-row term, k reads of (du_odd, argmax) chunks per node on average. A correctness path (no timed configuration reaches it).
+template <typename T>
+__global__ __launch_bounds__(MRB_THREADS) void mr_bwd_big_kernel(const T* __restrict__ du, const int32_t* __restrict__ idx,
+                                                                 const uint8_t* __restrict__ argmax, int N, int C, int k,
+                                                                 T* __restrict__ dy) {
+  extern __shared__ __attribute__((aligned(16))) char mrg_smem[];
+  constexpr int NV = Chunk<T>::N;
+  int* cnt = reinterpret_cast<int*>(mrg_smem);                      // [N]   in-degree, then fill cursor
+  int* start = cnt + N;                                             // [N+1]
+  int* src = start + N + 1;                                         // [N*k] (m << 8) | j
+  const int b = blockIdx.x, t = threadIdx.x;
+  const long row0 = (long)b * N;
+  const int CV = C / NV, total = N * CV, E = N * k;
+  const T* dub = du + row0 * (2L * C);
+  const uint8_t* amb = argmax + row0 * C;
+  const int32_t* nbb = idx + row0 * k;
+  for (int n = t; n < N; n += MRB_THREADS) cnt[n] = 0;
+  __syncthreads();
+  for (int e = t; e < E; e += MRB_THREADS) atomicAdd(&cnt[min(max(nbb[e], 0), N - 1)], 1);
+  __syncthreads();
+  if (t < 64) {                                              // exclusive scan of cnt[0..N) by one wave
+    const int per = (N + 63) / 64;
+    int loc = 0;
+    for (int i2 = 0; i2 < per; ++i2) { const int n = t * per + i2; if (n < N) loc += cnt[n]; }
+    int inc = loc;
+#pragma unroll
+    for (int o2 = 1; o2 < 64; o2 <<= 1) { const int v = __shfl_up(inc, o2, 64); if (t >= o2) inc += v; }
+    int run = inc - loc;
+    for (int i2 = 0; i2 < per; ++i2) {
+      const int n = t * per + i2;
+      if (n < N) { start[n] = run; const int c2 = cnt[n]; cnt[n] = run; run += c2; }
+    }
+    if (t == 63) start[N] = inc;
+  }
+  __syncthreads();
+  for (int e = t; e < E; e += MRB_THREADS) {
+    const int tg = min(max(nbb[e], 0), N - 1);
+    const int p = atomicAdd(&cnt[tg], 1);
+    src[p] = ((e / k) << 8) | (e % k);
+  }
+  __syncthreads();
+  for (int q = t; q < total; q += MRB_THREADS) {
+    const int n = q / CV, c = (q % CV) * NV;
+    float g0[NV], g1[NV], v[NV];
+    Chunk<T>::load(dub + (long)q * 2 * NV, g0);
+    Chunk<T>::load(dub + (long)q * 2 * NV + NV, g1);
+#pragma unroll
+    for (int e = 0; e < NV / 2; ++e) {
+      v[e] = g0[2 * e] - g0[2 * e + 1];
+      v[NV / 2 + e] = g1[2 * e] - g1[2 * e + 1];
+    }
+    const int p1 = start[n + 1];
+    for (int p = start[n]; p < p1; ++p) {
+      const int s2 = src[p];
+      const int m = s2 >> 8, jj = s2 & 255;
+      Chunk<T>::load(dub + ((long)m * C + c) * 2, g0);
+      Chunk<T>::load(dub + ((long)m * C + c) * 2 + NV, g1);
+      const uint8_t* a = amb + (long)m * C + c;
+#pragma unroll
+      for (int e = 0; e < NV; e += 4) {
+        const uint32_t a4 = *reinterpret_cast<const uint32_t*>(a + e);
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+          const int ch = e + x;
+          const float o = ch < NV / 2 ? g0[2 * ch + 1] : g1[2 * (ch - NV / 2) + 1];
+          v[ch] += (int)((a4 >> (8 * x)) & 255u) == jj ? o : 0.f;
+        }
+      }
+    }
+    Chunk<T>::store(dy + row0 * C + (long)q * NV, v);
+  }
+}
+
 __global__ __launch_bounds__(256) void mr_bwd_own_kernel(const float* __restrict__ du, long total, float* __restrict__ dy) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) dy[i] = du[2 * i] - du[2 * i + 1];
 }
@@ -789,7 +864,21 @@ extern "C" int nsid_mr_aggregate_bwd(const void* du, const int32_t* idx, const u
                 argmax, N, C, k, total, static_cast<float*>(dy));
     return nsid_launch_status();
   }
-  NSID_REQUIRE(bytes <= 160 * 1024 && C % 4 == 0 && ((size_t)N * C * (esz + 1)) % 4 == 0);
+  if (bytes > 160 * 1024) {                  // bf16 storage, a clip beyond the LDS: the edge list alone stays there
+    const size_t gbytes = ((size_t)2 * N + 1 + (size_t)N * k) * sizeof(int);
+    NSID_REQUIRE(gbytes <= 160 * 1024 && C % 8 == 0 && N < (1 << 23));
+    static bool big_configured = false;
+    if (!big_configured) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(mr_bwd_big_kernel<__bf16>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+        return NSID_ELAUNCH;
+      big_configured = true;
+    }
+    NSID_LAUNCH((mr_bwd_big_kernel<__bf16>), dim3(B), dim3(MRB_THREADS), gbytes, static_cast<hipStream_t>(stream),
+                static_cast<const __bf16*>(du), idx, argmax, N, C, k, static_cast<__bf16*>(dy));
+    return nsid_launch_status();
+  }
+  NSID_REQUIRE(C % 4 == 0 && ((size_t)N * C * (esz + 1)) % 4 == 0);
   static bool configured = false;
   if (!configured) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(mr_bwd_kernel<float>),

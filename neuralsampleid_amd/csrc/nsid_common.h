@@ -205,7 +205,7 @@ static inline long nsid_tune(NsidTuneKey k) { return g_nsid_tune[k]; }
   X(ws_fwd) X(ws_bwd_data) X(ws_bwd_bnapply) /* wsgemm.hip: weight-stationary streaming forms */                   \
   X(wgrad_rect) X(wgrad_square) X(wgrad3) X(wgrad_grouped) X(wgrad_grouped_w3)                                                       \
   X(bn_bwd_apply) X(bn_bwd_apply_capped)                                                        \
-  X(knn2) X(knn2_pair) X(knn2_raw) X(knn_rank) X(knn_sel) X(knn_strips)                                                  \
+  X(knn2) X(knn2_pair) X(knn2_raw) X(knn_rank) X(knn_sel) X(knn_strips) X(knn_big)                                                  \
   X(mr_fwd_lds) X(mr_fwd_grid) X(mr_fwd_key) X(mr_bwd_sorted)                                                                  \
   X(ffn_fused)            /* eval-mode FFN in one launch (ffn_fused.hip) */                     \
   X(mrconv_fused)         /* eval-mode max-relative aggregation + grouped conv in one launch (mrconv_fused.hip) */

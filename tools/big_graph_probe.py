@@ -1,0 +1,89 @@
+#!/usr/bin/env python3
+"""Probe of graphs beyond 256 nodes (a cfg with n_mels = 256: 1 024 / 512 / 256 / 128 nodes by stage): kNN ids against the oracle,
+then eval forward and one training step of GraphEncoder against the oracle with the oracle's graphs forced (B = 2)."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+from oracle import ref_torch as R  # noqa: E402
+from synth import GRAFP_CFG, synth_randn, synth_state  # noqa: E402
+
+from neuralsampleid_amd import functional as F_, ops  # noqa: E402
+
+dev = "cuda"
+for (N, C, k, d) in [(1024, 64, 3, 1), (512, 128, 5, 1), (1024, 64, 9, 2), (512, 128, 18, 2), (320, 64, 4, 1)]:
+    B = 2
+    x = synth_randn(f"big{N}", B, N, C)
+    ref = R._knn_graph(x, k, d)
+    for dt in (torch.float32, torch.bfloat16):
+        xr = x.to(dt).float() if dt == torch.bfloat16 else x
+        refd = R._knn_graph(xr, k, d)
+        idx = ops.knn_graph(x.reshape(B * N, C).to(dev).to(dt).contiguous(), B, N, C, k, d).cpu().long()
+        same = (np.sort(idx.numpy(), -1) == np.sort(refd.numpy(), -1)).all(-1)
+        print(f"N={N} C={C} k={k} d={d} {dt}: rows with the oracle's set {same.mean():.5f}; self first {(idx[..., 0] == torch.arange(N)).float().mean():.4f}")
+print(ops.launch_counters()["knn_big"])
+
+# ---- the whole model at 1 024 nodes: eval forward and step 0 against the oracle, the oracle's graphs forced
+from neuralsampleid_amd.encoder.graph_encoder import GraphEncoder  # noqa: E402
+from neuralsampleid_amd.simclr.ntxent import ntxent_loss  # noqa: E402
+from neuralsampleid_amd.simclr.simclr import SimCLR  # noqa: E402
+
+cfg = dict(GRAFP_CFG, n_mels=256)
+B = 2
+x_i = (synth_randn("bigx_i", B, 256, cfg["n_frames"]) * 20 - 40)
+x_j = x_i + 3 * synth_randn("bigx_j", B, 256, cfg["n_frames"])
+for mode in ("fp32", "bf16"):
+    F_.set_activation_dtype(mode)
+    ops.set_gemm_precision(mode)
+    model = SimCLR(cfg, GraphEncoder(cfg, in_channels=cfg["n_filters"], k=3, size="t"))
+    model.load_state_dict(synth_state(model.state_dict()))
+    P = {n: v.clone() for n, v in model.state_dict().items() if "relative_pos" not in n}
+    plan = R.encoder_plan("t", 3)
+    model = model.to(dev)
+    R.TAPE = R.KnnTape()
+    with torch.no_grad():
+        h_r, _, z_r, _ = R.simclr_forward(x_i, x_j, P, cfg, plan, False)
+    tape = R.TAPE.recorded
+    R.TAPE = None
+    print("oracle graphs:", [tuple(t.shape) for t in tape[:12:2]])
+    model.eval()
+    F_.TAPE = F_.KnnTape(replay=tape)
+    with torch.no_grad():
+        h, _, z, _ = model(x_i.to(dev), x_j.to(dev))
+    own = F_.TAPE.recorded
+    F_.TAPE = None
+    same = [float((np.sort(a.cpu().numpy(), -1) == np.sort(b.numpy(), -1)).all(-1).mean()) for a, b in zip(own, tape)]
+    print(mode, "eval: max |dz|", float((z.cpu() - z_r).abs().max()), "rel h", float((h.cpu().float() - h_r).norm() / h_r.norm()),
+          "own sets equal", min(same))
+    # step 0
+    keys = R.trainable_keys(P)
+    for k_ in keys:
+        P[k_].requires_grad_(True)
+    R.TAPE = R.KnnTape()
+    st = R.BNState()
+    h_i, h_j, z_i, z_j = R.simclr_forward(x_i, x_j, P, cfg, plan, True, st)
+    loss_r = R.ntxent(z_i, z_j, cfg["tau"])
+    loss_r.backward()
+    tape = R.TAPE.recorded
+    R.TAPE = None
+    model.train()
+    F_.TAPE = F_.KnnTape(replay=tape)
+    model.zero_grad()
+    a, b_, c, d_ = model(x_i.to(dev), x_j.to(dev))
+    loss = ntxent_loss(c, d_, cfg)
+    loss.backward()
+    F_.TAPE = None
+    gn_r = float(torch.sqrt(sum(P[k_].grad.double().pow(2).sum() for k_ in keys if P[k_].grad is not None)))
+    gn = float(torch.sqrt(sum(p.grad.double().pow(2).sum() for p in model.parameters() if p.grad is not None)))
+    late = "projector.2.weight"
+    g_l = dict(model.named_parameters())[late].grad.cpu()
+    print(mode, "train: |dloss|", abs(float(loss) - float(loss_r)), "gnorm rel", abs(gn - gn_r) / gn_r,
+          "late grad rel", float((g_l - P[late].grad).norm() / P[late].grad.norm()), "max |dz|", float((c.detach().cpu() - z_i.detach()).abs().max()))
+    print({k_: v for k_, v in ops.launch_counters().items() if v and k_.startswith(("knn", "mr_"))})
+F_.set_activation_dtype("fp32")
+ops.set_gemm_precision("fp32")
