@@ -82,7 +82,7 @@ for mode in ("fp32", "bf16"):
     gn = float(torch.sqrt(sum(p.grad.double().pow(2).sum() for p in model.parameters() if p.grad is not None)))
     late = "projector.2.weight"
     g_l = dict(model.named_parameters())[late].grad.cpu()
-    print(mode, "train: |dloss|", abs(float(loss) - float(loss_r)), "gnorm rel", abs(gn - gn_r) / gn_r,
+    print(mode, "train: |dloss|", abs(float(loss.detach()) - float(loss_r.detach())), "gnorm rel", abs(gn - gn_r) / gn_r,
           "late grad rel", float((g_l - P[late].grad).norm() / P[late].grad.norm()), "max |dz|", float((c.detach().cpu() - z_i.detach()).abs().max()))
     print({k_: v for k_, v in ops.launch_counters().items() if v and k_.startswith(("knn", "mr_"))})
 F_.set_activation_dtype("fp32")
